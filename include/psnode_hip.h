@@ -1,0 +1,161 @@
+/*
+ * psnode_hip.h -- C ABI of the MI355X (gfx950) fixed-grid neural-ODE/DAE integrator.
+ *
+ * This is the drop-in boundary for the hot path of xxh0523/Py_PSNODE.  The reference has no FFI of
+ * its own (it is pure Python/PyTorch); each entry point below replaces the
+ * Python interface named in its comment (file:line under /root/reference), and is what a ctypes
+ * binding inside the reference's `neural_dae` package would bind (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs.  No torch types.  All float data is fp32.
+ *   - every pointer is a DEVICE pointer unless the comment says "host".
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises the device, allocates user-visible memory or keeps a reference to its arguments
+ *     beyond the enqueue.  Re-entrant across streams/devices; no global mutable state.
+ *   - scratch memory is caller-provided (`workspace`); its size comes from psnode_workspace_bytes().
+ *   - return value: PSNODE_OK (0) or a negative psnode_status; never throws/aborts.
+ *     psnode_status_string() maps a status to text.
+ *   - tensors are TIME-MAJOR logical [T,B,D] views described by (ptr, stride_t, stride_b) in ELEMENTS
+ *     with the last dimension contiguous -- exactly what the scripts hand the solver:
+ *     `x.permute(1,0,2)` of B-major [B,T,D] memory (neural_00_ODE_01_no_encode.py:82-84).
+ */
+#ifndef PSNODE_HIP_H
+#define PSNODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSNODE_ABI_VERSION 1
+#define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
+#define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
+
+typedef enum {
+    PSNODE_OK = 0,
+    PSNODE_ERR_NULL = -1,        /* required pointer is NULL */
+    PSNODE_ERR_DIMS = -2,        /* bad / inconsistent dimensions (e.g. first Linear in_features != recipe) */
+    PSNODE_ERR_METHOD = -3,      /* unknown method id */
+    PSNODE_ERR_WORKSPACE = -4,   /* workspace too small or misaligned */
+    PSNODE_ERR_UNSUPPORTED = -5, /* shape outside kernel limits, or the requested kernel is not available for it */
+    PSNODE_ERR_HIP = -6          /* a HIP runtime call failed (launch error, bad stream, ...) */
+} psnode_status;
+
+/* my_fixed_grid.py:12 (Euler), :20 (Midpoint), :35 (RK4 = 3/8-rule rk4_alt_step_func) */
+typedef enum { PSNODE_EULER = 0, PSNODE_MIDPOINT = 1, PSNODE_RK4_38 = 2 } psnode_method;
+
+/* kernel selection: AUTO picks the MFMA kernel when the shape has one, else the generic kernel */
+typedef enum { PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2 } psnode_kernel;
+
+/* flags: teacher forcing of my_solvers.py:52 (input_true_x) and :82 (input_true_x, input_true_i) */
+#define PSNODE_FLAG_INPUT_TRUE_X 1u
+#define PSNODE_FLAG_INPUT_TRUE_I 2u
+
+/* An nn.Sequential(Linear, ELU, Linear, ..., Linear) exactly as nn.Linear stores it:
+ * weight[l] row-major [out_dim[l], in] (in = in_dim for l = 0, else out_dim[l-1]), bias[l] [out_dim[l]].
+ * ELU(alpha=1) follows every layer but the last.
+ * Replaces the forward of DE_Func.x_dot / AE_Func.i_calculator
+ * (neural_00_ODE_01_no_encode.py:61-68, neural_01_DAE_01_no_encode.py:64-83). */
+typedef struct {
+    int32_t n_layers;
+    int32_t in_dim;
+    int32_t out_dim[PSNODE_MAX_LAYERS];
+    const float* weight[PSNODE_MAX_LAYERS];
+    const float* bias[PSNODE_MAX_LAYERS];
+} psnode_mlp_f32;
+
+/* strided time-major view [T,B,D], element strides, last dim contiguous */
+typedef struct {
+    const float* ptr;
+    int64_t stride_t;
+    int64_t stride_b;
+} psnode_view_f32;
+
+/* Arguments of FixedGridODESolver.integrate_ODE (my_solvers.py:52-80) with a recognised DE_Func
+ * (neural_00_ODE_01_no_encode.py:58-68; latent variant neural_00_ODE_02_direct_encode.py:49-57).
+ *
+ *   xs[0] = x[0];  for k in 0..T-2:  dt = t[k+1]-t[k];
+ *     zk  = event_idx[k] >= 0 ? z_jump[:, event_idx[k]] : z[k]
+ *     src = INPUT_TRUE_X ? x[k] : xs[k];   xs[k+1] = src + step(method, f(. ; zk), dt, src)
+ *   f(x; z) = MLP_de( cat(a0, cat(x,z) - a0, cat(x,z)) ),  a0 = all_initial
+ */
+typedef struct {
+    int32_t method;            /* psnode_method */
+    int32_t kernel;            /* psnode_kernel */
+    uint32_t flags;            /* PSNODE_FLAG_INPUT_TRUE_X */
+    int32_t x_dim, z_dim;
+    int64_t T, B;
+    psnode_mlp_f32 de;         /* in_dim must equal 3*(x_dim+z_dim), last out_dim must equal x_dim */
+    psnode_view_f32 t;         /* [T,B,1] */
+    psnode_view_f32 x;         /* [T,B,x_dim]; only x[0] is read unless INPUT_TRUE_X */
+    psnode_view_f32 z;         /* [T,B,z_dim] */
+    const float* all_initial;  /* [B, x_dim+z_dim] contiguous */
+    const int32_t* event_idx;  /* int32[T-1], -1 = no event at that step; NULL = no events */
+    const float* z_jump;       /* [B,nE,z_dim] : z_jump[b*zj_stride_b + e*zj_stride_e + d] */
+    int64_t zj_stride_b, zj_stride_e;
+    float* x_out;              /* [T,B,x_dim] contiguous (my_solvers.py:62) */
+} psnode_ode_args_f32;
+
+/* Arguments of FixedGridODESolver.integrate_DAE (my_solvers.py:82-131) with recognised DE_Func/AE_Func
+ * (neural_01_DAE_01_no_encode.py:61-83; latent variant neural_01_DAE_02_direct_encode.py:70-100).
+ *
+ *   x0 = x_init; i0 = g(TRUE_X ? x[0] : x0; z[0], v[0]);  xs[0]=x0; is[0]=i0
+ *   for k: [event: zk,vk <- jumps; i0 = g(x0; zk, vk)]
+ *          x1 = step(f(. ; zk, vk, TRUE_I ? i[k] : i0), start = TRUE_X ? x[k] : x0)
+ *          i1 = g(TRUE_X ? x[k+1] : x1; z[k+1], v[k+1]);  xs[k+1]=x1; is[k+1]=i1; x0=x1; i0=i1
+ *   f = MLP_de(cat(a0, s-a0, s)), s = cat(x,z,v,i);   g = MLP_ae(cat(a0, x, z, v))
+ */
+typedef struct {
+    int32_t method, kernel;
+    uint32_t flags;            /* PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I */
+    int32_t x_dim, z_dim, v_dim, i_dim;
+    int64_t T, B;
+    psnode_mlp_f32 de;         /* in_dim = 3*(x+z+v+i), out = x_dim */
+    psnode_mlp_f32 ae;         /* in_dim = (x+z+v+i) + (x+z+v), out = i_dim */
+    psnode_view_f32 t, x, z, v, i;   /* x, i only read under teacher forcing (may be NULL otherwise) */
+    const float* x_init;       /* [B,x_dim] contiguous */
+    const float* all_initial;  /* [B, x+z+v+i] contiguous */
+    const int32_t* event_idx;  /* as above */
+    const float* z_jump;       /* [B,nE,z_dim] */
+    int64_t zj_stride_b, zj_stride_e;
+    const float* v_jump;       /* [B,nE,v_dim] */
+    int64_t vj_stride_b, vj_stride_e;
+    float* x_out;              /* [T,B,x_dim] contiguous */
+    float* i_out;              /* [T,B,i_dim] contiguous */
+} psnode_dae_args_f32;
+
+/* ABI / build identification. */
+int32_t psnode_abi_version(void);
+const char* psnode_build_info(void);               /* e.g. "psnode_hip gfx950 ..." (static storage) */
+const char* psnode_status_string(int32_t status);  /* static storage */
+
+/* Scratch bytes needed by an integrate call with these MLPs (ae may be NULL).  Host-only, no HIP calls. */
+size_t psnode_workspace_bytes(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
+
+/* Replaces ODE_Event.event_fn + jump_change_fn's index search (neural_base.py:52-62, 178-196), resolved
+ * once per call on the device instead of one host sync per step:
+ *   event_idx[k] = e such that event_times[e*stride_e] == clock[k*stride_k] (exact fp32 equality), else -1
+ * for k in [0, n_steps).  `clock` is trajectory 0's time column, `event_times` trajectory 0's event list.
+ * If several e match, *dup_flag (optional int32, device) is set to 1 and the first match is used
+ * (the reference raises on that input). */
+int32_t psnode_event_table_f32(int64_t n_steps, const float* clock, int64_t stride_k,
+                               const float* event_times, int64_t stride_e, int32_t n_events,
+                               int32_t* event_idx, int32_t* dup_flag, void* stream);
+
+/* Replaces FixedGridODESolver.integrate_ODE (my_solvers.py:52-80) + Euler/Midpoint/RK4._step_func
+ * (my_fixed_grid.py:12-59) + DE_Func.forward for the whole batch and all T-1 steps. */
+int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces FixedGridODESolver.integrate_DAE (my_solvers.py:82-131) + step functions + DE_Func/AE_Func forwards. */
+int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
+int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
+int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSNODE_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libpsnode_hip.so (the C ABI declared in include/psnode_hip.h).
+
+The library is the product's only compute path.  There is no fallback: if it cannot be loaded,
+`load()` raises `PsnodeLibraryError` and every fused call fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+MAX_LAYERS = 8
+MAX_WIDTH = 1024
+
+OK = 0
+EULER, MIDPOINT, RK4_38 = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
+
+LIB_NAME = "libpsnode_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+EXPORTS = (
+    "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
+    "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
+    "psnode_ode_kernel_for", "psnode_dae_kernel_for",
+)
+
+
+class PsnodeLibraryError(RuntimeError):
+    pass
+
+
+class PsnodeStatusError(RuntimeError):
+    pass
+
+
+class MlpF32(ctypes.Structure):
+    _fields_ = [("n_layers", c_int32), ("in_dim", c_int32), ("out_dim", c_int32 * MAX_LAYERS),
+                ("weight", c_void_p * MAX_LAYERS), ("bias", c_void_p * MAX_LAYERS)]
+
+
+class ViewF32(ctypes.Structure):
+    _fields_ = [("ptr", c_void_p), ("stride_t", c_int64), ("stride_b", c_int64)]
+
+
+class OdeArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("kernel", c_int32), ("flags", c_uint32), ("x_dim", c_int32), ("z_dim", c_int32),
+                ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("t", ViewF32), ("x", ViewF32), ("z", ViewF32),
+                ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
+                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_out", c_void_p)]
+
+
+class DaeArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("kernel", c_int32), ("flags", c_uint32),
+                ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
+                ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("ae", MlpF32),
+                ("t", ViewF32), ("x", ViewF32), ("z", ViewF32), ("v", ViewF32), ("i", ViewF32),
+                ("x_init", c_void_p), ("all_initial", c_void_p), ("event_idx", c_void_p),
+                ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
+                ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64),
+                ("x_out", c_void_p), ("i_out", c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load libpsnode_hip.so once.  `import torch` must come first so that the HIP runtime torch bundles
+    (libamdhip64.so.7) is the one instance both sides share."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (ordering requirement above)
+    if not os.path.exists(LIB_PATH):
+        raise PsnodeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C py_psnode_amd/csrc`.  There is no non-HIP fallback for the fused integrator.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise PsnodeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    lib.psnode_abi_version.restype = c_int32
+    lib.psnode_build_info.restype = c_char_p
+    lib.psnode_status_string.restype = c_char_p
+    lib.psnode_status_string.argtypes = [c_int32]
+    lib.psnode_workspace_bytes.restype = c_size_t
+    lib.psnode_workspace_bytes.argtypes = [ctypes.POINTER(MlpF32), ctypes.POINTER(MlpF32)]
+    lib.psnode_event_table_f32.restype = c_int32
+    lib.psnode_event_table_f32.argtypes = [c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.psnode_ode_integrate_f32.restype = c_int32
+    lib.psnode_ode_integrate_f32.argtypes = [ctypes.POINTER(OdeArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_dae_integrate_f32.restype = c_int32
+    lib.psnode_dae_integrate_f32.argtypes = [ctypes.POINTER(DaeArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_ode_kernel_for.restype = c_int32
+    lib.psnode_ode_kernel_for.argtypes = [ctypes.POINTER(OdeArgsF32)]
+    lib.psnode_dae_kernel_for.restype = c_int32
+    lib.psnode_dae_kernel_for.argtypes = [ctypes.POINTER(DaeArgsF32)]
+    if lib.psnode_abi_version() != 1:
+        raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != OK:
+        msg = load().psnode_status_string(status).decode()
+        if status in (-2, -3, -5):
+            raise ValueError(f"{what}: {msg} (status {status})")
+        raise PsnodeStatusError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,292 @@
+// C ABI of libpsnode_hip.so (see include/psnode_hip.h): argument validation, workspace carving,
+// weight packing and kernel dispatch.  Everything is enqueued on the caller's stream.
+#include <stdio.h>
+#include <string.h>
+
+#include "psnode_common.h"
+
+namespace psnode {
+namespace {
+
+constexpr size_t kAlignFloats = 64;   // 256-byte alignment of every workspace segment
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t transposed_floats(const psnode_mlp_f32* m) {
+    if (!m) return 0;
+    size_t tot = 0;
+    int k = m->in_dim;
+    for (int l = 0; l < m->n_layers; ++l) {
+        tot += round_up((size_t)k * m->out_dim[l], kAlignFloats);
+        k = m->out_dim[l];
+    }
+    return tot;
+}
+
+int check_mlp(const psnode_mlp_f32& m, int want_in, int want_out) {
+    if (m.n_layers < 1 || m.n_layers > kMaxLayers) return PSNODE_ERR_DIMS;
+    if (m.in_dim != want_in || m.in_dim < 1 || m.in_dim > PSNODE_MAX_WIDTH) return PSNODE_ERR_DIMS;
+    for (int l = 0; l < m.n_layers; ++l) {
+        if (m.out_dim[l] < 1 || m.out_dim[l] > PSNODE_MAX_WIDTH) return PSNODE_ERR_DIMS;
+        if (!m.weight[l] || !m.bias[l]) return PSNODE_ERR_NULL;
+    }
+    if (m.out_dim[m.n_layers - 1] != want_out) return PSNODE_ERR_DIMS;
+    return PSNODE_OK;
+}
+
+// Fills `d` and assigns the transposed-weight segments; returns the next free float of the workspace.
+float* bind_mlp(const psnode_mlp_f32& m, MlpDev& d, float* ws) {
+    d.n_layers = m.n_layers;
+    d.in_dim = m.in_dim;
+    int k = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        d.out_dim[l] = m.out_dim[l];
+        d.w[l] = m.weight[l];
+        d.bias[l] = m.bias[l];
+        d.wt[l] = ws;
+        ws += round_up((size_t)k * m.out_dim[l], kAlignFloats);
+        k = m.out_dim[l];
+    }
+    return ws;
+}
+
+int max_width(const psnode_mlp_f32& m) {
+    int w = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) w = m.out_dim[l] > w ? m.out_dim[l] : w;
+    return w;
+}
+
+struct PackArgs {
+    int n;                       // layers in total (de then ae)
+    int K[2 * kMaxLayers], N[2 * kMaxLayers];
+    const float* w[2 * kMaxLayers];
+    float* wt[2 * kMaxLayers];
+};
+
+// wt[k][j] = w[j][k] for every layer of both MLPs in one launch (blockIdx.y = layer).
+__global__ void pack_transpose_kernel(const PackArgs p) {
+    const int l = blockIdx.y;
+    const int K = p.K[l], N = p.N[l];
+    const float* __restrict__ w = p.w[l];
+    float* __restrict__ wt = p.wt[l];
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < K * N; idx += gridDim.x * blockDim.x) {
+        const int k = idx / N, j = idx % N;
+        wt[idx] = w[(size_t)j * K + k];
+    }
+}
+
+void add_pack(PackArgs& p, const MlpDev& d) {
+    int k = d.in_dim;
+    for (int l = 0; l < d.n_layers; ++l) {
+        p.K[p.n] = k;
+        p.N[p.n] = d.out_dim[l];
+        p.w[p.n] = d.w[l];
+        p.wt[p.n] = const_cast<float*>(d.wt[l]);
+        ++p.n;
+        k = d.out_dim[l];
+    }
+}
+
+__global__ void event_table_kernel(long long n_steps, const float* clock, long long stride_k, const float* ev_times,
+                                   long long stride_e, int n_events, int* event_idx, int* dup_flag) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_steps) return;
+    const float tk = clock[k * stride_k];
+    int hit = -1, cnt = 0;
+    for (int e = 0; e < n_events; ++e) {
+        if (ev_times[e * stride_e] == tk) {   // exact equality, like Tensor.__contains__ (neural_base.py:54)
+            if (hit < 0) hit = e;
+            ++cnt;
+        }
+    }
+    event_idx[k] = hit;
+    if (cnt > 1 && dup_flag) *dup_flag = 1;
+}
+
+ViewDev view(const psnode_view_f32& v) { return ViewDev{v.ptr, v.stride_t, v.stride_b}; }
+
+int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, const psnode_mlp_f32* ae, void* workspace,
+             size_t workspace_bytes, hipStream_t stream) {
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return PSNODE_ERR_WORKSPACE;
+    if (workspace_bytes < psnode_workspace_bytes(de, ae)) return PSNODE_ERR_WORKSPACE;
+    float* ws = static_cast<float*>(workspace);
+    ws = bind_mlp(*de, d.de, ws);
+    if (dae) ws = bind_mlp(*ae, d.ae, ws);
+    d.maxw = max_width(*de);
+    if (dae && max_width(*ae) > d.maxw) d.maxw = max_width(*ae);
+
+    const bool has_mfma = dae ? mfma_dae_supported(d) : mfma_ode_supported(d);
+    if (kernel == PSNODE_KERNEL_MFMA && !has_mfma) return PSNODE_ERR_UNSUPPORTED;
+    const bool use_mfma = has_mfma && kernel != PSNODE_KERNEL_GENERIC;
+    if (d.T < 1 || d.B < 1) return PSNODE_ERR_DIMS;
+
+    hipError_t e;
+    if (use_mfma) {
+        e = launch_mfma(d, dae, ws, stream);
+    } else {
+        if (generic_lds_bytes(d, dae) > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
+        PackArgs p;
+        p.n = 0;
+        add_pack(p, d.de);
+        if (dae) add_pack(p, d.ae);
+        hipLaunchKernelGGL(pack_transpose_kernel, dim3(8, p.n), dim3(256), 0, stream, p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = launch_generic(d, dae, stream);
+    }
+    return e == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+int fill_ode(const psnode_ode_args_f32* a, IntegrateDev& d) {
+    if (!a) return PSNODE_ERR_NULL;
+    if (a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return PSNODE_ERR_METHOD;
+    if (a->x_dim < 1 || a->z_dim < 0 || a->T < 1 || a->B < 1) return PSNODE_ERR_DIMS;
+    const int n = a->x_dim + a->z_dim;
+    int rc = check_mlp(a->de, 3 * n, a->x_dim);
+    if (rc) return rc;
+    if (!a->t.ptr || !a->x.ptr || !a->all_initial || !a->x_out) return PSNODE_ERR_NULL;
+    if (a->z_dim > 0 && !a->z.ptr) return PSNODE_ERR_NULL;
+    if (a->event_idx && a->z_dim > 0 && !a->z_jump) return PSNODE_ERR_NULL;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method;
+    d.flags = a->flags & PSNODE_FLAG_INPUT_TRUE_X;
+    d.xd = a->x_dim;
+    d.zd = a->z_dim;
+    d.T = a->T;
+    d.B = a->B;
+    d.t = view(a->t);
+    d.x = view(a->x);
+    d.z = view(a->z);
+    d.a0 = a->all_initial;
+    d.ev = a->event_idx;
+    d.zj = a->z_jump;
+    d.zjb = a->zj_stride_b;
+    d.zje = a->zj_stride_e;
+    d.xo = a->x_out;
+    return PSNODE_OK;
+}
+
+int fill_dae(const psnode_dae_args_f32* a, IntegrateDev& d) {
+    if (!a) return PSNODE_ERR_NULL;
+    if (a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return PSNODE_ERR_METHOD;
+    if (a->x_dim < 1 || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1 || a->T < 1 || a->B < 1) return PSNODE_ERR_DIMS;
+    const int n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
+    int rc = check_mlp(a->de, 3 * n, a->x_dim);
+    if (rc) return rc;
+    rc = check_mlp(a->ae, n + a->x_dim + a->z_dim + a->v_dim, a->i_dim);
+    if (rc) return rc;
+    if (!a->t.ptr || !a->x_init || !a->all_initial || !a->x_out || !a->i_out) return PSNODE_ERR_NULL;
+    if ((a->z_dim > 0 && !a->z.ptr) || (a->v_dim > 0 && !a->v.ptr)) return PSNODE_ERR_NULL;
+    if ((a->flags & PSNODE_FLAG_INPUT_TRUE_X) && !a->x.ptr) return PSNODE_ERR_NULL;
+    if ((a->flags & PSNODE_FLAG_INPUT_TRUE_I) && !a->i.ptr) return PSNODE_ERR_NULL;
+    if (a->event_idx && ((a->z_dim > 0 && !a->z_jump) || (a->v_dim > 0 && !a->v_jump))) return PSNODE_ERR_NULL;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method;
+    d.flags = a->flags & (PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I);
+    d.xd = a->x_dim;
+    d.zd = a->z_dim;
+    d.vd = a->v_dim;
+    d.id = a->i_dim;
+    d.T = a->T;
+    d.B = a->B;
+    d.t = view(a->t);
+    d.x = view(a->x);
+    d.z = view(a->z);
+    d.v = view(a->v);
+    d.i = view(a->i);
+    d.x_init = a->x_init;
+    d.a0 = a->all_initial;
+    d.ev = a->event_idx;
+    d.zj = a->z_jump;
+    d.zjb = a->zj_stride_b;
+    d.zje = a->zj_stride_e;
+    d.vj = a->v_jump;
+    d.vjb = a->vj_stride_b;
+    d.vje = a->vj_stride_e;
+    d.xo = a->x_out;
+    d.io = a->i_out;
+    return PSNODE_OK;
+}
+
+// dims-only view of the args for the *_kernel_for queries (pointers unused)
+void bind_dims(const psnode_mlp_f32& m, MlpDev& d) {
+    d.n_layers = m.n_layers;
+    d.in_dim = m.in_dim;
+    for (int l = 0; l < m.n_layers && l < kMaxLayers; ++l) d.out_dim[l] = m.out_dim[l];
+}
+
+}  // namespace
+}  // namespace psnode
+
+using namespace psnode;
+
+extern "C" {
+
+int32_t psnode_abi_version(void) { return PSNODE_ABI_VERSION; }
+
+const char* psnode_build_info(void) { return "psnode_hip abi " "1" " gfx950 (generic + mfma kernels), built " __DATE__; }
+
+const char* psnode_status_string(int32_t s) {
+    switch (s) {
+        case PSNODE_OK: return "ok";
+        case PSNODE_ERR_NULL: return "required pointer is NULL";
+        case PSNODE_ERR_DIMS: return "bad or inconsistent dimensions";
+        case PSNODE_ERR_METHOD: return "unknown integration method";
+        case PSNODE_ERR_WORKSPACE: return "workspace missing, misaligned (256 B) or too small";
+        case PSNODE_ERR_UNSUPPORTED: return "shape not supported by the requested kernel";
+        case PSNODE_ERR_HIP: return "HIP runtime error";
+        default: return "unknown status";
+    }
+}
+
+size_t psnode_workspace_bytes(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
+    if (!de) return 0;
+    const size_t f = transposed_floats(de) + transposed_floats(ae) + mfma_pack_floats(de, ae) + kAlignFloats;
+    return f * sizeof(float);
+}
+
+int32_t psnode_event_table_f32(int64_t n_steps, const float* clock, int64_t stride_k, const float* event_times,
+                               int64_t stride_e, int32_t n_events, int32_t* event_idx, int32_t* dup_flag, void* stream) {
+    if (n_steps <= 0) return PSNODE_OK;
+    if (!clock || !event_idx || (n_events > 0 && !event_times)) return PSNODE_ERR_NULL;
+    if (n_events < 0) return PSNODE_ERR_DIMS;
+    const unsigned grid = (unsigned)((n_steps + 255) / 256);
+    hipLaunchKernelGGL(event_table_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), (long long)n_steps, clock,
+                       (long long)stride_k, event_times, (long long)stride_e, (int)n_events, event_idx, dup_flag);
+    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspace, size_t workspace_bytes, void* stream) {
+    IntegrateDev d;
+    const int rc = fill_ode(args, d);
+    if (rc) return rc;
+    return dispatch(d, false, args->kernel, &args->de, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspace, size_t workspace_bytes, void* stream) {
+    IntegrateDev d;
+    const int rc = fill_dae(args, d);
+    if (rc) return rc;
+    return dispatch(d, true, args->kernel, &args->de, &args->ae, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* a) {
+    if (!a) return PSNODE_ERR_NULL;
+    IntegrateDev d;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.T = a->T; d.B = a->B;
+    bind_dims(a->de, d.de);
+    return mfma_ode_supported(d) ? PSNODE_KERNEL_MFMA : PSNODE_KERNEL_GENERIC;
+}
+
+int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {
+    if (!a) return PSNODE_ERR_NULL;
+    IntegrateDev d;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.vd = a->v_dim; d.id = a->i_dim;
+    d.T = a->T; d.B = a->B;
+    bind_dims(a->de, d.de);
+    bind_dims(a->ae, d.ae);
+    return mfma_dae_supported(d) ? PSNODE_KERNEL_MFMA : PSNODE_KERNEL_GENERIC;
+}
+
+}  // extern "C"

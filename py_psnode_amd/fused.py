@@ -1,0 +1,315 @@
+"""Host side of the fused HIP integrator: recognise the reference's MLP right-hand sides, marshal
+tensors into the C ABI (include/psnode_hip.h) and enqueue on the caller's current HIP stream.
+
+Raw-tensor entry points (`ode_integrate`, `dae_integrate`) take MLPs as [(W[out,in], b[out]), ...]
+exactly as nn.Linear stores them; `plan_ode` / `plan_dae` do the recognition for the solver classes
+in py_psnode_amd.neural_dae.  Nothing here computes on the CPU and nothing here imports oracle/.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+Layers = Sequence[Tuple[torch.Tensor, torch.Tensor]]
+
+METHOD_ID = {"euler": _lib.EULER, "midpoint": _lib.MIDPOINT, "rk4": _lib.RK4_38}
+KERNEL_ID = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA}
+
+
+# ----------------------------------------------------------------------------- recognition
+def sequential_layers(seq) -> Optional[List[Tuple[torch.Tensor, torch.Tensor]]]:
+    """[(W,b), ...] if `seq` is nn.Sequential(Linear, ELU(alpha=1), Linear, ..., Linear), else None
+    (the only MLP shape the reference's live right-hand sides use, neural_00_ODE_01_no_encode.py:61-64)."""
+    if not isinstance(seq, nn.Sequential) or len(seq) == 0 or len(seq) % 2 == 0:
+        return None
+    out = []
+    for k, m in enumerate(seq):
+        if k % 2 == 0:
+            if type(m) is not nn.Linear or m.bias is None:
+                return None
+            out.append((m.weight, m.bias))
+        else:
+            if type(m) is not nn.ELU or m.alpha != 1.0:
+                return None
+    if len(out) > _lib.MAX_LAYERS:
+        return None
+    for (w, _), (w2, _) in zip(out[:-1], out[1:]):
+        if w2.shape[1] != w.shape[0]:
+            return None
+    return out
+
+
+def de_layers_of(x_func, n: int, x_dim: int):
+    """Layers of a DE_Func (attribute `x_dot`, input recipe cat(a0, s-a0, s))."""
+    if not isinstance(x_func, nn.Module) or _overrides_forward_hooks(x_func):
+        return None
+    layers = sequential_layers(getattr(x_func, "x_dot", None))
+    if layers is None or layers[0][0].shape[1] != 3 * n or layers[-1][0].shape[0] != x_dim:
+        return None
+    if not _only_params_of(x_func, x_func.x_dot):
+        return None
+    return layers
+
+
+def ae_layers_of(i_func, n: int, m: int, i_dim: int):
+    """Layers of an AE_Func (attribute `i_calculator`, input recipe cat(a0, x, z, v))."""
+    if not isinstance(i_func, nn.Module) or _overrides_forward_hooks(i_func):
+        return None
+    layers = sequential_layers(getattr(i_func, "i_calculator", None))
+    if layers is None or layers[0][0].shape[1] != n + m or layers[-1][0].shape[0] != i_dim:
+        return None
+    if not _only_params_of(i_func, i_func.i_calculator):
+        return None
+    return layers
+
+
+def _overrides_forward_hooks(mod: nn.Module) -> bool:
+    return bool(mod._forward_hooks) or bool(mod._forward_pre_hooks)
+
+
+def _only_params_of(mod: nn.Module, seq: nn.Module) -> bool:
+    """A module is taken to follow the DE / AE input recipe when its only parameters are those of its
+    `x_dot` / `i_calculator` Sequential (true of every live DE_Func / AE_Func in the reference scripts; the
+    legacy neural_base.DE_Func has many more sub-modules and neither attribute, so it never gets here)."""
+    return {id(p) for p in mod.parameters()} == {id(p) for p in seq.parameters()}
+
+
+# ----------------------------------------------------------------------------- marshalling
+def _f32_dev(t: torch.Tensor, dev, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: fused integrator is fp32-only, got {t.dtype}")
+    if t.device != dev:
+        raise ValueError(f"{name}: on {t.device}, expected {dev}")
+    return t.detach()
+
+
+def _view(t: Optional[torch.Tensor], dev, name: str, keep: list) -> _lib.ViewF32:
+    """[T,B,D] tensor -> strided view struct; copies only when the last dim is not unit-stride."""
+    if t is None or t.shape[-1] == 0:
+        return _lib.ViewF32(None, 0, 0)
+    t = _f32_dev(t, dev, name)
+    if t.shape[-1] > 1 and t.stride(2) != 1:
+        t = t.contiguous()
+    keep.append(t)
+    return _lib.ViewF32(t.data_ptr(), t.stride(0), t.stride(1))
+
+
+def _mlp(layers: Layers, dev, name: str, keep: list) -> _lib.MlpF32:
+    m = _lib.MlpF32()
+    if not 1 <= len(layers) <= _lib.MAX_LAYERS:
+        raise ValueError(f"{name}: {len(layers)} Linear layers, supported 1..{_lib.MAX_LAYERS}")
+    m.n_layers = len(layers)
+    m.in_dim = layers[0][0].shape[1]
+    for k, (w, b) in enumerate(layers):
+        w = _f32_dev(w, dev, f"{name}.weight[{k}]").contiguous()
+        b = _f32_dev(b, dev, f"{name}.bias[{k}]").contiguous()
+        keep += [w, b]
+        m.out_dim[k] = w.shape[0]
+        m.weight[k] = w.data_ptr()
+        m.bias[k] = b.data_ptr()
+    return m
+
+
+def _jump(j: Optional[torch.Tensor], dev, name: str, keep: list):
+    if j is None or j.shape[-1] == 0:
+        return None, 0, 0
+    j = _f32_dev(j, dev, name)
+    if j.shape[-1] > 1 and j.stride(2) != 1:
+        j = j.contiguous()
+    keep.append(j)
+    return j.data_ptr(), j.stride(0), j.stride(1)
+
+
+def event_table(t: torch.Tensor, event_t: Optional[torch.Tensor], check_duplicates: bool = False) -> Optional[torch.Tensor]:
+    """int32[T-1] device table: index of the event at each step, -1 = none.
+
+    Same decision as ODE_Event.event_fn / jump_change_fn (neural_base.py:52-62): trajectory 0's clock
+    against trajectory 0's event list, exact fp32 equality -- resolved by one tiny kernel instead of one
+    host sync per step.  `check_duplicates` synchronises and raises where the reference would
+    (two events at one time make its `.view(z0.shape)` fail).
+    """
+    T = t.shape[0]
+    if event_t is None or T < 2:
+        return None
+    lib = _lib.load()
+    dev = t.device
+    t = _f32_dev(t, dev, "t")
+    event_t = _f32_dev(event_t, dev, "event_t")
+    tab = torch.empty(T - 1, dtype=torch.int32, device=dev)
+    dup = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_ev = event_t.shape[1]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.psnode_event_table_f32(T - 1, t.data_ptr(), t.stride(0), event_t.data_ptr(), event_t.stride(1), n_ev,
+                                    tab.data_ptr(), dup.data_ptr(), st)
+    _lib.check(rc, "psnode_event_table_f32")
+    if check_duplicates and int(dup.item()):
+        raise RuntimeError("two events share one time stamp: the reference's jump_change_fn cannot view "
+                           "z_jump[:, mask] as z0.shape (neural_base.py:61)")
+    return tab
+
+
+def _workspace(lib, de: _lib.MlpF32, ae, dev) -> torch.Tensor:
+    nbytes = lib.psnode_workspace_bytes(ctypes.byref(de), ctypes.byref(ae) if ae is not None else None)
+    return torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+
+
+def _aligned_ptr(ws: torch.Tensor):
+    p = (ws.data_ptr() + 255) // 256 * 256
+    return p, ws.numel() - (p - ws.data_ptr())
+
+
+def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=None, z_jump=None,
+                  input_true_x: bool = False, kernel: str = "auto", event_idx: Optional[torch.Tensor] = None,
+                  check_events: bool = False) -> torch.Tensor:
+    """Fused integrate_ODE (replaces my_solvers.py:52-80 + my_fixed_grid.py + DE_Func.forward).
+
+    t[T,B,1], x[T,B,xd], z[T,B,zd] may be arbitrary strided views with a unit-stride last dim
+    (the scripts pass permute(1,0,2) views); returns a fresh contiguous xs[T,B,xd].
+    """
+    lib = _lib.load()
+    dev = x.device
+    if dev.type != "cuda":
+        raise ValueError("fused integrator needs tensors on a HIP device")
+    T, B, xd = x.shape
+    zd = z.shape[-1]
+    keep: list = []
+    a = _lib.OdeArgsF32()
+    a.method = METHOD_ID[method]
+    a.kernel = KERNEL_ID[kernel]
+    a.flags = _lib.FLAG_INPUT_TRUE_X if input_true_x else 0
+    a.x_dim, a.z_dim, a.T, a.B = xd, zd, T, B
+    a.de = _mlp(de_layers, dev, "de", keep)
+    a.t = _view(t, dev, "t", keep)
+    a.x = _view(x, dev, "x", keep)
+    a.z = _view(z, dev, "z", keep)
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    if a0.shape != (B, xd + zd):
+        raise ValueError(f"all_initial has shape {tuple(a0.shape)}, expected {(B, xd + zd)}")
+    keep.append(a0)
+    a.all_initial = a0.data_ptr()
+    with torch.cuda.device(dev):
+        if event_idx is None:
+            event_idx = event_table(t, event_t, check_events)
+        if event_idx is not None:
+            keep.append(event_idx)
+            a.event_idx = event_idx.data_ptr()
+            a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+        out = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+        a.x_out = out.data_ptr()
+        ws = _workspace(lib, a.de, None, dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_ode_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_ode_integrate_f32")
+    # the stream-ordered caching allocator keeps `keep`/`ws` storage valid until the kernel has run
+    return out
+
+
+def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, x, z, v, i, all_initial,
+                  event_t=None, z_jump=None, v_jump=None, input_true_x: bool = False, input_true_i: bool = False,
+                  kernel: str = "auto", event_idx: Optional[torch.Tensor] = None, check_events: bool = False):
+    """Fused integrate_DAE (replaces my_solvers.py:82-131 + step functions + DE_Func/AE_Func forwards)."""
+    lib = _lib.load()
+    dev = x_init.device
+    if dev.type != "cuda":
+        raise ValueError("fused integrator needs tensors on a HIP device")
+    T, B = t.shape[0], t.shape[1]
+    xd, zd, vd, idim = x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]
+    keep: list = []
+    a = _lib.DaeArgsF32()
+    a.method = METHOD_ID[method]
+    a.kernel = KERNEL_ID[kernel]
+    a.flags = (_lib.FLAG_INPUT_TRUE_X if input_true_x else 0) | (_lib.FLAG_INPUT_TRUE_I if input_true_i else 0)
+    a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = xd, zd, vd, idim, T, B
+    a.de = _mlp(de_layers, dev, "de", keep)
+    a.ae = _mlp(ae_layers, dev, "ae", keep)
+    a.t = _view(t, dev, "t", keep)
+    a.x = _view(x if input_true_x else None, dev, "x", keep)
+    a.z = _view(z, dev, "z", keep)
+    a.v = _view(v, dev, "v", keep)
+    a.i = _view(i if input_true_i else None, dev, "i", keep)
+    if input_true_x and x.shape[-1] != xd:
+        raise ValueError("input_true_x needs dataset x of width x_init.shape[-1]")
+    xi = _f32_dev(x_init, dev, "x_init").contiguous()
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    if a0.shape != (B, xd + zd + vd + idim):
+        raise ValueError(f"all_initial has shape {tuple(a0.shape)}, expected {(B, xd + zd + vd + idim)}")
+    keep += [xi, a0]
+    a.x_init, a.all_initial = xi.data_ptr(), a0.data_ptr()
+    with torch.cuda.device(dev):
+        if event_idx is None:
+            event_idx = event_table(t, event_t, check_events)
+        if event_idx is not None:
+            keep.append(event_idx)
+            a.event_idx = event_idx.data_ptr()
+            a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+            a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
+        xs = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+        is_ = torch.empty((T, B, idim), dtype=torch.float32, device=dev)
+        a.x_out, a.i_out = xs.data_ptr(), is_.data_ptr()
+        ws = _workspace(lib, a.de, a.ae, dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_dae_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_dae_integrate_f32")
+    return xs, is_
+
+
+# ----------------------------------------------------------------------------- planning for the solver classes
+def _event_tensors(event_fn, jump_change_fn, want_v: bool):
+    """(ok, event_t, z_jump, v_jump).  Events can be fused when both callbacks are the bound methods of one
+    ODE_Event / DAE_Event-like object (attributes event_t, z_jump[, v_jump]) -- neural_base.py:43-65,169-196."""
+    if event_fn is None:
+        return True, None, None, None       # my_solvers.py:70: `event_fn is not None and ...`
+    ev = getattr(event_fn, "__self__", None)
+    if ev is None or getattr(jump_change_fn, "__self__", None) is not ev:
+        return False, None, None, None
+    if getattr(event_fn, "__name__", "") != "event_fn" or getattr(jump_change_fn, "__name__", "") != "jump_change_fn":
+        return False, None, None, None
+    if not getattr(type(ev), "_psnode_event", False):
+        return False, None, None, None
+    if ev.event_t is None:
+        return True, None, None, None       # neural_base.py:53
+    return True, ev.event_t, ev.z_jump, (getattr(ev, "v_jump", None) if want_v else None)
+
+
+def _needs_autograd(tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
+    """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump)."""
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 3 or z.dim() != 3:
+        return None
+    xd, zd = x.shape[-1], z.shape[-1]
+    if all_initial.dim() != 2 or all_initial.shape[-1] != xd + zd:
+        return None
+    layers = de_layers_of(x_func, xd + zd, xd)
+    if layers is None:
+        return None
+    ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
+    if not ok:
+        return None
+    if _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb]):
+        return None
+    return layers, event_t, z_jump
+
+
+def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn):
+    if x_init.device.type != "cuda" or x_init.dtype != torch.float32 or z.dim() != 3:
+        return None
+    xd, zd, vd, idim = x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]
+    n = xd + zd + vd + idim
+    if all_initial.dim() != 2 or all_initial.shape[-1] != n:
+        return None
+    de = de_layers_of(x_func, n, xd)
+    ae = ae_layers_of(i_func, n, xd + zd + vd, idim)
+    if de is None or ae is None:
+        return None
+    ok, event_t, z_jump, v_jump = _event_tensors(event_fn, jump_change_fn, True)
+    if not ok:
+        return None
+    if _needs_autograd([x_init, z, v, i, all_initial, z_jump, v_jump] + [p for wb in list(de) + list(ae) for p in wb]):
+        return None
+    return de, ae, event_t, z_jump, v_jump

@@ -1,0 +1,142 @@
+"""The model glue of the four reference training scripts, as one parametrised pair of classes.
+
+    ODE_Model(x_dim, z_dim, hidden_dim, direct_encode=False)   neural_00_ODE_01_no_encode.py:71-91
+                                                               neural_00_ODE_02_direct_encode.py:60-89
+    DAE_Model(x_dim, z_dim, v_dim, i_dim, hidden_dim, direct_encode=False)
+                                                               neural_01_DAE_01_no_encode.py:86-115
+                                                               neural_01_DAE_02_direct_encode.py:103-153
+
+Sub-module and parameter names equal the scripts' (`de_func.x_dot.0.weight`, `x_encoder.2.bias`,
+`init_func.init_fun.4.weight`, ...), so their checkpoints load with load_state_dict.  Inputs are B-major
+[B,T,D]; the solver gets permute(1,0,2) views and the result is permuted back, as upstream.
+The scripts hard-code Euler(); pass `solver=` or assign `model.solver = RK4()`.
+"""
+import torch
+import torch.nn as nn
+
+from .neural_dae import DAE_Event, Euler, ODE_Event
+
+
+def _elu_mlp(*dims):
+    mods = []
+    for k in range(len(dims) - 1):
+        mods.append(nn.Linear(int(dims[k]), int(dims[k + 1])))
+        if k + 2 < len(dims):
+            mods.append(nn.ELU())
+    return nn.Sequential(*mods)
+
+
+def _tm(a):
+    return a.permute(1, 0, 2)
+
+
+class DE_Func(nn.Module):
+    """x_dot MLP over cat(a0, s - a0, s), s = cat(xt, zt[, vt, it]).  `widths` = (in_state_width, hidden..., out)."""
+
+    def __init__(self, state_width, hidden_dims, out_dim):
+        super().__init__()
+        self.x_dot = _elu_mlp(3 * state_width, *hidden_dims, out_dim)
+
+    def forward(self, t0, xt, zt, all_initial, vt=None, it=None):
+        s = torch.cat((xt, zt) if vt is None else (xt, zt, vt, it), dim=-1)
+        return self.x_dot(torch.cat((all_initial, s - all_initial, s), dim=-1))
+
+
+class AE_Func(nn.Module):
+    """i_calculator MLP over cat(a0, xt, zt, vt)."""
+
+    def __init__(self, in_width, hidden_dims, out_dim):
+        super().__init__()
+        self.i_calculator = _elu_mlp(in_width, *hidden_dims, out_dim)
+
+    def forward(self, xt, zt, vt, all_initial):
+        return self.i_calculator(torch.cat((all_initial, xt, zt, vt), dim=-1))
+
+
+class Init_Func(nn.Module):
+    def __init__(self, x_dim, z_dim, v_dim, i_dim, hidden_dim):
+        super().__init__()
+        self.init_fun = _elu_mlp(z_dim + v_dim + i_dim, hidden_dim, hidden_dim, x_dim)
+
+    def forward(self, z0, v0, i0):
+        return self.init_fun(torch.cat([z0, v0, i0], dim=-1))
+
+
+class ODE_Model(nn.Module):
+    def __init__(self, x_dim, z_dim, hidden_dim, direct_encode=False, solver=None):
+        super().__init__()
+        H = hidden_dim
+        self.hidden_dim = H
+        self.direct_encode = direct_encode
+        if direct_encode:
+            self.x_encoder = _elu_mlp(x_dim, H, H)
+            self.x_decoder = _elu_mlp(H, H, x_dim)
+            self.z_encoder = _elu_mlp(z_dim, H, H)
+            self.de_func = DE_Func(2 * H, (H,), H)                 # Linear(6H,H) ELU Linear(H,H)
+        else:
+            self.de_func = DE_Func(x_dim + z_dim, (H, H, H), x_dim)
+        self.solver = solver if solver is not None else Euler()
+        self.event = ODE_Event()
+
+    def forward(self, t, x, z, event_t, z_jump):
+        if not self.direct_encode:
+            self.event.set_event(t=event_t, z=z_jump)
+            a0 = torch.cat((_tm(x)[0], _tm(z)[0]), dim=-1)
+            xs = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=_tm(x), z=_tm(z), all_initial=a0,
+                                           event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
+            return _tm(xs)
+        Xh = _tm(self.x_encoder(x))
+        Zh = _tm(self.z_encoder(z))
+        a0 = torch.cat((Xh[0], Zh[0]), dim=-1)
+        self.event.set_event(t=event_t, z=self.z_encoder(z_jump))
+        Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh, z=Zh, all_initial=a0,
+                                           event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
+        return _tm(self.x_decoder(Xh_sol)), _tm(self.x_decoder(Xh))
+
+
+class DAE_Model(nn.Module):
+    def __init__(self, x_dim, z_dim, v_dim, i_dim, hidden_dim, direct_encode=False, solver=None):
+        super().__init__()
+        H = hidden_dim
+        self.hidden_dim = H
+        self.direct_encode = direct_encode
+        if direct_encode:
+            self.x_encoder = _elu_mlp(x_dim, H, H)
+            self.x_decoder = _elu_mlp(H, H, x_dim)
+            self.z_encoder = _elu_mlp(z_dim, H, H) if z_dim != 0 else None
+            self.v_encoder = _elu_mlp(v_dim, H, H)
+            self.i_encoder = _elu_mlp(i_dim, H, H)
+            self.i_decoder = _elu_mlp(H, H, i_dim)
+        self.init_func = Init_Func(x_dim, z_dim, v_dim, i_dim, H)
+        if direct_encode:
+            parts = 3 if z_dim == 0 else 4                         # latent blocks in all_initial (x, [z,] v, i)
+            self.de_func = DE_Func(parts * H, (H,), H)             # Linear(12H|9H, H) ELU Linear(H,H)
+            self.ae_func = AE_Func((2 * parts - 1) * H, (H,), H)   # Linear(7H|5H, H) ELU Linear(H,H)
+        else:
+            n = x_dim + z_dim + v_dim + i_dim
+            self.de_func = DE_Func(n, (H, H, H), x_dim)
+            self.ae_func = AE_Func(n + x_dim + z_dim + v_dim, (H, H, H), i_dim)
+        self.solver = solver if solver is not None else Euler()
+        self.event = DAE_Event()
+
+    def forward(self, t, x, z, v, i, event_t, z_jump, v_jump, input_true_x=False, input_true_i=False):
+        x0 = self.init_func(z0=_tm(z)[0], v0=_tm(v)[0], i0=_tm(i)[0])
+        if not self.direct_encode:
+            self.event.set_event(t=event_t, z=z_jump, v=v_jump)
+            a0 = torch.cat((x0, _tm(z)[0], _tm(v)[0], _tm(i)[0]), dim=-1)
+            xs, is_ = self.solver.integrate_DAE(x_init=x0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=_tm(x),
+                                                z=_tm(z), v=_tm(v), i=_tm(i), all_initial=a0,
+                                                event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
+                                                input_true_x=input_true_x, input_true_i=input_true_i)
+            return _tm(xs), _tm(is_)
+        enc_z = (lambda a: a) if self.z_encoder is None else self.z_encoder
+        Xh0 = self.x_encoder(x0)
+        Xh, Zh, Vh, Ih = _tm(self.x_encoder(x)), _tm(enc_z(z)), _tm(self.v_encoder(v)), _tm(self.i_encoder(i))
+        a0 = torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), dim=-1)
+        self.event.set_event(t=event_t, z=enc_z(z_jump), v=self.v_encoder(v_jump))
+        Xh_sol, Ih_sol = self.solver.integrate_DAE(x_init=Xh0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=Xh,
+                                                   z=Zh, v=Vh, i=Ih, all_initial=a0, event_fn=self.event.event_fn,
+                                                   jump_change_fn=self.event.jump_change_fn)
+        x_pred = self.x_decoder(Xh_sol)
+        x_pred[0] = x0                                             # neural_01_DAE_02_direct_encode.py:150
+        return _tm(x_pred), _tm(self.i_decoder(Ih_sol)), _tm(self.x_decoder(Xh)), _tm(self.i_decoder(Ih))

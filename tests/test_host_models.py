@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference interface, checked on CPU against goldens captured from the reference.
+
+These run the solver's callback walk (CPU tensors can never take the HIP route) -- they pin the model glue,
+event semantics, keyword conventions and state-dict key names, not the kernels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_ORACLE, T, load, rel_err
+from py_psnode_amd import models
+from py_psnode_amd import neural_dae as nd
+
+SOLVERS = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}
+
+
+def _load_sd(model, d):
+    sd = {k[4:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("sd__")}
+    assert set(sd) == set(model.state_dict()), "state-dict keys differ from the reference's"
+    model.load_state_dict(sd)
+
+
+def _build(tag):
+    if tag == "ode01":
+        return models.ODE_Model(8, 2, 64)
+    if tag == "ode02":
+        return models.ODE_Model(8, 2, 16, direct_encode=True)
+    if tag == "dae01":
+        return models.DAE_Model(8, 2, 2, 2, 64)
+    if tag == "dae02":
+        return models.DAE_Model(8, 2, 2, 2, 16, direct_encode=True)
+    return models.DAE_Model(8, 0, 2, 2, 16, direct_encode=True)
+
+
+@pytest.mark.parametrize("tag", ["ode01", "ode02", "dae01", "dae02", "dae02_z0"])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_model_forward_matches_reference(tag, method):
+    d = load(f"g4_model_{tag}.npz")
+    m = _build(tag)
+    _load_sd(m, d)
+    m.solver = SOLVERS[method]()
+    with torch.no_grad():
+        if tag.startswith("ode"):
+            out = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), event_t=T(d["event_t"]), z_jump=T(d["z_jump"]))
+        else:
+            out = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), v=T(d["v"]), i=T(d["i"]), event_t=T(d["event_t"]),
+                    z_jump=T(d["z_jump"]), v_jump=T(d["v_jump"]))
+    out = out if isinstance(out, tuple) else (out,)
+    for k, o in enumerate(out):
+        assert rel_err(o, d[f"{method}_out{k}"]) <= TOL_ORACLE, (tag, method, k)
+
+
+def test_dae01_teacher_forcing():
+    d = load("g4_model_dae01.npz")
+    m = _build("dae01")
+    _load_sd(m, d)
+    m.solver = nd.RK4()
+    with torch.no_grad():
+        xs, is_ = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), v=T(d["v"]), i=T(d["i"]), event_t=T(d["event_t"]),
+                    z_jump=T(d["z_jump"]), v_jump=T(d["v_jump"]), input_true_x=True, input_true_i=True)
+    assert rel_err(xs, d["rk4_truexi_out0"]) <= TOL_ORACLE
+    assert rel_err(is_, d["rk4_truexi_out1"]) <= TOL_ORACLE
+
+
+def test_output_layout_like_reference():
+    """solver returns contiguous [T,B,D]; the model's permuted view has strides (xd, B*xd, 1)."""
+    d = load("g4_model_ode01.npz")
+    m = _build("ode01")
+    _load_sd(m, d)
+    with torch.no_grad():
+        out = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), event_t=T(d["event_t"]), z_jump=T(d["z_jump"]))
+    B, Tn, xd = d["x"].shape
+    assert out.shape == (B, Tn, xd) and out.stride() == (xd, B * xd, 1)
+
+
+def test_training_walk_backpropagates():
+    """The scripts call loss.backward() through the integrator (neural_00_ODE_01_no_encode.py:359)."""
+    torch.manual_seed(0)
+    m = models.ODE_Model(3, 1, 8, solver=nd.RK4())
+    B, Tn = 4, 6
+    t = (torch.arange(Tn) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    x, z = 0.1 * torch.randn(B, Tn, 3), 0.1 * torch.randn(B, Tn, 1)
+    out = m(t=t, x=x, z=z, event_t=torch.full((B, 1, 1), -1.0), z_jump=torch.zeros(B, 1, 1))
+    out.pow(2).mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_solver_public_surface():
+    s = nd.RK4()
+    for attr in ("order", "step_size", "interp", "grid_constructor", "enable_cal_time", "assert_time", "cal_time", "total_time"):
+        assert hasattr(s, attr)
+    assert (nd.Euler.order, nd.Midpoint.order, nd.RK4.order) == (1, 2, 4)
+    with pytest.raises(ValueError):
+        nd.Euler(step_size=0.1, grid_constructor=lambda f, x, t: t)
+    with pytest.raises(TypeError):
+        nd.FixedGridODESolver()          # abstract, as upstream
+
+
+def test_step_integrate_matches_reference():
+    d = load("g1_single_step.npz")
+    de = models.DE_Func(10, (64, 64, 64), 8)
+    de.load_state_dict({k[5:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("ode__")})
+    dd = models.DE_Func(14, (64, 64, 64), 8)
+    dd.load_state_dict({k[5:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("dae__")})
+    x0, z0, v0, i0, t0, dt, t1 = (T(d[k]) for k in ("x0", "z0", "v0", "i0", "t0", "dt", "t1"))
+    with torch.no_grad():
+        for name, cls in SOLVERS.items():
+            x1, f0 = cls().step_integrate(func=de, t0=t0, dt=dt, t1=t1, x0=x0, z0=z0, all_initial=T(d["a0_ode"]))
+            assert rel_err(x1, d[f"ode_{name}_x1"]) <= TOL_ORACLE and rel_err(f0, d[f"ode_{name}_f0"]) <= TOL_ORACLE
+            x1, f0 = cls().step_integrate(func=dd, t0=t0, dt=dt, t1=t1, x0=x0, z0=z0, v0=v0, i0=i0, all_initial=T(d["a0_dae"]))
+            assert rel_err(x1, d[f"dae_{name}_x1"]) <= TOL_ORACLE and rel_err(f0, d[f"dae_{name}_f0"]) <= TOL_ORACLE
+
+
+def test_event_objects():
+    ev = nd.ODE_Event()
+    assert ev.event_fn(torch.zeros(3, 1)) is False
+    et = torch.tensor([[[0.2], [0.5]]]).repeat(3, 1, 1)
+    zj = torch.arange(12.0).view(3, 2, 2)
+    ev.set_event(et, zj)
+    assert ev.event_fn(torch.full((3, 1), 0.5)) is True and ev.event_fn(torch.full((3, 1), 0.3)) is False
+    z0 = torch.zeros(3, 2, requires_grad=True)
+    out = ev.jump_change_fn(torch.full((3, 1), 0.5), z0)
+    assert torch.equal(out, zj[:, 1]) and not out.requires_grad
+    dup = nd.ODE_Event()
+    dup.set_event(torch.tensor([[[0.5], [0.5]]]).repeat(3, 1, 1), zj)
+    with pytest.raises(RuntimeError):
+        dup.jump_change_fn(torch.full((3, 1), 0.5), torch.zeros(3, 2))
+
+
+def test_require_mode_raises_on_cpu():
+    m = models.ODE_Model(3, 1, 8, solver=nd.Euler())
+    m.solver.fused = "require"
+    B, Tn = 2, 3
+    t = (torch.arange(Tn) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    with torch.no_grad(), pytest.raises(nd.NotFusableError):
+        m(t=t, x=torch.zeros(B, Tn, 3), z=torch.zeros(B, Tn, 1), event_t=torch.full((B, 1, 1), -1.0), z_jump=torch.zeros(B, 1, 1))
+
+
+def test_dataset_npz_roundtrip(tmp_path):
+    N, Tn = 6, 5
+    rng = np.random.default_rng(0)
+    p = tmp_path / "s.npz"
+    np.savez(p, name=np.array([["a", "u"]]), t=np.tile(np.arange(Tn, dtype=np.float32).reshape(1, Tn, 1), (N, 1, 1)),
+             x=rng.standard_normal((N, Tn, 3)).astype(np.float32), z=rng.standard_normal((N, Tn, 1)).astype(np.float32),
+             event_t=np.full((N, 1, 1), -1, np.float32), z_jump=np.zeros((N, 1, 1), np.float32))
+    ds = nd.ODE_Curves_Sample(str(p), "cpu", num_sample=4, cut_length=3)
+    assert len(ds) == 4 and ds[0][1].shape == (3, 3) and ds.mask.shape == ds.x.shape
+    idx = np.random.default_rng(42).choice(np.arange(N), 4, replace=False)
+    assert np.array_equal(ds.x.numpy(), np.load(p)["x"][idx][:, :3])
