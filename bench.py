@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- integrated state-steps/sec of the fused HIP integrator (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch: a full integrate_ODE of B trajectories over T-1 grid
+steps (default workload = BASELINE.json configs[1]: ODE_01 RK4, B=4096, T=1001, x8 z2 H64, fp32), inputs
+already resident in HBM.  At N>1 every rank integrates its own B trajectories (weak scaling, no data-path
+collective inside the integration) and an RCCL all-gather reassembles the [T, N*B, xd] batch "for the loss"
+(north_star); the timed region covers both.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel vs the fp32 MFMA/VALU peak (157.3 TFLOP/s) -- the bound that binds this path
+                (arithmetic intensity ~1900 flop/B); `hbm_*` fields give the HBM view north_star
+                also asks for.  Kernel time is measured live with HIP events around every launch in the timed region.
+  cpu_baseline  oracle/psnode_oracle.py (PyTorch-CPU restatement of the reference, "port") timed on this host's
+                cores on a bounded sample of the same workload.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0        # HBM3E spec
+
+WORKLOADS = {
+    # name: (kind, B, T, dims, H, hidden layers)
+    "ode01": dict(kind="ode", B=4096, T=1001, xd=8, zd=2, H=64, nh=3),
+    "dae01": dict(kind="dae", B=4096, T=1001, xd=8, zd=2, vd=2, id=2, H=64, nh=3),
+    "ode02_latent16": dict(kind="ode", B=4096, T=1001, xd=16, zd=16, H=16, nh=1),
+}
+
+
+def mlp(dims, gen_seed):
+    torch.manual_seed(gen_seed)
+    lin = [torch.nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]
+    return [(l.weight.detach().clone(), l.bias.detach().clone()) for l in lin]
+
+
+def mlp_macs(layers):
+    return sum(w.shape[0] * w.shape[1] for w, _ in layers)
+
+
+def make_problem(w, B, T, seed_offset=0):
+    """Synthetic batch in the scripts' layout: B-major [B,T,D] memory, solver gets permute(1,0,2) views."""
+    g = torch.Generator().manual_seed(1 + seed_offset)
+    xd, zd = w["xd"], w["zd"]
+    vd, idim = w.get("vd", 0), w.get("id", 0)
+    n = xd + zd + vd + idim
+    p = dict(de=mlp([3 * n] + [w["H"]] * w["nh"] + [xd], 0))
+    p["t"] = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
+    p["x"] = torch.zeros(B, T, xd)
+    p["x"][:, 0] = 0.1 * torch.randn(B, xd, generator=g)
+    p["z"] = 0.1 * torch.randn(B, T, zd, generator=g)
+    p["event_t"] = torch.full((B, 2, 1), -1.0)          # "no events" as the scripts encode it
+    p["z_jump"] = torch.zeros(B, 2, zd)
+    if w["kind"] == "dae":
+        p["ae"] = mlp([n + xd + zd + vd] + [w["H"]] * w["nh"] + [idim], 7)
+        p["v"] = 0.1 * torch.randn(B, T, vd, generator=g)
+        p["i"] = 0.1 * torch.randn(B, T, idim, generator=g)
+        p["v_jump"] = torch.zeros(B, 2, vd)
+        p["x_init"] = p["x"][:, 0].clone()
+        p["a0"] = torch.cat((p["x_init"], p["z"][:, 0], p["v"][:, 0], p["i"][:, 0]), -1)
+    else:
+        p["a0"] = torch.cat((p["x"][:, 0], p["z"][:, 0]), -1)
+    return p
+
+
+def to_dev(p, dev):
+    out = {}
+    for k, v in p.items():
+        out[k] = [(a.to(dev), b.to(dev)) for a, b in v] if isinstance(v, list) else v.to(dev)
+    return out
+
+
+def tmv(a):
+    return a.permute(1, 0, 2)
+
+
+def run_fused(fused, w, p, method, kernel):
+    if w["kind"] == "ode":
+        return (fused.ode_integrate(method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
+                                    event_t=p["event_t"], z_jump=p["z_jump"], kernel=kernel),)
+    return fused.dae_integrate(method, p["de"], p["ae"], p["x_init"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), tmv(p["v"]),
+                               tmv(p["i"]), p["a0"], event_t=p["event_t"], z_jump=p["z_jump"], v_jump=p["v_jump"], kernel=kernel)
+
+
+def run_oracle(O, w, p, method, T):
+    sl = lambda a: tmv(a)[:T]
+    if w["kind"] == "ode":
+        return O.integrate_ode(method, p["de"], sl(p["t"]), sl(p["x"]), sl(p["z"]), p["a0"], p["event_t"], p["z_jump"])
+    return O.integrate_dae(method, p["de"], p["ae"], p["x_init"], sl(p["t"]), sl(p["x"]), sl(p["z"]), sl(p["v"]), sl(p["i"]),
+                           p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
+
+
+def flops_per_state_step(w, p, method):
+    stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    f = 2 * stages * mlp_macs(p["de"])
+    if w["kind"] == "dae":
+        f += 2 * mlp_macs(p["ae"])
+    return f
+
+
+def bytes_per_state_step(w):
+    """Compulsory HBM traffic per state-step: read t + external inputs, write the outputs."""
+    rd = 4 * (1 + w["zd"] + w.get("vd", 0))
+    wr = 4 * (w["xd"] + w.get("id", 0))
+    return rd + wr
+
+
+def cpu_baseline(w, p_cpu, method, budget_s=12.0):
+    from oracle import psnode_oracle as O
+    T_s = min(101, w["T"])               # bounded sample: same batch, first 100 grid steps
+    n_threads = torch.get_num_threads()
+    run_oracle(O, w, p_cpu, method, min(T_s, 6))           # warm-up (thread pool, allocator)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 9 and (time.perf_counter() - t_start < budget_s or not times):
+        t0 = time.perf_counter()
+        run_oracle(O, w, p_cpu, method, T_s)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": w["B"] * (T_s - 1) / med, "unit": "state-steps/s", "cores": n_threads, "kind": "port",
+            "sample": f"oracle/psnode_oracle.py (PyTorch-CPU fp32, reference op order), same batch B={w['B']}, first {T_s - 1} of "
+                      f"{w['T'] - 1} steps, median of {len(times)} runs ({med:.3f} s each), torch threads={n_threads}, "
+                      f"host cpus={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ode01", choices=sorted(WORKLOADS))
+    ap.add_argument("--method", default="rk4", choices=["euler", "midpoint", "rk4"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--batch", type=int, default=None, help="override trajectories per GPU")
+    ap.add_argument("--grid", type=int, default=None, help="override grid points T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (the fused integrator has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from py_psnode_amd import _lib, fused
+    lib = _lib.load()
+
+    w = dict(WORKLOADS[args.workload])
+    if args.batch:
+        w["B"] = args.batch
+    if args.grid:
+        w["T"] = args.grid
+    B, T = w["B"], w["T"]
+    p_cpu = make_problem(w, B, T, seed_offset=rank)
+    p = to_dev(p_cpu, dev)
+    n_out = 1 if w["kind"] == "ode" else 2
+    gathered = None
+    if world > 1 and not args.no_gather:
+        widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
+        gathered = [torch.empty((world, T, B, d), dtype=torch.float32, device=dev) for d in widths]
+
+    def one_step():
+        outs = run_fused(fused, w, p, args.method, args.kernel)
+        if gathered is not None:
+            for g, o in zip(gathered, outs):
+                dist.all_gather_into_tensor(g, o)
+        return outs
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        outs = run_fused(fused, w, p, args.method, args.kernel)
+        ev[k][1].record()
+        if gathered is not None:
+            for g, o in zip(gathered, outs):
+                dist.all_gather_into_tensor(g, o)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    if dist is not None:
+        tt = torch.tensor([elapsed, kern_avg_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kern_avg_ms = float(tt[0]), float(tt[1])
+
+    finite = bool(torch.isfinite(outs[0]).all())
+    state_steps_launch = B * (T - 1)
+    flops = flops_per_state_step(w, p_cpu, args.method)
+    bts = bytes_per_state_step(w)
+    value = world * state_steps_launch * args.steps / elapsed
+    ach_tf = flops * state_steps_launch / (kern_avg_ms * 1e-3) / 1e12
+    ach_gbs = bts * state_steps_launch / (kern_avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        if w["kind"] == "ode":
+            a = _lib.OdeArgsF32()
+            a.method, a.x_dim, a.z_dim, a.T, a.B = fused.METHOD_ID[args.method], w["xd"], w["zd"], T, B
+            a.de = fused._mlp(p["de"], dev, "de", [])
+            auto_kernel = lib.psnode_ode_kernel_for(a)
+        else:
+            a = _lib.DaeArgsF32()
+            a.method, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = fused.METHOD_ID[args.method], w["xd"], w["zd"], w["vd"], w["id"], T, B
+            a.de = fused._mlp(p["de"], dev, "de", [])
+            a.ae = fused._mlp(p["ae"], dev, "ae", [])
+            auto_kernel = lib.psnode_dae_kernel_for(a)
+        kname = args.kernel if args.kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}:{args.method}:{kname}:B{B}:T{T}")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "integrated state-steps/sec (batch x steps/s), RK4 neural-ODE, batch 4096" if (args.workload, args.method, B) == ("ode01", "rk4", 4096)
+                      else f"integrated state-steps/sec, {args.workload} {args.method}, batch {B}",
+            "value": value, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {args.method}: B={B} trajectories/GPU x {T - 1} steps, x{w['xd']} z{w['zd']}"
+                                   + (f" v{w['vd']} i{w['id']}" if w["kind"] == "dae" else "") + f" H{w['H']}, fp32, h=0.01, no events",
+                       "kernel": kname, "trajectories_total": world * B,
+                       "collective": ("rccl all_gather of xs shards [T,B,xd]" if gathered is not None else "none"),
+                       "outputs_finite": finite},
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "kernel_ms": kern_avg_ms, "flop_per_state_step": flops,
+                         "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
+                         "bytes_per_state_step": bts},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method)
+            res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
