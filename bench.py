@@ -118,8 +118,20 @@ def bytes_per_state_step(w):
 def cpu_baseline(w, p_cpu, method, budget_s=12.0):
     from oracle import psnode_oracle as O
     T_s = min(101, w["T"])               # bounded sample: same batch, first 100 grid steps
-    n_threads = torch.get_num_threads()
-    run_oracle(O, w, p_cpu, method, min(T_s, 6))           # warm-up (thread pool, allocator)
+    # The path is ~300 small ATen ops per step: all host threads is far from the fastest setting on a many-core
+    # node (oversubscription).  Probe a few thread counts on a 10-step sample and give the CPU its best one.
+    default_threads = torch.get_num_threads()
+    best = (float("inf"), default_threads)
+    for nt in sorted({4, 8, 16, 32, 64, default_threads}):
+        if nt > (os.cpu_count() or nt):
+            continue
+        torch.set_num_threads(nt)
+        run_oracle(O, w, p_cpu, method, 3)                 # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        run_oracle(O, w, p_cpu, method, min(T_s, 11))
+        best = min(best, (time.perf_counter() - t0, nt))
+    n_threads = best[1]
+    torch.set_num_threads(n_threads)
     times = []
     t_start = time.perf_counter()
     while len(times) < 9 and (time.perf_counter() - t_start < budget_s or not times):

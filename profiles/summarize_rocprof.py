@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 results .db (rocpd sqlite) into the per-kernel stats table we commit under profiles/.
+
+    python profiles/summarize_rocprof.py gpurun_out/<dir>/<name>_results.db > profiles/<round>_<what>_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
+    print(f"# {'calls':>6} {'total_us':>14} {'avg_us':>12} {'pct':>7}  kernel")
+    for name, calls, tot, avg, pct in rows[:12]:
+        print(f"  {calls:>6} {tot:>14.2f} {avg:>12.3f} {pct:>7.3f}  {name[:150]}")
+    try:
+        k = list(cur.execute(
+            "select s.kernel_name, d.workgroup_size_x, d.grid_size_x, d.group_segment_size, d.private_segment_size, s.arch_vgpr_count, "
+            "s.accum_vgpr_count, s.sgpr_count from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+            "group by s.kernel_name order by sum(d.end - d.start) desc limit 4"))
+        print("# dominant kernels: name | workgroup | grid | LDS bytes | scratch | arch_vgpr | accum_vgpr | sgpr")
+        for r in k:
+            print("  " + " | ".join(str(x)[:110] for x in r))
+    except sqlite3.Error as e:
+        print(f"# (launch geometry unavailable: {e})")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,11 +1,379 @@
-// MFMA (v_mfma_f32_16x16x4_f32) fused integrator kernels for gfx950 -- see DESIGN.md "K1".
+// MFMA fused integrator (K1) for the reference's default right-hand side: in -> 64 -> 64 -> 64 -> x_dim ELU-MLP.
+//
+// Mapping (DESIGN.md "K1"):  one workgroup = 4 waves = one tile of 16 trajectories, walked through ALL T-1 steps.
+//   D[unit][traj] = W[unit][k] * act[k][traj]   on v_mfma_f32_16x16x4_f32 (exact fp32, 256 flop/clk/CU):
+//   A operand = weights (lane l: unit l&15 of the wave's 16-unit slice, k-slot l>>4)  -- resident in VGPRs for the
+//               whole launch, so the 43 KB of weights are read from HBM/L2 once per workgroup;
+//   B operand = activations (lane l: k-slot l>>4, trajectory l&15);
+//   D         = lane l holds units 4*(l>>4)+r (r = 0..3) of trajectory l&15.
+// Layer plan per RHS evaluation (4 waves, w = wave id):
+//   L1  in->64   split-N: wave w makes hidden units 16w..16w+15.  The input cat(a0, s-a0, s) is never materialised:
+//                the a0 part (+bias) is a per-trajectory constant computed once, the z part once per step (zero-order
+//                hold), only the 2*NX x-dependent MFMAs run per stage -- same products, different summation order.
+//   L2,L3 64->64 split-N: ELU -> every wave publishes its 4 values/lane with ONE lane-linear ds_write_b128, one
+//                s_barrier, three ds_read_b128.  The k-order is permuted (k = 16w' + 4g + r) so that lane (g, traj)
+//                needs exactly what lane (g, traj) of the other waves holds: no shuffles, no bank conflicts.
+//                The wave's own quarter of K is multiplied before the barrier (hides part of the round trip).
+//   L4  64->x    split-K: wave w multiplies ITS OWN 16 hidden units (no exchange between L3 and L4), partial sums are
+//                all-reduced through LDS in a fixed order so every wave holds the identical x_dot.
+//   => 3 exchanges per evaluation, 40 MFMAs per wave per evaluation (84 % of them on useful K).
+// The state x, the RK stage values and dt live in registers, replicated in the four waves (x-dim d = 4r+g sits in
+// lane group g, register r, so L4's output rows feed L1's B operands directly).  External inputs are prefetched one
+// step ahead straight from the caller's strided (B-major) memory; wave 0 stores x[k+1].
 #include "psnode_common.h"
 
 namespace psnode {
+namespace {
 
-bool mfma_ode_supported(const IntegrateDev&) { return false; }
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 64;
+constexpr int NW = HID / 16;   // waves per workgroup
+constexpr int TBM = 16;        // trajectories per workgroup
+constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8
+
+// Per-(wave, lane) register image of the packed weights: pack[wave][reg][lane].
+template <int NX, int NZM>
+struct Regs {
+    static constexpr int W1XS = 0;            // L1 columns of the `s` block, x dims        (NX)
+    static constexpr int W1XD = NX;           // L1 columns of the `s - a0` block, x dims   (NX)
+    static constexpr int W1Z = 2 * NX;        // L1 columns of both blocks, external dims   (NZM)
+    static constexpr int B1 = W1Z + NZM;      // bias rows (D layout)                       (4)
+    static constexpr int W2 = B1 + 4;         // (16) chunk c = source wave (w+c)&3
+    static constexpr int B2 = W2 + 16;
+    static constexpr int W3 = B2 + 4;
+    static constexpr int B3 = W3 + 16;
+    static constexpr int W4 = B3 + 4;         // (4) this wave's K quarter
+    static constexpr int B4 = W4 + 4;
+    static constexpr int COUNT = B4 + 4;      // followed by NA registers of the a0 block of L1
+};
+
+struct PackMfma {
+    int xd, ne, n, NX, NZM, NA;
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+    float* out;
+};
+
+__global__ void pack_mfma_kernel(const PackMfma p) {
+    const int W1XD = p.NX, W1Z = 2 * p.NX, B1 = W1Z + p.NZM, W2 = B1 + 4, B2 = W2 + 16, W3 = B2 + 4, B3 = W3 + 16, W4 = B3 + 4,
+              B4 = W4 + 4, COUNT = B4 + 4;
+    const int R = COUNT + p.NA;
+    const int K1 = 3 * p.n;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NW * R * 64; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, reg = (idx >> 6) % R, w = (idx >> 6) / R;
+        const int i = lane & 15, g = lane >> 4, u = 16 * w + i;
+        float v = 0.0f;
+        if (reg < W1XD) {
+            const int d = 4 * reg + g;
+            if (d < p.xd) v = p.w1[u * K1 + 2 * p.n + d];
+        } else if (reg < W1Z) {
+            const int d = 4 * (reg - W1XD) + g;
+            if (d < p.xd) v = p.w1[u * K1 + p.n + d];
+        } else if (reg < B1) {
+            const int q = 4 * (reg - W1Z) + g;
+            if (q < p.ne) v = p.w1[u * K1 + p.n + p.xd + q];
+            else if (q < 2 * p.ne) v = p.w1[u * K1 + 2 * p.n + p.xd + (q - p.ne)];
+        } else if (reg < W2) {
+            v = p.b1[16 * w + 4 * g + (reg - B1)];
+        } else if (reg < B2) {
+            const int kk = reg - W2, ws = (w + (kk >> 2)) & 3;
+            v = p.w2[u * HID + 16 * ws + 4 * g + (kk & 3)];
+        } else if (reg < W3) {
+            v = p.b2[16 * w + 4 * g + (reg - B2)];
+        } else if (reg < B3) {
+            const int kk = reg - W3, ws = (w + (kk >> 2)) & 3;
+            v = p.w3[u * HID + 16 * ws + 4 * g + (kk & 3)];
+        } else if (reg < W4) {
+            v = p.b3[16 * w + 4 * g + (reg - B3)];
+        } else if (reg < B4) {
+            const int d = 4 * (i & 3) + (i >> 2);   // output row i carries x-dim d
+            if (d < p.xd) v = p.w4[d * HID + 16 * w + 4 * g + (reg - W4)];
+        } else if (reg < COUNT) {
+            const int d = 4 * (reg - B4) + g;
+            if (d < p.xd) v = p.b4[d];
+        } else {
+            const int q = 4 * (reg - COUNT) + g;
+            if (q < p.n) v = p.w1[u * K1 + q];
+        }
+        p.out[idx] = v;
+    }
+}
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ELU(alpha=1) at expm1 quality without the libm call: degree-7 Taylor on [-0.25, 0] (truncation 1.5e-9 relative),
+// exp2-based exp(x)-1 below (result in (-1,-0.22], absolute error ~1 ulp of exp).
+__device__ __forceinline__ float elu_fast(float x) {
+    const float xn = fminf(x, 0.0f);
+    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(xn, p, 1.0f / 120.0f);
+    p = fmaf(xn, p, 1.0f / 24.0f);
+    p = fmaf(xn, p, 1.0f / 6.0f);
+    p = fmaf(xn, p, 0.5f);
+    p = fmaf(xn, p, 1.0f);
+    p = xn * p;
+    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
+    const float neg = xn > -0.25f ? p : e;
+    return x > 0.0f ? x : neg;
+}
+
+__device__ __forceinline__ f4 elu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+
+// LDS-only workgroup barrier: wait for this wave's LDS traffic, not for its outstanding global prefetches.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int METHOD, int NX, int NZM, bool TRUE_X>
+__global__ __launch_bounds__(256) void ode_mfma_kernel(const IntegrateDev a, const float* __restrict__ pack, const int NA) {
+    using R = Regs<NX, NZM>;
+    __shared__ f4 xbuf[2][NW][64];
+
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = l >> 4, j = l & 15;
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const int xd = a.xd, ne = a.zd, n = xd + ne;
+
+    // ---- weights -> registers (once per launch)
+    const float* pw = pack + (size_t)w * (R::COUNT + NA) * 64 + l;
+    float w1xs[NX], w1xd[NX], w1z[NZM > 0 ? NZM : 1], w2[16], w3[16], w4[4];
+    f4 b1r, b2r, b3r, b4r;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) { w1xs[r] = pw[(R::W1XS + r) * 64]; w1xd[r] = pw[(R::W1XD + r) * 64]; }
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) w1z[m] = pw[(R::W1Z + m) * 64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { w2[k] = pw[(R::W2 + k) * 64]; w3[k] = pw[(R::W3 + k) * 64]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w4[r] = pw[(R::W4 + r) * 64];
+        b1r[r] = pw[(R::B1 + r) * 64]; b2r[r] = pw[(R::B2 + r) * 64]; b3r[r] = pw[(R::B3 + r) * 64]; b4r[r] = pw[(R::B4 + r) * 64];
+    }
+
+    // ---- per-trajectory constants
+    float x[NX], a0x[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        const int d = 4 * r + g;
+        a0x[r] = d < xd ? a.a0[b * n + d] : 0.0f;
+        x[r] = d < xd ? a.x.p[b * a.x.sb + d] : 0.0f;
+    }
+    int eidx[NZM > 0 ? NZM : 1];
+    float a0e[NZM > 0 ? NZM : 1];
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) {
+        const int q = 4 * m + g;
+        eidx[m] = q < ne ? q : (q < 2 * ne ? q - ne : ne - 1);
+        a0e[m] = q < ne ? a.a0[b * n + xd + q] : 0.0f;
+    }
+    f4 c0 = b1r;   // bias + W1[:, a0 block] . a0 : constant for the whole launch
+    for (int m = 0; m < NA; ++m) {
+        const int q = 4 * m + g;
+        const float av = q < n ? a.a0[b * n + q] : 0.0f;
+        c0 = mfma4(pw[(R::COUNT + m) * 64], av, c0);
+    }
+
+    const float* tp = a.t.p + b * a.t.sb;
+    const float* zp = a.z.p + b * a.z.sb;
+    const float* zjp = a.zj + b * a.zjb;
+
+    // external inputs of step k (event index ev >= 0: the whole batch takes z_jump[:, ev] for this step)
+    const long long zst = a.z.st, zje = a.zje, tst = a.t.st, nT = a.T;
+    auto load_ext = [&](long long k, int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
+        const long long off = ev >= 0 ? ev * zje : k * zst;
+        const float* src = (ev >= 0 ? zjp : zp) + off;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) dst[m] = src[eidx[m]];
+    };
+
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (4 * r + g < xd) a.xo[b * xd + 4 * r + g] = x[r];
+    }
+    if (nT < 2) return;
+
+    float t_cur = tp[0], t_nxt = tp[tst];
+    float ext_nxt[NZM > 0 ? NZM : 1] = {};
+    load_ext(0, a.ev ? a.ev[0] : -1, ext_nxt);
+    // Event index of step k+1, fetched one iteration before the prefetch that needs it.  The address is made
+    // formally per-lane (opaque zero) so the value stays in a VGPR instead of a load -> s_waitcnt -> readfirstlane.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int* evp = a.ev + lane_zero;
+    int ev_n1 = (a.ev && nT > 2) ? evp[1] : -1;
+    int p = 0;   // exchange buffer parity
+
+    // one 64->64 layer: publish own activations, multiply own K quarter, barrier, multiply the other three quarters
+    auto mid = [&](const float (&wm)[16], const f4 bias, const f4 h) -> f4 {
+        xbuf[p][w][l] = h;
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = mfma4(wm[0], h[0], accA);
+        accB = mfma4(wm[1], h[1], accB);
+        accA = mfma4(wm[2], h[2], accA);
+        accB = mfma4(wm[3], h[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f4 v = xbuf[p][(w + c) & 3][l];
+            accA = mfma4(wm[4 * c + 0], v[0], accA);
+            accB = mfma4(wm[4 * c + 1], v[1], accB);
+            accA = mfma4(wm[4 * c + 2], v[2], accA);
+            accB = mfma4(wm[4 * c + 3], v[3], accB);
+        }
+        p ^= 1;
+        return elu4(accA + accB);
+    };
+
+    // one RHS evaluation at xs with this step's constant part cz; returns x_dot in the x register layout
+    auto rhs = [&](const float (&xs)[NX], const f4 cz) -> f4 {
+        // L1
+        f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            accA = mfma4(w1xs[r], xs[r], accA);
+            accB = mfma4(w1xd[r], xs[r] - a0x[r], accB);
+        }
+        f4 h = elu4(accA + accB);
+        // L2, L3
+        h = mid(w2, b2r, h);
+        h = mid(w3, b3r, h);
+        // L4: own K quarter, then all-reduce in a fixed order
+        accA = mfma4(w4[0], h[0], f4{0.f, 0.f, 0.f, 0.f});
+        accB = mfma4(w4[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        accA = mfma4(w4[2], h[2], accA);
+        accB = mfma4(w4[3], h[3], accB);
+        xbuf[p][w][l] = accA + accB;
+        lds_barrier();
+        f4 out = b4r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out += xbuf[p][c][l];
+        p ^= 1;
+        return out;
+    };
+
+    for (long long k = 0; k + 1 < nT; ++k) {
+        const float h_ = t_nxt - t_cur;
+        t_cur = t_nxt;
+        float extv[NZM > 0 ? NZM : 1];
+#pragma unroll
+        for (int m = 0; m < (NZM > 0 ? NZM : 1); ++m) extv[m] = ext_nxt[m];
+        float xsrc[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xsrc[r] = x[r];
+        if constexpr (TRUE_X) {   // teacher forcing: the step starts from the dataset's x[k] (my_solvers.py:72)
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xsrc[r] = 4 * r + g < xd ? a.x.p[k * a.x.st + b * a.x.sb + 4 * r + g] : 0.0f;
+        }
+        // prefetch the next step's inputs (consumed one full step later)
+        if (k + 2 < nT) {
+            t_nxt = tp[(k + 2) * tst];
+            load_ext(k + 1, ev_n1, ext_nxt);
+            ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+        }
+        // per-step constant of L1: c0 + W1[:, ext columns] . (z - a0z | z)
+        f4 cz = c0;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) cz = mfma4(w1z[m], extv[m] - a0e[m], cz);
+
+        const f4 k1 = rhs(xsrc, cz);
+        if constexpr (METHOD == PSNODE_EULER) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + h_ * k1[r];
+        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+            float xs[NX];
+            const float hh = 0.5f * h_;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + k1[r] * hh;
+            const f4 k2 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + h_ * k2[r];
+        } else {
+            float xs[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * k1[r] * kOneThird;
+            const f4 k2 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * (k2[r] - k1[r] * kOneThird);
+            const f4 k3 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * (k1[r] - k2[r] + k3[r]);
+            const f4 k4 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + (k1[r] + 3.0f * (k2[r] + k3[r]) + k4[r]) * h_ * 0.125f;
+        }
+        if (w == 0 && valid) {
+            float* o = a.xo + ((k + 1) * a.B + b) * xd;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) if (4 * r + g < xd) o[4 * r + g] = x[r];
+        }
+    }
+}
+
+template <int METHOD, int NX, bool TRUE_X>
+hipError_t launch_nzm(const IntegrateDev& a, const float* pack, int NA, int NZM, hipStream_t s) {
+    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(256);
+    switch (NZM) {
+        case 0: hipLaunchKernelGGL((ode_mfma_kernel<METHOD, NX, 0, TRUE_X>), grid, block, 0, s, a, pack, NA); break;
+        case 1: hipLaunchKernelGGL((ode_mfma_kernel<METHOD, NX, 1, TRUE_X>), grid, block, 0, s, a, pack, NA); break;
+        case 2: hipLaunchKernelGGL((ode_mfma_kernel<METHOD, NX, 2, TRUE_X>), grid, block, 0, s, a, pack, NA); break;
+        default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
+template <int METHOD>
+hipError_t launch_method(const IntegrateDev& a, const float* pack, int NA, int NZM, hipStream_t s) {
+    if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_nzm<METHOD, kNXc, true>(a, pack, NA, NZM, s);
+    return launch_nzm<METHOD, kNXc, false>(a, pack, NA, NZM, s);
+}
+
+constexpr int kMaxNZM = 2;
+constexpr int kNX = kNXc;
+
+int nzm_of(const IntegrateDev& a) { return (2 * a.zd + 3) / 4; }
+int na_of(const IntegrateDev& a) { return (a.xd + a.zd + 3) / 4; }
+
+}  // namespace
+
+bool mfma_ode_supported(const IntegrateDev& a) {
+    const MlpDev& m = a.de;
+    if (m.n_layers != 4 || m.out_dim[0] != HID || m.out_dim[1] != HID || m.out_dim[2] != HID) return false;
+    if (a.xd < 1 || a.xd > 4 * kNX || m.out_dim[3] != a.xd) return false;
+    if (m.in_dim != 3 * (a.xd + a.zd)) return false;
+    return nzm_of(a) <= kMaxNZM;
+}
+
 bool mfma_dae_supported(const IntegrateDev&) { return false; }
-size_t mfma_pack_floats(const psnode_mlp_f32*, const psnode_mlp_f32*) { return 0; }
-hipError_t launch_mfma(const IntegrateDev&, bool, float*, hipStream_t) { return hipErrorNotSupported; }
+
+size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32*) {
+    if (!de || de->n_layers != 4) return 0;
+    // upper bound of NW * (COUNT + NA) * 64 for any supported shape
+    const int n = de->in_dim / 3;
+    return (size_t)NW * (2 * kNX + kMaxNZM + 4 + 20 + 20 + 8 + (n + 3) / 4 + 4) * 64;
+}
+
+hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
+    if (dae) return hipErrorNotSupported;
+    const int NZM = nzm_of(a), NA = na_of(a);
+    PackMfma p;
+    p.xd = a.xd; p.ne = a.zd; p.n = a.xd + a.zd; p.NX = kNX; p.NZM = NZM; p.NA = NA;
+    p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
+    p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
+    p.out = pack;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    switch (a.method) {
+        case PSNODE_EULER: return launch_method<PSNODE_EULER>(a, pack, NA, NZM, stream);
+        case PSNODE_MIDPOINT: return launch_method<PSNODE_MIDPOINT>(a, pack, NA, NZM, stream);
+        default: return launch_method<PSNODE_RK4_38>(a, pack, NA, NZM, stream);
+    }
+}
 
 }  // namespace psnode

@@ -136,6 +136,45 @@ def test_other_shapes_generic(xd, zd, H, nh):
     assert rel_err(out.cpu(), ref) <= TOL_GPU
 
 
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (5, 3), (8, 4), (1, 1), (8, 0)])
+def test_mfma_kernel_shapes(xd, zd, method):
+    """Every (x_dim, z_dim) class of the MFMA kernel (NX=2; NZM=0,1,2), forced with kernel='mfma', with events,
+    per-trajectory clocks and a ragged last tile."""
+    B, Tn = 37, 14
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=11)
+    g = torch.Generator().manual_seed(12)
+    t = t * (0.5 + torch.rand(1, B, 1, generator=g))
+    t[:, 0] = torch.arange(Tn, dtype=torch.float32).view(Tn, 1) * 0.01      # trajectory 0 = the event clock
+    ev = torch.stack([t[4, :, :], t[9, :, :]], dim=1).contiguous()           # [B,2,1]
+    zj = 0.1 * torch.randn(B, 2, zd, generator=g)
+    ref = O.integrate_ode(method, ls, t, x, z, a0, ev, zj)
+    out = fused().ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel="mfma")
+    assert rel_err(out.cpu(), ref) <= TOL_GPU
+    xt = 0.1 * torch.randn(Tn, B, xd, generator=g)
+    xt[0] = x[0]
+    ref = O.integrate_ode(method, ls, t, xt, z, a0, ev, zj, input_true_x=True)
+    out = fused().ode_integrate(method, dl(ls), t.cuda(), xt.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), input_true_x=True, kernel="mfma")
+    assert rel_err(out.cpu(), ref) <= TOL_GPU
+
+
+def test_auto_picks_mfma_for_reference_shape():
+    import ctypes
+    from py_psnode_amd import _lib
+    lib = _lib.load()
+    a = _lib.OdeArgsF32()
+    a.method, a.x_dim, a.z_dim, a.T, a.B = _lib.RK4_38, 8, 2, 1001, 4096
+    a.de.n_layers, a.de.in_dim = 4, 30
+    for k, o in enumerate((64, 64, 64, 8)):
+        a.de.out_dim[k] = o
+    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+    a.de.out_dim[1] = 32
+    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
+    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=32)
+    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel for H=32
+        fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
+
+
 def test_full_size_subset_vs_oracle():
     """BASELINE config 2 (B=4096, T=1001, RK4): trajectories are independent, so 48 of them taken from the
     full GPU run must match the oracle run on just those 48."""
