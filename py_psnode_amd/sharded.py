@@ -1,0 +1,74 @@
+"""Multi-GPU data parallelism over trajectories: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).
+
+Trajectories never interact inside the solver (every op of my_solvers.py:66-78 is row-wise over the batch), so each
+rank integrates its own contiguous slice with the single-GPU kernel and NO collective touches the data path.  The only
+cross-batch coupling of the reference is that trajectory 0 decides the event steps for everybody
+(neural_base.py:54,61): rank 0 builds the int32 event table from the global trajectory 0 and broadcasts it.
+One all-gather of the [T, B/G, D] shards reassembles the batch "for the loss" (BASELINE.json north_star).
+"""
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """Contiguous, near-equal slice [lo, hi) of `total` trajectories for `rank`."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_event_table(t_local: torch.Tensor, event_t_local: Optional[torch.Tensor], group=None,
+                          table_fn: Optional[Callable] = None) -> Optional[torch.Tensor]:
+    """int32[T-1] event table every rank must use: computed on rank 0 (owner of global trajectory 0), broadcast.
+    `event_t_local is None` must hold on all ranks or none."""
+    if event_t_local is None:
+        return None
+    T = t_local.shape[0]
+    if T < 2:
+        return None
+    if table_fn is None:
+        from . import fused
+        table_fn = fused.event_table
+    tab = table_fn(t_local, event_t_local) if dist.get_rank(group) == 0 else torch.empty(T - 1, dtype=torch.int32, device=t_local.device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(tab, src=src, group=group)
+    return tab
+
+
+def all_gather_batch(shard: torch.Tensor, group=None) -> torch.Tensor:
+    """[T, Bl, D] shards (equal Bl on every rank) -> [T, G*Bl, D] view in rank order, one all_gather_into_tensor.
+    The gathered storage is rank-major [G, T, Bl, D]; the result is its [T, G*Bl, D] rearrangement (one device copy)."""
+    world = dist.get_world_size(group)
+    shard = shard.contiguous()
+    T, Bl, D = shard.shape
+    flat = torch.empty((world * T, Bl, D), dtype=shard.dtype, device=shard.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(flat, shard, group=group)
+    return flat.view(world, T, Bl, D).permute(1, 0, 2, 3).reshape(T, world * Bl, D)
+
+
+def integrate_ode_sharded(method, de_layers, t, x, z, all_initial, event_t=None, z_jump=None, input_true_x=False,
+                          group=None, gather=True, local_fn: Optional[Callable] = None, table_fn: Optional[Callable] = None, **kw):
+    """Each rank passes ITS shard (t[T,Bl,1], x[T,Bl,xd], z[T,Bl,zd], all_initial[Bl,n], event_t/z_jump[Bl,nE,.]).
+    Returns the gathered [T, G*Bl, xd] (gather=True) or the local [T,Bl,xd]."""
+    if local_fn is None:
+        from . import fused
+        local_fn = fused.ode_integrate
+    tab = broadcast_event_table(t, event_t, group, table_fn)
+    xs = local_fn(method, de_layers, t, x, z, all_initial, z_jump=z_jump, input_true_x=input_true_x, event_idx=tab, **kw)
+    return all_gather_batch(xs, group) if gather else xs
+
+
+def integrate_dae_sharded(method, de_layers, ae_layers, x_init, t, x, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None,
+                          input_true_x=False, input_true_i=False, group=None, gather=True, local_fn: Optional[Callable] = None,
+                          table_fn: Optional[Callable] = None, **kw):
+    if local_fn is None:
+        from . import fused
+        local_fn = fused.dae_integrate
+    tab = broadcast_event_table(t, event_t, group, table_fn)
+    xs, is_ = local_fn(method, de_layers, ae_layers, x_init, t, x, z, v, i, all_initial, z_jump=z_jump, v_jump=v_jump,
+                       input_true_x=input_true_x, input_true_i=input_true_i, event_idx=tab, **kw)
+    if not gather:
+        return xs, is_
+    return all_gather_batch(xs, group), all_gather_batch(is_, group)

@@ -1,0 +1,79 @@
+"""world_size-2 `gloo` test of the multi-GPU path on CPU: shard -> integrate locally -> all-gather == unsharded.
+
+The HIP kernel cannot run here, so the per-rank integrate is the CPU oracle (tests may use it); what is under test is
+py_psnode_amd/sharded.py: slicing, the broadcast of the event table decided by GLOBAL trajectory 0, and the gather."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _oracle_local(method, de, t, x, z, a0, z_jump=None, input_true_x=False, event_idx=None):
+    """Oracle driven by an explicit per-step event table (what the sharded wrapper hands every rank)."""
+    from oracle import psnode_oracle as O
+    xs = torch.zeros(x.shape)
+    cur = x[0]
+    xs[0] = cur
+    for k in range(t.shape[0] - 1):
+        zk = z[k]
+        if event_idx is not None and int(event_idx[k]) >= 0:
+            zk = z_jump[:, int(event_idx[k])]
+        src = x[k] if input_true_x else cur
+        cur, _ = O.step(method, lambda xx: O.de_rhs(de, xx, (zk,), a0), t[k], t[k + 1] - t[k], t[k + 1], src)
+        xs[k + 1] = cur
+    return xs
+
+
+def _table(t, event_t):
+    from oracle import psnode_oracle as O
+    return torch.tensor(O.event_step_table(t, event_t), dtype=torch.int32)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import T, layers, load, tm
+        from py_psnode_amd import sharded
+        d = load("g2_ode.npz")
+        de = layers(d, "de__x_dot")
+        t, x, z = tm(d["t"]), tm(d["x"]), tm(d["z"])
+        a0, ev, zj = T(d["all_initial"]), T(d["event_t"]), T(d["z_jump"])
+        B = t.shape[1]
+        lo, hi = sharded.shard_bounds(B, rank, world)
+        # make rank 1's local trajectory 0 carry a DIFFERENT clock: the table must still come from global trajectory 0
+        tl = t[:, lo:hi].clone()
+        if rank == 1:
+            tl[:, 0] = tl[:, 0] + 0.123
+        out = sharded.integrate_ode_sharded("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_t=ev[lo:hi], z_jump=zj[lo:hi],
+                                            local_fn=_oracle_local, table_fn=_table)
+        ref = T(d["rk4_events"]).clone()
+        if rank == 0:
+            # trajectory `B/2` (rank 1's first) was integrated with the shifted clock but identical dt -> same result
+            q.put((tuple(out.shape), float((out - ref).abs().max())))
+        bounds = [sharded.shard_bounds(10, r, 3) for r in range(3)]
+        assert bounds == [(0, 4), (4, 7), (7, 10)]
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_shard_then_gather_equals_unsharded():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, "worker failed"
+    shape, err = q.get(timeout=10)
+    assert shape == (101, 32, 8)
+    assert err <= 2e-6
