@@ -158,6 +158,52 @@ def test_mfma_kernel_shapes(xd, zd, method):
     assert rel_err(out.cpu(), ref) <= TOL_GPU
 
 
+def _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=0, H=64):
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    n = xd + zd + vd + idim
+    mk = lambda dims: [(l.weight.detach(), l.bias.detach()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
+    de, ae = mk([3 * n, H, H, H, xd]), mk([n + xd + zd + vd, H, H, H, idim])
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g)) if B > 1 else t[:, 1:]
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    x, z, v, i, xi = r(Tn, B, xd), r(Tn, B, zd), r(Tn, B, vd), r(Tn, B, idim), r(B, xd)
+    a0 = torch.cat((xi, z[0], v[0], i[0]), -1)
+    ev = torch.stack([t[3, :, :], t[Tn - 2, :, :]], dim=1).contiguous() if Tn > 5 else None
+    return de, ae, t, x, z, v, i, xi, a0, ev, r(B, 2, zd), r(B, 2, vd)
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd,vd,idim", [(8, 2, 2, 2), (8, 0, 2, 2), (5, 1, 1, 1), (8, 2, 2, 4), (3, 1, 0, 1), (8, 4, 3, 1), (2, 2, 4, 2)])
+def test_mfma_dae_kernel_shapes(xd, zd, vd, idim, method):
+    """Every (NZM, NZA) class of the DAE MFMA kernel, forced with kernel='mfma': events (incl. the i0 recompute),
+    all four teacher-forcing combinations, per-trajectory clocks, ragged last tile."""
+    B, Tn = 21, 11
+    de, ae, t, x, z, v, i, xi, a0, ev, zj, vj = _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=21)
+    c = lambda a: a.cuda()
+    for tx in (False, True):
+        for ti in (False, True):
+            ref_x, ref_i = O.integrate_dae(method, de, ae, xi, t, x, z, v, i, a0, ev, zj, vj, input_true_x=tx, input_true_i=ti)
+            xs, is_ = fused().dae_integrate(method, dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), event_t=c(ev),
+                                            z_jump=c(zj), v_jump=c(vj), input_true_x=tx, input_true_i=ti, kernel="mfma")
+            assert rel_err(xs.cpu(), ref_x) <= TOL_GPU, (tx, ti)
+            assert rel_err(is_.cpu(), ref_i) <= TOL_GPU, (tx, ti)
+
+
+def test_dae_full_size_subset_vs_oracle():
+    """BASELINE config 4 (DAE_01 RK4, B=4096, T=1001): 24 trajectories of the full GPU run vs the oracle on those 24."""
+    B, Tn = 4096, 1001
+    de, ae, t, x, z, v, i, xi, a0, _, _, _ = _synthetic_dae(B, Tn, 8, 2, 2, 2, seed=5)
+    c = lambda a: a.cuda()
+    xs, is_ = fused().dae_integrate("rk4", dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0))
+    idx = torch.tensor(sorted(set(range(0, B, 190)) | {B - 1, 16}))
+    ref_x, ref_i = O.integrate_dae("rk4", de, ae, xi[idx], t[:, idx], x[:, idx], z[:, idx], v[:, idx], i[:, idx], a0[idx])
+    assert torch.isfinite(xs).all() and torch.isfinite(is_).all()
+    assert rel_err(xs[:, idx.cuda()].cpu(), ref_x) <= TOL_GPU
+    assert rel_err(is_[:, idx.cuda()].cpu(), ref_i) <= TOL_GPU
+
+
 def test_auto_picks_mfma_for_reference_shape():
     import ctypes
     from py_psnode_amd import _lib
@@ -170,6 +216,12 @@ def test_auto_picks_mfma_for_reference_shape():
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
     a.de.out_dim[1] = 32
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
+    d = _lib.DaeArgsF32()
+    d.method, d.x_dim, d.z_dim, d.v_dim, d.i_dim, d.T, d.B = _lib.RK4_38, 8, 2, 2, 2, 1001, 4096
+    d.de.n_layers, d.de.in_dim, d.ae.n_layers, d.ae.in_dim = 4, 42, 4, 26
+    for k, (o1, o2) in enumerate(zip((64, 64, 64, 8), (64, 64, 64, 2))):
+        d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
+    assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA
     ls, t, x, z, a0 = _synthetic_ode(4, 3, H=32)
     with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel for H=32
         fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
