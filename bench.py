@@ -35,6 +35,8 @@ WORKLOADS = {
     "ode01": dict(kind="ode", B=4096, T=1001, xd=8, zd=2, H=64, nh=3),
     "dae01": dict(kind="dae", B=4096, T=1001, xd=8, zd=2, vd=2, id=2, H=64, nh=3),
     "ode02_latent16": dict(kind="ode", B=4096, T=1001, xd=16, zd=16, H=16, nh=1),
+    # BASELINE config 3: whole ODE_02 direct_encode forward (enc x, enc z, latent integrate, dec pred, dec recon), H=16
+    "ode02": dict(kind="ode02_model", B=4096, T=1001, xd=8, zd=2, H=16, nh=1),
 }
 
 
@@ -54,14 +56,24 @@ def make_problem(w, B, T, seed_offset=0):
     xd, zd = w["xd"], w["zd"]
     vd, idim = w.get("vd", 0), w.get("id", 0)
     n = xd + zd + vd + idim
-    p = dict(de=mlp([3 * n] + [w["H"]] * w["nh"] + [xd], 0))
+    if w["kind"] == "ode02_model":
+        from py_psnode_amd import models
+        from py_psnode_amd import neural_dae as nd
+        torch.manual_seed(0)
+        model = models.ODE_Model(xd, zd, w["H"], direct_encode=True, solver=nd.RK4())
+        model.solver.fused = "require"
+        p = dict(model=model, de=[(l.weight.detach(), l.bias.detach()) for l in model.de_func.x_dot if isinstance(l, torch.nn.Linear)])
+    else:
+        p = dict(de=mlp([3 * n] + [w["H"]] * w["nh"] + [xd], 0))
     p["t"] = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
     p["x"] = torch.zeros(B, T, xd)
     p["x"][:, 0] = 0.1 * torch.randn(B, xd, generator=g)
     p["z"] = 0.1 * torch.randn(B, T, zd, generator=g)
     p["event_t"] = torch.full((B, 2, 1), -1.0)          # "no events" as the scripts encode it
     p["z_jump"] = torch.zeros(B, 2, zd)
-    if w["kind"] == "dae":
+    if w["kind"] == "ode02_model":
+        p["a0"] = torch.zeros(1)
+    elif w["kind"] == "dae":
         p["ae"] = mlp([n + xd + zd + vd] + [w["H"]] * w["nh"] + [idim], 7)
         p["v"] = 0.1 * torch.randn(B, T, vd, generator=g)
         p["i"] = 0.1 * torch.randn(B, T, idim, generator=g)
@@ -74,9 +86,13 @@ def make_problem(w, B, T, seed_offset=0):
 
 
 def to_dev(p, dev):
+    import copy
     out = {}
     for k, v in p.items():
-        out[k] = [(a.to(dev), b.to(dev)) for a, b in v] if isinstance(v, list) else v.to(dev)
+        if isinstance(v, torch.nn.Module):
+            out[k] = copy.deepcopy(v).to(dev)
+        else:
+            out[k] = [(a.to(dev), b.to(dev)) for a, b in v] if isinstance(v, list) else v.to(dev)
     return out
 
 
@@ -85,6 +101,9 @@ def tmv(a):
 
 
 def run_fused(fused, w, p, method, kernel):
+    if w["kind"] == "ode02_model":
+        with torch.no_grad():
+            return p["model"](t=p["t"], x=p["x"], z=p["z"], event_t=p["event_t"], z_jump=p["z_jump"])[:1]
     if w["kind"] == "ode":
         return (fused.ode_integrate(method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                     event_t=p["event_t"], z_jump=p["z_jump"], kernel=kernel),)
@@ -94,6 +113,16 @@ def run_fused(fused, w, p, method, kernel):
 
 def run_oracle(O, w, p, method, T):
     sl = lambda a: tmv(a)[:T]
+    if w["kind"] == "ode02_model":
+        import torch.nn.functional as F
+        m = p["model"]
+        seq = lambda s, a: F.linear(F.elu(F.linear(a, s[0].weight, s[0].bias)), s[2].weight, s[2].bias)
+        with torch.no_grad():
+            x, z = p["x"][:, :T], p["z"][:, :T]
+            Xh, Zh = tmv(seq(m.x_encoder, x)), tmv(seq(m.z_encoder, z))
+            de = [(l.weight, l.bias) for l in m.de_func.x_dot if isinstance(l, torch.nn.Linear)]
+            sol = O.integrate_ode(method, de, sl(p["t"]), Xh, Zh, torch.cat((Xh[0], Zh[0]), -1), p["event_t"], seq(m.z_encoder, p["z_jump"]))
+            return seq(m.x_decoder, sol), seq(m.x_decoder, Xh)
     if w["kind"] == "ode":
         return O.integrate_ode(method, p["de"], sl(p["t"]), sl(p["x"]), sl(p["z"]), p["a0"], p["event_t"], p["z_jump"])
     return O.integrate_dae(method, p["de"], p["ae"], p["x_init"], sl(p["t"]), sl(p["x"]), sl(p["z"]), sl(p["v"]), sl(p["i"]),
@@ -103,6 +132,9 @@ def run_oracle(O, w, p, method, T):
 def flops_per_state_step(w, p, method):
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     f = 2 * stages * mlp_macs(p["de"])
+    if w["kind"] == "ode02_model":   # + enc x, enc z, 2x dec per grid point (2 880 flop at H=16)
+        H, xd, zd = w["H"], w["xd"], w["zd"]
+        f += 2 * ((xd * H + H * H) + (zd * H + H * H) + 2 * (H * H + H * xd))
     if w["kind"] == "dae":
         f += 2 * mlp_macs(p["ae"])
     return f
@@ -110,6 +142,8 @@ def flops_per_state_step(w, p, method):
 
 def bytes_per_state_step(w):
     """Compulsory HBM traffic per state-step: read t + external inputs, write the outputs."""
+    if w["kind"] == "ode02_model":   # fully fused ideal: read x, z, t; write x_pred, x_re
+        return 4 * (w["xd"] + w["zd"] + 1 + 2 * w["xd"])
     rd = 4 * (1 + w["zd"] + w.get("vd", 0))
     wr = 4 * (w["xd"] + w.get("id", 0))
     return rd + wr
@@ -188,6 +222,11 @@ def main():
     B, T = w["B"], w["T"]
     p_cpu = make_problem(w, B, T, seed_offset=rank)
     p = to_dev(p_cpu, dev)
+    if w["kind"] == "ode02_model":
+        from py_psnode_amd import neural_dae as nd
+        for mdl in (p["model"], p_cpu["model"]):
+            mdl.solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[args.method]()
+            mdl.solver.fused, mdl.solver.kernel = "require", args.kernel
     n_out = 1 if w["kind"] == "ode" else 2
     gathered = None
     if world > 1 and not args.no_gather:
@@ -237,7 +276,9 @@ def main():
     ach_gbs = bts * state_steps_launch / (kern_avg_ms * 1e-3) / 1e9
 
     if rank == 0:
-        if w["kind"] == "ode":
+        if w["kind"] == "ode02_model":
+            auto_kernel = 2
+        elif w["kind"] == "ode":
             a = _lib.OdeArgsF32()
             a.method, a.x_dim, a.z_dim, a.T, a.B = fused.METHOD_ID[args.method], w["xd"], w["zd"], T, B
             a.de = fused._mlp(p["de"], dev, "de", [])

@@ -151,6 +151,15 @@ int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspac
 /* Replaces FixedGridODESolver.integrate_DAE (my_solvers.py:82-131) + step functions + DE_Func/AE_Func forwards. */
 int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Row-wise 2-layer ELU-MLP  out[r,:] = W2.ELU(W1.in[r,:] + b1) + b2  over `rows` rows (row strides in elements).
+ * Replaces the forward of the direct_encode encoders/decoders nn.Sequential(Linear, ELU, Linear) applied to every
+ * (b,t) row: x_encoder / z_encoder / x_decoder (neural_00_ODE_02_direct_encode.py:64-69,74-88) and
+ * v_encoder / i_encoder / i_decoder (neural_01_DAE_02_direct_encode.py:107-118,126-152).
+ * Supported: hidden width 16 (the scripts' default hidden_dim), in/out width 1..16 -- see psnode_mlp_rows_supported. */
+int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* mlp);
+int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, float* out,
+                            int64_t out_row_stride, void* stream);
+
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
-    "psnode_ode_kernel_for", "psnode_dae_kernel_for",
+    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
 )
 
 
@@ -94,6 +94,10 @@ def load():
     lib.psnode_ode_kernel_for.argtypes = [ctypes.POINTER(OdeArgsF32)]
     lib.psnode_dae_kernel_for.restype = c_int32
     lib.psnode_dae_kernel_for.argtypes = [ctypes.POINTER(DaeArgsF32)]
+    lib.psnode_mlp_rows_supported.restype = c_int32
+    lib.psnode_mlp_rows_supported.argtypes = [ctypes.POINTER(MlpF32)]
+    lib.psnode_mlp_rows_f32.restype = c_int32
+    lib.psnode_mlp_rows_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

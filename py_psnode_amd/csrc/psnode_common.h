@@ -63,4 +63,10 @@ bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 
+// psnode_latent.hip (direct_encode latent shapes, hidden_dim 16)
+bool latent_shape_ok(const IntegrateDev& a, bool dae);
+bool latent_ptrs_ok(const IntegrateDev& a, bool dae);
+size_t latent_pack_floats();
+hipError_t launch_latent(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+
 }  // namespace psnode

@@ -256,6 +256,41 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
     return xs, is_
 
 
+def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
+    """Fused `nn.Sequential(Linear, ELU, Linear)` over the last dim of `inp` (any leading shape) on the HIP row kernel:
+    the encoders / decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:64-69)."""
+    lib = _lib.load()
+    dev = inp.device
+    keep: list = []
+    m = _mlp(layers, dev, "mlp", keep)
+    if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
+        raise ValueError("mlp_rows: needs Linear(in<=16, 16) ELU Linear(16, out<=16)")
+    x = _f32_dev(inp, dev, "input")
+    if x.shape[-1] != m.in_dim:
+        raise ValueError(f"mlp_rows: input width {x.shape[-1]}, expected {m.in_dim}")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty((*x.shape[:-1], layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.psnode_mlp_rows_f32(ctypes.byref(m), x2.shape[0], x2.data_ptr(), x2.stride(0), out.data_ptr(), out.shape[-1],
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_mlp_rows_f32")
+    return out
+
+
+def rows_layers_of(seq, inp: torch.Tensor):
+    """Layers if `seq(inp)` can run on the row kernel (2-layer ELU-MLP, hidden 16, fp32 HIP tensor, no autograd)."""
+    if inp.device.type != "cuda" or inp.dtype != torch.float32 or inp.numel() == 0:
+        return None
+    layers = sequential_layers(seq)
+    if layers is None or len(layers) != 2 or layers[0][0].shape[0] != 16 or layers[0][0].shape[1] > 16 or layers[1][0].shape[0] > 16:
+        return None
+    if _needs_autograd([inp] + [p for wb in layers for p in wb]):
+        return None
+    return layers
+
+
 # ----------------------------------------------------------------------------- planning for the solver classes
 def _event_tensors(event_fn, jump_change_fn, want_v: bool):
     """(ok, event_t, z_jump, v_jump).  Events can be fused when both callbacks are the bound methods of one

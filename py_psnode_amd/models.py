@@ -30,6 +30,14 @@ def _tm(a):
     return a.permute(1, 0, 2)
 
 
+def _rows(seq, inp):
+    """Encoder / decoder over every (b,t) row: the fused HIP row kernel when the call is fusable (fp32 HIP tensor,
+    Linear-ELU-Linear with hidden 16, no autograd), otherwise the module itself (training, CPU, other widths)."""
+    from . import fused
+    layers = fused.rows_layers_of(seq, inp)
+    return fused.mlp_rows(layers, inp) if layers is not None else seq(inp)
+
+
 class DE_Func(nn.Module):
     """x_dot MLP over cat(a0, s - a0, s), s = cat(xt, zt[, vt, it]).  `widths` = (in_state_width, hidden..., out)."""
 
@@ -85,13 +93,13 @@ class ODE_Model(nn.Module):
             xs = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=_tm(x), z=_tm(z), all_initial=a0,
                                            event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
             return _tm(xs)
-        Xh = _tm(self.x_encoder(x))
-        Zh = _tm(self.z_encoder(z))
+        Xh = _tm(_rows(self.x_encoder, x))
+        Zh = _tm(_rows(self.z_encoder, z))
         a0 = torch.cat((Xh[0], Zh[0]), dim=-1)
-        self.event.set_event(t=event_t, z=self.z_encoder(z_jump))
+        self.event.set_event(t=event_t, z=_rows(self.z_encoder, z_jump))
         Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh, z=Zh, all_initial=a0,
                                            event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
-        return _tm(self.x_decoder(Xh_sol)), _tm(self.x_decoder(Xh))
+        return _tm(_rows(self.x_decoder, Xh_sol)), _tm(_rows(self.x_decoder, Xh))
 
 
 class DAE_Model(nn.Module):
@@ -129,14 +137,14 @@ class DAE_Model(nn.Module):
                                                 event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
                                                 input_true_x=input_true_x, input_true_i=input_true_i)
             return _tm(xs), _tm(is_)
-        enc_z = (lambda a: a) if self.z_encoder is None else self.z_encoder
-        Xh0 = self.x_encoder(x0)
-        Xh, Zh, Vh, Ih = _tm(self.x_encoder(x)), _tm(enc_z(z)), _tm(self.v_encoder(v)), _tm(self.i_encoder(i))
+        enc_z = (lambda a: a) if self.z_encoder is None else (lambda a: _rows(self.z_encoder, a))
+        Xh0 = _rows(self.x_encoder, x0)
+        Xh, Zh, Vh, Ih = _tm(_rows(self.x_encoder, x)), _tm(enc_z(z)), _tm(_rows(self.v_encoder, v)), _tm(_rows(self.i_encoder, i))
         a0 = torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), dim=-1)
-        self.event.set_event(t=event_t, z=enc_z(z_jump), v=self.v_encoder(v_jump))
+        self.event.set_event(t=event_t, z=enc_z(z_jump), v=_rows(self.v_encoder, v_jump))
         Xh_sol, Ih_sol = self.solver.integrate_DAE(x_init=Xh0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=Xh,
                                                    z=Zh, v=Vh, i=Ih, all_initial=a0, event_fn=self.event.event_fn,
                                                    jump_change_fn=self.event.jump_change_fn)
-        x_pred = self.x_decoder(Xh_sol)
+        x_pred = _rows(self.x_decoder, Xh_sol)
         x_pred[0] = x0                                             # neural_01_DAE_02_direct_encode.py:150
-        return _tm(x_pred), _tm(self.i_decoder(Ih_sol)), _tm(self.x_decoder(Xh)), _tm(self.i_decoder(Ih))
+        return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _tm(_rows(self.x_decoder, Xh)), _tm(_rows(self.i_decoder, Ih))

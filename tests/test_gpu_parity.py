@@ -204,6 +204,72 @@ def test_dae_full_size_subset_vs_oracle():
     assert rel_err(is_[:, idx.cuda()].cpu(), ref_i) <= TOL_GPU
 
 
+@pytest.mark.parametrize("method", METHODS)
+def test_latent_ode_kernel(method):
+    """direct_encode ODE latent shape (Linear(6H,H) ELU Linear(H,H), H=16) on the single-wave MFMA kernel, with events,
+    per-trajectory clocks, a ragged tile and the scripts' strided views."""
+    B, Tn, H = 37, 13, 16
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=H, zd=H, H=H, n_hidden=1, seed=31)
+    g = torch.Generator().manual_seed(32)
+    t = t * (0.5 + torch.rand(1, B, 1, generator=g))
+    t[:, 0] = torch.arange(Tn, dtype=torch.float32).view(Tn, 1) * 0.01
+    ev = torch.stack([t[2, :, :], t[9, :, :]], dim=1).contiguous()
+    zj = 0.1 * torch.randn(B, 2, H, generator=g)
+    ref = O.integrate_ode(method, ls, t, x, z, a0, ev, zj)
+    bm = lambda a: a.permute(1, 0, 2).contiguous().cuda().permute(1, 0, 2)      # B-major memory, time-major view
+    out = fused().ode_integrate(method, dl(ls), bm(t), bm(x), bm(z), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel="mfma")
+    assert rel_err(out.cpu(), ref) <= TOL_GPU
+    gen = fused().ode_integrate(method, dl(ls), bm(t), bm(x), bm(z), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel="generic")
+    assert rel_err(gen.cpu(), ref) <= TOL_GPU
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("zd", [16, 0])
+def test_latent_dae_kernel(method, zd):
+    """direct_encode DAE latent shapes (12H|9H -> H -> H and 7H|5H -> H -> H, H=16), with and without z."""
+    import torch.nn as nn
+    B, Tn, H = 21, 9, 16
+    g = torch.Generator().manual_seed(41)
+    torch.manual_seed(41)
+    nblk = 4 if zd else 3
+    mk = lambda dims: [(l.weight.detach(), l.bias.detach()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
+    de, ae = mk([3 * nblk * H, H, H]), mk([(2 * nblk - 1) * H, H, H])
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    x, z, v, i, xi = r(Tn, B, H), r(Tn, B, zd), r(Tn, B, H), r(Tn, B, H), r(B, H)
+    a0 = torch.cat((xi, z[0], v[0], i[0]), -1)
+    ev = torch.stack([t[3, :, :], t[6, :, :]], dim=1).contiguous()
+    zj, vj = r(B, 2, zd), r(B, 2, H)
+    ref_x, ref_i = O.integrate_dae(method, de, ae, xi, t, x, z, v, i, a0, ev, zj, vj)
+    c = lambda a: a.cuda()
+    xs, is_ = fused().dae_integrate(method, dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), event_t=c(ev), z_jump=c(zj),
+                                    v_jump=c(vj), kernel="mfma")
+    assert rel_err(xs.cpu(), ref_x) <= TOL_GPU and rel_err(is_.cpu(), ref_i) <= TOL_GPU
+
+
+@pytest.mark.parametrize("din,dout", [(8, 16), (2, 16), (16, 8), (16, 2), (16, 16), (3, 5), (6, 16)])
+@pytest.mark.parametrize("rows", [1, 17, 4100])
+def test_row_mlp_kernel(din, dout, rows):
+    """Encoder / decoder row kernel vs the nn.Sequential it replaces (fp32 reference on CPU)."""
+    import torch.nn as nn
+    torch.manual_seed(din * 100 + dout)
+    seq = nn.Sequential(nn.Linear(din, 16), nn.ELU(), nn.Linear(16, dout))
+    inp = torch.randn(rows, din)
+    with torch.no_grad():
+        ref = seq(inp)
+    ls = [(seq[0].weight.detach().cuda(), seq[0].bias.detach().cuda()), (seq[2].weight.detach().cuda(), seq[2].bias.detach().cuda())]
+    out = fused().mlp_rows(ls, inp.cuda())
+    assert out.shape == ref.shape
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # strided 3-D input like the scripts' [B,T,D] tensors
+    if rows == 4100:
+        inp3 = torch.randn(41, 100, din)
+        with torch.no_grad():
+            ref3 = seq(inp3)
+        out3 = fused().mlp_rows(ls, inp3.cuda())
+        assert out3.shape == ref3.shape and float((out3.cpu() - ref3).abs().max()) <= 2e-6 * max(1.0, float(ref3.abs().max()))
+
+
 def test_auto_picks_mfma_for_reference_shape():
     import ctypes
     from py_psnode_amd import _lib
