@@ -16,7 +16,8 @@ KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
 LIB_NAME = "libpsnode_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
+LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",

@@ -45,9 +45,47 @@ struct IntegrateDev {
     int maxw;              // widest activation vector (generic kernel LDS sizing)
 };
 
-// ELU(alpha=1) with the negative branch at expm1 quality: ATen's CPU kernel (what the reference runs)
-// returns expm1(x) for x <= 0 -- checked bitwise in the build container ("ELU").
+// ELU(alpha=1) with the negative branch at expm1 quality: ATen's CPU kernel (what the reference runs) returns
+// expm1(x) for x <= 0 -- checked bitwise in the build container ("ELU").
+// libm flavour, used by the generic kernel:
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+
+// Inline flavour for the MFMA kernels (no libm call, branch free):
+//   xn = min(x, 0);  q(xn) = degree-7 Taylor of expm1 for xn > -0.25 (truncation 1.5e-9 relative),
+//   exp2(xn*log2e) - 1 below (result in (-1, -0.22]: absolute error ~1 ulp of exp, <= 1.4e-7 relative);
+//   ELU(x) = max(x, 0) + q(xn)   (one of the two terms is exactly 0).
+// This min / max+add form measured 2 % faster than a v_med3 form and 6 % faster than a sign select on K1
+// (profiles/scripts/k1_elu_ab.sh, interleaved A/B on one MI355X: 4.998 / 5.110 / 5.298 ms).
+// PSNODE_ELU=1 (experiments only) is the exp2-only form: same trajectory-level error on the goldens but only ABSOLUTE
+// 2^-24 accuracy near 0-, i.e. no relative accuracy for tiny activations -- not used.
+#ifndef PSNODE_ELU
+#define PSNODE_ELU 0
+#endif
+__device__ __forceinline__ float elu_fast(float x) {
+#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 1)   // timing experiment: ELU -> one max (WRONG results)
+    return fmaxf(x, -0.5f);
+#elif PSNODE_ELU == 1
+    return fmaxf(x, __builtin_amdgcn_exp2f(fminf(x, 0.0f) * 1.44269504088896340736f) - 1.0f);
+#else
+    const float xn = fminf(x, 0.0f);
+#if PSNODE_ELU == 5     // A/B: Estrin evaluation of the same polynomial (shorter dependency chain, 2 more ops)
+    const float x2 = xn * xn, x4 = x2 * x2;
+    const float qa = fmaf(xn, 0.5f, 1.0f), qb = fmaf(xn, 1.0f / 24.0f, 1.0f / 6.0f), qc = fmaf(xn, 1.0f / 720.0f, 1.0f / 120.0f);
+    const float lo = fmaf(qb, x2, qa), hi = fmaf(x2, 1.0f / 5040.0f, qc);
+    float p = xn * fmaf(hi, x4, lo);
+#else
+    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(xn, p, 1.0f / 120.0f);
+    p = fmaf(xn, p, 1.0f / 24.0f);
+    p = fmaf(xn, p, 1.0f / 6.0f);
+    p = fmaf(xn, p, 0.5f);
+    p = fmaf(xn, p, 1.0f);
+    p = xn * p;
+#endif
+    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
+    return fmaxf(x, 0.0f) + (xn > -0.25f ? p : e);
+#endif
+}
 
 // fp32(1/3): the reference multiplies fp32 tensors by the python double 1/3, which ATen rounds to fp32
 // (my_fixed_grid.py:8,43-44).

@@ -20,20 +20,7 @@ constexpr int LTB = 16;    // trajectories per wave
 
 __device__ __forceinline__ f4 lmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ float lelu(float x) {   // same ELU as psnode_mfma.hip (expm1 quality)
-    const float xn = fminf(x, 0.0f);
-    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
-    p = fmaf(xn, p, 1.0f / 120.0f);
-    p = fmaf(xn, p, 1.0f / 24.0f);
-    p = fmaf(xn, p, 1.0f / 6.0f);
-    p = fmaf(xn, p, 0.5f);
-    p = fmaf(xn, p, 1.0f);
-    p = xn * p;
-    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
-    const float neg = xn > -0.25f ? p : e;
-    return x > 0.0f ? x : neg;
-}
-__device__ __forceinline__ f4 lelu4(f4 v) { return f4{lelu(v[0]), lelu(v[1]), lelu(v[2]), lelu(v[3])}; }
+__device__ __forceinline__ f4 lelu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
 
 // Packed image per lane (identical for every wave): pack[reg][lane]
 //   DE: S[blk][m] (NBLK*4) | D[blk][m] (NBLK*4) | B1 (4) | W2 (4) | B2 (4) | A0[m] (n/4)          NBLK = 1 + NBE

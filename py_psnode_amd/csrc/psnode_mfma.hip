@@ -24,6 +24,8 @@
 // q < ne and ext[q-ne] for ne <= q < 2ne (ext = z | v | i).  The AE's output rows are laid out so that the algebraic
 // variable an ext slot needs appears in that very lane, row m: the DAE feedback i -> DE input needs no data movement.
 // External inputs are prefetched one step ahead straight from the caller's strided (B-major) memory.
+#include <type_traits>
+
 #include "psnode_common.h"
 
 namespace psnode {
@@ -125,26 +127,13 @@ __global__ void pack_mfma_kernel(const PackMfma p) {
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// ELU(alpha=1) at expm1 quality without the libm call: degree-7 Taylor on [-0.25, 0] (truncation 1.5e-9 relative),
-// exp2-based exp(x)-1 below (result in (-1,-0.22], absolute error ~1 ulp of exp).
-__device__ __forceinline__ float elu_fast(float x) {
-    const float xn = fminf(x, 0.0f);
-    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
-    p = fmaf(xn, p, 1.0f / 120.0f);
-    p = fmaf(xn, p, 1.0f / 24.0f);
-    p = fmaf(xn, p, 1.0f / 6.0f);
-    p = fmaf(xn, p, 0.5f);
-    p = fmaf(xn, p, 1.0f);
-    p = xn * p;
-    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
-    const float neg = xn > -0.25f ? p : e;
-    return x > 0.0f ? x : neg;
-}
-
 __device__ __forceinline__ f4 elu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
 
 // LDS-only workgroup barrier: wait for this wave's LDS traffic, not for its outstanding global prefetches.
 __device__ __forceinline__ void lds_barrier() {
+#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 2)   // timing experiment: no barrier (WRONG results)
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -288,7 +277,11 @@ __global__ __launch_bounds__(256) void integrate_mfma_kernel(const IntegrateDev 
         lds_barrier();
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
+#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 4)   // timing experiment: no LDS read (WRONG results)
+            const f4 v = h * (float)c;
+#else
             const f4 v = xbuf[p][(w + c) & 3][l];
+#endif
             accA = mfma4(wm[4 * c + 0], v[0], accA);
             accB = mfma4(wm[4 * c + 1], v[1], accB);
             accA = mfma4(wm[4 * c + 2], v[2], accA);
@@ -297,8 +290,10 @@ __global__ __launch_bounds__(256) void integrate_mfma_kernel(const IntegrateDev 
         p ^= 1;
         return elu4(accA + accB);
     };
-    // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows
-    auto tail = [&](const f4 pre1, const Tail& t) -> f4 {
+    // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows.
+    // ROWS2: only rows r < 2 of the output carry data (the DE with x_dim <= 8): all-reduce 8 bytes per lane instead of 16.
+    auto tail = [&](const f4 pre1, const Tail& t, auto rows2) -> f4 {
+        constexpr bool ROWS2 = decltype(rows2)::value;
         f4 h = elu4(pre1);
         h = mid(t.w2, t.b2, h);
         h = mid(t.w3, t.b3, h);
@@ -306,11 +301,21 @@ __global__ __launch_bounds__(256) void integrate_mfma_kernel(const IntegrateDev 
         f4 accB = mfma4(t.w4[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
         accA = mfma4(t.w4[2], h[2], accA);
         accB = mfma4(t.w4[3], h[3], accB);
-        xbuf[p][w][l] = accA + accB;
-        lds_barrier();
+        const f4 part = accA + accB;
         f4 out = t.b4;
+        if constexpr (ROWS2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2* xb2 = reinterpret_cast<f2*>(&xbuf[p][0][0]);
+            xb2[w * 64 + l] = f2{part[0], part[1]};
+            lds_barrier();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out += xbuf[p][c][l];
+            for (int c = 0; c < 4; ++c) { const f2 q = xb2[c * 64 + l]; out[0] += q[0]; out[1] += q[1]; }
+        } else {
+            xbuf[p][w][l] = part;
+            lds_barrier();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out += xbuf[p][c][l];
+        }
         p ^= 1;
         return out;
     };
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void integrate_mfma_kernel(const IntegrateDev 
             accA = mfma4(w1xs[r], xs[r], accA);
             accB = mfma4(w1xd[r], xs[r] - a0x[r], accB);
         }
-        return tail(accA + accB, de);
+        return tail(accA + accB, de, std::integral_constant<bool, (NX <= 2)>{});
     };
     // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
     auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv) -> f4 {
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void integrate_mfma_kernel(const IntegrateDev 
             for (int r = 0; r < NX; ++r) acc = mfma4(aw1x[r], xa[r], acc);
 #pragma unroll
             for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
-            return tail(acc, ae);
+            return tail(acc, ae, std::false_type{});
         }
         return acc;
     };

@@ -16,20 +16,6 @@ constexpr int RH = 16;
 
 __device__ __forceinline__ f4 rmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ float relu1(float x) {   // ELU(alpha=1), expm1 quality (same as psnode_mfma.hip)
-    const float xn = fminf(x, 0.0f);
-    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
-    p = fmaf(xn, p, 1.0f / 120.0f);
-    p = fmaf(xn, p, 1.0f / 24.0f);
-    p = fmaf(xn, p, 1.0f / 6.0f);
-    p = fmaf(xn, p, 0.5f);
-    p = fmaf(xn, p, 1.0f);
-    p = xn * p;
-    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
-    const float neg = xn > -0.25f ? p : e;
-    return x > 0.0f ? x : neg;
-}
-
 struct RowsArgs {
     const float *w1, *b1, *w2, *b2, *in;
     float* out;
@@ -79,7 +65,7 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
         f4 acc = b1r;
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc = rmfma(w1[m], v[m], acc);
-        const f4 h = f4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
+        const f4 h = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
         f4 oA = rmfma(w2[0], h[0], b2r), oB = rmfma(w2[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
         oA = rmfma(w2[2], h[2], oA);
         oB = rmfma(w2[3], h[3], oB);
