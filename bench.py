@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--grid", type=int, default=None, help="override grid points T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
+    ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,9 +209,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from py_psnode_amd import _lib, fused
@@ -229,13 +234,31 @@ def main():
             mdl.solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[args.method]()
             mdl.solver.fused, mdl.solver.kernel = "require", args.kernel
     n_out = 1 if w["kind"] == "ode" else 2
+    from py_psnode_amd import sharded
+    do_gather = (world > 1 or args.force_dist) and not args.no_gather
+    pipelined = do_gather and w["kind"] == "ode" and args.chunks > 1
     gathered = None
-    if world > 1 and not args.no_gather:
+    if do_gather and not pipelined:
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
-        gathered = [torch.empty((world, T, B, d), dtype=torch.float32, device=dev) for d in widths]
+        gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
 
-    def one_step():
+    def one_step(ev_pair=None):
+        """One pass of the hot path (+ the all-gather at N>1).  ev_pair brackets the compute-stream kernels only."""
+        if ev_pair:
+            ev_pair[0].record()
+        if pipelined:
+            tab = fused.event_table(tmv(p["t"]), p["event_t"])
+            xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
+                                                           event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
+                                                           kernel=args.kernel)
+            if ev_pair:
+                ev_pair[1].record()
+            for wk in works:
+                wk.wait()
+            return (xs,)
         outs = run_fused(fused, w, p, args.method, args.kernel)
+        if ev_pair:
+            ev_pair[1].record()
         if gathered is not None:
             for g, o in zip(gathered, outs):
                 dist.all_gather_into_tensor(g, o)
@@ -253,12 +276,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        outs = run_fused(fused, w, p, args.method, args.kernel)
-        ev[k][1].record()
-        if gathered is not None:
-            for g, o in zip(gathered, outs):
-                dist.all_gather_into_tensor(g, o)
+        outs = one_step(ev[k])
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -307,7 +325,8 @@ def main():
             "config": {"workload": f"{args.workload} {args.method}: B={B} trajectories/GPU x {T - 1} steps, x{w['xd']} z{w['zd']}"
                                    + (f" v{w['vd']} i{w['id']}" if w["kind"] == "dae" else "") + f" H{w['H']}, fp32, h=0.01, no events",
                        "kernel": kname, "trajectories_total": world * B,
-                       "collective": ("rccl all_gather of xs shards [T,B,xd]" if gathered is not None else "none"),
+                       "collective": ((f"rccl all_gather of xs shards [T,B,xd], {args.chunks} time chunks overlapped with the integration"
+                                       if pipelined else "rccl all_gather of xs shards [T,B,xd]") if do_gather else "none"),
                        "outputs_finite": finite},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel_ms": kern_avg_ms, "flop_per_state_step": flops,
@@ -317,6 +336,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

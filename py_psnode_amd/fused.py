@@ -163,17 +163,21 @@ def _aligned_ptr(ws: torch.Tensor):
 
 def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=None, z_jump=None,
                   input_true_x: bool = False, kernel: str = "auto", event_idx: Optional[torch.Tensor] = None,
-                  check_events: bool = False) -> torch.Tensor:
+                  check_events: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused integrate_ODE (replaces my_solvers.py:52-80 + my_fixed_grid.py + DE_Func.forward).
 
     t[T,B,1], x[T,B,xd], z[T,B,zd] may be arbitrary strided views with a unit-stride last dim
     (the scripts pass permute(1,0,2) views); returns a fresh contiguous xs[T,B,xd].
+    Only x[0] is read unless input_true_x, so x may be a [1,B,xd] view (time-chunked launches restart from the previous
+    chunk's last row); `out` (contiguous [T,B,xd]) lets the caller place the result, e.g. in a slice of a larger buffer.
     """
     lib = _lib.load()
     dev = x.device
     if dev.type != "cuda":
         raise ValueError("fused integrator needs tensors on a HIP device")
-    T, B, xd = x.shape
+    T, B, xd = t.shape[0], x.shape[1], x.shape[2]
+    if x.shape[0] < (T if input_true_x else 1):
+        raise ValueError("x has fewer grid points than t")
     zd = z.shape[-1]
     keep: list = []
     a = _lib.OdeArgsF32()
@@ -197,7 +201,10 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
             keep.append(event_idx)
             a.event_idx = event_idx.data_ptr()
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
-        out = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+        elif out.shape != (T, B, xd) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != dev:
+            raise ValueError("out must be a contiguous fp32 [T,B,xd] tensor on the inputs' device")
         a.x_out = out.data_ptr()
         ws = _workspace(lib, a.de, None, dev)
         wp, wn = _aligned_ptr(ws)
@@ -209,8 +216,9 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
 
 def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, x, z, v, i, all_initial,
                   event_t=None, z_jump=None, v_jump=None, input_true_x: bool = False, input_true_i: bool = False,
-                  kernel: str = "auto", event_idx: Optional[torch.Tensor] = None, check_events: bool = False):
-    """Fused integrate_DAE (replaces my_solvers.py:82-131 + step functions + DE_Func/AE_Func forwards)."""
+                  kernel: str = "auto", event_idx: Optional[torch.Tensor] = None, check_events: bool = False, out=None):
+    """Fused integrate_DAE (replaces my_solvers.py:82-131 + step functions + DE_Func/AE_Func forwards).
+    `out` = (xs, is) contiguous [T,B,xd] / [T,B,id] tensors to write into (time-chunked launches)."""
     lib = _lib.load()
     dev = x_init.device
     if dev.type != "cuda":
@@ -246,8 +254,13 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
             a.event_idx = event_idx.data_ptr()
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
             a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
-        xs = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
-        is_ = torch.empty((T, B, idim), dtype=torch.float32, device=dev)
+        if out is None:
+            xs = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+            is_ = torch.empty((T, B, idim), dtype=torch.float32, device=dev)
+        else:
+            xs, is_ = out
+            if xs.shape != (T, B, xd) or is_.shape != (T, B, idim) or not (xs.is_contiguous() and is_.is_contiguous()):
+                raise ValueError("out must be contiguous fp32 ([T,B,xd], [T,B,id])")
         a.x_out, a.i_out = xs.data_ptr(), is_.data_ptr()
         ws = _workspace(lib, a.de, a.ae, dev)
         wp, wn = _aligned_ptr(ws)

@@ -324,6 +324,33 @@ def test_accuracy_equivalent_to_reference_vs_fp64():
     assert elem_err(out, truth) <= 3 * elem_err(T(d["rk4"]), truth) + 1e-7
 
 
+def test_time_chunked_launches_are_bit_identical():
+    """The multi-GPU pipeline integrates in time chunks that restart from the previous chunk's last row; that must
+    reproduce the single launch bit for bit (ODE with events, and DAE where the restart recomputes i0)."""
+    from py_psnode_amd import sharded
+    d = load("g2_ode.npz")
+    de = dl(layers(d, "de__x_dot"))
+    t, x, z = (T(d[k]).cuda().permute(1, 0, 2) for k in ("t", "x", "z"))
+    a0, ev, zj = T(d["all_initial"]).cuda(), T(d["event_t"]).cuda(), T(d["z_jump"]).cuda()
+    f = fused()
+    tab = f.event_table(t, ev)
+    one = f.ode_integrate("rk4", de, t, x, z, a0, event_idx=tab, z_jump=zj)
+    xs, _ = sharded.integrate_ode_pipelined("rk4", de, t, x, z, a0, event_idx=tab, z_jump=zj, chunks=5, gather=False)
+    assert torch.equal(xs, one)
+    d = load("g3_dae.npz")
+    de, ae = dl(layers(d, "de__x_dot")), dl(layers(d, "ae__i_calculator"))
+    t, x, z, v, i = (T(d[k]).cuda().permute(1, 0, 2) for k in ("t", "x", "z", "v", "i"))
+    xi, a0 = T(d["x_init"]).cuda(), T(d["all_initial"]).cuda()
+    one_x, one_i = f.dae_integrate("rk4", de, ae, xi, t, x, z, v, i, a0)
+    Tn, B = t.shape[0], t.shape[1]
+    xs, is_ = torch.empty(Tn, B, 8, device="cuda"), torch.empty(Tn, B, 2, device="cuda")
+    bnd = sharded.chunk_bounds(Tn, 3)
+    for c in range(3):
+        s, r1 = max(bnd[c] - 1, 0), bnd[c + 1]
+        f.dae_integrate("rk4", de, ae, xi if c == 0 else xs[s], t[s:r1], x[s:r1], z[s:r1], v[s:r1], i[s:r1], a0, out=(xs[s:r1], is_[s:r1]))
+    assert torch.equal(xs, one_x) and torch.equal(is_, one_i)
+
+
 def test_batch_permutation_equivariance_full_size():
     B, Tn = 4096, 201
     ls, t, x, z, a0 = _synthetic_ode(B, Tn, seed=2)

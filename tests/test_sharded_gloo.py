@@ -14,10 +14,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _oracle_local(method, de, t, x, z, a0, z_jump=None, input_true_x=False, event_idx=None):
+def _oracle_local(method, de, t, x, z, a0, z_jump=None, input_true_x=False, event_idx=None, out=None):
     """Oracle driven by an explicit per-step event table (what the sharded wrapper hands every rank)."""
     from oracle import psnode_oracle as O
-    xs = torch.zeros(x.shape)
+    xs = torch.zeros(t.shape[0], x.shape[1], x.shape[2])
     cur = x[0]
     xs[0] = cur
     for k in range(t.shape[0] - 1):
@@ -27,6 +27,9 @@ def _oracle_local(method, de, t, x, z, a0, z_jump=None, input_true_x=False, even
         src = x[k] if input_true_x else cur
         cur, _ = O.step(method, lambda xx: O.de_rhs(de, xx, (zk,), a0), t[k], t[k + 1] - t[k], t[k + 1], src)
         xs[k + 1] = cur
+    if out is not None:
+        out.copy_(xs)
+        return out
     return xs
 
 
@@ -54,6 +57,12 @@ def _worker(rank, world, port, q):
         out = sharded.integrate_ode_sharded("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_t=ev[lo:hi], z_jump=zj[lo:hi],
                                             local_fn=_oracle_local, table_fn=_table)
         ref = T(d["rk4_events"]).clone()
+        # time-chunked + pipelined gather: same numbers, reassembled from the chunk-major buffers
+        tab = sharded.broadcast_event_table(tl, ev[lo:hi], table_fn=_table)
+        xs_l, gathered = sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab,
+                                                         z_jump=zj[lo:hi], chunks=3, local_fn=_oracle_local)
+        assert torch.equal(sharded.assemble(gathered, tl.shape[0]), out), "pipelined gather differs from the one-shot gather"
+        assert sharded.chunk_bounds(1001, 4) == [0, 250, 500, 751, 1001] and sharded.chunk_bounds(2, 4) == [0, 1, 2]
         if rank == 0:
             # trajectory `B/2` (rank 1's first) was integrated with the shifted clock but identical dt -> same result
             q.put((tuple(out.shape), float((out - ref).abs().max())))
