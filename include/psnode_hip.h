@@ -160,6 +160,39 @@ int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* mlp);
 int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, float* out,
                             int64_t out_row_stride, void* stream);
 
+/* Backward (discretise-then-optimise) pass through psnode_ode_integrate_f32: what loss.backward() computes when it
+ * walks the unrolled T-step autograd graph of integrate_ODE (neural_00_ODE_01_no_encode.py:358-360 through
+ * my_solvers.py:66-78), in one launch.  Inputs: the forward arguments, the forward result xs and dL/dxs.
+ * Outputs: dL/dx[0], dL/dz (per grid point; steps that took a jump put their gradient into grad_z_jump instead),
+ * dL/dall_initial and dL/d(parameters) as ONE flat vector in nn.Linear order
+ * [W1 (64 x 3n), b1, W2, b2, W3, b3, W4 (x_dim x 64), b4] (psnode_ode_backward_param_count floats).
+ * Supported: the MFMA shape class (3n -> 64 -> 64 -> 64 -> x_dim, x_dim <= 8, z_dim <= 4), no teacher forcing;
+ * t carries no gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
+typedef struct {
+    int32_t method;
+    int32_t x_dim, z_dim;
+    int64_t T, B;
+    psnode_mlp_f32 de;
+    psnode_view_f32 t, z;
+    const float* all_initial;        /* [B, x+z] contiguous */
+    const int32_t* event_idx;        /* as in the forward call, or NULL */
+    const float* z_jump;
+    int64_t zj_stride_b, zj_stride_e;
+    int32_t n_events;
+    const float* xs;                 /* forward result [T,B,x_dim] contiguous */
+    const float* grad_xs;            /* dL/dxs         [T,B,x_dim] contiguous */
+    float* grad_x0;                  /* [B,x_dim] */
+    float* grad_z;                   /* [T,B,z_dim] contiguous, or NULL */
+    float* grad_z_jump;              /* [B,n_events,z_dim] contiguous, zero-initialised by the caller, or NULL */
+    float* grad_all_initial;         /* [B, x+z] */
+    float* grad_params;              /* flat, psnode_ode_backward_param_count() floats */
+} psnode_ode_bwd_args_f32;
+
+int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* args);
+int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* args);
+size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* args);
+int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);

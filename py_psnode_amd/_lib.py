@@ -23,6 +23,8 @@ EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
     "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
+    "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
+    "psnode_ode_backward_f32",
 )
 
 
@@ -59,6 +61,14 @@ class DaeArgsF32(ctypes.Structure):
                 ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
                 ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64),
                 ("x_out", c_void_p), ("i_out", c_void_p)]
+
+
+class OdeBwdArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64), ("de", MlpF32),
+                ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
+                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("n_events", c_int32), ("xs", c_void_p), ("grad_xs", c_void_p),
+                ("grad_x0", c_void_p), ("grad_z", c_void_p), ("grad_z_jump", c_void_p), ("grad_all_initial", c_void_p),
+                ("grad_params", c_void_p)]
 
 
 _lib = None
@@ -99,6 +109,14 @@ def load():
     lib.psnode_mlp_rows_supported.argtypes = [ctypes.POINTER(MlpF32)]
     lib.psnode_mlp_rows_f32.restype = c_int32
     lib.psnode_mlp_rows_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.psnode_ode_backward_supported.restype = c_int32
+    lib.psnode_ode_backward_supported.argtypes = [ctypes.POINTER(OdeBwdArgsF32)]
+    lib.psnode_ode_backward_param_count.restype = c_int64
+    lib.psnode_ode_backward_param_count.argtypes = [ctypes.POINTER(OdeBwdArgsF32)]
+    lib.psnode_ode_backward_workspace_bytes.restype = c_size_t
+    lib.psnode_ode_backward_workspace_bytes.argtypes = [ctypes.POINTER(OdeBwdArgsF32)]
+    lib.psnode_ode_backward_f32.restype = c_int32
+    lib.psnode_ode_backward_f32.argtypes = [ctypes.POINTER(OdeBwdArgsF32), c_void_p, c_size_t, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

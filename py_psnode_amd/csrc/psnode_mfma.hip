@@ -26,103 +26,17 @@
 // External inputs are prefetched one step ahead straight from the caller's strided (B-major) memory.
 #include <type_traits>
 
-#include "psnode_common.h"
+#include "psnode_pack.h"
 
 namespace psnode {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int HID = 64;
-constexpr int NW = HID / 16;   // waves per workgroup
-constexpr int TBM = 16;        // trajectories per workgroup
-constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8
-constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <= 16
-
-// Register image of one packed MLP, per (wave, lane): pack[wave][reg][lane].
-// DE: W1A = columns of the `s` block (x dims), W1B = columns of the `s-a0` block (x dims), W1E = NE ext registers.
-// AE: W1A = columns of x, W1B unused (count 0), W1E = NE registers of the z|v columns.
-template <int NX, int NB, int NE>
-struct Regs {
-    static constexpr int W1A = 0;
-    static constexpr int W1B = NX;
-    static constexpr int W1E = NX + NB;
-    static constexpr int B1 = W1E + NE;
-    static constexpr int W2 = B1 + 4;         // (16) chunk c = source wave (w+c)&3
-    static constexpr int B2 = W2 + 16;
-    static constexpr int W3 = B2 + 4;
-    static constexpr int B3 = W3 + 16;
-    static constexpr int W4 = B3 + 4;         // (4) this wave's K quarter
-    static constexpr int B4 = W4 + 4;
-    static constexpr int COUNT = B4 + 4;      // followed by NA registers of the a0 columns of L1
-};
-constexpr int kMaxRegs = 2 * kNXc + kMaxNZM + 52;
-
-// ext slot q -> index into ext = z | v | i, or -1 (padding)
-__host__ __device__ inline int slot_ext(int q, int ne) { return q < ne ? q : (q < 2 * ne ? q - ne : -1); }
-
-struct PackMfma {
-    int ae;                 // 0: DE image, 1: AE image
-    int xd, ne, n, nzv;     // ne = z+v+i (DE ext), n = xd+ne, nzv = z+v
-    int NX, NB, NE, NA;
-    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
-    int out_dim;            // x_dim (DE) or i_dim (AE)
-    float* out;
-};
-
 __global__ void pack_mfma_kernel(const PackMfma p) {
-    const int W1B = p.NX, W1E = p.NX + p.NB, B1 = W1E + p.NE, W2 = B1 + 4, B2 = W2 + 16, W3 = B2 + 4, B3 = W3 + 16, W4 = B3 + 4,
-              B4 = W4 + 4, COUNT = B4 + 4;
-    const int R = COUNT + p.NA;
-    const int K1 = p.ae ? p.n + p.xd + p.nzv : 3 * p.n;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NW * R * 64; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, reg = (idx >> 6) % R, w = (idx >> 6) / R;
-        const int i = lane & 15, g = lane >> 4, u = 16 * w + i;
-        float v = 0.0f;
-        if (reg < W1B) {                      // x columns: DE `s` block / AE x block
-            const int d = 4 * reg + g;
-            if (d < p.xd) v = p.w1[u * K1 + (p.ae ? p.n : 2 * p.n) + d];
-        } else if (reg < W1E) {               // DE `s - a0` block, x dims
-            const int d = 4 * (reg - W1B) + g;
-            if (d < p.xd) v = p.w1[u * K1 + p.n + d];
-        } else if (reg < B1) {                // external-input columns
-            const int q = 4 * (reg - W1E) + g;
-            if (p.ae) {
-                if (q < p.nzv) v = p.w1[u * K1 + p.n + p.xd + q];
-            } else {
-                if (q < p.ne) v = p.w1[u * K1 + p.n + p.xd + q];
-                else if (q < 2 * p.ne) v = p.w1[u * K1 + 2 * p.n + p.xd + (q - p.ne)];
-            }
-        } else if (reg < W2) {
-            v = p.b1[16 * w + 4 * g + (reg - B1)];
-        } else if (reg < B2) {
-            const int kk = reg - W2, ws = (w + (kk >> 2)) & 3;
-            v = p.w2[u * HID + 16 * ws + 4 * g + (kk & 3)];
-        } else if (reg < W3) {
-            v = p.b2[16 * w + 4 * g + (reg - B2)];
-        } else if (reg < B3) {
-            const int kk = reg - W3, ws = (w + (kk >> 2)) & 3;
-            v = p.w3[u * HID + 16 * ws + 4 * g + (kk & 3)];
-        } else if (reg < W4) {
-            v = p.b3[16 * w + 4 * g + (reg - B3)];
-        } else if (reg < COUNT) {
-            // output row rho = 4*gr + rr (A operand: rho = i; bias in D layout: gr = g, rr = reg - B4)
-            const bool bias = reg >= B4;
-            const int gr = bias ? g : (i >> 2), rr = bias ? reg - B4 : (i & 3);
-            int o;                            // which output the row carries, -1 = none
-            if (p.ae) {                       // row (gr, m) <- the i-dim DE ext slot q = 4m+gr needs
-                const int e = slot_ext(4 * rr + gr, p.ne);
-                o = e >= p.nzv ? e - p.nzv : -1;
-            } else {                          // row (gr, rr) <- x-dim 4*rr+gr
-                o = 4 * rr + gr;
-            }
-            if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * HID + 16 * w + 4 * g + (reg - W4)];
-        } else {
-            const int q = 4 * (reg - COUNT) + g;
-            if (q < p.n) v = p.w1[u * K1 + q];
-        }
-        p.out[idx] = v;
-    }
+    const int R = pack_fwd_count(p);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NW * R * 64; idx += gridDim.x * blockDim.x)
+        p.out[idx] = pack_fwd_value(p, (idx >> 6) / R, (idx >> 6) % R, idx & 63);
 }
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

@@ -1,0 +1,100 @@
+// Packed register images of the MFMA kernels: shared by the forward kernels (psnode_mfma.hip) and the backward
+// kernel (psnode_backward.hip).  pack[wave][reg][lane]; lane l: i = l&15 (A-operand row / B-operand column),
+// g = l>>4 (k-slot of A and B operands, row group of D).
+#pragma once
+#include "psnode_common.h"
+
+namespace psnode {
+
+constexpr int HID = 64;
+constexpr int NW = HID / 16;   // waves per workgroup
+constexpr int TBM = 16;        // trajectories per workgroup
+constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8
+constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <= 16
+
+// Forward image of one MLP.
+// DE: W1A = columns of the `s` block (x dims), W1B = columns of the `s-a0` block (x dims), W1E = NE ext registers.
+// AE: W1A = columns of x, W1B unused (count 0), W1E = NE registers of the z|v columns.
+template <int NX, int NB, int NE>
+struct Regs {
+    static constexpr int W1A = 0;
+    static constexpr int W1B = NX;
+    static constexpr int W1E = NX + NB;
+    static constexpr int B1 = W1E + NE;
+    static constexpr int W2 = B1 + 4;         // (16) chunk c = source wave (w+c)&3
+    static constexpr int B2 = W2 + 16;
+    static constexpr int W3 = B2 + 4;
+    static constexpr int B3 = W3 + 16;
+    static constexpr int W4 = B3 + 4;         // (4) this wave's K quarter
+    static constexpr int B4 = W4 + 4;
+    static constexpr int COUNT = B4 + 4;      // followed by NA registers of the a0 columns of L1
+};
+constexpr int kMaxRegs = 2 * kNXc + kMaxNZM + 52;
+
+// ext slot q -> index into ext = z | v | i, or -1 (padding)
+__host__ __device__ inline int slot_ext(int q, int ne) { return q < ne ? q : (q < 2 * ne ? q - ne : -1); }
+
+struct PackMfma {
+    int ae;                 // 0: DE image, 1: AE image
+    int xd, ne, n, nzv;     // ne = z+v+i (DE ext), n = xd+ne, nzv = z+v
+    int NX, NB, NE, NA;
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+    int out_dim;            // x_dim (DE) or i_dim (AE)
+    float* out;
+};
+
+__host__ __device__ inline int pack_fwd_count(const PackMfma& p) { return p.NX + p.NB + p.NE + 52 + p.NA; }
+
+// value of forward-image register `reg` (0 .. pack_fwd_count) for wave w, lane `lane`
+__device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int lane) {
+    const int W1B = p.NX, W1E = p.NX + p.NB, B1 = W1E + p.NE, W2 = B1 + 4, B2 = W2 + 16, W3 = B2 + 4, B3 = W3 + 16, W4 = B3 + 4,
+              B4 = W4 + 4, COUNT = B4 + 4;
+    const int K1 = p.ae ? p.n + p.xd + p.nzv : 3 * p.n;
+    const int i = lane & 15, g = lane >> 4, u = 16 * w + i;
+    float v = 0.0f;
+    if (reg < W1B) {                      // x columns: DE `s` block / AE x block
+        const int d = 4 * reg + g;
+        if (d < p.xd) v = p.w1[u * K1 + (p.ae ? p.n : 2 * p.n) + d];
+    } else if (reg < W1E) {               // DE `s - a0` block, x dims
+        const int d = 4 * (reg - W1B) + g;
+        if (d < p.xd) v = p.w1[u * K1 + p.n + d];
+    } else if (reg < B1) {                // external-input columns
+        const int q = 4 * (reg - W1E) + g;
+        if (p.ae) {
+            if (q < p.nzv) v = p.w1[u * K1 + p.n + p.xd + q];
+        } else {
+            if (q < p.ne) v = p.w1[u * K1 + p.n + p.xd + q];
+            else if (q < 2 * p.ne) v = p.w1[u * K1 + 2 * p.n + p.xd + (q - p.ne)];
+        }
+    } else if (reg < W2) {
+        v = p.b1[16 * w + 4 * g + (reg - B1)];
+    } else if (reg < B2) {
+        const int kk = reg - W2, ws = (w + (kk >> 2)) & 3;
+        v = p.w2[u * HID + 16 * ws + 4 * g + (kk & 3)];
+    } else if (reg < W3) {
+        v = p.b2[16 * w + 4 * g + (reg - B2)];
+    } else if (reg < B3) {
+        const int kk = reg - W3, ws = (w + (kk >> 2)) & 3;
+        v = p.w3[u * HID + 16 * ws + 4 * g + (kk & 3)];
+    } else if (reg < W4) {
+        v = p.b3[16 * w + 4 * g + (reg - B3)];
+    } else if (reg < COUNT) {
+        // output row rho = 4*gr + rr (A operand: rho = i; bias in D layout: gr = g, rr = reg - B4)
+        const bool bias = reg >= B4;
+        const int gr = bias ? g : (i >> 2), rr = bias ? reg - B4 : (i & 3);
+        int o;                            // which output the row carries, -1 = none
+        if (p.ae) {                       // row (gr, m) <- the i-dim DE ext slot q = 4m+gr needs
+            const int e = slot_ext(4 * rr + gr, p.ne);
+            o = e >= p.nzv ? e - p.nzv : -1;
+        } else {                          // row (gr, rr) <- x-dim 4*rr+gr
+            o = 4 * rr + gr;
+        }
+        if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * HID + 16 * w + 4 * g + (reg - W4)];
+    } else {
+        const int q = 4 * (reg - COUNT) + g;
+        if (q < p.n) v = p.w1[u * K1 + q];
+    }
+    return v;
+}
+
+}  // namespace psnode

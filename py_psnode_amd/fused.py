@@ -269,6 +269,68 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
     return xs, is_
 
 
+def _bwd_args(method, de_layers, x_dim, z_dim, T, B, dev, keep):
+    a = _lib.OdeBwdArgsF32()
+    a.method = METHOD_ID[method]
+    a.x_dim, a.z_dim, a.T, a.B = x_dim, z_dim, T, B
+    a.de = _mlp(de_layers, dev, "de", keep)
+    return a
+
+
+def ode_backward_supported(method: str, de_layers: Layers, x_dim: int, z_dim: int) -> bool:
+    """True if the fused backward kernel covers this shape (the MFMA class: 3n->64->64->64->x, x<=8, z<=4)."""
+    if len(de_layers) != 4 or de_layers[0][0].device.type != "cuda":
+        return False
+    lib = _lib.load()
+    a = _bwd_args(method, de_layers, x_dim, z_dim, 2, 1, de_layers[0][0].device, [])
+    return bool(lib.psnode_ode_backward_supported(ctypes.byref(a)))
+
+
+def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True):
+    """Backward pass of `ode_integrate` (input_true_x=False) in one launch.
+    Returns (grad_x0 [B,xd], grad_z [T,B,zd] | None, grad_z_jump | None, grad_all_initial [B,n], [grad W1, b1, ..., W4, b4])."""
+    lib = _lib.load()
+    dev = xs.device
+    T, B, xd = xs.shape
+    zd = z.shape[-1]
+    keep: list = []
+    a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep)
+    a.t = _view(t, dev, "t", keep)
+    a.z = _view(z, dev, "z", keep)
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    xs_c = _f32_dev(xs, dev, "xs").contiguous()
+    g_c = _f32_dev(grad_xs, dev, "grad_xs").contiguous()
+    keep += [a0, xs_c, g_c]
+    a.all_initial, a.xs, a.grad_xs = a0.data_ptr(), xs_c.data_ptr(), g_c.data_ptr()
+    gzj = None
+    if event_idx is not None:
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+        if z_jump is not None and zd > 0:
+            a.n_events = z_jump.shape[1]
+            gzj = torch.zeros((B, z_jump.shape[1], zd), dtype=torch.float32, device=dev)
+            a.grad_z_jump = gzj.data_ptr()
+    with torch.cuda.device(dev):
+        gx0 = torch.empty((B, xd), dtype=torch.float32, device=dev)
+        ga0 = torch.empty((B, xd + zd), dtype=torch.float32, device=dev)
+        gz = torch.empty((T, B, zd), dtype=torch.float32, device=dev) if (need_grad_z and zd > 0) else None
+        npar = lib.psnode_ode_backward_param_count(ctypes.byref(a))
+        gpar = torch.empty(npar, dtype=torch.float32, device=dev)
+        a.grad_x0, a.grad_all_initial, a.grad_params = gx0.data_ptr(), ga0.data_ptr(), gpar.data_ptr()
+        a.grad_z = gz.data_ptr() if gz is not None else None
+        nbytes = lib.psnode_ode_backward_workspace_bytes(ctypes.byref(a))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_ode_backward_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_ode_backward_f32")
+    grads, off = [], 0
+    for w, b in de_layers:
+        grads.append(gpar[off:off + w.numel()].view_as(w)); off += w.numel()
+        grads.append(gpar[off:off + b.numel()].view_as(b)); off += b.numel()
+    return gx0, gz, gzj, ga0, grads
+
+
 def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     """Fused `nn.Sequential(Linear, ELU, Linear)` over the last dim of `inp` (any leading shape) on the HIP row kernel:
     the encoders / decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:64-69)."""
@@ -327,7 +389,7 @@ def _needs_autograd(tensors) -> bool:
 
 
 def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
-    """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump)."""
+    """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump, needs_autograd)."""
     if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 3 or z.dim() != 3:
         return None
     xd, zd = x.shape[-1], z.shape[-1]
@@ -339,9 +401,8 @@ def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
     ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
     if not ok:
         return None
-    if _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb]):
-        return None
-    return layers, event_t, z_jump
+    needs_grad = _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb])
+    return layers, event_t, z_jump, needs_grad
 
 
 def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn):

@@ -69,12 +69,17 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
         if self.fused != "off":
             plan = _fused.plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn)
             if plan is not None:
-                layers, event_t, z_jump = plan
-                return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
-                                            input_true_x=input_true_x, kernel=self.kernel)
+                layers, event_t, z_jump, needs_grad = plan
+                if not needs_grad:
+                    return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
+                                                input_true_x=input_true_x, kernel=self.kernel)
+                # training: fused forward + fused backward when the backward kernel covers the shape
+                if not input_true_x and _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1]):
+                    from ..autograd import fused_ode_integrate
+                    return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump)
             if self.fused == "require":
-                raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style "
-                                      "ELU-MLP `x_dot`, ODE_Event callbacks and no autograd)")
+                raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style ELU-MLP "
+                                      "`x_dot`, ODE_Event callbacks; with autograd: the 3n-64-64-64-x shape class, no teacher forcing)")
         return self._walk_ode(x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x)
 
     def _walk_ode(self, x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x):

@@ -1,0 +1,116 @@
+"""Gradients of the fused backward kernel vs an fp64 autograd walk of the same algorithm (the reference's training path:
+loss.backward() through integrate_ODE).  Tolerance: 2e-4 of each gradient tensor's max magnitude (fp32 accumulation over
+steps x stages x trajectories against an fp64 truth)."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _case(B, Tn, xd, zd, seed, events):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    n = xd + zd
+    dims = [3 * n, 64, 64, 64, xd]
+    lin = [nn.Linear(dims[k], dims[k + 1]) for k in range(4)]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    if B > 1:
+        t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g))
+    x = 0.1 * torch.randn(Tn, B, xd, generator=g)
+    z = 0.1 * torch.randn(Tn, B, zd, generator=g)
+    ev = torch.stack([t[2, :, :], t[Tn - 3, :, :]], dim=1).contiguous() if events else None
+    zj = 0.1 * torch.randn(B, 2, zd, generator=g) if events else None
+    G = torch.randn(Tn, B, xd, generator=g)
+    return lin, t, x, z, ev, zj, G
+
+
+def _truth(method, lin, t, x, z, ev, zj, G):
+    """fp64 autograd through the callback walk (py_psnode_amd's own generic loop == the reference's loop)."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    xd, zd = x.shape[-1], z.shape[-1]
+    de = models.DE_Func(xd + zd, (64, 64, 64), xd).double()
+    with torch.no_grad():
+        for k, l in enumerate(lin):
+            de.x_dot[2 * k].weight.copy_(l.weight.double())
+            de.x_dot[2 * k].bias.copy_(l.bias.double())
+    solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+    solver.fused = "off"
+    xq, zq = x.double().requires_grad_(True), z.double().requires_grad_(True)
+    zjq = zj.double().requires_grad_(True) if zj is not None else None
+    event = nd.ODE_Event()
+    if ev is not None:
+        event.set_event(ev.double(), zjq)
+    a0 = torch.cat((xq[0], zq[0]), -1)
+    xs = solver.integrate_ODE(x_func=de, t=t.double(), x=xq, z=zq, all_initial=a0, event_fn=event.event_fn if ev is not None else None,
+                              jump_change_fn=event.jump_change_fn if ev is not None else None)
+    (xs * G.double()).sum().backward()
+    return xs.detach(), xq.grad, zq.grad, (zjq.grad if zjq is not None else None), [p.grad for p in de.x_dot.parameters()]
+
+
+def _close(a, b, what):
+    scale = float(b.abs().max())
+    err = float((a.double().cpu() - b).abs().max())
+    assert err <= TOL * max(scale, 1e-6), f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("xd,zd,events", [(8, 2, True), (8, 2, False), (5, 3, True), (3, 0, False), (8, 4, True)])
+def test_fused_backward_matches_fp64_autograd(method, xd, zd, events):
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    B, Tn = 21, 12
+    lin, t, x, z, ev, zj, G = _case(B, Tn, xd, zd, seed=100 + xd * 10 + zd, events=events)
+    xs_ref, gx_ref, gz_ref, gzj_ref, gp_ref = _truth(method, lin, t, x, z, ev, zj, G)
+
+    de = models.DE_Func(xd + zd, (64, 64, 64), xd)
+    with torch.no_grad():
+        for k, l in enumerate(lin):
+            de.x_dot[2 * k].weight.copy_(l.weight)
+            de.x_dot[2 * k].bias.copy_(l.bias)
+    de = de.cuda()
+    solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+    solver.fused = "require"                      # training must take the fused forward + fused backward route
+    xg, zg = x.cuda().requires_grad_(True), z.cuda().requires_grad_(True)
+    zjg = zj.cuda().requires_grad_(True) if zj is not None else None
+    event = nd.ODE_Event()
+    if ev is not None:
+        event.set_event(ev.cuda(), zjg)
+    a0 = torch.cat((xg[0], zg[0]), -1)
+    xs = solver.integrate_ODE(x_func=de, t=t.cuda(), x=xg, z=zg, all_initial=a0, event_fn=event.event_fn if ev is not None else None,
+                              jump_change_fn=event.jump_change_fn if ev is not None else None)
+    assert xs.grad_fn is not None and type(xs.grad_fn).__name__.startswith("_FusedOde")
+    (xs * G.cuda()).sum().backward()
+    _close(xs.detach(), xs_ref, "xs")
+    _close(xg.grad, gx_ref, "grad x")           # only x[0] gets gradient (directly and through all_initial)
+    if zd:
+        _close(zg.grad, gz_ref, "grad z")
+        if zj is not None:
+            _close(zjg.grad, gzj_ref, "grad z_jump")
+    for k, (p, r) in enumerate(zip(de.x_dot.parameters(), gp_ref)):
+        _close(p.grad, r, f"grad param {k}")
+
+
+def test_training_step_of_the_script_model_runs_fused():
+    """ODE_Model forward + masked MSE + backward + Adam step on the GPU (the scripts' train loop body) on the fused route."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(0)
+    m = models.ODE_Model(8, 2, 64, solver=nd.RK4()).cuda()
+    m.solver.fused = "require"
+    B, Tn = 64, 50
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1).cuda()
+    x, z = (0.1 * torch.randn(B, Tn, 8)).cuda(), (0.1 * torch.randn(B, Tn, 2)).cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    losses = []
+    for _ in range(5):
+        pred = m(t=t, x=x, z=z, event_t=torch.full((B, 1, 1), -1.0).cuda(), z_jump=torch.zeros(B, 1, 2).cuda())
+        loss = nn.functional.mse_loss(pred, x)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert losses[-1] < losses[0]
