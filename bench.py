@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--grid", type=int, default=None, help="override grid points T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
+    ap.add_argument("--train", action="store_true", help="time forward + backward (fused autograd route) instead of the forward alone")
+    ap.add_argument("--train-baseline-steps", type=int, default=0,
+                    help="with --train: also time the unrolled PyTorch-autograd walk on the GPU for this many grid steps")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap)")
     args = ap.parse_args()
@@ -242,10 +245,31 @@ def main():
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
         gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
 
+    train_state = {}
+    if args.train:
+        assert w["kind"] == "ode", "--train covers the ODE workload"
+        from py_psnode_amd import autograd as pag
+        train_state["params"] = [q.clone().requires_grad_(True) for wb in p["de"] for q in wb]
+        train_state["layers"] = [(train_state["params"][k], train_state["params"][k + 1]) for k in range(0, 8, 2)]
+        train_state["G"] = torch.randn(T, B, w["xd"], device=dev)
+
+    def train_step():
+        for q in train_state["params"]:
+            q.grad = None
+        xs = pag.fused_ode_integrate(args.method, args.kernel, train_state["layers"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
+                                     p["event_t"], p["z_jump"])
+        (xs * train_state["G"]).sum().backward()
+        return (xs.detach(),)
+
     def one_step(ev_pair=None):
         """One pass of the hot path (+ the all-gather at N>1).  ev_pair brackets the compute-stream kernels only."""
         if ev_pair:
             ev_pair[0].record()
+        if args.train:
+            outs = train_step()
+            if ev_pair:
+                ev_pair[1].record()
+            return outs
         if pipelined:
             tab = fused.event_table(tmv(p["t"]), p["event_t"])
             xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
@@ -289,6 +313,8 @@ def main():
     finite = bool(torch.isfinite(outs[0]).all())
     state_steps_launch = B * (T - 1)
     flops = flops_per_state_step(w, p_cpu, args.method)
+    if args.train:
+        flops *= 3   # forward + recomputed forward... counted as the usual fwd + 2x bwd GEMM work (data + weight gradients)
     bts = bytes_per_state_step(w)
     value = world * state_steps_launch * args.steps / elapsed
     ach_tf = flops * state_steps_launch / (kern_avg_ms * 1e-3) / 1e12
@@ -333,6 +359,26 @@ def main():
                          "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_state_step": bts},
         }
+        if args.train:
+            res["metric"] = f"training state-steps/sec (forward + backward), {args.workload} {args.method}, batch {B}"
+            res["config"]["workload"] += " | forward + fused backward (sum-weighted loss)"
+            if args.train_baseline_steps > 0:
+                # the route the reference's scripts take: unrolled autograd through the per-step Python loop, on this GPU
+                from py_psnode_amd import models
+                from py_psnode_amd import neural_dae as nd
+                Ts = args.train_baseline_steps + 1
+                de = models.DE_Func(w["xd"] + w["zd"], (w["H"],) * w["nh"], w["xd"]).to(dev)
+                solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[args.method]()
+                solver.fused = "off"
+                def walk():
+                    de.zero_grad()
+                    xs = solver.integrate_ODE(x_func=de, t=tmv(p["t"])[:Ts], x=tmv(p["x"])[:Ts], z=tmv(p["z"])[:Ts], all_initial=p["a0"])
+                    (xs * train_state["G"][:Ts]).sum().backward()
+                walk(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter(); walk(); torch.cuda.synchronize(dev)
+                dtw = time.perf_counter() - t0
+                res["autograd_walk_gpu"] = {"value": B * (Ts - 1) / dtw, "unit": "state-steps/s", "sample": f"{Ts - 1} steps, unrolled PyTorch autograd on the same GPU",
+                                            "fused_over_walk": value / (B * (Ts - 1) / dtw)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
