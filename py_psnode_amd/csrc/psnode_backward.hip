@@ -249,23 +249,46 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     float ga0z = 0.f;
     f2 gcarry = {0.f, 0.f};
 
-    for (long long k = nT - 2; k >= 0; --k) {
-        // ---- inputs of step k
-        const float h_ = tp[(k + 1) * tst] - tp[k * tst];
-        const int ev = a.ev ? a.ev[k] : -1;
-        float extv[NZM > 0 ? NZM : 1];
-        {
-            const float* src = ev >= 0 ? zjp + ev * zje : zp + k * zst;
+    // inputs of a step, prefetched one iteration ahead (the sweep runs k = T-2 .. 0)
+    auto load_ext = [&](long long k, int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
+        const float* src = ev >= 0 ? zjp + ev * zje : zp + k * zst;
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) extv[m] = 4 * m + g < 2 * ne ? src[eidx[m]] : 0.0f;
-        }
-        float x0[NX];
-        f2 g1 = gcarry;
+        for (int m = 0; m < NZM; ++m) dst[m] = 4 * m + g < 2 * ne ? src[eidx[m]] : 0.0f;
+    };
+    auto load_state = [&](long long k, float (&xk)[NX], float (&gk1)[NX]) {   // xs[k] and dL/dxs[k+1]
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
             const bool on = 4 * r + g < xd;
-            x0[r] = on ? d.xs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
-            g1[r] += (on && valid) ? d.gout[((k + 1) * a.B + b) * xd + 4 * r + g] : 0.0f;
+            xk[r] = on ? d.xs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
+            gk1[r] = (on && valid) ? d.gout[((k + 1) * a.B + b) * xd + 4 * r + g] : 0.0f;
+        }
+    };
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int* evp = a.ev + lane_zero;                    // per-lane load: the value stays in a VGPR until it is used
+    float t_hi = nT >= 2 ? tp[(nT - 1) * tst] : 0.0f, t_lo = nT >= 2 ? tp[(nT - 2) * tst] : 0.0f;
+    int ev_cur = (a.ev && nT >= 2) ? a.ev[nT - 2] : -1;
+    int ev_n1 = (a.ev && nT >= 3) ? evp[nT - 3] : -1;
+    float ext_n[NZM > 0 ? NZM : 1] = {}, x_n[NX] = {}, g_n[NX] = {};
+    if (nT >= 2) { load_ext(nT - 2, ev_cur, ext_n); load_state(nT - 2, x_n, g_n); }
+
+    for (long long k = nT - 2; k >= 0; --k) {
+        // ---- inputs of step k (already in registers); issue the loads of step k-1
+        const float h_ = t_hi - t_lo;
+        const int ev = ev_cur;
+        float extv[NZM > 0 ? NZM : 1], x0[NX];
+        f2 g1 = gcarry;
+#pragma unroll
+        for (int m = 0; m < (NZM > 0 ? NZM : 1); ++m) extv[m] = ext_n[m];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { x0[r] = x_n[r]; g1[r] += g_n[r]; }
+        if (k >= 1) {
+            t_hi = t_lo;
+            t_lo = tp[(k - 1) * tst];
+            load_ext(k - 1, ev_n1, ext_n);
+            load_state(k - 1, x_n, g_n);
+            ev_cur = ev_n1;
+            ev_n1 = (a.ev && k >= 2) ? evp[k - 2] : -1;
         }
         f4 cz = c0;
 #pragma unroll

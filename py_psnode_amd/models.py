@@ -93,13 +93,16 @@ class ODE_Model(nn.Module):
             xs = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=_tm(x), z=_tm(z), all_initial=a0,
                                            event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
             return _tm(xs)
-        Xh = _tm(_rows(self.x_encoder, x))
+        Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view
+        Xh = _tm(Xh_bt)
         Zh = _tm(_rows(self.z_encoder, z))
         a0 = torch.cat((Xh[0], Zh[0]), dim=-1)
         self.event.set_event(t=event_t, z=_rows(self.z_encoder, z_jump))
         Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh, z=Zh, all_initial=a0,
                                            event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
-        return _tm(_rows(self.x_decoder, Xh_sol)), _tm(_rows(self.x_decoder, Xh))
+        # reconstruction: decoding the B-major tensor gives the same [B,T,xd] values as upstream's
+        # x_decoder(Xh).permute(1,0,2) without first materialising the permuted view
+        return _tm(_rows(self.x_decoder, Xh_sol)), _rows(self.x_decoder, Xh_bt)
 
 
 class DAE_Model(nn.Module):
@@ -139,7 +142,8 @@ class DAE_Model(nn.Module):
             return _tm(xs), _tm(is_)
         enc_z = (lambda a: a) if self.z_encoder is None else (lambda a: _rows(self.z_encoder, a))
         Xh0 = _rows(self.x_encoder, x0)
-        Xh, Zh, Vh, Ih = _tm(_rows(self.x_encoder, x)), _tm(enc_z(z)), _tm(_rows(self.v_encoder, v)), _tm(_rows(self.i_encoder, i))
+        Xh_bt, Ih_bt = _rows(self.x_encoder, x), _rows(self.i_encoder, i)
+        Xh, Zh, Vh, Ih = _tm(Xh_bt), _tm(enc_z(z)), _tm(_rows(self.v_encoder, v)), _tm(Ih_bt)
         a0 = torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), dim=-1)
         self.event.set_event(t=event_t, z=enc_z(z_jump), v=_rows(self.v_encoder, v_jump))
         Xh_sol, Ih_sol = self.solver.integrate_DAE(x_init=Xh0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=Xh,
@@ -147,4 +151,4 @@ class DAE_Model(nn.Module):
                                                    jump_change_fn=self.event.jump_change_fn)
         x_pred = _rows(self.x_decoder, Xh_sol)
         x_pred[0] = x0                                             # neural_01_DAE_02_direct_encode.py:150
-        return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _tm(_rows(self.x_decoder, Xh)), _tm(_rows(self.i_decoder, Ih))
+        return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _rows(self.x_decoder, Xh_bt), _rows(self.i_decoder, Ih_bt)
