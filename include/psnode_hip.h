@@ -166,10 +166,12 @@ int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float
  * Outputs: dL/dx[0], dL/dz (per grid point; steps that took a jump put their gradient into grad_z_jump instead),
  * dL/dall_initial and dL/d(parameters) as ONE flat vector in nn.Linear order
  * [W1 (64 x 3n), b1, W2, b2, W3, b3, W4 (x_dim x 64), b4] (psnode_ode_backward_param_count floats).
- * Supported: the MFMA shape class (3n -> 64 -> 64 -> 64 -> x_dim, x_dim <= 8, z_dim <= 4), no teacher forcing;
- * t carries no gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
+ * Kernels: the MFMA backward for the shape class 3n -> 64 -> 64 -> 64 -> x_dim (x_dim <= 8, z_dim <= 4), the generic
+ * backward for any MLP whose activations + parameter gradients fit the 160 KB LDS.  No teacher forcing; t carries no
+ * gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
 typedef struct {
     int32_t method;
+    int32_t kernel;                  /* psnode_kernel: AUTO = MFMA backward when the shape has one, else generic */
     int32_t x_dim, z_dim;
     int64_t T, B;
     psnode_mlp_f32 de;
@@ -192,6 +194,39 @@ int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* args);
 int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* args);
 size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* args);
 int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward pass through psnode_dae_integrate_f32 (no teacher forcing): loss.backward() through integrate_DAE
+ * (neural_01_DAE_01_no_encode.py:422-424 over my_solvers.py:94-129), including the AE head, the feedback of the
+ * algebraic variable into the DE input and the event-time recomputation i0 = g(x0; jumps).
+ * grad_params_de / grad_params_ae: flat nn.Linear-order vectors (psnode_dae_backward_param_counts). */
+typedef struct {
+    int32_t method;
+    int32_t x_dim, z_dim, v_dim, i_dim;
+    int64_t T, B;
+    psnode_mlp_f32 de, ae;
+    psnode_view_f32 t, z, v;
+    const float* all_initial;        /* [B, x+z+v+i] */
+    const int32_t* event_idx;
+    const float* z_jump; int64_t zj_stride_b, zj_stride_e;
+    const float* v_jump; int64_t vj_stride_b, vj_stride_e;
+    int32_t n_events;
+    const float* xs;                 /* forward results [T,B,x_dim], [T,B,i_dim] contiguous */
+    const float* is;
+    const float* grad_xs;            /* dL/dxs, dL/dis (grad_is may be NULL = zeros) */
+    const float* grad_is;
+    float* grad_x_init;              /* [B,x_dim] */
+    float* grad_z;                   /* [T,B,z_dim] or NULL */
+    float* grad_v;                   /* [T,B,v_dim] or NULL */
+    float* grad_z_jump;              /* [B,n_events,z_dim], zero-initialised by the caller, or NULL */
+    float* grad_v_jump;              /* [B,n_events,v_dim], zero-initialised by the caller, or NULL */
+    float* grad_all_initial;         /* [B, x+z+v+i] */
+    float* grad_params_de;
+    float* grad_params_ae;
+} psnode_dae_bwd_args_f32;
+
+int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* args);
+size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* args);
+int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);

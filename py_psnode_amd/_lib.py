@@ -24,7 +24,7 @@ EXPORTS = (
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
     "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
-    "psnode_ode_backward_f32",
+    "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
 )
 
 
@@ -64,11 +64,22 @@ class DaeArgsF32(ctypes.Structure):
 
 
 class OdeBwdArgsF32(ctypes.Structure):
-    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64), ("de", MlpF32),
-                ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
+    _fields_ = [("method", c_int32), ("kernel", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64),
+                ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("n_events", c_int32), ("xs", c_void_p), ("grad_xs", c_void_p),
                 ("grad_x0", c_void_p), ("grad_z", c_void_p), ("grad_z_jump", c_void_p), ("grad_all_initial", c_void_p),
                 ("grad_params", c_void_p)]
+
+
+class DaeBwdArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
+                ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("ae", MlpF32), ("t", ViewF32), ("z", ViewF32), ("v", ViewF32),
+                ("all_initial", c_void_p), ("event_idx", c_void_p),
+                ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
+                ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64), ("n_events", c_int32),
+                ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
+                ("grad_x_init", c_void_p), ("grad_z", c_void_p), ("grad_v", c_void_p), ("grad_z_jump", c_void_p),
+                ("grad_v_jump", c_void_p), ("grad_all_initial", c_void_p), ("grad_params_de", c_void_p), ("grad_params_ae", c_void_p)]
 
 
 _lib = None
@@ -117,6 +128,12 @@ def load():
     lib.psnode_ode_backward_workspace_bytes.argtypes = [ctypes.POINTER(OdeBwdArgsF32)]
     lib.psnode_ode_backward_f32.restype = c_int32
     lib.psnode_ode_backward_f32.argtypes = [ctypes.POINTER(OdeBwdArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_dae_backward_supported.restype = c_int32
+    lib.psnode_dae_backward_supported.argtypes = [ctypes.POINTER(DaeBwdArgsF32)]
+    lib.psnode_dae_backward_workspace_bytes.restype = c_size_t
+    lib.psnode_dae_backward_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdArgsF32)]
+    lib.psnode_dae_backward_f32.restype = c_int32
+    lib.psnode_dae_backward_f32.argtypes = [ctypes.POINTER(DaeBwdArgsF32), c_void_p, c_size_t, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

@@ -42,3 +42,51 @@ def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=No
         z_jump = None
     params = [p for wb in layers for p in wb]
     return _FusedOde.apply(method, kernel, event_idx, t, x[0], z, all_initial, z_jump, *params)
+
+
+class _FusedDae(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, method, kernel, event_idx, n_de, t, x_init, z, v, i_shape_like, all_initial, z_jump, v_jump, *params):
+        de = [(params[k], params[k + 1]) for k in range(0, 2 * n_de, 2)]
+        ae = [(params[k], params[k + 1]) for k in range(2 * n_de, len(params), 2)]
+        T, B = t.shape[0], t.shape[1]
+        x_dummy = x_init.new_zeros((1, B, 0))
+        xs, is_ = fused.dae_integrate(method, de, ae, x_init, t, x_dummy, z, v, i_shape_like, all_initial, z_jump=z_jump, v_jump=v_jump,
+                                      event_idx=event_idx, kernel=kernel)
+        ctx.method, ctx.n_de, ctx.event_idx = method, n_de, event_idx
+        ctx.has_zj, ctx.has_vj = z_jump is not None, v_jump is not None
+        ctx.save_for_backward(t, z, v, all_initial, xs, is_, *((z_jump,) if z_jump is not None else ()),
+                              *((v_jump,) if v_jump is not None else ()), *params)
+        return xs, is_
+
+    @staticmethod
+    def backward(ctx, grad_xs, grad_is):
+        sv = list(ctx.saved_tensors)
+        t, z, v, a0, xs, is_ = sv[:6]
+        k = 6
+        z_jump = sv[k] if ctx.has_zj else None
+        k += int(ctx.has_zj)
+        v_jump = sv[k] if ctx.has_vj else None
+        k += int(ctx.has_vj)
+        params = sv[k:]
+        de = [(params[q], params[q + 1]) for q in range(0, 2 * ctx.n_de, 2)]
+        ae = [(params[q], params[q + 1]) for q in range(2 * ctx.n_de, len(params), 2)]
+        g = fused.dae_backward(ctx.method, de, ae, t, z, v, a0, xs, is_, grad_xs, grad_is, event_idx=ctx.event_idx, z_jump=z_jump, v_jump=v_jump)
+        gz = g["z"] if g["z"] is not None else (torch.zeros_like(z) if ctx.needs_input_grad[6] else None)
+        gv = g["v"] if g["v"] is not None else (torch.zeros_like(v) if ctx.needs_input_grad[7] else None)
+        return (None, None, None, None, None, g["x_init"], gz, gv, None, g["all_initial"],
+                g["z_jump"] if ctx.needs_input_grad[10] else None, g["v_jump"] if ctx.needs_input_grad[11] else None, *g["de"], *g["ae"])
+
+
+def fused_dae_integrate(method, kernel, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None):
+    """Differentiable fused integrate_DAE (no teacher forcing): gradients flow to x_init, z, v, all_initial, the jump inputs and
+    both MLPs.  `i` only provides the width of the algebraic variable (the dataset values are unused without teacher forcing)."""
+    with torch.no_grad():
+        event_idx = fused.event_table(t, event_t)
+    if event_idx is None:
+        z_jump = v_jump = None
+    else:
+        z_jump = z_jump if (z_jump is not None and z_jump.shape[-1] > 0) else None
+        v_jump = v_jump if (v_jump is not None and v_jump.shape[-1] > 0) else None
+    params = [p for wb in list(de_layers) + list(ae_layers) for p in wb]
+    return _FusedDae.apply(method, kernel, event_idx, len(de_layers), t, x_init, z, v, i.detach(), all_initial, z_jump, v_jump, *params)

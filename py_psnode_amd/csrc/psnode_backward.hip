@@ -531,34 +531,63 @@ bool bwd_shape_ok(const psnode_ode_bwd_args_f32* a) {
 
 using namespace psnode;
 
+namespace {
+int generic_np(const psnode_mlp_f32& m) {
+    int np = 0, k = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) { np += m.out_dim[l] * (k + 1); k = m.out_dim[l]; }
+    return np;
+}
+bool ode_generic_ok(const psnode_ode_bwd_args_f32* a) {
+    const psnode_mlp_f32& m = a->de;
+    if (a->x_dim < 1 || a->z_dim < 0 || m.n_layers < 1 || m.n_layers > kMaxLayers) return false;
+    if (m.in_dim != 3 * (a->x_dim + a->z_dim) || m.out_dim[m.n_layers - 1] != a->x_dim) return false;
+    return generic_bwd_fits(&a->de, nullptr, a->x_dim, a->z_dim, 0, 0) != 0;
+}
+bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && bwd_shape_ok(a); }
+}  // namespace
+
 extern "C" int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* a) {
-    return a && a->method >= PSNODE_EULER && a->method <= PSNODE_RK4_38 && bwd_shape_ok(a);
+    if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
+    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a);
+    return use_mfma_bwd(a) || ode_generic_ok(a);
 }
 
 extern "C" int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* a) {
-    return a && bwd_shape_ok(a) ? bwd_np(a->x_dim, a->z_dim) : 0;
+    return a && a->de.n_layers >= 1 && a->de.n_layers <= kMaxLayers ? generic_np(a->de) : 0;
 }
 
 extern "C" size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* a) {
-    if (!a || !bwd_shape_ok(a)) return 0;
-    const int n = a->x_dim + a->z_dim;
-    const size_t pack = (size_t)NW * (kMaxRegs + (n + 3) / 4 + BWCOUNT) * 64;
-    const size_t nwg = (size_t)((a->B + TBM - 1) / TBM);
-    return (pack + nwg * bwd_np(a->x_dim, a->z_dim) + 64) * sizeof(float);
+    if (!a || !psnode_ode_backward_supported(a)) return 0;
+    size_t floats = generic_bwd_workspace_floats(&a->de, nullptr, a->B);
+    if (bwd_shape_ok(a)) {
+        const int n = a->x_dim + a->z_dim;
+        const size_t pack = (size_t)NW * (kMaxRegs + (n + 3) / 4 + BWCOUNT) * 64;
+        const size_t nwg = (size_t)((a->B + TBM - 1) / TBM);
+        const size_t f2 = pack + nwg * bwd_np(a->x_dim, a->z_dim) + 64;
+        floats = f2 > floats ? f2 : floats;
+    }
+    return floats * sizeof(float);
 }
 
 extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, void* workspace, size_t workspace_bytes, void* stream) {
     if (!a) return PSNODE_ERR_NULL;
     if (a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return PSNODE_ERR_METHOD;
     if (a->T < 1 || a->B < 1) return PSNODE_ERR_DIMS;
-    if (!bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;
-    for (int l = 0; l < 4; ++l) if (!a->de.weight[l] || !a->de.bias[l]) return PSNODE_ERR_NULL;
+    if (!psnode_ode_backward_supported(a)) return PSNODE_ERR_UNSUPPORTED;
+    for (int l = 0; l < a->de.n_layers; ++l) if (!a->de.weight[l] || !a->de.bias[l]) return PSNODE_ERR_NULL;
     if (!a->t.ptr || !a->all_initial || !a->xs || !a->grad_xs || !a->grad_x0 || !a->grad_all_initial || !a->grad_params) return PSNODE_ERR_NULL;
     if (a->z_dim > 0 && !a->z.ptr) return PSNODE_ERR_NULL;
     if (a->event_idx && a->z_dim > 0 && !a->z_jump) return PSNODE_ERR_NULL;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!use_mfma_bwd(a)) {
+        return generic_backward_launch(a->method, a->x_dim, a->z_dim, 0, 0, a->T, a->B, &a->de, nullptr,
+                                       ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},
+                                       ViewDev{nullptr, 0, 0}, a->all_initial, a->event_idx, a->z_jump, a->zj_stride_b, a->zj_stride_e, nullptr,
+                                       0, 0, a->n_events, a->xs, nullptr, a->grad_xs, nullptr, a->grad_x0, a->grad_z, nullptr, a->grad_z_jump,
+                                       nullptr, a->grad_all_initial, a->grad_params, nullptr, static_cast<float*>(workspace), s);
+    }
     const int xd = a->x_dim, zd = a->z_dim, n = xd + zd, NZM = bwd_nzm(zd), NA = (n + 3) / 4;
     float* pack = static_cast<float*>(workspace);
     float* wpart = pack + (size_t)NW * (kMaxRegs + NA + BWCOUNT) * 64;
@@ -590,4 +619,42 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     const int nwg = (int)((a->B + TBM - 1) / TBM);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((d.NP + 255) / 256), dim3(256), 0, s, wpart, a->grad_params, d.NP, nwg);
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* a) {
+    if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
+    if (a->x_dim < 1 || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1) return 0;
+    const int n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
+    const psnode_mlp_f32 &d = a->de, &g = a->ae;
+    if (d.n_layers < 1 || d.n_layers > kMaxLayers || g.n_layers < 1 || g.n_layers > kMaxLayers) return 0;
+    if (d.in_dim != 3 * n || d.out_dim[d.n_layers - 1] != a->x_dim) return 0;
+    if (g.in_dim != n + a->x_dim + a->z_dim + a->v_dim || g.out_dim[g.n_layers - 1] != a->i_dim) return 0;
+    return generic_bwd_fits(&a->de, &a->ae, a->x_dim, a->z_dim, a->v_dim, a->i_dim);
+}
+
+extern "C" size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* a) {
+    if (!a || !psnode_dae_backward_supported(a)) return 0;
+    return generic_bwd_workspace_floats(&a->de, &a->ae, a->B) * sizeof(float);
+}
+
+extern "C" int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* a, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a) return PSNODE_ERR_NULL;
+    if (a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return PSNODE_ERR_METHOD;
+    if (a->T < 1 || a->B < 1) return PSNODE_ERR_DIMS;
+    if (!psnode_dae_backward_supported(a)) return PSNODE_ERR_UNSUPPORTED;
+    for (int l = 0; l < a->de.n_layers; ++l) if (!a->de.weight[l] || !a->de.bias[l]) return PSNODE_ERR_NULL;
+    for (int l = 0; l < a->ae.n_layers; ++l) if (!a->ae.weight[l] || !a->ae.bias[l]) return PSNODE_ERR_NULL;
+    if (!a->t.ptr || !a->all_initial || !a->xs || !a->is || !a->grad_xs || !a->grad_x_init || !a->grad_all_initial || !a->grad_params_de ||
+        !a->grad_params_ae)
+        return PSNODE_ERR_NULL;
+    if ((a->z_dim > 0 && !a->z.ptr) || (a->v_dim > 0 && !a->v.ptr)) return PSNODE_ERR_NULL;
+    if (a->event_idx && ((a->z_dim > 0 && !a->z_jump) || (a->v_dim > 0 && !a->v_jump))) return PSNODE_ERR_NULL;
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_dae_backward_workspace_bytes(a))
+        return PSNODE_ERR_WORKSPACE;
+    return generic_backward_launch(a->method, a->x_dim, a->z_dim, a->v_dim, a->i_dim, a->T, a->B, &a->de, &a->ae,
+                                   ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},
+                                   ViewDev{a->v.ptr, a->v.stride_t, a->v.stride_b}, a->all_initial, a->event_idx, a->z_jump, a->zj_stride_b,
+                                   a->zj_stride_e, a->v_jump, a->vj_stride_b, a->vj_stride_e, a->n_events, a->xs, a->is, a->grad_xs, a->grad_is,
+                                   a->grad_x_init, a->grad_z, a->grad_v, a->grad_z_jump, a->grad_v_jump, a->grad_all_initial,
+                                   a->grad_params_de, a->grad_params_ae, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
 }

@@ -56,37 +56,6 @@ int max_width(const psnode_mlp_f32& m) {
     return w;
 }
 
-struct PackArgs {
-    int n;                       // layers in total (de then ae)
-    int K[2 * kMaxLayers], N[2 * kMaxLayers];
-    const float* w[2 * kMaxLayers];
-    float* wt[2 * kMaxLayers];
-};
-
-// wt[k][j] = w[j][k] for every layer of both MLPs in one launch (blockIdx.y = layer).
-__global__ void pack_transpose_kernel(const PackArgs p) {
-    const int l = blockIdx.y;
-    const int K = p.K[l], N = p.N[l];
-    const float* __restrict__ w = p.w[l];
-    float* __restrict__ wt = p.wt[l];
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < K * N; idx += gridDim.x * blockDim.x) {
-        const int k = idx / N, j = idx % N;
-        wt[idx] = w[(size_t)j * K + k];
-    }
-}
-
-void add_pack(PackArgs& p, const MlpDev& d) {
-    int k = d.in_dim;
-    for (int l = 0; l < d.n_layers; ++l) {
-        p.K[p.n] = k;
-        p.N[p.n] = d.out_dim[l];
-        p.w[p.n] = d.w[l];
-        p.wt[p.n] = const_cast<float*>(d.wt[l]);
-        ++p.n;
-        k = d.out_dim[l];
-    }
-}
-
 __global__ void event_table_kernel(long long n_steps, const float* clock, long long stride_k, const float* ev_times,
                                    long long stride_e, int n_events, int* event_idx, int* dup_flag) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,12 +94,7 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
         e = launch_mfma(d, dae, ws, stream);
     } else {
         if (generic_lds_bytes(d, dae) > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
-        PackArgs p;
-        p.n = 0;
-        add_pack(p, d.de);
-        if (dae) add_pack(p, d.ae);
-        hipLaunchKernelGGL(pack_transpose_kernel, dim3(8, p.n), dim3(256), 0, stream, p);
-        e = hipGetLastError();
+        e = launch_pack_transpose(d.de, dae ? &d.ae : nullptr, stream);
         if (e == hipSuccess) e = launch_generic(d, dae, stream);
     }
     return e == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;

@@ -94,12 +94,22 @@ constexpr float kOneThird = 0.333333343267440796f;
 // psnode_generic.hip
 hipError_t launch_generic(const IntegrateDev& a, bool dae, hipStream_t stream);
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae);
+hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream);
 
 // psnode_mfma.hip
 bool mfma_ode_supported(const IntegrateDev& a);
 bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+
+// psnode_generic_bwd.hip (K5: generic fused backward, ODE and DAE)
+size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B);
+int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd, int zd, int vd, int id);
+int generic_backward_launch(int method, int xd, int zd, int vd, int id, long long T, long long B, const psnode_mlp_f32* de,
+                            const psnode_mlp_f32* ae, ViewDev t, ViewDev z, ViewDev v, const float* a0, const int* ev, const float* zj,
+                            long long zjb, long long zje, const float* vj, long long vjb, long long vje, int n_events, const float* xs,
+                            const float* is_, const float* gxs, const float* gis, float* gx0, float* gz, float* gv, float* gzj, float* gvj,
+                            float* ga0, float* gparams_de, float* gparams_ae, float* workspace, hipStream_t stream);
 
 // psnode_latent.hip (direct_encode latent shapes, hidden_dim 16)
 bool latent_shape_ok(const IntegrateDev& a, bool dae);

@@ -210,6 +210,50 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
 
 }  // namespace
 
+namespace {
+struct PackArgs {
+    int n;                       // layers in total (de then ae)
+    int K[2 * kMaxLayers], N[2 * kMaxLayers];
+    const float* w[2 * kMaxLayers];
+    float* wt[2 * kMaxLayers];
+};
+
+// wt[k][j] = w[j][k] for every layer of both MLPs in one launch (blockIdx.y = layer).
+__global__ void pack_transpose_kernel(const PackArgs p) {
+    const int l = blockIdx.y;
+    const int K = p.K[l], N = p.N[l];
+    const float* __restrict__ w = p.w[l];
+    float* __restrict__ wt = p.wt[l];
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < K * N; idx += gridDim.x * blockDim.x) {
+        const int k = idx / N, j = idx % N;
+        wt[idx] = w[(size_t)j * K + k];
+    }
+}
+
+void add_pack(PackArgs& p, const MlpDev& d) {
+    int k = d.in_dim;
+    for (int l = 0; l < d.n_layers; ++l) {
+        p.K[p.n] = k;
+        p.N[p.n] = d.out_dim[l];
+        p.w[p.n] = d.w[l];
+        p.wt[p.n] = const_cast<float*>(d.wt[l]);
+        ++p.n;
+        k = d.out_dim[l];
+    }
+}
+
+}  // namespace
+
+// wt[k][j] = w[j][k] for every layer of one or two MLPs, one launch
+hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream) {
+    PackArgs p;
+    p.n = 0;
+    add_pack(p, de);
+    if (ae) add_pack(p, *ae);
+    hipLaunchKernelGGL(pack_transpose_kernel, dim3(8, p.n), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae) {
     const int vd = dae ? a.vd : 0, id = dae ? a.id : 0;
     const int n = a.xd + a.zd + vd + id;

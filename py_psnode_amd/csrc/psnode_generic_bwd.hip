@@ -1,0 +1,500 @@
+// K5 -- generic fused backward pass (discretise-then-optimise) for ODE and DAE, any layer count / widths that fit LDS.
+// The always-available HIP path for training, as psnode_generic.hip is for the forward: shapes with an MFMA backward
+// (K4, psnode_backward.hip) use that one.
+//
+// One workgroup = 16 trajectories walked from the last grid point to the first, everything in LDS:
+//   * activations of ONE MLP evaluation for all layers, [unit][TP] with a padded row stride TP = 20 floats: 16 lanes
+//     reading 16 consecutive rows with ds_read_b128 then hit 16 disjoint bank quads (stride 16 would be 4..16-way);
+//   * parameter-gradient accumulators for every weight and bias (each element owned by one thread: no atomics),
+//     written once at the end as a per-workgroup partial and summed in a fixed order by reduce_partials (deterministic);
+//   * the RK adjoint state (stage inputs, k_s, g_k[s], carries) and the external-input gradients.
+// Per step: stage forwards (to rebuild the stage inputs), then for each stage in reverse a forward with stored
+// activations followed by the VJP:  delta_in = W^T delta_out * ELU'(.) (weights read row-major, coalesced over the input
+// index) and dW += delta (x) act in 4x4 register blocks.  DAE: the AE head's VJP is chained in through the algebraic
+// variable (i_{k+1} = g(x_{k+1}; z,v) feeds the DE of step k+1; at event steps i0 = g(x_k; jumps) instead).
+#include <string.h>
+
+#include "psnode_common.h"
+
+namespace psnode {
+namespace {
+
+constexpr int TB = 16;    // trajectories per workgroup
+constexpr int TP = 20;    // padded row stride (floats)
+constexpr int NT = 256;
+
+struct GMlp {
+    int L, in_dim;
+    int out_dim[kMaxLayers];
+    const float* w[kMaxLayers];    // row-major [out][in] (caller's nn.Linear weight)
+    const float* wt[kMaxLayers];   // transposed [in][out] (workspace)
+    const float* b[kMaxLayers];
+    int gw[kMaxLayers], gb[kMaxLayers];   // offsets of dW, db in the flat gradient vector (nn.Linear order)
+    int act[kMaxLayers + 1];              // row offsets of the layer activations (act[0] = input) in the acts buffer
+    int np;
+};
+
+struct GBwd {
+    int method, dae;
+    int xd, zd, vd, id;
+    long long T, B;
+    GMlp de, ae;
+    ViewDev t, z, v;
+    const float* a0;
+    const int* ev;
+    const float* zj; long long zjb, zje;
+    const float* vj; long long vjb, vje;
+    int n_events;
+    const float *xs, *is_, *gxs, *gis;
+    float *gx0, *gz, *gv, *gzj, *gvj, *ga0, *wpart;
+    int maxw, act_rows;
+};
+
+__device__ __forceinline__ float delu(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }   // ELU'(pre) from h = ELU(pre)
+
+// forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]]; ends with a barrier per layer
+__device__ void g_forward(const GMlp& m, float* acts) {
+    int K = m.in_dim;
+    for (int l = 0; l < m.L; ++l) {
+        const int N = m.out_dim[l];
+        const float* __restrict__ wt = m.wt[l];
+        const float* __restrict__ bias = m.b[l];
+        const float* in = acts + m.act[l] * TP;
+        float* out = acts + m.act[l + 1] * TP;
+        const bool last = (l + 1 == m.L);
+        for (int item = threadIdx.x; item < N * 4; item += NT) {
+            const int j = item % N, g = item / N;
+            const float b = bias[j];
+            float a0 = b, a1 = b, a2 = b, a3 = b;
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) {
+                const float wk = wt[(size_t)k * N + j];
+                const float4 v = *reinterpret_cast<const float4*>(in + k * TP + g * 4);
+                a0 = fmaf(wk, v.x, a0); a1 = fmaf(wk, v.y, a1); a2 = fmaf(wk, v.z, a2); a3 = fmaf(wk, v.w, a3);
+            }
+            if (!last) { a0 = elu1(a0); a1 = elu1(a1); a2 = elu1(a2); a3 = elu1(a3); }
+            *reinterpret_cast<float4*>(out + j * TP + g * 4) = make_float4(a0, a1, a2, a3);
+        }
+        __syncthreads();
+        K = N;
+    }
+}
+
+// VJP of the MLP: `din` holds delta of the output [N_L][TP]; returns the buffer with the input gradient [in_dim][TP].
+// Accumulates dW, db into gacc.  Ends with a barrier.
+__device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc) {
+    const int tid = threadIdx.x, jg = tid >> 4, kk = tid & 15;
+    for (int l = m.L - 1; l >= 0; --l) {
+        const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
+        const float* a_in = acts + m.act[l] * TP;
+        // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr]; 4 x 4 blocks: rows j0..j0+3, columns k0 + 16 m
+        float* gw = gacc + m.gw[l];
+        for (int j0 = 4 * jg; j0 < N; j0 += 64) {
+            for (int k0 = kk; k0 < K; k0 += 64) {
+                float acc[4][4] = {};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // trajectory quad
+                    float4 dj[4], ak[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dj[r] = j0 + r < N ? *reinterpret_cast<const float4*>(din + (j0 + r) * TP + 4 * q) : make_float4(0, 0, 0, 0);
+                        ak[r] = k0 + 16 * r < K ? *reinterpret_cast<const float4*>(a_in + (k0 + 16 * r) * TP + 4 * q) : make_float4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[r][c] = fmaf(dj[r].w, ak[c].w, fmaf(dj[r].z, ak[c].z, fmaf(dj[r].y, ak[c].y, fmaf(dj[r].x, ak[c].x, acc[r][c]))));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (j0 + r < N && k0 + 16 * c < K) gw[(j0 + r) * K + k0 + 16 * c] += acc[r][c];
+            }
+        }
+        // ---- db[j] += sum_tr delta[j][tr]
+        for (int j = tid; j < N; j += NT) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < TB; ++c) s += din[j * TP + c];
+            gacc[m.gb[l] + j] += s;
+        }
+        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers)
+        const float* __restrict__ w = m.w[l];
+        for (int item = tid; item < K * 4; item += NT) {
+            const int k = item % K, g = item / K;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < N; ++j) {
+                const float wj = w[(size_t)j * K + k];
+                const float4 v = *reinterpret_cast<const float4*>(din + j * TP + g * 4);
+                a0 = fmaf(wj, v.x, a0); a1 = fmaf(wj, v.y, a1); a2 = fmaf(wj, v.z, a2); a3 = fmaf(wj, v.w, a3);
+            }
+            if (l > 0) {
+                const float4 h = *reinterpret_cast<const float4*>(a_in + k * TP + g * 4);
+                a0 *= delu(h.x); a1 *= delu(h.y); a2 *= delu(h.z); a3 *= delu(h.w);
+            }
+            *reinterpret_cast<float4*>(dout + k * TP + g * 4) = make_float4(a0, a1, a2, a3);
+        }
+        __syncthreads();
+        float* tmp = din; din = dout; dout = tmp;
+    }
+    return din;
+}
+
+__device__ __forceinline__ float tab_a(int method, int s, int j) {
+    if (method == PSNODE_MIDPOINT) return 0.5f;
+    if (method == PSNODE_RK4_38) {
+        if (s == 1) return kOneThird;
+        if (s == 2) return j == 0 ? -kOneThird : 1.0f;
+        if (s == 3) return j == 1 ? -1.0f : 1.0f;
+    }
+    return 0.0f;
+}
+__device__ __forceinline__ float tab_b(int method, int s) {
+    if (method == PSNODE_EULER) return 1.0f;
+    if (method == PSNODE_MIDPOINT) return s == 1 ? 1.0f : 0.0f;
+    return (s == 0 || s == 3) ? 0.125f : 0.375f;
+}
+
+__global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * TB;
+    const bool dae = a.dae != 0;
+    const int xd = a.xd, zd = a.zd, vd = dae ? a.vd : 0, id = dae ? a.id : 0;
+    const int nzv = zd + vd, ne = nzv + id, n = xd + ne;
+    const int S = a.method == PSNODE_EULER ? 1 : (a.method == PSNODE_MIDPOINT ? 2 : 4);
+    const int nx = xd * TP;
+
+    float* acts = lds;                            // [act_rows][TP]
+    float* dA = acts + a.act_rows * TP;           // [maxw][TP]
+    float* dB = dA + a.maxw * TP;
+    float* a0s = dB + a.maxw * TP;                // [n][TP]
+    float* ga0s = a0s + n * TP;                   // [n][TP]
+    float* ext = ga0s + n * TP;                   // [ne][TP]  z | v | i fed to the DE of this step
+    float* gext = ext + ne * TP;                  // [ne][TP]
+    float* x0 = gext + ne * TP;                   // [xd][TP]
+    float* xst = x0 + nx;                         // [4][xd][TP]
+    float* ks = xst + 4 * nx;                     // [4][xd][TP]
+    float* gks = ks + 4 * nx;                     // [4][xd][TP]
+    float* gx0 = gks + 4 * nx;                    // [xd][TP]
+    float* gxc = gx0 + nx;                        // [xd][TP]  carried dL/dx_{k+1}
+    float* gic = gxc + nx;                        // [id][TP]  carried dL/di_{k+1}
+    float* dts = gic + id * TP;                   // [TP]
+    float* gacc = dts + TP;                       // [np_de + np_ae]
+    float* gacc_ae = gacc + a.de.np;
+
+    auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
+    auto on = [&](int c) -> bool { return b0 + c < a.B; };
+    // loops over [rows][TB] tiles: idx -> (r, c)
+#define TILE_LOOP(rows) for (int idx = tid, r = tid / TB, c = tid % TB; idx < (rows) * TB; idx += NT, r = idx / TB, c = idx % TB)
+
+    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) gacc[e] = 0.0f;
+    TILE_LOOP(n) { a0s[r * TP + c] = a.a0[gb(c) * n + r]; ga0s[r * TP + c] = 0.0f; }
+    TILE_LOOP(xd) gxc[r * TP + c] = on(c) ? a.gxs[((a.T - 1) * a.B + gb(c)) * xd + r] : 0.0f;
+    TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[((a.T - 1) * a.B + gb(c)) * id + r] : 0.0f;
+    TILE_LOOP(nzv) {   // the last grid point's z|v only receive the AE part (DAE) or nothing (ODE)
+        if (!on(c)) continue;
+        const bool isz = r < zd;
+        float* dst = isz ? a.gz : a.gv;
+        if (dst) dst[((a.T - 1) * a.B + b0 + c) * (isz ? zd : vd) + (isz ? r : r - zd)] = 0.0f;
+    }
+    __syncthreads();
+
+    // DE input rows of acts: a0 | s - a0 | s  with s = x | ext
+    auto de_input = [&](const float* xs_rows) {
+        float* u = acts + a.de.act[0] * TP;
+        TILE_LOOP(n) {
+            const float s = r < xd ? xs_rows[r * TP + c] : ext[(r - xd) * TP + c];
+            const float i0 = a0s[r * TP + c];
+            u[r * TP + c] = i0;
+            u[(n + r) * TP + c] = s - i0;
+            u[(2 * n + r) * TP + c] = s;
+        }
+        __syncthreads();
+    };
+    // AE input rows: a0 | x | z | v ; x from xrows (LDS) ; z|v from grid point jzv (>= 0) or from ext
+    auto ae_input = [&](const float* xrows, long long jzv) {
+        float* u = acts + a.ae.act[0] * TP;
+        TILE_LOOP(n + xd + nzv) {
+            float v;
+            if (r < n) v = a0s[r * TP + c];
+            else if (r < n + xd) v = xrows[(r - n) * TP + c];
+            else if (jzv < 0) v = ext[(r - n - xd) * TP + c];
+            else if (r < n + xd + zd) v = a.z.p[jzv * a.z.st + gb(c) * a.z.sb + (r - n - xd)];
+            else v = a.v.p[jzv * a.v.st + gb(c) * a.v.sb + (r - n - xd - zd)];
+            u[r * TP + c] = v;
+        }
+        __syncthreads();
+    };
+    // VJP of the AE head at (xrows; z|v of grid point jzv or the jumped ext rows) with output gradient `gi`:
+    // adds to gx_dst, ga0s, and to the z|v gradients (global gz/gv at jzv, or the jump gradients of event ev)
+    auto ae_vjp = [&](const float* xrows, long long jzv, int ev, const float* gi, float* gx_dst) {
+        ae_input(xrows, jzv);
+        g_forward(a.ae, acts);
+        TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
+        __syncthreads();
+        const float* gu = g_vjp(a.ae, acts, dA, dB, gacc_ae);
+        TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
+        TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
+        TILE_LOOP(nzv) {
+            if (!on(c)) continue;
+            const float g = gu[(n + xd + r) * TP + c];
+            const bool isz = r < zd;
+            const int d_ = isz ? r : r - zd, w_ = isz ? zd : vd;
+            if (jzv >= 0) {
+                float* dst = isz ? a.gz : a.gv;
+                if (dst) dst[(jzv * a.B + b0 + c) * w_ + d_] += g;
+            } else {
+                float* dst = isz ? a.gzj : a.gvj;
+                if (dst) dst[((b0 + c) * a.n_events + ev) * w_ + d_] += g;
+            }
+        }
+        __syncthreads();
+    };
+
+    for (long long k = a.T - 2; k >= 0; --k) {
+        const int ev = a.ev ? a.ev[k] : -1;
+        if (tid < TB) dts[tid] = a.t.p[(k + 1) * a.t.st + gb(tid) * a.t.sb] - a.t.p[k * a.t.st + gb(tid) * a.t.sb];
+        TILE_LOOP(nzv) {
+            const long long b = gb(c);
+            float v;
+            if (r < zd) v = ev >= 0 ? a.zj[b * a.zjb + ev * a.zje + r] : a.z.p[k * a.z.st + b * a.z.sb + r];
+            else v = ev >= 0 ? a.vj[b * a.vjb + ev * a.vje + (r - zd)] : a.v.p[k * a.v.st + b * a.v.sb + (r - zd)];
+            ext[r * TP + c] = v;
+        }
+        TILE_LOOP(xd) x0[r * TP + c] = a.xs[(k * a.B + gb(c)) * xd + r];
+        __syncthreads();
+        if (dae) {
+            // (1) AE head at the end of step k: i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]) carries gic
+            TILE_LOOP(xd) xst[r * TP + c] = a.xs[((k + 1) * a.B + gb(c)) * xd + r];
+            __syncthreads();
+            ae_vjp(xst, k + 1, -1, gic, gxc);
+            // (2) algebraic input of this step's DE
+            if (ev >= 0) {
+                ae_input(x0, -1);
+                g_forward(a.ae, acts);
+                const float* out = acts + a.ae.act[a.ae.L] * TP;
+                TILE_LOOP(id) ext[(nzv + r) * TP + c] = out[r * TP + c];
+            } else {
+                TILE_LOOP(id) ext[(nzv + r) * TP + c] = a.is_[(k * a.B + gb(c)) * id + r];
+            }
+            __syncthreads();
+        }
+        // (3a) stage inputs and slopes
+        for (int s = 0; s < S; ++s) {
+            TILE_LOOP(xd) {
+                float acc = 0.0f;
+                for (int j = 0; j < s; ++j) acc += tab_a(a.method, s, j) * ks[j * nx + r * TP + c];
+                xst[s * nx + r * TP + c] = s == 0 ? x0[r * TP + c] : x0[r * TP + c] + dts[c] * acc;
+            }
+            __syncthreads();
+            de_input(xst + s * nx);
+            g_forward(a.de, acts);
+            const float* out = acts + a.de.act[a.de.L] * TP;
+            TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
+            __syncthreads();
+        }
+        // (3b) stages backwards
+        TILE_LOOP(xd) {
+            const float g1 = gxc[r * TP + c];
+            gx0[r * TP + c] = g1;
+            for (int s = 0; s < S; ++s) gks[s * nx + r * TP + c] = dts[c] * tab_b(a.method, s) * g1;
+        }
+        TILE_LOOP(ne) gext[r * TP + c] = 0.0f;
+        __syncthreads();
+        for (int s = S - 1; s >= 0; --s) {
+            de_input(xst + s * nx);
+            g_forward(a.de, acts);
+            TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
+            __syncthreads();
+            const float* gu = g_vjp(a.de, acts, dA, dB, gacc);
+            TILE_LOOP(n) {
+                const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
+                ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
+                if (r < xd) {
+                    gx0[r * TP + c] += gs;
+                    for (int j = 0; j < s; ++j) gks[j * nx + r * TP + c] += dts[c] * tab_a(a.method, s, j) * gs;
+                } else {
+                    gext[(r - xd) * TP + c] += gs;
+                }
+            }
+            __syncthreads();
+        }
+        // (4) gradients of this step's external inputs
+        TILE_LOOP(nzv) {
+            if (!on(c)) continue;
+            const float g = gext[r * TP + c];
+            const bool isz = r < zd;
+            const int d_ = isz ? r : r - zd, w_ = isz ? zd : vd;
+            float* dst = isz ? a.gz : a.gv;
+            float* dj = isz ? a.gzj : a.gvj;
+            if (ev >= 0) {
+                if (dj) dj[((b0 + c) * a.n_events + ev) * w_ + d_] = g;
+                if (dst) dst[(k * a.B + b0 + c) * w_ + d_] = 0.0f;
+            } else if (dst) {
+                dst[(k * a.B + b0 + c) * w_ + d_] = g;
+            }
+        }
+        if (dae) {
+            __syncthreads();
+            if (ev >= 0) {   // i_in = g(x_k; jumps): its gradient flows into x_k and the jump inputs; i_k itself was unused
+                ae_vjp(x0, -1, ev, gext + nzv * TP, gx0);
+                TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[(k * a.B + gb(c)) * id + r] : 0.0f;
+            } else {
+                TILE_LOOP(id) gic[r * TP + c] = gext[(nzv + r) * TP + c] + ((on(c) && a.gis) ? a.gis[(k * a.B + gb(c)) * id + r] : 0.0f);
+            }
+        }
+        __syncthreads();
+        TILE_LOOP(xd) gxc[r * TP + c] = gx0[r * TP + c] + (on(c) ? a.gxs[(k * a.B + gb(c)) * xd + r] : 0.0f);
+        __syncthreads();
+    }
+    if (dae) {   // i_0 = g(x_0; z[0], v[0])   (my_solvers.py:95)
+        TILE_LOOP(xd) x0[r * TP + c] = a.xs[gb(c) * xd + r];
+        __syncthreads();
+        ae_vjp(x0, 0, -1, gic, gxc);
+    }
+    TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
+    TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
+    float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
+    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc[e];
+#undef TILE_LOOP
+}
+
+__global__ void reduce_partials_g(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
+                                  int np_ae, int nwg) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
+    if (pidx >= np) return;
+    float acc = 0.0f;
+    for (int g = 0; g < nwg; ++g) acc += part[(size_t)g * np + pidx];
+    if (pidx < np_de) out_de[pidx] = acc;
+    else out_ae[pidx - np_de] = acc;
+}
+
+int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
+    g.L = m.n_layers;
+    g.in_dim = m.in_dim;
+    int k = m.in_dim, off = 0, rows = 0;
+    g.act[0] = 0;
+    rows = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        g.out_dim[l] = m.out_dim[l];
+        g.w[l] = m.weight[l];
+        g.b[l] = m.bias[l];
+        g.wt[l] = ws;
+        ws += ((size_t)k * m.out_dim[l] + 63) / 64 * 64;
+        g.gw[l] = off; off += m.out_dim[l] * k;
+        g.gb[l] = off; off += m.out_dim[l];
+        g.act[l + 1] = rows;
+        rows += m.out_dim[l];
+        k = m.out_dim[l];
+    }
+    g.np = off;
+    return rows;
+}
+
+size_t gbwd_lds_floats(const GBwd& a) {
+    const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
+    return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
+           (size_t)id * TP + TP + a.de.np + (a.dae ? a.ae.np : 0);
+}
+
+int mlp_maxw(const psnode_mlp_f32& m) {
+    int w = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) w = m.out_dim[l] > w ? m.out_dim[l] : w;
+    return w;
+}
+size_t mlp_wt_floats(const psnode_mlp_f32& m) {
+    size_t tot = 0;
+    int k = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) { tot += ((size_t)k * m.out_dim[l] + 63) / 64 * 64; k = m.out_dim[l]; }
+    return tot;
+}
+int mlp_np(const psnode_mlp_f32& m) {
+    int np = 0, k = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) { np += m.out_dim[l] * (k + 1); k = m.out_dim[l]; }
+    return np;
+}
+bool mlp_ok(const psnode_mlp_f32& m, int in_dim, int out_dim) {
+    if (m.n_layers < 1 || m.n_layers > kMaxLayers || m.in_dim != in_dim || m.out_dim[m.n_layers - 1] != out_dim) return false;
+    for (int l = 0; l < m.n_layers; ++l)
+        if (m.out_dim[l] < 1 || m.out_dim[l] > PSNODE_MAX_WIDTH || !m.weight[l] || !m.bias[l]) return false;
+    return true;
+}
+
+}  // namespace
+
+// shared by the ODE and DAE entry points (psnode_backward.hip calls this for kernel = generic / unsupported MFMA shapes)
+size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B) {
+    const size_t nwg = (size_t)((B + TB - 1) / TB);
+    return mlp_wt_floats(*de) + (ae ? mlp_wt_floats(*ae) : 0) + nwg * (size_t)(mlp_np(*de) + (ae ? mlp_np(*ae) : 0)) + 64;
+}
+
+int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd, int zd, int vd, int id) {
+    GBwd a;
+    memset(&a, 0, sizeof(a));
+    a.dae = ae != nullptr; a.xd = xd; a.zd = zd; a.vd = vd; a.id = id;
+    float* ws = nullptr;
+    int rows = fill_gmlp(*de, a.de, ws);
+    a.maxw = mlp_maxw(*de);
+    if (ae) {
+        const int r2 = fill_gmlp(*ae, a.ae, ws);
+        rows = r2 > rows ? r2 : rows;
+        a.maxw = mlp_maxw(*ae) > a.maxw ? mlp_maxw(*ae) : a.maxw;
+    }
+    a.act_rows = rows;
+    return gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024;
+}
+
+// launches pack (transpose), the backward kernel and the partial reduction
+int generic_backward_launch(int method, int xd, int zd, int vd, int id, long long T, long long B, const psnode_mlp_f32* de,
+                            const psnode_mlp_f32* ae, ViewDev t, ViewDev z, ViewDev v, const float* a0, const int* ev, const float* zj,
+                            long long zjb, long long zje, const float* vj, long long vjb, long long vje, int n_events, const float* xs,
+                            const float* is_, const float* gxs, const float* gis, float* gx0, float* gz, float* gv, float* gzj, float* gvj,
+                            float* ga0, float* gparams_de, float* gparams_ae, float* workspace, hipStream_t stream) {
+    const bool dae = ae != nullptr;
+    const int n = xd + zd + (dae ? vd + id : 0);
+    if (!mlp_ok(*de, 3 * n, xd)) return PSNODE_ERR_DIMS;
+    if (dae && !mlp_ok(*ae, n + xd + zd + vd, id)) return PSNODE_ERR_DIMS;
+    GBwd a;
+    memset(&a, 0, sizeof(a));
+    a.method = method; a.dae = dae; a.xd = xd; a.zd = zd; a.vd = vd; a.id = id; a.T = T; a.B = B;
+    float* ws = workspace;
+    int rows = fill_gmlp(*de, a.de, ws);
+    a.maxw = mlp_maxw(*de);
+    if (dae) {
+        const int r2 = fill_gmlp(*ae, a.ae, ws);
+        rows = r2 > rows ? r2 : rows;
+        a.maxw = mlp_maxw(*ae) > a.maxw ? mlp_maxw(*ae) : a.maxw;
+    }
+    a.act_rows = rows;
+    a.t = t; a.z = z; a.v = v; a.a0 = a0; a.ev = ev; a.zj = zj; a.zjb = zjb; a.zje = zje; a.vj = vj; a.vjb = vjb; a.vje = vje;
+    a.n_events = n_events; a.xs = xs; a.is_ = is_; a.gxs = gxs; a.gis = gis; a.gx0 = gx0; a.gz = gz; a.gv = gv; a.gzj = gzj; a.gvj = gvj;
+    a.ga0 = ga0; a.wpart = ws;
+    const size_t lds = gbwd_lds_floats(a) * sizeof(float);
+    if (lds > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
+    // transposed weights for the forward recomputation
+    MlpDev mde, mae;
+    memset(&mde, 0, sizeof(mde));
+    memset(&mae, 0, sizeof(mae));
+    auto to_dev = [](const GMlp& g, MlpDev& m) {
+        m.n_layers = g.L; m.in_dim = g.in_dim;
+        for (int l = 0; l < g.L; ++l) { m.out_dim[l] = g.out_dim[l]; m.w[l] = g.w[l]; m.wt[l] = g.wt[l]; m.bias[l] = g.b[l]; }
+    };
+    to_dev(a.de, mde);
+    if (dae) to_dev(a.ae, mae);
+    if (launch_pack_transpose(mde, dae ? &mae : nullptr, stream) != hipSuccess) return PSNODE_ERR_HIP;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PSNODE_ERR_HIP;
+    const unsigned nwg = (unsigned)((B + TB - 1) / TB);
+    hipLaunchKernelGGL(generic_backward_kernel, dim3(nwg), dim3(NT), lds, stream, a);
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    const int np = a.de.np + (dae ? a.ae.np : 0);
+    hipLaunchKernelGGL(reduce_partials_g, dim3((np + 255) / 256), dim3(256), 0, stream, a.wpart, gparams_de, gparams_ae, a.de.np,
+                       dae ? a.ae.np : 0, (int)nwg);
+    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+}  // namespace psnode

@@ -269,24 +269,104 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
     return xs, is_
 
 
-def _bwd_args(method, de_layers, x_dim, z_dim, T, B, dev, keep):
+def _bwd_args(method, de_layers, x_dim, z_dim, T, B, dev, keep, kernel="auto"):
     a = _lib.OdeBwdArgsF32()
     a.method = METHOD_ID[method]
+    a.kernel = KERNEL_ID[kernel]
     a.x_dim, a.z_dim, a.T, a.B = x_dim, z_dim, T, B
     a.de = _mlp(de_layers, dev, "de", keep)
     return a
 
 
-def ode_backward_supported(method: str, de_layers: Layers, x_dim: int, z_dim: int) -> bool:
-    """True if the fused backward kernel covers this shape (the MFMA class: 3n->64->64->64->x, x<=8, z<=4)."""
-    if len(de_layers) != 4 or de_layers[0][0].device.type != "cuda":
+def ode_backward_supported(method: str, de_layers: Layers, x_dim: int, z_dim: int, kernel: str = "auto") -> bool:
+    """True if a fused backward kernel covers this shape: the MFMA class (3n->64->64->64->x, x<=8, z<=4) or any MLP whose
+    activations and parameter gradients fit the LDS (generic backward)."""
+    if de_layers[0][0].device.type != "cuda" or len(de_layers) > _lib.MAX_LAYERS:
         return False
     lib = _lib.load()
-    a = _bwd_args(method, de_layers, x_dim, z_dim, 2, 1, de_layers[0][0].device, [])
+    a = _bwd_args(method, de_layers, x_dim, z_dim, 2, 1, de_layers[0][0].device, [], kernel)
     return bool(lib.psnode_ode_backward_supported(ctypes.byref(a)))
 
 
-def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True):
+def _split_grads(flat, layers):
+    out, off = [], 0
+    for w, b in layers:
+        out.append(flat[off:off + w.numel()].view_as(w)); off += w.numel()
+        out.append(flat[off:off + b.numel()].view_as(b)); off += b.numel()
+    return out
+
+
+def dae_backward_supported(method: str, de_layers: Layers, ae_layers: Layers, x_dim, z_dim, v_dim, i_dim) -> bool:
+    if de_layers[0][0].device.type != "cuda" or max(len(de_layers), len(ae_layers)) > _lib.MAX_LAYERS:
+        return False
+    lib = _lib.load()
+    a = _lib.DaeBwdArgsF32()
+    a.method = METHOD_ID[method]
+    a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = x_dim, z_dim, v_dim, i_dim, 2, 1
+    dev = de_layers[0][0].device
+    a.de, a.ae = _mlp(de_layers, dev, "de", []), _mlp(ae_layers, dev, "ae", [])
+    return bool(lib.psnode_dae_backward_supported(ctypes.byref(a)))
+
+
+def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
+                 z_jump=None, v_jump=None):
+    """Backward pass of `dae_integrate` (no teacher forcing) in one launch (generic backward kernel).
+    Returns dict(x_init, z, v, z_jump, v_jump, all_initial, de=[...], ae=[...]) of gradients."""
+    lib = _lib.load()
+    dev = xs.device
+    T, B, xd = xs.shape
+    zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
+    keep: list = []
+    a = _lib.DaeBwdArgsF32()
+    a.method = METHOD_ID[method]
+    a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = xd, zd, vd, idim, T, B
+    a.de, a.ae = _mlp(de_layers, dev, "de", keep), _mlp(ae_layers, dev, "ae", keep)
+    a.t, a.z, a.v = _view(t, dev, "t", keep), _view(z, dev, "z", keep), _view(v, dev, "v", keep)
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    xs_c, is_c = _f32_dev(xs, dev, "xs").contiguous(), _f32_dev(is_, dev, "is").contiguous()
+    gx_c = _f32_dev(grad_xs, dev, "grad_xs").contiguous() if grad_xs is not None else torch.zeros_like(xs_c)
+    gi_c = _f32_dev(grad_is, dev, "grad_is").contiguous() if grad_is is not None else None
+    keep += [a0, xs_c, is_c, gx_c, gi_c]
+    a.all_initial, a.xs, a.is_, a.grad_xs = a0.data_ptr(), xs_c.data_ptr(), is_c.data_ptr(), gx_c.data_ptr()
+    a.grad_is = gi_c.data_ptr() if gi_c is not None else None
+    g = {"z_jump": None, "v_jump": None}
+    if event_idx is not None:
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+        a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
+        n_ev = (z_jump if z_jump is not None else v_jump).shape[1]
+        a.n_events = n_ev
+        if zd > 0:
+            g["z_jump"] = torch.zeros((B, n_ev, zd), dtype=torch.float32, device=dev)
+            a.grad_z_jump = g["z_jump"].data_ptr()
+        if vd > 0:
+            g["v_jump"] = torch.zeros((B, n_ev, vd), dtype=torch.float32, device=dev)
+            a.grad_v_jump = g["v_jump"].data_ptr()
+    with torch.cuda.device(dev):
+        g["x_init"] = torch.empty((B, xd), dtype=torch.float32, device=dev)
+        g["all_initial"] = torch.empty((B, xd + zd + vd + idim), dtype=torch.float32, device=dev)
+        g["z"] = torch.empty((T, B, zd), dtype=torch.float32, device=dev) if zd > 0 else None
+        g["v"] = torch.empty((T, B, vd), dtype=torch.float32, device=dev) if vd > 0 else None
+        npd = sum(w.numel() + b.numel() for w, b in de_layers)
+        npa = sum(w.numel() + b.numel() for w, b in ae_layers)
+        gde = torch.empty(npd, dtype=torch.float32, device=dev)
+        gae = torch.empty(npa, dtype=torch.float32, device=dev)
+        a.grad_x_init, a.grad_all_initial = g["x_init"].data_ptr(), g["all_initial"].data_ptr()
+        a.grad_z = g["z"].data_ptr() if g["z"] is not None else None
+        a.grad_v = g["v"].data_ptr() if g["v"] is not None else None
+        a.grad_params_de, a.grad_params_ae = gde.data_ptr(), gae.data_ptr()
+        nbytes = lib.psnode_dae_backward_workspace_bytes(ctypes.byref(a))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_dae_backward_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_dae_backward_f32")
+    g["de"], g["ae"] = _split_grads(gde, de_layers), _split_grads(gae, ae_layers)
+    return g
+
+
+def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True,
+                 kernel: str = "auto"):
     """Backward pass of `ode_integrate` (input_true_x=False) in one launch.
     Returns (grad_x0 [B,xd], grad_z [T,B,zd] | None, grad_z_jump | None, grad_all_initial [B,n], [grad W1, b1, ..., W4, b4])."""
     lib = _lib.load()
@@ -294,7 +374,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     T, B, xd = xs.shape
     zd = z.shape[-1]
     keep: list = []
-    a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep)
+    a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep, kernel)
     a.t = _view(t, dev, "t", keep)
     a.z = _view(z, dev, "z", keep)
     a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
@@ -324,11 +404,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_ode_backward_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_ode_backward_f32")
-    grads, off = [], 0
-    for w, b in de_layers:
-        grads.append(gpar[off:off + w.numel()].view_as(w)); off += w.numel()
-        grads.append(gpar[off:off + b.numel()].view_as(b)); off += b.numel()
-    return gx0, gz, gzj, ga0, grads
+    return gx0, gz, gzj, ga0, _split_grads(gpar, de_layers)
 
 
 def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
@@ -419,6 +495,5 @@ def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change
     ok, event_t, z_jump, v_jump = _event_tensors(event_fn, jump_change_fn, True)
     if not ok:
         return None
-    if _needs_autograd([x_init, z, v, i, all_initial, z_jump, v_jump] + [p for wb in list(de) + list(ae) for p in wb]):
-        return None
-    return de, ae, event_t, z_jump, v_jump
+    needs_grad = _needs_autograd([x_init, z, v, all_initial, z_jump, v_jump] + [p for wb in list(de) + list(ae) for p in wb])
+    return de, ae, event_t, z_jump, v_jump, needs_grad

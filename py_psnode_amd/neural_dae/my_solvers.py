@@ -102,10 +102,15 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
         if self.fused != "off":
             plan = _fused.plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn)
             if plan is not None:
-                de, ae, event_t, z_jump, v_jump = plan
-                return _fused.dae_integrate(self.method, de, ae, x_init, t, x, z, v, i, all_initial, event_t=event_t,
-                                            z_jump=z_jump, v_jump=v_jump, input_true_x=input_true_x,
-                                            input_true_i=input_true_i, kernel=self.kernel)
+                de, ae, event_t, z_jump, v_jump, needs_grad = plan
+                if not needs_grad:
+                    return _fused.dae_integrate(self.method, de, ae, x_init, t, x, z, v, i, all_initial, event_t=event_t,
+                                                z_jump=z_jump, v_jump=v_jump, input_true_x=input_true_x,
+                                                input_true_i=input_true_i, kernel=self.kernel)
+                if not (input_true_x or input_true_i) and _fused.dae_backward_supported(
+                        self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]):
+                    from ..autograd import fused_dae_integrate
+                    return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump)
             if self.fused == "require":
                 raise NotFusableError("integrate_DAE: call is not fusable (needs fp32 HIP tensors, DE_Func/AE_Func-style "
                                       "ELU-MLPs, DAE_Event callbacks and no autograd)")
