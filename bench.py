@@ -247,15 +247,24 @@ def main():
 
     train_state = {}
     if args.train:
-        assert w["kind"] == "ode", "--train covers the ODE workload"
+        assert w["kind"] in ("ode", "dae"), "--train covers the ode01 / dae01 workloads"
         from py_psnode_amd import autograd as pag
-        train_state["params"] = [q.clone().requires_grad_(True) for wb in p["de"] for q in wb]
-        train_state["layers"] = [(train_state["params"][k], train_state["params"][k + 1]) for k in range(0, 8, 2)]
+        mk = lambda ls: [q.clone().requires_grad_(True) for wb in ls for q in wb]
+        pair = lambda ps: [(ps[k], ps[k + 1]) for k in range(0, len(ps), 2)]
+        train_state["params"] = mk(p["de"]) + (mk(p["ae"]) if w["kind"] == "dae" else [])
+        nde = 2 * len(p["de"])
+        train_state["layers"] = pair(train_state["params"][:nde])
+        train_state["ae_layers"] = pair(train_state["params"][nde:])
         train_state["G"] = torch.randn(T, B, w["xd"], device=dev)
 
     def train_step():
         for q in train_state["params"]:
             q.grad = None
+        if w["kind"] == "dae":
+            xs, is_ = pag.fused_dae_integrate(args.method, args.kernel, train_state["layers"], train_state["ae_layers"], p["x_init"], tmv(p["t"]),
+                                              tmv(p["z"]), tmv(p["v"]), tmv(p["i"]), p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
+            ((xs * train_state["G"]).sum() + is_.sum()).backward()
+            return (xs.detach(), is_.detach())
         xs = pag.fused_ode_integrate(args.method, args.kernel, train_state["layers"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                      p["event_t"], p["z_jump"])
         (xs * train_state["G"]).sum().backward()
@@ -362,7 +371,7 @@ def main():
         if args.train:
             res["metric"] = f"training state-steps/sec (forward + backward), {args.workload} {args.method}, batch {B}"
             res["config"]["workload"] += " | forward + fused backward (sum-weighted loss)"
-            if args.train_baseline_steps > 0:
+            if args.train_baseline_steps > 0 and w["kind"] == "ode":
                 # the route the reference's scripts take: unrolled autograd through the per-step Python loop, on this GPU
                 from py_psnode_amd import models
                 from py_psnode_amd import neural_dae as nd
