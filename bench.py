@@ -319,6 +319,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(tt[0]), float(tt[1])
 
+    gather_only_ms = None
+    if do_gather and w["kind"] == "ode":
+        # config 5 also wants the gather alone: one un-pipelined all-gather of a full [T,B,xd] shard, after the timed region
+        flat = torch.empty((world * T, B, w["xd"]), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(flat, outs[0])
+        fence()
+        tg = time.perf_counter()
+        for _ in range(3):
+            dist.all_gather_into_tensor(flat, outs[0])
+        fence()
+        gather_only_ms = (time.perf_counter() - tg) / 3 * 1e3
+        del flat
+
     finite = bool(torch.isfinite(outs[0]).all())
     state_steps_launch = B * (T - 1)
     flops = flops_per_state_step(w, p_cpu, args.method)
@@ -362,7 +375,7 @@ def main():
                        "kernel": kname, "trajectories_total": world * B,
                        "collective": ((f"rccl all_gather of xs shards [T,B,xd], {args.chunks} time chunks overlapped with the integration"
                                        if pipelined else "rccl all_gather of xs shards [T,B,xd]") if do_gather else "none"),
-                       "outputs_finite": finite},
+                       "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel_ms": kern_avg_ms, "flop_per_state_step": flops,
                          "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
