@@ -87,6 +87,21 @@ __device__ __forceinline__ float elu_fast(float x) {
 #endif
 }
 
+// Cooperative copy of `count` floats global -> LDS by a 256-thread workgroup (float4 when both sides are 16-B aligned),
+// followed by a barrier.  Used by the generic kernels to stage one layer's weights (or a chunk of it) per use.
+constexpr int kWBuf = 4096;   // floats (16 KB)
+__device__ __forceinline__ void stage_weights(const float* __restrict__ src, float* dst, int count) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int n4 = count >> 2;
+        for (int i = tid; i < n4; i += nt) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int i = (n4 << 2) + tid; i < count; i += nt) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < count; i += nt) dst[i] = src[i];
+    }
+    __syncthreads();
+}
+
 // fp32(1/3): the reference multiplies fp32 tensors by the python double 1/3, which ATen rounds to fp32
 // (my_fixed_grid.py:8,43-44).
 constexpr float kOneThird = 0.333333343267440796f;

@@ -18,35 +18,39 @@ constexpr int TB = 16;    // trajectories per workgroup
 constexpr int NT = 256;   // threads per workgroup (4 waves)
 
 // MLP over the TB columns. `in` holds [K][TB]; returns the buffer holding [N_last][TB].
-// Ends with a __syncthreads() after every layer.
-__device__ float* mlp_eval(const MlpDev& m, float* in, float* out) {
+// Each layer's transposed weights ([in][out]) are staged through the LDS buffer `wbuf` in chunks of whole input rows,
+// so the inner loop reads one conflict-free ds_read_b32 (weight) and one broadcast ds_read_b128 (4 trajectories) per
+// FMA quad instead of a global load.  Partial sums of multi-chunk layers live in `out`.  Barrier after every chunk.
+__device__ float* mlp_eval(const MlpDev& m, float* in, float* out, float* wbuf) {
     int K = m.in_dim;
     for (int l = 0; l < m.n_layers; ++l) {
         const int N = m.out_dim[l];
         const float* __restrict__ wt = m.wt[l];
         const float* __restrict__ bias = m.bias[l];
         const bool last = (l + 1 == m.n_layers);
-        for (int item = threadIdx.x; item < N * (TB / 4); item += NT) {
-            const int j = item % N, g = item / N;
-            const float b = bias[j];
-            float a0 = b, a1 = b, a2 = b, a3 = b;
-            const float* col = in + g * 4;
-            const float* w = wt + j;
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {
-                const float wk = w[(size_t)k * N];
-                const float4 v = *reinterpret_cast<const float4*>(col + k * TB);
-                a0 = fmaf(wk, v.x, a0);
-                a1 = fmaf(wk, v.y, a1);
-                a2 = fmaf(wk, v.z, a2);
-                a3 = fmaf(wk, v.w, a3);
+        const int KC = kWBuf / N > 0 ? kWBuf / N : 1;            // input rows per staged chunk (N <= 1024 < kWBuf)
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            const int kc = K - k0 < KC ? K - k0 : KC;
+            stage_weights(wt + (size_t)k0 * N, wbuf, kc * N);
+            const bool first = k0 == 0, final = k0 + kc >= K;
+            for (int item = threadIdx.x; item < N * (TB / 4); item += NT) {
+                const int j = item % N, g = item / N;
+                float4 acc;
+                if (first) { const float b = bias[j]; acc = make_float4(b, b, b, b); }
+                else acc = *reinterpret_cast<const float4*>(out + j * TB + g * 4);
+                const float* col = in + (k0 * TB) + g * 4;
+                const float* w = wbuf + j;
+#pragma unroll 8
+                for (int k = 0; k < kc; ++k) {
+                    const float wk = w[k * N];
+                    const float4 v = *reinterpret_cast<const float4*>(col + k * TB);
+                    acc.x = fmaf(wk, v.x, acc.x); acc.y = fmaf(wk, v.y, acc.y); acc.z = fmaf(wk, v.z, acc.z); acc.w = fmaf(wk, v.w, acc.w);
+                }
+                if (final && !last) { acc.x = elu1(acc.x); acc.y = elu1(acc.y); acc.z = elu1(acc.z); acc.w = elu1(acc.w); }
+                *reinterpret_cast<float4*>(out + j * TB + g * 4) = acc;
             }
-            if (!last) {
-                a0 = elu1(a0); a1 = elu1(a1); a2 = elu1(a2); a3 = elu1(a3);
-            }
-            *reinterpret_cast<float4*>(out + j * TB + g * 4) = make_float4(a0, a1, a2, a3);
+            __syncthreads();
         }
-        __syncthreads();
         float* tmp = in; in = out; out = tmp;
         K = N;
     }
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     float* kbuf = xst + xd * TB;       // [4][xd][TB]
     float* icur = kbuf + 4 * xd * TB;  // [id][TB]
     float* dts = icur + id * TB;       // [TB]
+    float* wbuf = dts + TB;            // [kWBuf] staged weights
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
     const bool true_x = (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
                 actA[idx] = v;
             }
             __syncthreads();
-            const float* out = mlp_eval(a.ae, actA, actB);
+            const float* out = mlp_eval(a.ae, actA, actB, wbuf);
             for (int idx = tid; idx < id * TB; idx += NT) icur[idx] = out[idx];
             __syncthreads();
         }
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
             actA[2 * n * TB + idx] = s;
         }
         __syncthreads();
-        return mlp_eval(a.de, actA, actB);
+        return mlp_eval(a.de, actA, actB, wbuf);
     };
 
     const int nstage = a.method == PSNODE_EULER ? 1 : (a.method == PSNODE_MIDPOINT ? 2 : 4);
@@ -258,7 +263,7 @@ size_t generic_lds_bytes(const IntegrateDev& a, bool dae) {
     const int vd = dae ? a.vd : 0, id = dae ? a.id : 0;
     const int n = a.xd + a.zd + vd + id;
     const size_t rows = 2 * (size_t)a.maxw + n + (n - a.xd) + 3 * (size_t)a.xd + 4 * (size_t)a.xd + id + 1;
-    return rows * TB * sizeof(float);
+    return (rows * TB + kWBuf) * sizeof(float);
 }
 
 hipError_t launch_generic(const IntegrateDev& a, bool dae, hipStream_t stream) {

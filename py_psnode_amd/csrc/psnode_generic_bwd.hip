@@ -52,8 +52,9 @@ struct GBwd {
 
 __device__ __forceinline__ float delu(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }   // ELU'(pre) from h = ELU(pre)
 
-// forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]]; ends with a barrier per layer
-__device__ void g_forward(const GMlp& m, float* acts) {
+// forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]].  Weights (transposed copy) are staged
+// through `wbuf` in chunks of input rows; barrier after every chunk.
+__device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
     int K = m.in_dim;
     for (int l = 0; l < m.L; ++l) {
         const int N = m.out_dim[l];
@@ -62,27 +63,36 @@ __device__ void g_forward(const GMlp& m, float* acts) {
         const float* in = acts + m.act[l] * TP;
         float* out = acts + m.act[l + 1] * TP;
         const bool last = (l + 1 == m.L);
-        for (int item = threadIdx.x; item < N * 4; item += NT) {
-            const int j = item % N, g = item / N;
-            const float b = bias[j];
-            float a0 = b, a1 = b, a2 = b, a3 = b;
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {
-                const float wk = wt[(size_t)k * N + j];
-                const float4 v = *reinterpret_cast<const float4*>(in + k * TP + g * 4);
-                a0 = fmaf(wk, v.x, a0); a1 = fmaf(wk, v.y, a1); a2 = fmaf(wk, v.z, a2); a3 = fmaf(wk, v.w, a3);
+        const int KC = kWBuf / N > 0 ? kWBuf / N : 1;
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            const int kc = K - k0 < KC ? K - k0 : KC;
+            stage_weights(wt + (size_t)k0 * N, wbuf, kc * N);
+            const bool first = k0 == 0, final = k0 + kc >= K;
+            for (int item = threadIdx.x; item < N * 4; item += NT) {
+                const int j = item % N, g = item / N;
+                float4 acc;
+                if (first) { const float b = bias[j]; acc = make_float4(b, b, b, b); }
+                else acc = *reinterpret_cast<const float4*>(out + j * TP + g * 4);
+                const float* col = in + k0 * TP + g * 4;
+                const float* w = wbuf + j;
+#pragma unroll 8
+                for (int k = 0; k < kc; ++k) {
+                    const float wk = w[k * N];
+                    const float4 v = *reinterpret_cast<const float4*>(col + k * TP);
+                    acc.x = fmaf(wk, v.x, acc.x); acc.y = fmaf(wk, v.y, acc.y); acc.z = fmaf(wk, v.z, acc.z); acc.w = fmaf(wk, v.w, acc.w);
+                }
+                if (final && !last) { acc.x = elu1(acc.x); acc.y = elu1(acc.y); acc.z = elu1(acc.z); acc.w = elu1(acc.w); }
+                *reinterpret_cast<float4*>(out + j * TP + g * 4) = acc;
             }
-            if (!last) { a0 = elu1(a0); a1 = elu1(a1); a2 = elu1(a2); a3 = elu1(a3); }
-            *reinterpret_cast<float4*>(out + j * TP + g * 4) = make_float4(a0, a1, a2, a3);
+            __syncthreads();
         }
-        __syncthreads();
         K = N;
     }
 }
 
 // VJP of the MLP: `din` holds delta of the output [N_L][TP]; returns the buffer with the input gradient [in_dim][TP].
 // Accumulates dW, db into gacc.  Ends with a barrier.
-__device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc) {
+__device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc, float* wbuf) {
     const int tid = threadIdx.x, jg = tid >> 4, kk = tid & 15;
     for (int l = m.L - 1; l >= 0; --l) {
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
@@ -120,24 +130,34 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
             for (int c = 0; c < TB; ++c) s += din[j * TP + c];
             gacc[m.gb[l] + j] += s;
         }
-        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers)
-        const float* __restrict__ w = m.w[l];
-        for (int item = tid; item < K * 4; item += NT) {
-            const int k = item % K, g = item / K;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 4
-            for (int j = 0; j < N; ++j) {
-                const float wj = w[(size_t)j * K + k];
-                const float4 v = *reinterpret_cast<const float4*>(din + j * TP + g * 4);
-                a0 = fmaf(wj, v.x, a0); a1 = fmaf(wj, v.y, a1); a2 = fmaf(wj, v.z, a2); a3 = fmaf(wj, v.w, a3);
-            }
-            if (l > 0) {
-                const float4 h = *reinterpret_cast<const float4*>(a_in + k * TP + g * 4);
-                a0 *= delu(h.x); a1 *= delu(h.y); a2 *= delu(h.z); a3 *= delu(h.w);
-            }
-            *reinterpret_cast<float4*>(dout + k * TP + g * 4) = make_float4(a0, a1, a2, a3);
-        }
+        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers); row-major W staged in chunks of
+        //      output rows, partial sums in dout
         __syncthreads();
+        const float* __restrict__ w = m.w[l];
+        const int JC = kWBuf / K > 0 ? kWBuf / K : 1;
+        for (int j0 = 0; j0 < N; j0 += JC) {
+            const int jc = N - j0 < JC ? N - j0 : JC;
+            stage_weights(w + (size_t)j0 * K, wbuf, jc * K);
+            const bool first = j0 == 0, final = j0 + jc >= N;
+            for (int item = tid; item < K * 4; item += NT) {
+                const int k = item % K, g = item / K;
+                float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dout + k * TP + g * 4);
+                const float* wl = wbuf + k;
+                const float* dcol = din + j0 * TP + g * 4;
+#pragma unroll 8
+                for (int j = 0; j < jc; ++j) {
+                    const float wj = wl[j * K];
+                    const float4 v = *reinterpret_cast<const float4*>(dcol + j * TP);
+                    acc.x = fmaf(wj, v.x, acc.x); acc.y = fmaf(wj, v.y, acc.y); acc.z = fmaf(wj, v.z, acc.z); acc.w = fmaf(wj, v.w, acc.w);
+                }
+                if (final && l > 0) {
+                    const float4 h = *reinterpret_cast<const float4*>(a_in + k * TP + g * 4);
+                    acc.x *= delu(h.x); acc.y *= delu(h.y); acc.z *= delu(h.z); acc.w *= delu(h.w);
+                }
+                *reinterpret_cast<float4*>(dout + k * TP + g * 4) = acc;
+            }
+            __syncthreads();
+        }
         float* tmp = din; din = dout; dout = tmp;
     }
     return din;
@@ -183,7 +203,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     float* gxc = gx0 + nx;                        // [xd][TP]  carried dL/dx_{k+1}
     float* gic = gxc + nx;                        // [id][TP]  carried dL/di_{k+1}
     float* dts = gic + id * TP;                   // [TP]
-    float* gacc = dts + TP;                       // [np_de + np_ae]
+    float* wbuf = dts + TP;                       // [kWBuf] staged weights
+    float* gacc = wbuf + kWBuf;                   // [np_de + np_ae]
     float* gacc_ae = gacc + a.de.np;
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
@@ -233,10 +254,10 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // adds to gx_dst, ga0s, and to the z|v gradients (global gz/gv at jzv, or the jump gradients of event ev)
     auto ae_vjp = [&](const float* xrows, long long jzv, int ev, const float* gi, float* gx_dst) {
         ae_input(xrows, jzv);
-        g_forward(a.ae, acts);
+        g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = g_vjp(a.ae, acts, dA, dB, gacc_ae);
+        const float* gu = g_vjp(a.ae, acts, dA, dB, gacc_ae, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
         TILE_LOOP(nzv) {
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             // (2) algebraic input of this step's DE
             if (ev >= 0) {
                 ae_input(x0, -1);
-                g_forward(a.ae, acts);
+                g_forward(a.ae, acts, wbuf);
                 const float* out = acts + a.ae.act[a.ae.L] * TP;
                 TILE_LOOP(id) ext[(nzv + r) * TP + c] = out[r * TP + c];
             } else {
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             }
             __syncthreads();
             de_input(xst + s * nx);
-            g_forward(a.de, acts);
+            g_forward(a.de, acts, wbuf);
             const float* out = acts + a.de.act[a.de.L] * TP;
             TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
             __syncthreads();
@@ -307,10 +328,10 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         __syncthreads();
         for (int s = S - 1; s >= 0; --s) {
             de_input(xst + s * nx);
-            g_forward(a.de, acts);
+            g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
-            const float* gu = g_vjp(a.de, acts, dA, dB, gacc);
+            const float* gu = g_vjp(a.de, acts, dA, dB, gacc, wbuf);
             TILE_LOOP(n) {
                 const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
@@ -398,7 +419,7 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + a.de.np + (a.dae ? a.ae.np : 0);
+           (size_t)id * TP + TP + kWBuf + a.de.np + (a.dae ? a.ae.np : 0);
 }
 
 int mlp_maxw(const psnode_mlp_f32& m) {
