@@ -52,9 +52,17 @@ struct GBwd {
 
 __device__ __forceinline__ float delu(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }   // ELU'(pre) from h = ELU(pre)
 
-// forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]].  Weights (transposed copy) are staged
-// through `wbuf` in chunks of input rows; barrier after every chunk.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v gm(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// All three matrix products below run on v_mfma_f32_16x16x4_f32 with operands read straight from LDS (lane l:
+// i = j = l&15, k-slot g = l>>4).  Output tiles of 16 rows are dealt round-robin to the four waves.
+
+// forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]].
+// out[u][traj] = sum_k W[u][k] in[k][traj]:  A[i][g] = W^T staged in `wbuf` as [k][N] (chunks of input rows, partial sums
+// of multi-chunk layers live in `out`), B[g][j] = in[k = 4q+g][traj j].  Barrier after every chunk.
 __device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     int K = m.in_dim;
     for (int l = 0; l < m.L; ++l) {
         const int N = m.out_dim[l];
@@ -63,26 +71,35 @@ __device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
         const float* in = acts + m.act[l] * TP;
         float* out = acts + m.act[l + 1] * TP;
         const bool last = (l + 1 == m.L);
-        const int KC = kWBuf / N > 0 ? kWBuf / N : 1;
+        const int KC = (kWBuf / N) & ~3;   // input rows per chunk: a multiple of 4, >= 4 because N <= PSNODE_MAX_WIDTH = kWBuf / 4
         for (int k0 = 0; k0 < K; k0 += KC) {
             const int kc = K - k0 < KC ? K - k0 : KC;
             stage_weights(wt + (size_t)k0 * N, wbuf, kc * N);
             const bool first = k0 == 0, final = k0 + kc >= K;
-            for (int item = threadIdx.x; item < N * 4; item += NT) {
-                const int j = item % N, g = item / N;
-                float4 acc;
-                if (first) { const float b = bias[j]; acc = make_float4(b, b, b, b); }
-                else acc = *reinterpret_cast<const float4*>(out + j * TP + g * 4);
-                const float* col = in + k0 * TP + g * 4;
-                const float* w = wbuf + j;
-#pragma unroll 8
-                for (int k = 0; k < kc; ++k) {
-                    const float wk = w[k * N];
-                    const float4 v = *reinterpret_cast<const float4*>(col + k * TP);
-                    acc.x = fmaf(wk, v.x, acc.x); acc.y = fmaf(wk, v.y, acc.y); acc.z = fmaf(wk, v.z, acc.z); acc.w = fmaf(wk, v.w, acc.w);
+            for (int mt = wave; mt * 16 < N; mt += 4) {
+                const int u = 16 * mt + i;
+                f4v accA, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int uu = 16 * mt + 4 * g + r;
+                    accA[r] = uu < N ? (first ? bias[uu] : out[uu * TP + i]) : 0.0f;
                 }
-                if (final && !last) { acc.x = elu1(acc.x); acc.y = elu1(acc.y); acc.z = elu1(acc.z); acc.w = elu1(acc.w); }
-                *reinterpret_cast<float4*>(out + j * TP + g * 4) = acc;
+                for (int kq = 0; kq < kc; kq += 8) {
+                    const int ka = kq + g, kb = kq + 4 + g;
+                    const float a0 = (ka < kc && u < N) ? wbuf[ka * N + u] : 0.0f, b0 = ka < kc ? in[(k0 + ka) * TP + i] : 0.0f;
+                    const float a1 = (kb < kc && u < N) ? wbuf[kb * N + u] : 0.0f, b1 = kb < kc ? in[(k0 + kb) * TP + i] : 0.0f;
+                    accA = gm(a0, b0, accA);
+                    accB = gm(a1, b1, accB);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int uu = 16 * mt + 4 * g + r;
+                    if (uu < N) {
+                        float v = accA[r] + accB[r];
+                        if (final && !last) v = elu1(v);
+                        out[uu * TP + i] = v;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -93,34 +110,27 @@ __device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
 // VJP of the MLP: `din` holds delta of the output [N_L][TP]; returns the buffer with the input gradient [in_dim][TP].
 // Accumulates dW, db into gacc.  Ends with a barrier.
 __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc, float* wbuf) {
-    const int tid = threadIdx.x, jg = tid >> 4, kk = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     for (int l = m.L - 1; l >= 0; --l) {
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
         const float* a_in = acts + m.act[l] * TP;
-        // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr]; 4 x 4 blocks: rows j0..j0+3, columns k0 + 16 m
+        // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr]: 16x16 tiles, contraction over the 16 trajectories
+        //      A[i][g] = delta[16 mt + i][tr = 4q+g], B[g][j] = a_in[16 kt + j][tr]; each tile is owned by one wave
         float* gw = gacc + m.gw[l];
-        for (int j0 = 4 * jg; j0 < N; j0 += 64) {
-            for (int k0 = kk; k0 < K; k0 += 64) {
-                float acc[4][4] = {};
+        const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            const int mt = tile / ntk, kt = tile % ntk;
+            const int ju = 16 * mt + i, ku = 16 * kt + i;
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {          // trajectory quad
-                    float4 dj[4], ak[4];
+            for (int q = 0; q < 4; ++q) {
+                const int tr = 4 * q + g;
+                acc = gm(ju < N ? din[ju * TP + tr] : 0.0f, ku < K ? a_in[ku * TP + tr] : 0.0f, acc);
+            }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dj[r] = j0 + r < N ? *reinterpret_cast<const float4*>(din + (j0 + r) * TP + 4 * q) : make_float4(0, 0, 0, 0);
-                        ak[r] = k0 + 16 * r < K ? *reinterpret_cast<const float4*>(a_in + (k0 + 16 * r) * TP + 4 * q) : make_float4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[r][c] = fmaf(dj[r].w, ak[c].w, fmaf(dj[r].z, ak[c].z, fmaf(dj[r].y, ak[c].y, fmaf(dj[r].x, ak[c].x, acc[r][c]))));
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (j0 + r < N && k0 + 16 * c < K) gw[(j0 + r) * K + k0 + 16 * c] += acc[r][c];
+            for (int r = 0; r < 4; ++r) {
+                const int jr = 16 * mt + 4 * g + r;
+                if (jr < N && ku < K) gw[jr * K + ku] += acc[r];
             }
         }
         // ---- db[j] += sum_tr delta[j][tr]
@@ -130,31 +140,39 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
             for (int c = 0; c < TB; ++c) s += din[j * TP + c];
             gacc[m.gb[l] + j] += s;
         }
-        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers); row-major W staged in chunks of
-        //      output rows, partial sums in dout
+        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers): A[i][g] = W[j = 4q+g][16 kt + i] from the
+        //      row-major weights staged in chunks of output rows, B[g][j] = delta[4q+g][traj]; partial sums in dout
         __syncthreads();
         const float* __restrict__ w = m.w[l];
-        const int JC = kWBuf / K > 0 ? kWBuf / K : 1;
+        const int JC = (kWBuf / K) & ~3;
         for (int j0 = 0; j0 < N; j0 += JC) {
             const int jc = N - j0 < JC ? N - j0 : JC;
             stage_weights(w + (size_t)j0 * K, wbuf, jc * K);
             const bool first = j0 == 0, final = j0 + jc >= N;
-            for (int item = tid; item < K * 4; item += NT) {
-                const int k = item % K, g = item / K;
-                float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dout + k * TP + g * 4);
-                const float* wl = wbuf + k;
-                const float* dcol = din + j0 * TP + g * 4;
-#pragma unroll 8
-                for (int j = 0; j < jc; ++j) {
-                    const float wj = wl[j * K];
-                    const float4 v = *reinterpret_cast<const float4*>(dcol + j * TP);
-                    acc.x = fmaf(wj, v.x, acc.x); acc.y = fmaf(wj, v.y, acc.y); acc.z = fmaf(wj, v.z, acc.z); acc.w = fmaf(wj, v.w, acc.w);
+            for (int kt = wave; kt * 16 < K; kt += 4) {
+                const int ku = 16 * kt + i;
+                f4v accA, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = 16 * kt + 4 * g + r;
+                    accA[r] = (!first && kr < K) ? dout[kr * TP + i] : 0.0f;
                 }
-                if (final && l > 0) {
-                    const float4 h = *reinterpret_cast<const float4*>(a_in + k * TP + g * 4);
-                    acc.x *= delu(h.x); acc.y *= delu(h.y); acc.z *= delu(h.z); acc.w *= delu(h.w);
+                for (int jq = 0; jq < jc; jq += 8) {
+                    const int ja = jq + g, jb = jq + 4 + g;
+                    const float a0 = (ja < jc && ku < K) ? wbuf[ja * K + ku] : 0.0f, b0 = ja < jc ? din[(j0 + ja) * TP + i] : 0.0f;
+                    const float a1 = (jb < jc && ku < K) ? wbuf[jb * K + ku] : 0.0f, b1 = jb < jc ? din[(j0 + jb) * TP + i] : 0.0f;
+                    accA = gm(a0, b0, accA);
+                    accB = gm(a1, b1, accB);
                 }
-                *reinterpret_cast<float4*>(dout + k * TP + g * 4) = acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = 16 * kt + 4 * g + r;
+                    if (kr < K) {
+                        float v = accA[r] + accB[r];
+                        if (final && l > 0) v *= delu(a_in[kr * TP + i]);
+                        dout[kr * TP + i] = v;
+                    }
+                }
             }
             __syncthreads();
         }
