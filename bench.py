@@ -35,6 +35,7 @@ WORKLOADS = {
     "ode01": dict(kind="ode", B=4096, T=1001, xd=8, zd=2, H=64, nh=3),
     "dae01": dict(kind="dae", B=4096, T=1001, xd=8, zd=2, vd=2, id=2, H=64, nh=3),
     "ode02_latent16": dict(kind="ode", B=4096, T=1001, xd=16, zd=16, H=16, nh=1),
+    "ode02_latent64": dict(kind="ode", B=4096, T=1001, xd=64, zd=64, H=64, nh=1),   # hidden_dim 64 (generic kernel)
     # BASELINE config 3: whole ODE_02 direct_encode forward (enc x, enc z, latent integrate, dec pred, dec recon), H=16
     "ode02": dict(kind="ode02_model", B=4096, T=1001, xd=8, zd=2, H=16, nh=1),
 }

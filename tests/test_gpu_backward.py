@@ -51,6 +51,8 @@ def _truth(method, lin, t, x, z, ev, zj, G):
 
 
 def _close(a, b, what):
+    if b is None:                      # parameter unused by the reference graph (e.g. T = 1): gradient must be zero
+        b = torch.zeros(a.shape, dtype=torch.float64)
     scale = float(b.abs().max())
     err = float((a.double().cpu() - b).abs().max())
     assert err <= TOL * max(scale, 1e-6), f"{what}: err {err:.3e} vs scale {scale:.3e}"
@@ -203,3 +205,71 @@ def test_fused_dae_backward_matches_fp64_autograd(method, events):
         _close(a, b, nme)
     for k, (a, b) in enumerate(zip(out[7], ref[7])):
         _close(a, b, f"grad param {k}")
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "generic"])
+@pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3)])
+def test_backward_edge_sizes(B, Tn, kernel):
+    """T = 1 (no step at all), T = 2, single trajectory, ragged tiles -- both backward kernels against fp64 autograd."""
+    from py_psnode_amd import fused
+    lin, t, x, z, _, _, G = _case(B, Tn, 8, 2, seed=900 + B, events=False)
+    xs_ref, gx_ref, gz_ref, _, gp_ref = _truth("rk4", lin, t, x, z, None, None, G)
+    layers = [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in lin]
+    a0 = torch.cat((x[0], z[0]), -1).cuda()
+    xs = fused.ode_integrate("rk4", layers, t.cuda(), x.cuda(), z.cuda(), a0)
+    gx0, gz, _, ga0, gp = fused.ode_backward("rk4", layers, t.cuda(), z.cuda(), a0, xs, G.cuda(), kernel=kernel)
+    _close(xs, xs_ref, "xs")
+    _close(gx0 + ga0[:, :8], gx_ref[0], "grad x0")
+    gz_tot = gz.clone()
+    gz_tot[0] += ga0[:, 8:]
+    _close(gz_tot, gz_ref, "grad z")
+    for k, (a, b) in enumerate(zip(gp, gp_ref)):
+        _close(a, b, f"grad param {k}")
+
+
+def test_dae_backward_without_z_and_odd_widths():
+    """DAE generic backward with z_dim = 0 and non-multiple-of-16 widths (raw-tensor API) vs fp64 autograd of the oracle loop."""
+    from oracle import psnode_oracle as O
+    from py_psnode_amd import fused
+    B, Tn, xd, zd, vd, idim, H = 9, 6, 5, 0, 3, 2, 24
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    n = xd + zd + vd + idim
+    mk = lambda dims: [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]
+    de_l, ae_l = mk([3 * n, H, H, xd]), mk([n + xd + zd + vd, H, idim])
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1)
+    z, v, xi, i0 = r(Tn, B, zd), r(Tn, B, vd), r(B, xd), r(B, idim)
+    Gx, Gi = torch.randn(Tn, B, xd, generator=g), torch.randn(Tn, B, idim, generator=g)
+    # fp64 truth: differentiable restatement of the DAE loop (no events, no teacher forcing)
+    D = lambda a: a.double()
+    leaf = lambda p_: p_.detach().double().requires_grad_(True)
+    de64 = [(leaf(l.weight), leaf(l.bias)) for l in de_l]
+    ae64 = [(leaf(l.weight), leaf(l.bias)) for l in ae_l]
+    vq, xiq = D(v).requires_grad_(True), D(xi).requires_grad_(True)
+    a0q = torch.cat((xiq, D(z[0]), vq[0], D(i0)), -1)
+    x_cur, i_cur = xiq, O.ae_rhs(ae64, xiq, D(z[0]), vq[0], a0q)
+    xs_l, is_l = [x_cur], [i_cur]
+    for k in range(Tn - 1):
+        dt = D(t[k + 1] - t[k])
+        x_cur, _ = O.step("rk4", lambda xx: O.de_rhs(de64, xx, (D(z[k]), vq[k], i_cur), a0q), D(t[k]), dt, D(t[k + 1]), x_cur)
+        i_cur = O.ae_rhs(ae64, x_cur, D(z[k + 1]), vq[k + 1], a0q)
+        xs_l.append(x_cur); is_l.append(i_cur)
+    xs_ref, is_ref = torch.stack(xs_l), torch.stack(is_l)
+    ((xs_ref * D(Gx)).sum() + (is_ref * D(Gi)).sum()).backward()
+    c = lambda a: a.cuda()
+    de = [(c(l.weight.detach()), c(l.bias.detach())) for l in de_l]
+    ae = [(c(l.weight.detach()), c(l.bias.detach())) for l in ae_l]
+    a0 = torch.cat((xi, z[0], v[0], i0), -1)
+    xe = torch.zeros(Tn, B, 0)
+    xs, is_ = fused.dae_integrate("rk4", de, ae, c(xi), c(t), c(xe), c(z), c(v), c(torch.zeros(Tn, B, idim)), c(a0))
+    gr = fused.dae_backward("rk4", de, ae, c(t), c(z), c(v), c(a0), xs, is_, c(Gx), c(Gi))
+    _close(xs, xs_ref.detach(), "xs"); _close(is_, is_ref.detach(), "is")
+    _close(gr["x_init"] + gr["all_initial"][:, :xd], xiq.grad, "grad x_init")
+    gv = gr["v"].clone(); gv[0] += gr["all_initial"][:, xd + zd:xd + zd + vd]
+    _close(gv, vq.grad, "grad v")
+    flat_ref = [q.grad for wb in de64 for q in wb]
+    for k, (a, b) in enumerate(zip(gr["de"], flat_ref)):
+        _close(a, b, f"grad de {k}")
+    for k, (a, b) in enumerate(zip(gr["ae"], [q.grad for wb in ae64 for q in wb])):
+        _close(a, b, f"grad ae {k}")
