@@ -36,6 +36,10 @@ class PsnodeStatusError(RuntimeError):
     pass
 
 
+class UnsupportedShapeError(ValueError):
+    """PSNODE_ERR_UNSUPPORTED: no kernel covers this shape (e.g. an MLP too wide for the generic kernel's LDS budget)."""
+
+
 class MlpF32(ctypes.Structure):
     _fields_ = [("n_layers", c_int32), ("in_dim", c_int32), ("out_dim", c_int32 * MAX_LAYERS),
                 ("weight", c_void_p * MAX_LAYERS), ("bias", c_void_p * MAX_LAYERS)]
@@ -143,6 +147,8 @@ def load():
 def check(status, what):
     if status != OK:
         msg = load().psnode_status_string(status).decode()
-        if status in (-2, -3, -5):
+        if status == -5:
+            raise UnsupportedShapeError(f"{what}: {msg} (status {status})")
+        if status in (-2, -3):
             raise ValueError(f"{what}: {msg} (status {status})")
         raise PsnodeStatusError(f"{what}: {msg} (status {status})")

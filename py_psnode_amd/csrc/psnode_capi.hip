@@ -25,9 +25,11 @@ size_t transposed_floats(const psnode_mlp_f32* m) {
 
 int check_mlp(const psnode_mlp_f32& m, int want_in, int want_out) {
     if (m.n_layers < 1 || m.n_layers > kMaxLayers) return PSNODE_ERR_DIMS;
-    if (m.in_dim != want_in || m.in_dim < 1 || m.in_dim > PSNODE_MAX_WIDTH) return PSNODE_ERR_DIMS;
+    if (m.in_dim != want_in || m.in_dim < 1) return PSNODE_ERR_DIMS;
+    if (m.in_dim > PSNODE_MAX_WIDTH) return PSNODE_ERR_UNSUPPORTED;       // consistent, but wider than any kernel takes
     for (int l = 0; l < m.n_layers; ++l) {
-        if (m.out_dim[l] < 1 || m.out_dim[l] > PSNODE_MAX_WIDTH) return PSNODE_ERR_DIMS;
+        if (m.out_dim[l] < 1) return PSNODE_ERR_DIMS;
+        if (m.out_dim[l] > PSNODE_MAX_WIDTH) return PSNODE_ERR_UNSUPPORTED;
         if (!m.weight[l] || !m.bias[l]) return PSNODE_ERR_NULL;
     }
     if (m.out_dim[m.n_layers - 1] != want_out) return PSNODE_ERR_DIMS;
@@ -83,6 +85,9 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
     if (dae) ws = bind_mlp(*ae, d.ae, ws);
     d.maxw = max_width(*de);
     if (dae && max_width(*ae) > d.maxw) d.maxw = max_width(*ae);
+    d.maxo = 1;
+    for (int l = 0; l < de->n_layers; ++l) d.maxo = de->out_dim[l] > d.maxo ? de->out_dim[l] : d.maxo;
+    if (dae) for (int l = 0; l < ae->n_layers; ++l) d.maxo = ae->out_dim[l] > d.maxo ? ae->out_dim[l] : d.maxo;
 
     const bool has_mfma = dae ? mfma_dae_supported(d) : mfma_ode_supported(d);
     if (kernel == PSNODE_KERNEL_MFMA && !has_mfma) return PSNODE_ERR_UNSUPPORTED;

@@ -42,7 +42,8 @@ struct IntegrateDev {
     long long vjb, vje;
     float* xo;
     float* io;
-    int maxw;              // widest activation vector (generic kernel LDS sizing)
+    int maxw;              // widest activation vector incl. the MLP inputs (generic kernel buffer A)
+    int maxo;              // widest layer OUTPUT (generic kernel buffer B: it only ever holds layer outputs)
 };
 
 // ELU(alpha=1) with the negative branch at expm1 quality: ATen's CPU kernel (what the reference runs) returns

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     const int ne = n - xd;             // external rows: z | v | i
 
     float* actA = lds;
-    float* actB = actA + a.maxw * TB;
-    float* a0 = actB + a.maxw * TB;    // [n][TB]
+    float* actB = actA + a.maxw * TB;  // ping-pong partner: holds layer outputs only -> maxo rows
+    float* a0 = actB + a.maxo * TB;    // [n][TB]
     float* ext = a0 + n * TB;          // [ne][TB] z | v | i fed to the DE stages of this step
     float* xcur = ext + ne * TB;       // [xd][TB] running state
     float* xsrc = xcur + xd * TB;      // [xd][TB] start of this step (xcur, or dataset x under teacher forcing)
@@ -262,7 +262,7 @@ hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae) {
     const int vd = dae ? a.vd : 0, id = dae ? a.id : 0;
     const int n = a.xd + a.zd + vd + id;
-    const size_t rows = 2 * (size_t)a.maxw + n + (n - a.xd) + 3 * (size_t)a.xd + 4 * (size_t)a.xd + id + 1;
+    const size_t rows = (size_t)a.maxw + a.maxo + n + (n - a.xd) + 3 * (size_t)a.xd + 4 * (size_t)a.xd + id + 1;
     return (rows * TB + kWBuf) * sizeof(float);
 }
 

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import fused as _fused
+from .._lib import UnsupportedShapeError
 
 
 class NotFusableError(RuntimeError):
@@ -71,10 +72,14 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
             if plan is not None:
                 layers, event_t, z_jump, needs_grad = plan
                 if not needs_grad:
-                    return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
-                                                input_true_x=input_true_x, kernel=self.kernel)
+                    try:
+                        return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
+                                                    input_true_x=input_true_x, kernel=self.kernel)
+                    except UnsupportedShapeError:      # no kernel covers the shape (too wide for LDS): user callables it is
+                        if self.fused == "require":
+                            raise
                 # training: fused forward + fused backward when the backward kernel covers the shape
-                if not input_true_x and _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1]):
+                elif not input_true_x and _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1]):
                     from ..autograd import fused_ode_integrate
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump)
             if self.fused == "require":
@@ -104,10 +109,14 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
             if plan is not None:
                 de, ae, event_t, z_jump, v_jump, needs_grad = plan
                 if not needs_grad:
-                    return _fused.dae_integrate(self.method, de, ae, x_init, t, x, z, v, i, all_initial, event_t=event_t,
-                                                z_jump=z_jump, v_jump=v_jump, input_true_x=input_true_x,
-                                                input_true_i=input_true_i, kernel=self.kernel)
-                if not (input_true_x or input_true_i) and _fused.dae_backward_supported(
+                    try:
+                        return _fused.dae_integrate(self.method, de, ae, x_init, t, x, z, v, i, all_initial, event_t=event_t,
+                                                    z_jump=z_jump, v_jump=v_jump, input_true_x=input_true_x,
+                                                    input_true_i=input_true_i, kernel=self.kernel)
+                    except UnsupportedShapeError:
+                        if self.fused == "require":
+                            raise
+                elif not (input_true_x or input_true_i) and _fused.dae_backward_supported(
                         self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]):
                     from ..autograd import fused_dae_integrate
                     return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump)

@@ -421,3 +421,46 @@ def test_order_of_accuracy_full_batch():
         ratios[method] = [errs[k] / errs[k + 1] for k in range(2)]
     assert all(8.0 < r < 24.0 for r in ratios["rk4"]), ratios
     assert all(1.8 < r < 2.2 for r in ratios["euler"]), ratios
+
+
+def test_dae02_shipped_config_hidden64_runs_fused():
+    """neural_01_DAE_02_direct_encode.py ships with hidden = 64 (its debug override, :267): latent blocks of 64, DE 768->64->64,
+    AE 448->64->64.  No MFMA specialisation -> generic kernel; must still be a HIP launch ('require') and match the model
+    evaluated by the callback walk on the CPU."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(5)
+    B, Tn = 19, 9
+    m = models.DAE_Model(8, 2, 2, 2, 64, direct_encode=True, solver=nd.RK4())
+    g = torch.Generator().manual_seed(6)
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    x, z, v, i = r(B, Tn, 8), r(B, Tn, 2), r(B, Tn, 2), r(B, Tn, 2)
+    ev, zj, vj = t[:, [3, 6], :].contiguous(), r(B, 2, 2), r(B, 2, 2)
+    with torch.no_grad():
+        ref = m(t=t, x=x, z=z, v=v, i=i, event_t=ev, z_jump=zj, v_jump=vj)
+        mg = m.cuda()
+        mg.solver.fused = "require"
+        c = lambda a: a.cuda()
+        out = mg(t=c(t), x=c(x), z=c(z), v=c(v), i=c(i), event_t=c(ev), z_jump=c(zj), v_jump=c(vj))
+    for k, (o, rr) in enumerate(zip(out, ref)):
+        assert rel_err(o.cpu(), rr, bdim=0) <= TOL_GPU, k
+
+
+def test_shapes_beyond_every_kernel_fall_back_to_the_walk():
+    """An MLP too wide for the generic kernel's LDS budget: 'auto' walks the user's modules, 'require' raises."""
+    from py_psnode_amd import _lib, models
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(1)
+    de = models.DE_Func(700, (64,), 350).cuda()          # in_features 2100 > PSNODE_MAX_WIDTH
+    B, Tn = 3, 3
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1).cuda()
+    x, z = 0.1 * torch.randn(Tn, B, 350).cuda(), 0.1 * torch.randn(Tn, B, 350).cuda()
+    a0 = torch.cat((x[0], z[0]), -1)
+    s = nd.Euler()
+    with torch.no_grad():
+        out = s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
+        assert out.shape == x.shape and torch.isfinite(out).all()
+        s.fused = "require"
+        with pytest.raises((_lib.UnsupportedShapeError, ValueError)):
+            s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
