@@ -133,4 +133,10 @@ bool latent_ptrs_ok(const IntegrateDev& a, bool dae);
 size_t latent_pack_floats();
 hipError_t launch_latent(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 
+// psnode_latent64.hip (direct_encode latent shapes, hidden_dim 64)
+bool latent64_shape_ok(const IntegrateDev& a, bool dae);
+bool latent64_ptrs_ok(const IntegrateDev& a, bool dae);
+size_t latent64_pack_floats();
+hipError_t launch_latent64(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+
 }  // namespace psnode

@@ -426,12 +426,14 @@ bool shape_ok(const MlpDev& m, int in_dim, int out_dim) {
 
 bool mfma_ode_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, false)) return a.a0 == nullptr || latent_ptrs_ok(a, false);   // a0 == NULL: dims-only query
+    if (latent64_shape_ok(a, false)) return a.a0 == nullptr || latent64_ptrs_ok(a, false);
     if (a.xd < 1 || a.xd > 4 * kNXc || !shape_ok(a.de, 3 * (a.xd + a.zd), a.xd)) return false;
     return nzm_of(a, false) <= 2;
 }
 
 bool mfma_dae_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, true)) return a.a0 == nullptr || latent_ptrs_ok(a, true);
+    if (latent64_shape_ok(a, true)) return a.a0 == nullptr || latent64_ptrs_ok(a, true);
     const int n = a.xd + a.zd + a.vd + a.id;
     if (a.xd < 1 || a.xd > 4 * kNXc || a.id < 1) return false;
     if (!shape_ok(a.de, 3 * n, a.xd) || !shape_ok(a.ae, n + a.xd + a.zd + a.vd, a.id)) return false;
@@ -443,7 +445,7 @@ bool mfma_dae_supported(const IntegrateDev& a) {
 }
 
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
-    if (de && de->n_layers == 2) return latent_pack_floats();
+    if (de && de->n_layers == 2) return latent_pack_floats() > latent64_pack_floats() ? latent_pack_floats() : latent64_pack_floats();
     if (!de || de->n_layers != 4) return 0;
     const int n = de->in_dim / 3;
     const size_t one = (size_t)NW * (kMaxRegs + (n + 3) / 4) * 64;
@@ -452,6 +454,7 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
 
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
     if (latent_shape_ok(a, dae)) return launch_latent(a, dae, pack, stream);
+    if (latent64_shape_ok(a, dae)) return launch_latent64(a, dae, pack, stream);
     const int NZM = nzm_of(a, dae), NA = na_of(a, dae);
     const int ne = a.zd + (dae ? a.vd + a.id : 0);
     PackMfma p;

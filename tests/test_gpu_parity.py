@@ -247,6 +247,46 @@ def test_latent_dae_kernel(method, zd):
     assert rel_err(xs.cpu(), ref_x) <= TOL_GPU and rel_err(is_.cpu(), ref_i) <= TOL_GPU
 
 
+@pytest.mark.parametrize("method", METHODS)
+def test_latent64_ode_kernel(method):
+    """direct_encode ODE latent shape with hidden 64 (384 -> 64 -> 64) on K3c (kernel='mfma') vs the oracle."""
+    B, Tn, H = 21, 11, 64
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=H, zd=H, H=H, n_hidden=1, seed=51)
+    g = torch.Generator().manual_seed(52)
+    t = t * (0.5 + torch.rand(1, B, 1, generator=g))
+    t[:, 0] = torch.arange(Tn, dtype=torch.float32).view(Tn, 1) * 0.01
+    ev = torch.stack([t[2, :, :], t[8, :, :]], dim=1).contiguous()
+    zj = 0.1 * torch.randn(B, 2, H, generator=g)
+    ref = O.integrate_ode(method, ls, t, x, z, a0, ev, zj)
+    bm = lambda a: a.permute(1, 0, 2).contiguous().cuda().permute(1, 0, 2)
+    out = fused().ode_integrate(method, dl(ls), bm(t), bm(x), bm(z), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel="mfma")
+    assert rel_err(out.cpu(), ref) <= TOL_GPU
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("zd", [64, 0])
+def test_latent64_dae_kernel(method, zd):
+    """direct_encode DAE latent shapes with hidden 64 (768|576 -> 64 -> 64 and 448|320 -> 64 -> 64): the shipped DAE_02 config."""
+    import torch.nn as nn
+    B, Tn, H = 19, 8, 64
+    g = torch.Generator().manual_seed(61)
+    torch.manual_seed(61)
+    nblk = 4 if zd else 3
+    mk = lambda dims: [(l.weight.detach(), l.bias.detach()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
+    de, ae = mk([3 * nblk * H, H, H]), mk([(2 * nblk - 1) * H, H, H])
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    x, z, v, i, xi = r(Tn, B, H), r(Tn, B, zd), r(Tn, B, H), r(Tn, B, H), r(B, H)
+    a0 = torch.cat((xi, z[0], v[0], i[0]), -1)
+    ev = torch.stack([t[3, :, :], t[Tn - 2, :, :]], dim=1).contiguous()      # an event on the last step too
+    zj, vj = r(B, 2, zd), r(B, 2, H)
+    ref_x, ref_i = O.integrate_dae(method, de, ae, xi, t, x, z, v, i, a0, ev, zj, vj)
+    c = lambda a: a.cuda()
+    xs, is_ = fused().dae_integrate(method, dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), event_t=c(ev), z_jump=c(zj),
+                                    v_jump=c(vj), kernel="mfma")
+    assert rel_err(xs.cpu(), ref_x) <= TOL_GPU and rel_err(is_.cpu(), ref_i) <= TOL_GPU
+
+
 @pytest.mark.parametrize("din,dout", [(8, 16), (2, 16), (16, 8), (16, 2), (16, 16), (3, 5), (6, 16)])
 @pytest.mark.parametrize("rows", [1, 17, 4100])
 def test_row_mlp_kernel(din, dout, rows):
