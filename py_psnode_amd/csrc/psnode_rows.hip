@@ -12,7 +12,6 @@ namespace psnode {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int RH = 16;
 
 __device__ __forceinline__ f4 rmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -24,26 +23,37 @@ struct RowsArgs {
 };
 
 // NM = MFMAs of layer 1 = ceil(in_dim / 4); lane group g supplies columns NM*g + m.
-template <int NM>
+// HT = hidden tiles (hidden width 16*HT: 1 or 4), OT = output tiles (ceil(out_dim / 16): 1 or 4).  One wave owns its 16 rows
+// through both layers: hidden unit 16*ht + 4g + r of L1's D tile ht is k-slot g of L2's MFMA (ht, r) -- no exchange.
+template <int NM, int HT, int OT>
 __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
+    constexpr int HID = 16 * HT;
     const int l = threadIdx.x & 63, g = l >> 4, j = l & 15, i = l & 15;
     // weights -> registers
-    float w1[NM], w2[4];
-    f4 b1r, b2r;
+    float w1[HT][NM], w2[OT][HT * 4];
+    f4 b1r[HT], b2r[OT];
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int c = NM * g + m;
-        w1[m] = c < a.in_dim ? a.w1[i * a.in_dim + c] : 0.0f;
+    for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int c = NM * g + m;
+            w1[ht][m] = c < a.in_dim ? a.w1[(16 * ht + i) * a.in_dim + c] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1r[ht][r] = a.b1[16 * ht + 4 * g + r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        w2[r] = i < a.out_dim ? a.w2[i * RH + 4 * g + r] : 0.0f;
-        b1r[r] = a.b1[4 * g + r];
-        b2r[r] = 4 * g + r < a.out_dim ? a.b2[4 * g + r] : 0.0f;
+    for (int ot = 0; ot < OT; ++ot) {
+        const int o = 16 * ot + i;
+#pragma unroll
+        for (int q = 0; q < HT * 4; ++q) w2[ot][q] = o < a.out_dim ? a.w2[o * HID + 16 * (q >> 2) + 4 * g + (q & 3)] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2r[ot][r] = 16 * ot + 4 * g + r < a.out_dim ? a.b2[16 * ot + 4 * g + r] : 0.0f;
     }
     const long long tiles = (a.rows + 15) / 16;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-    const bool vec_in = (NM == 2 || NM == 4) && a.in_dim == 4 * NM && a.in_stride % NM == 0 && (reinterpret_cast<uintptr_t>(a.in) % (4 * NM)) == 0;
+    constexpr int VB = NM == 2 ? 8 : 16;   // bytes of one vector load
+    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
     const bool vec_out = a.out_dim % 4 == 0 && a.out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     for (long long t = wave; t < tiles; t += nwaves) {
         const long long row = t * 16 + j;
@@ -51,9 +61,12 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
         const float* src = a.in + (valid ? row : a.rows - 1) * a.in_stride + NM * g;
         float v[NM];
         if (vec_in) {
-            if constexpr (NM == 4) {
-                const f4 q = *reinterpret_cast<const f4*>(src);
-                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            if constexpr (NM % 4 == 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < NM / 4; ++c4) {
+                    const f4 q = reinterpret_cast<const f4*>(src)[c4];
+                    v[4 * c4] = q[0]; v[4 * c4 + 1] = q[1]; v[4 * c4 + 2] = q[2]; v[4 * c4 + 3] = q[3];
+                }
             } else if constexpr (NM == 2) {
                 const float2 q = *reinterpret_cast<const float2*>(src);
                 v[0] = q.x; v[1] = q.y;
@@ -62,23 +75,44 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) v[m] = NM * g + m < a.in_dim ? src[m] : 0.0f;
         }
-        f4 acc = b1r;
+        f4 h[HT];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) acc = rmfma(w1[m], v[m], acc);
-        const f4 h = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
-        f4 oA = rmfma(w2[0], h[0], b2r), oB = rmfma(w2[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
-        oA = rmfma(w2[2], h[2], oA);
-        oB = rmfma(w2[3], h[3], oB);
-        const f4 o = oA + oB;
-        if (valid && 4 * g < a.out_dim) {
-            float* dst = a.out + row * a.out_stride + 4 * g;
-            if (vec_out) {
-                *reinterpret_cast<f4*>(dst) = o;
-            } else {
+        for (int ht = 0; ht < HT; ++ht) {
+            f4 acc = b1r[ht];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * g + r < a.out_dim) dst[r] = o[r];
+            for (int m = 0; m < NM; ++m) acc = rmfma(w1[ht][m], v[m], acc);
+            h[ht] = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            f4 oA = b2r[ot], oB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) {
+                oA = rmfma(w2[ot][4 * ht + 0], h[ht][0], oA); oB = rmfma(w2[ot][4 * ht + 1], h[ht][1], oB);
+                oA = rmfma(w2[ot][4 * ht + 2], h[ht][2], oA); oB = rmfma(w2[ot][4 * ht + 3], h[ht][3], oB);
+            }
+            const f4 o = oA + oB;
+            if (valid && 16 * ot + 4 * g < a.out_dim) {
+                float* dst = a.out + row * a.out_stride + 16 * ot + 4 * g;
+                if (vec_out) {
+                    *reinterpret_cast<f4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (16 * ot + 4 * g + r < a.out_dim) dst[r] = o[r];
+                }
             }
         }
+    }
+}
+
+template <int HT, int OT>
+void launch_rows(int NM, dim3 grid, dim3 block, hipStream_t s, const RowsArgs& a) {
+    switch (NM) {
+        case 1: hipLaunchKernelGGL((rows_kernel<1, HT, OT>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((rows_kernel<2, HT, OT>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((rows_kernel<3, HT, OT>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((rows_kernel<4, HT, OT>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((rows_kernel<16, HT, OT>), grid, block, 0, s, a); break;   // in_dim = 64 (decoders at hidden 64)
     }
 }
 
@@ -88,7 +122,13 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
 using namespace psnode;
 
 extern "C" int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* m) {
-    return m && m->n_layers == 2 && m->in_dim >= 1 && m->in_dim <= 16 && m->out_dim[0] == RH && m->out_dim[1] >= 1 && m->out_dim[1] <= 16;
+    // encoders: in <= 16 -> H -> H ; decoders: H -> H -> out <= 16 ; H in {16, 64}.  (A 64-wide input is the decoder's case:
+    // there the first layer is H -> H, i.e. in_dim == H.)
+    if (!m || m->n_layers != 2 || m->in_dim < 1 || m->out_dim[1] < 1) return 0;
+    const int H = m->out_dim[0];
+    if (H != 16 && H != 64) return 0;
+    const bool in_ok = m->in_dim <= 16 || (m->in_dim == 64 && H == 64), out_ok = m->out_dim[1] <= 16 || m->out_dim[1] == H;
+    return in_ok && out_ok;
 }
 
 extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride, float* out,
@@ -104,12 +144,9 @@ extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, co
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride over the rest
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int NM = (m->in_dim + 3) / 4;
-    switch (NM) {
-        case 1: hipLaunchKernelGGL(rows_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(rows_kernel<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(rows_kernel<3>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(rows_kernel<4>, grid, block, 0, s, a); break;
-    }
+    const int NM = (m->in_dim + 3) / 4, H = m->out_dim[0], OT = (m->out_dim[1] + 15) / 16;
+    if (H == 16) launch_rows<1, 1>(NM, grid, block, s, a);
+    else if (OT == 1) launch_rows<4, 1>(NM, grid, block, s, a);
+    else launch_rows<4, 4>(NM, grid, block, s, a);
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }

@@ -415,7 +415,7 @@ def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     keep: list = []
     m = _mlp(layers, dev, "mlp", keep)
     if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
-        raise ValueError("mlp_rows: needs Linear(in<=16, 16) ELU Linear(16, out<=16)")
+        raise ValueError("mlp_rows: needs Linear(in, H) ELU Linear(H, out) with H in {16, 64}, in <= 16 (or in = H = 64), out <= 16 (or out = H)")
     x = _f32_dev(inp, dev, "input")
     if x.shape[-1] != m.in_dim:
         raise ValueError(f"mlp_rows: input width {x.shape[-1]}, expected {m.in_dim}")
@@ -435,7 +435,10 @@ def rows_layers_of(seq, inp: torch.Tensor):
     if inp.device.type != "cuda" or inp.dtype != torch.float32 or inp.numel() == 0:
         return None
     layers = sequential_layers(seq)
-    if layers is None or len(layers) != 2 or layers[0][0].shape[0] != 16 or layers[0][0].shape[1] > 16 or layers[1][0].shape[0] > 16:
+    if layers is None or len(layers) != 2:
+        return None
+    H, din, dout = layers[0][0].shape[0], layers[0][0].shape[1], layers[1][0].shape[0]
+    if H not in (16, 64) or not (din <= 16 or (din == 64 and H == 64)) or not (dout <= 16 or dout == H):
         return None
     if _needs_autograd([inp] + [p for wb in layers for p in wb]):
         return None

@@ -293,7 +293,20 @@ def test_row_mlp_kernel(din, dout, rows):
     """Encoder / decoder row kernel vs the nn.Sequential it replaces (fp32 reference on CPU)."""
     import torch.nn as nn
     torch.manual_seed(din * 100 + dout)
-    seq = nn.Sequential(nn.Linear(din, 16), nn.ELU(), nn.Linear(16, dout))
+    _row_mlp_case(din, 16, dout, rows)
+
+
+@pytest.mark.parametrize("din,dout", [(8, 64), (2, 64), (64, 8), (64, 2), (64, 64), (5, 64)])
+@pytest.mark.parametrize("rows", [17, 4100])
+def test_row_mlp_kernel_hidden64(din, dout, rows):
+    """Hidden 64 (the shipped DAE_02 config): encoders in->64->64, decoders 64->64->out."""
+    _row_mlp_case(din, 64, dout, rows)
+
+
+def _row_mlp_case(din, H, dout, rows):
+    import torch.nn as nn
+    torch.manual_seed(din * 100 + dout)
+    seq = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout))
     inp = torch.randn(rows, din)
     with torch.no_grad():
         ref = seq(inp)
