@@ -86,37 +86,11 @@ __device__ __forceinline__ f4 elu4b(f4 v) { return f4{elu_fast(v[0]), elu_fast(v
 __device__ __forceinline__ f4 dact(f4 h) {
     return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
 }
-__device__ __forceinline__ void bwd_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-template <int METHOD> struct Tableau;
-template <> struct Tableau<PSNODE_EULER> { static constexpr int S = 1; };
-template <> struct Tableau<PSNODE_MIDPOINT> { static constexpr int S = 2; };
-template <> struct Tableau<PSNODE_RK4_38> { static constexpr int S = 4; };
-// a[s][j] (coefficient of k_j in the input of stage s) and b[s]
-template <int METHOD> __device__ __forceinline__ constexpr float tab_a(int s, int j) {
-    if (METHOD == PSNODE_MIDPOINT) return 0.5f;
-    if (METHOD == PSNODE_RK4_38) {
-        if (s == 1) return kOneThird;
-        if (s == 2) return j == 0 ? -kOneThird : 1.0f;
-        if (s == 3) return j == 1 ? -1.0f : 1.0f;
-    }
-    return 0.0f;
-}
-template <int METHOD> __device__ __forceinline__ constexpr float tab_b(int s) {
-    if (METHOD == PSNODE_EULER) return 1.0f;
-    if (METHOD == PSNODE_MIDPOINT) return s == 1 ? 1.0f : 0.0f;
-    return (s == 0 || s == 3) ? 0.125f : 0.375f;
-}
-
 constexpr int SCR = 64 * 4 + 4 * 8;   // padded transpose tile per wave (floats)
 
 template <int METHOD, int NZM>
 __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const float* __restrict__ pack, const int NA) {
-    constexpr int NX = kNXc, S = Tableau<METHOD>::S;
+    constexpr int NX = kNXc, S = rk_stages(METHOD);
     using RD = Regs<NX, NX, NZM>;
     const IntegrateDev& a = d.a;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -197,7 +171,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
         f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
         accA = bmfma(wm[0], h[0], accA); accB = bmfma(wm[1], h[1], accB);
         accA = bmfma(wm[2], h[2], accA); accB = bmfma(wm[3], h[3], accB);
-        bwd_barrier();
+        lds_barrier();
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
             const f4 v = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
@@ -211,7 +185,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     auto allreduce2 = [&](const f4 part, const f4 init) -> f2 {
         f2* xb2 = reinterpret_cast<f2*>(xbuf + p * NW * 64);
         xb2[w * 64 + l] = f2{part[0], part[1]};
-        bwd_barrier();
+        lds_barrier();
         f2 out = f2{init[0], init[1]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) out += xb2[c * 64 + l];
@@ -222,7 +196,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     auto reduce_scatter = [&](const f4 (&part)[4]) -> f4 {
 #pragma unroll
         for (int c = 1; c < 4; ++c) rsbuf[((q * NW + ((w + c) & 3)) * NW + w) * 64 + l] = part[c];
-        bwd_barrier();
+        lds_barrier();
         f4 out = part[0];
 #pragma unroll
         for (int c = 1; c < 4; ++c) out += rsbuf[((q * NW + w) * NW + ((w + c) & 3)) * 64 + l];
@@ -304,7 +278,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
             for (int r = 0; r < NX; ++r) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int jj = 0; jj < s; ++jj) acc += tab_a<METHOD>(s, jj) * ks[jj][r];
+                for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj][r];
                 xst[s][r] = s == 0 ? x0[r] : x0[r] + h_ * acc;
             }
             f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
@@ -327,7 +301,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
         // ---- phase B: stages backwards
         f2 gks[S], gx0 = g1;
 #pragma unroll
-        for (int s = 0; s < S; ++s) gks[s] = (h_ * tab_b<METHOD>(s)) * g1;
+        for (int s = 0; s < S; ++s) gks[s] = (h_ * rk_b(METHOD, s)) * g1;
         f4 l1t1 = {0.f, 0.f, 0.f, 0.f};   // z rows of W1^T delta1, this wave's partial, summed over the stages
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
@@ -392,7 +366,7 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
             // RK adjoint
             gx0 += gx;
 #pragma unroll
-            for (int jj = 0; jj < s; ++jj) gks[jj] += (h_ * tab_a<METHOD>(s, jj)) * gx;
+            for (int jj = 0; jj < s; ++jj) gks[jj] += (h_ * rk_a(METHOD, s, jj)) * gx;
         }
         gcarry = gx0;
         // ---- gradient of this step's external input (sum over waves), a0-z accumulation

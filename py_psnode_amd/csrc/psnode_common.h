@@ -103,9 +103,35 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ src, flo
     __syncthreads();
 }
 
+// LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), not for its outstanding global prefetches --
+// a plain __syncthreads() would also drain vmcnt and serialise the one-step-ahead loads of the MFMA kernels.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // fp32(1/3): the reference multiplies fp32 tensors by the python double 1/3, which ATen rounds to fp32
 // (my_fixed_grid.py:8,43-44).
 constexpr float kOneThird = 0.333333343267440796f;
+
+// Butcher tableau of the three fixed-grid methods (my_fixed_grid.py:12-59): a(s, j) = coefficient of k_j in the input of
+// stage s, b(s) = weight of k_s in the update.  RK4 is the 3/8 rule.  Used by the backward kernels (adjoint recursion).
+__host__ __device__ __forceinline__ constexpr int rk_stages(int method) { return method == PSNODE_EULER ? 1 : (method == PSNODE_MIDPOINT ? 2 : 4); }
+__host__ __device__ __forceinline__ constexpr float rk_a(int method, int s, int j) {
+    if (method == PSNODE_MIDPOINT) return 0.5f;
+    if (method == PSNODE_RK4_38) {
+        if (s == 1) return kOneThird;
+        if (s == 2) return j == 0 ? -kOneThird : 1.0f;
+        if (s == 3) return j == 1 ? -1.0f : 1.0f;
+    }
+    return 0.0f;
+}
+__host__ __device__ __forceinline__ constexpr float rk_b(int method, int s) {
+    if (method == PSNODE_EULER) return 1.0f;
+    if (method == PSNODE_MIDPOINT) return s == 1 ? 1.0f : 0.0f;
+    return (s == 0 || s == 3) ? 0.125f : 0.375f;
+}
 
 // psnode_generic.hip
 hipError_t launch_generic(const IntegrateDev& a, bool dae, hipStream_t stream);

@@ -181,21 +181,6 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
     return din;
 }
 
-__device__ __forceinline__ float tab_a(int method, int s, int j) {
-    if (method == PSNODE_MIDPOINT) return 0.5f;
-    if (method == PSNODE_RK4_38) {
-        if (s == 1) return kOneThird;
-        if (s == 2) return j == 0 ? -kOneThird : 1.0f;
-        if (s == 3) return j == 1 ? -1.0f : 1.0f;
-    }
-    return 0.0f;
-}
-__device__ __forceinline__ float tab_b(int method, int s) {
-    if (method == PSNODE_EULER) return 1.0f;
-    if (method == PSNODE_MIDPOINT) return s == 1 ? 1.0f : 0.0f;
-    return (s == 0 || s == 3) ? 0.125f : 0.375f;
-}
-
 __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -203,7 +188,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     const bool dae = a.dae != 0;
     const int xd = a.xd, zd = a.zd, vd = dae ? a.vd : 0, id = dae ? a.id : 0;
     const int nzv = zd + vd, ne = nzv + id, n = xd + ne;
-    const int S = a.method == PSNODE_EULER ? 1 : (a.method == PSNODE_MIDPOINT ? 2 : 4);
+    const int S = rk_stages(a.method);
     const int nx = xd * TP;
 
     float* acts = lds;                            // [act_rows][TP]
@@ -326,7 +311,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         for (int s = 0; s < S; ++s) {
             TILE_LOOP(xd) {
                 float acc = 0.0f;
-                for (int j = 0; j < s; ++j) acc += tab_a(a.method, s, j) * ks[j * nx + r * TP + c];
+                for (int j = 0; j < s; ++j) acc += rk_a(a.method, s, j) * ks[j * nx + r * TP + c];
                 xst[s * nx + r * TP + c] = s == 0 ? x0[r * TP + c] : x0[r * TP + c] + dts[c] * acc;
             }
             __syncthreads();
@@ -340,7 +325,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         TILE_LOOP(xd) {
             const float g1 = gxc[r * TP + c];
             gx0[r * TP + c] = g1;
-            for (int s = 0; s < S; ++s) gks[s * nx + r * TP + c] = dts[c] * tab_b(a.method, s) * g1;
+            for (int s = 0; s < S; ++s) gks[s * nx + r * TP + c] = dts[c] * rk_b(a.method, s) * g1;
         }
         TILE_LOOP(ne) gext[r * TP + c] = 0.0f;
         __syncthreads();
@@ -355,7 +340,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
                 if (r < xd) {
                     gx0[r * TP + c] += gs;
-                    for (int j = 0; j < s; ++j) gks[j * nx + r * TP + c] += dts[c] * tab_a(a.method, s, j) * gs;
+                    for (int j = 0; j < s; ++j) gks[j * nx + r * TP + c] += dts[c] * rk_a(a.method, s, j) * gs;
                 } else {
                     gext[(r - xd) * TP + c] += gs;
                 }

@@ -22,12 +22,6 @@ constexpr int NW64 = 4;
 
 __device__ __forceinline__ f4 mf(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 elu4l(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
-__device__ __forceinline__ void barrier64() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // pack[wave][reg][lane]; every 64x64 block takes 16 registers: reg 4c+r = Blk[16w + i][16((w+c)&3) + 4g + r]
 //   DE: F[NBLK] | B1(4) | W2(16) | B2(4) | A0[NBLK]            F_b = Ws_b + Wd_b,  A0_b = Wa0_b - Wd_b
 //   AE: W[NBE]  | B1(4) | W2(16) | B2(4) | A0[NBLK]            blocks x | [z] | v right after the a0 group
@@ -125,7 +119,7 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
     // all-gather of a vector distributed 16 dims per wave (D layout f4) -> chunk layout in every wave
     auto gather = [&](const f4 own) -> V4 {
         xbuf[p][w][l] = own;
-        barrier64();
+        lds_barrier();
         V4 o;
         o.v[0] = own;
 #pragma unroll
@@ -180,7 +174,7 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         accA = mf(wr[0], own[0], accA); accB = mf(wr[1], own[1], accB);
         accA = mf(wr[2], own[2], accA); accB = mf(wr[3], own[3], accB);
         __builtin_amdgcn_sched_barrier(0);
-        barrier64();
+        lds_barrier();
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
             const f4 v = xbuf[p][(w + c) & 3][l];

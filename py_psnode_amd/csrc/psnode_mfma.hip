@@ -43,16 +43,6 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 
 __device__ __forceinline__ f4 elu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
 
-// LDS-only workgroup barrier: wait for this wave's LDS traffic, not for its outstanding global prefetches.
-__device__ __forceinline__ void lds_barrier() {
-#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 2)   // timing experiment: no barrier (WRONG results)
-    return;
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // layers 2..4 of one MLP, in registers
 struct Tail {
     float w2[16], w3[16], w4[4];
