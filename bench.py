@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
     ap.add_argument("--batch", type=int, default=None, help="override trajectories per GPU")
     ap.add_argument("--grid", type=int, default=None, help="override grid points T")
+    ap.add_argument("--hidden", type=int, default=None, help="override the MLPs' hidden width (the scripts' --hidden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
     ap.add_argument("--train", action="store_true", help="time forward + backward (fused autograd route) instead of the forward alone")
@@ -227,6 +228,8 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.batch:
         w["B"] = args.batch
+    if args.hidden:
+        w["H"] = args.hidden
     if args.grid:
         w["T"] = args.grid
     B, T = w["B"], w["T"]
@@ -366,8 +369,8 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "integrated state-steps/sec (batch x steps/s), RK4 neural-ODE, batch 4096" if (args.workload, args.method, B) == ("ode01", "rk4", 4096)
-                      else f"integrated state-steps/sec, {args.workload} {args.method}, batch {B}",
+            "metric": "integrated state-steps/sec (batch x steps/s), RK4 neural-ODE, batch 4096" if (args.workload, args.method, B, w["H"]) == ("ode01", "rk4", 4096, 64)
+                      else f"integrated state-steps/sec, {args.workload} {args.method}, batch {B}, hidden {w['H']}",
             "value": value, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -143,6 +143,8 @@ bool mfma_ode_supported(const IntegrateDev& a);
 bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+hipError_t launch_mfma_h32(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);    // psnode_mfma_h32.hip
+hipError_t launch_mfma_h128(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h128.hip
 
 // psnode_generic_bwd.hip (K5: generic fused backward, ODE and DAE)
 size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B);

@@ -1,0 +1,10 @@
+// K1/K2 for --hidden 128: 8 waves per 16-trajectory tile (kernel template in psnode_mfma_impl.h).
+#include "psnode_mfma_impl.h"
+
+namespace psnode {
+
+hipError_t launch_mfma_h128(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
+    return launch_mfma_nw<8>(a, dae, pack, stream);
+}
+
+}  // namespace psnode

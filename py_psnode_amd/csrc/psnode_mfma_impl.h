@@ -1,0 +1,506 @@
+// MFMA fused integrators (K1 = ODE, K2 = DAE) for the reference's default right-hand sides:
+//   DE: in -> H -> H -> H -> x_dim   and, for the DAE,   AE: in -> H -> H -> H -> i_dim   (ELU between layers),
+//   H = 16 * NWV in {32, 64, 128}: the scripts' --hidden knob (64 under their flg_debug override, 128 the argparse
+//   default, neural_00_ODE_01_no_encode.py:259,276).  The text below is written for H = 64 (NWV = 4 waves).
+//
+// Mapping (DESIGN.md "K1/K2"):  one workgroup = NWV waves = one tile of 16 trajectories, walked through ALL T-1 steps.
+//   D[unit][traj] = W[unit][k] * act[k][traj]   on v_mfma_f32_16x16x4_f32 (exact fp32, 256 flop/clk/CU):
+//   A operand = weights (lane l: unit l&15 of the wave's 16-unit slice, k-slot l>>4)  -- resident in VGPRs for the
+//               whole launch, so the weights are read from HBM/L2 once per workgroup;
+//   B operand = activations (lane l: k-slot g = l>>4, trajectory l&15);
+//   D         = lane l holds units 4*g+r (r = 0..3) of trajectory l&15.
+// Layer plan per MLP evaluation (4 waves, w = wave id):
+//   L1  in->64   split-N: wave w makes hidden units 16w..16w+15.  The input cat(a0, s-a0, s) (DE) / cat(a0, x, z, v)
+//                (AE) is never materialised: the a0 columns (+bias) are a per-trajectory constant computed once, the
+//                external-input columns once per step (zero-order hold), only the x-dependent MFMAs run per stage --
+//                same products, different summation order.
+//   L2,L3 64->64 split-N: ELU -> every wave publishes its 4 values/lane with ONE lane-linear ds_write_b128, one
+//                s_barrier, three ds_read_b128.  The k-order is permuted (k = 16w' + 4g + r) so that lane (g, traj)
+//                needs exactly what lane (g, traj) of the other waves holds: no shuffles, no bank conflicts.
+//                The wave's own quarter of K is multiplied before the barrier.
+//   L4  64->out  split-K: wave w multiplies ITS OWN 16 hidden units (no exchange between L3 and L4), partial sums are
+//                all-reduced through LDS in a fixed order so every wave holds the identical result.
+//   => 3 exchanges per evaluation, 40 MFMAs per wave per DE evaluation.
+// Register-resident state, replicated in the four waves: x-dim d = 4r+g sits in lane group g, register r (L4's output
+// rows feed L1's B operands directly).  External-input "slot" q = 4m+g of the per-step MFMA m carries ext[q]-a0 for
+// q < ne and ext[q-ne] for ne <= q < 2ne (ext = z | v | i).  The AE's output rows are laid out so that the algebraic
+// variable an ext slot needs appears in that very lane, row m: the DAE feedback i -> DE input needs no data movement.
+// External inputs are prefetched one step ahead straight from the caller's strided (B-major) memory.
+// This header is the kernel template; one translation unit per hidden width instantiates it (psnode_mfma.hip = 64,
+// psnode_mfma_h32.hip, psnode_mfma_h128.hip) so the widths compile in parallel.
+#pragma once
+#include <type_traits>
+
+#include "psnode_pack.h"
+
+namespace psnode {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ void pack_mfma_kernel(const PackMfma p) {
+    const int R = pack_fwd_count(p);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < p.nw * R * 64; idx += gridDim.x * blockDim.x)
+        p.out[idx] = pack_fwd_value(p, (idx >> 6) / R, (idx >> 6) % R, idx & 63);
+}
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f4 elu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+
+// layers 2..4 of one MLP, in registers (NWV = waves per tile = hidden / 16)
+template <int NWV>
+struct Tail {
+    float w2[4 * NWV], w3[4 * NWV], w4[4];
+    f4 b2, b3, b4;
+};
+
+__host__ __device__ constexpr bool ae_weights_in_lds(bool dae, int nwv) { return dae && nwv >= 8; }
+__host__ __device__ constexpr size_t ae_lds_bytes(int nwv) { return (size_t)2 * nwv * nwv * 64 * sizeof(f4); }
+
+template <int NX, int NB, int NE, int NWV, bool MID = true>
+__device__ __forceinline__ void load_tail(const float* pw, Tail<NWV>& t) {
+    using R = Regs<NX, NB, NE, NWV>;
+    if constexpr (MID) {
+#pragma unroll
+        for (int k = 0; k < 4 * NWV; ++k) { t.w2[k] = pw[(R::W2 + k) * 64]; t.w3[k] = pw[(R::W3 + k) * 64]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t.w4[r] = pw[(R::W4 + r) * 64];
+        t.b2[r] = pw[(R::B2 + r) * 64]; t.b3[r] = pw[(R::B3 + r) * 64]; t.b4[r] = pw[(R::B4 + r) * 64];
+    }
+}
+
+template <int N> struct Arr { float v[N > 0 ? N : 1]; };
+
+template <int METHOD, int NX, int NZM, int NZA, bool TRUE_X, bool DAE, int NWV>
+__global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const IntegrateDev a, const float* __restrict__ pack_de,
+                                                                  const float* __restrict__ pack_ae, const int NA) {
+    using RD = Regs<NX, NX, NZM, NWV>;
+    using RA = Regs<NX, 0, NZA, NWV>;
+    __shared__ f4 xbuf[2][NWV][64];
+    // 8 waves of 64 lanes leave 256 VGPRs per lane: the DAE's second weight set does not fit next to the DE's, so the
+    // AE's H->H weights live in (dynamic) LDS, each lane reading back exactly the A-operand values it wrote.
+    constexpr bool AE_LDS = ae_weights_in_lds(DAE, NWV);
+    extern __shared__ f4 aew[];   // AE_LDS: [layer 2|3][chunk][wave][lane]
+
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = l >> 4, j = l & 15;
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const int xd = a.xd, zd = a.zd, vd = DAE ? a.vd : 0, idim = DAE ? a.id : 0;
+    const int nzv = zd + vd, ne = nzv + idim, n = xd + ne;
+    const bool true_i = DAE && (a.flags & PSNODE_FLAG_INPUT_TRUE_I) != 0;
+
+    // ---- weights -> registers (once per launch)
+    const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
+    float w1xs[NX], w1xd[NX];
+    Arr<NZM> w1z;
+    f4 b1r;
+    Tail<NWV> de;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) { w1xs[r] = pw[(RD::W1A + r) * 64]; w1xd[r] = pw[(RD::W1B + r) * 64]; }
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) w1z.v[m] = pw[(RD::W1E + m) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1r[r] = pw[(RD::B1 + r) * 64];
+    load_tail<NX, NX, NZM, NWV>(pw, de);
+
+    const float* pwa = pack_ae + (size_t)w * (RA::COUNT + NA) * 64 + l;
+    float aw1x[NX];
+    Arr<NZA> aw1e;
+    f4 ab1r = f4{0.f, 0.f, 0.f, 0.f};
+    Tail<NWV> ae;
+    if constexpr (DAE) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) aw1x[r] = pwa[(RA::W1A + r) * 64];
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) aw1e.v[m] = pwa[(RA::W1E + m) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ab1r[r] = pwa[(RA::B1 + r) * 64];
+        load_tail<NX, 0, NZA, NWV, !AE_LDS>(pwa, ae);
+        if constexpr (AE_LDS) {
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) {
+                f4 q2, q3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q2[r] = pwa[(RA::W2 + 4 * c + r) * 64]; q3[r] = pwa[(RA::W3 + 4 * c + r) * 64]; }
+                aew[((0 * NWV + c) * NWV + w) * 64 + l] = q2;
+                aew[((1 * NWV + c) * NWV + w) * 64 + l] = q3;
+            }
+        }
+    }
+
+    // ---- per-trajectory constants
+    float x[NX], a0x[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        const int d = 4 * r + g;
+        a0x[r] = d < xd ? a.a0[b * n + d] : 0.0f;
+        x[r] = d < xd ? (DAE ? a.x_init[b * xd + d] : a.x.p[b * a.x.sb + d]) : 0.0f;
+    }
+    // DE ext slots of this lane: kind 0 = z column, 1 = v column, 2 = algebraic variable (register), 3 = padding
+    int ekind[NZM > 0 ? NZM : 1], ecol[NZM > 0 ? NZM : 1];
+    Arr<NZM> a0e;
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) {
+        const int q = 4 * m + g, e = slot_ext(q, ne);
+        ekind[m] = e < 0 ? 3 : (e < zd ? 0 : (e < nzv ? 1 : 2));
+        ecol[m] = e < 0 ? 0 : (e < zd ? e : (e < nzv ? e - zd : e - nzv));
+        a0e.v[m] = q < ne ? a.a0[b * n + xd + q] : 0.0f;
+    }
+    // AE ext slots (z | v at the right grid point, never jumped except in the event-time recompute)
+    int akind[NZA > 0 ? NZA : 1], acol[NZA > 0 ? NZA : 1];
+#pragma unroll
+    for (int m = 0; m < NZA; ++m) {
+        const int q = 4 * m + g;
+        akind[m] = q < zd ? 0 : (q < nzv ? 1 : 3);
+        acol[m] = q < zd ? q : (q < nzv ? q - zd : 0);
+    }
+    f4 c0 = b1r, c0a = ab1r;   // bias + W1[:, a0 columns] . a0 : constant for the whole launch
+    for (int m = 0; m < NA; ++m) {
+        const int q = 4 * m + g;
+        const float av = q < n ? a.a0[b * n + q] : 0.0f;
+        c0 = mfma4(pw[(RD::COUNT + m) * 64], av, c0);
+        if constexpr (DAE) c0a = mfma4(pwa[(RA::COUNT + m) * 64], av, c0a);
+    }
+
+    const long long tst = a.t.st, nT = a.T, zst = a.z.st, zje = a.zje, vst = a.v.st, vje = a.vje;
+    const float* tp = a.t.p + b * a.t.sb;
+    const float* zp = a.z.p + b * a.z.sb;
+    const float* zjp = a.zj + b * a.zjb;
+    const float* vp = a.v.p + b * a.v.sb;
+    const float* vjp = a.vj + b * a.vjb;
+
+    // z|v column of grid point k for one slot (ev >= 0: the batch takes the jump values for this step)
+    auto load_zv = [&](long long k, int ev, int kind, int col) -> float {
+        if (kind == 0) return (ev >= 0 ? zjp + ev * zje : zp + k * zst)[col];
+        if constexpr (DAE) {
+            if (kind == 1) return (ev >= 0 ? vjp + ev * vje : vp + k * vst)[col];
+        }
+        return 0.0f;
+    };
+    auto load_de_ext = [&](long long k, int ev, Arr<NZM>& dst) {
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) dst.v[m] = load_zv(k, ev, ekind[m], ecol[m]);
+    };
+    auto load_ae_ext = [&](long long k, int ev, Arr<NZA>& dst) {
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) dst.v[m] = load_zv(k, ev, akind[m], acol[m]);
+    };
+
+    int p = 0;   // exchange buffer parity
+
+    // one H->H layer: publish own activations, multiply own K slice, barrier, multiply the other NWV-1 slices
+    auto mid = [&](const float (&wm)[4 * NWV], const f4 bias, const f4 h) -> f4 {
+        xbuf[p][w][l] = h;
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = mfma4(wm[0], h[0], accA);
+        accB = mfma4(wm[1], h[1], accB);
+        accA = mfma4(wm[2], h[2], accA);
+        accB = mfma4(wm[3], h[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < NWV; ++c) {
+#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 4)   // timing experiment: no LDS read (WRONG results)
+            const f4 v = h * (float)c;
+#else
+            const f4 v = xbuf[p][(w + c) & (NWV - 1)][l];
+#endif
+            accA = mfma4(wm[4 * c + 0], v[0], accA);
+            accB = mfma4(wm[4 * c + 1], v[1], accB);
+            accA = mfma4(wm[4 * c + 2], v[2], accA);
+            accB = mfma4(wm[4 * c + 3], v[3], accB);
+        }
+        p ^= 1;
+        return elu4(accA + accB);
+    };
+    // the same layer with the weights of `layer` (0: L2, 1: L3) read from aew
+    auto mid_lds = [&](const int layer, const f4 bias, const f4 h) -> f4 {
+        xbuf[p][w][l] = h;
+        const f4* wl = aew + ((size_t)layer * NWV * NWV + w) * 64 + l;
+        f4 wq = wl[0];
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = mfma4(wq[0], h[0], accA);
+        accB = mfma4(wq[1], h[1], accB);
+        accA = mfma4(wq[2], h[2], accA);
+        accB = mfma4(wq[3], h[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < NWV; ++c) {
+            const f4 v = xbuf[p][(w + c) & (NWV - 1)][l];
+            wq = wl[c * NWV * 64];
+            accA = mfma4(wq[0], v[0], accA);
+            accB = mfma4(wq[1], v[1], accB);
+            accA = mfma4(wq[2], v[2], accA);
+            accB = mfma4(wq[3], v[3], accB);
+        }
+        p ^= 1;
+        return elu4(accA + accB);
+    };
+    // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows.
+    // ROWS2: only rows r < 2 of the output carry data (the DE with x_dim <= 8): all-reduce 8 bytes per lane instead of 16.
+    auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto from_lds) -> f4 {
+        constexpr bool ROWS2 = decltype(rows2)::value;
+        f4 h = elu4(pre1);
+        if constexpr (decltype(from_lds)::value) {
+            h = mid_lds(0, t.b2, h);
+            h = mid_lds(1, t.b3, h);
+        } else {
+            h = mid(t.w2, t.b2, h);
+            h = mid(t.w3, t.b3, h);
+        }
+        f4 accA = mfma4(t.w4[0], h[0], f4{0.f, 0.f, 0.f, 0.f});
+        f4 accB = mfma4(t.w4[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        accA = mfma4(t.w4[2], h[2], accA);
+        accB = mfma4(t.w4[3], h[3], accB);
+        const f4 part = accA + accB;
+        f4 out = t.b4;
+        if constexpr (ROWS2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2* xb2 = reinterpret_cast<f2*>(&xbuf[p][0][0]);
+            xb2[w * 64 + l] = f2{part[0], part[1]};
+            lds_barrier();
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) { const f2 q = xb2[c * 64 + l]; out[0] += q[0]; out[1] += q[1]; }
+        } else {
+            xbuf[p][w][l] = part;
+            lds_barrier();
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) out += xbuf[p][c][l];
+        }
+        p ^= 1;
+        return out;
+    };
+    // DE right-hand side at xs with this step's constant part cz
+    auto rhs = [&](const float (&xs)[NX], const f4 cz) -> f4 {
+        f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            accA = mfma4(w1xs[r], xs[r], accA);
+            accB = mfma4(w1xd[r], xs[r] - a0x[r], accB);
+        }
+        return tail(accA + accB, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{});
+    };
+    // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
+    auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv) -> f4 {
+        f4 acc = c0a;
+        if constexpr (DAE) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) acc = mfma4(aw1x[r], xa[r], acc);
+#pragma unroll
+            for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
+            return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{});
+        }
+        return acc;
+    };
+    auto load_x = [&](long long k, float (&dst)[NX]) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) dst[r] = 4 * r + g < xd ? a.x.p[k * a.x.st + b * a.x.sb + 4 * r + g] : 0.0f;
+    };
+    auto store_x = [&](long long k) {
+        if (w == 0 && valid) {
+            float* o = a.xo + (k * a.B + b) * xd;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) if (4 * r + g < xd) o[4 * r + g] = x[r];
+        }
+    };
+    // i_out: each i-dim is stored from its `s`-block slot (q >= ne) so that exactly one lane group writes it
+    auto store_i = [&](long long k, const f4 iv) {
+        if constexpr (DAE) {
+            if (w == 1 && valid) {
+                float* o = a.io + (k * a.B + b) * idim;
+#pragma unroll
+                for (int m = 0; m < NZM; ++m) if (ekind[m] == 2 && 4 * m + g >= ne) o[ecol[m]] = iv[m];
+            }
+        }
+    };
+
+    store_x(0);
+    f4 icur = f4{0.f, 0.f, 0.f, 0.f};
+    Arr<NZA> zva_nxt = {};
+    if constexpr (DAE) {   // my_solvers.py:95
+        Arr<NZA> zv0;
+        load_ae_ext(0, -1, zv0);
+        float xa[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xa[r] = x[r];
+        if constexpr (TRUE_X) load_x(0, xa);
+        icur = ae_eval(xa, zv0);
+        store_i(0, icur);
+        if (nT > 1) load_ae_ext(1, -1, zva_nxt);
+    }
+    if (nT < 2) return;
+
+    float t_cur = tp[0], t_nxt = tp[tst];
+    // Event index of step k+1, fetched one iteration before the prefetch that needs it.  The address is made
+    // formally per-lane (opaque zero) so the value stays in a VGPR instead of a load -> s_waitcnt -> readfirstlane.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int* evp = a.ev + lane_zero;
+    int ev_cur = a.ev ? a.ev[0] : -1;
+    int ev_n1 = (a.ev && nT > 2) ? evp[1] : -1;
+    Arr<NZM> ext_nxt = {};
+    load_de_ext(0, ev_cur, ext_nxt);
+
+    for (long long k = 0; k + 1 < nT; ++k) {
+        const float h_ = t_nxt - t_cur;
+        t_cur = t_nxt;
+        const Arr<NZM> extv = ext_nxt;
+        const Arr<NZA> zva = zva_nxt;     // raw z|v of grid point k+1 for the AE head at the end of this step
+        const int ev_now = ev_cur;
+
+        float xsrc[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xsrc[r] = x[r];
+        if constexpr (TRUE_X) load_x(k, xsrc);   // teacher forcing: the step starts from the dataset's x[k]
+        // prefetch the next step's inputs (consumed one full step later)
+        if (k + 2 < nT) {
+            t_nxt = tp[(k + 2) * tst];
+            load_de_ext(k + 1, ev_n1, ext_nxt);
+            if constexpr (DAE) load_ae_ext(k + 2, -1, zva_nxt);
+            ev_cur = ev_n1;
+            ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+        }
+        if constexpr (DAE) {
+            // event: i0 = g(x0; z_jump, v_jump) with the RUNNING state (my_solvers.py:108-110)
+            if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {
+                Arr<NZA> zvj;
+                load_ae_ext(k, ev_now, zvj);
+                icur = ae_eval(x, zvj);
+            }
+        }
+        // per-step constant of L1: c0 + W1[:, ext columns] . (ext - a0 | ext)
+        f4 cz = c0;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) {
+            float e = extv.v[m];
+            if constexpr (DAE) {
+                if (ekind[m] == 2) e = true_i ? a.i.p[k * a.i.st + b * a.i.sb + ecol[m]] : icur[m];
+            }
+            cz = mfma4(w1z.v[m], e - a0e.v[m], cz);
+        }
+
+        const f4 k1 = rhs(xsrc, cz);
+        if constexpr (METHOD == PSNODE_EULER) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + h_ * k1[r];
+        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+            float xs[NX];
+            const float hh = 0.5f * h_;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + k1[r] * hh;
+            const f4 k2 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + h_ * k2[r];
+        } else {
+            float xs[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * k1[r] * kOneThird;
+            const f4 k2 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * (k2[r] - k1[r] * kOneThird);
+            const f4 k3 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xs[r] = xsrc[r] + h_ * (k1[r] - k2[r] + k3[r]);
+            const f4 k4 = rhs(xs, cz);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + (k1[r] + 3.0f * (k2[r] + k3[r]) + k4[r]) * h_ * 0.125f;
+        }
+        store_x(k + 1);
+        if constexpr (DAE) {   // my_solvers.py:121: i1 at the right grid point, un-jumped inputs
+            float xa[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xa[r] = x[r];
+            if constexpr (TRUE_X) load_x(k + 1, xa);
+            icur = ae_eval(xa, zva);
+            store_i(k + 1, icur);
+        }
+    }
+}
+
+inline int nzm_of(const IntegrateDev& a, bool dae) { return (2 * (a.zd + (dae ? a.vd + a.id : 0)) + 3) / 4; }
+inline int nza_of(const IntegrateDev& a) { return (a.zd + a.vd + 3) / 4; }
+inline int na_of(const IntegrateDev& a, bool dae) { return (a.xd + a.zd + (dae ? a.vd + a.id : 0) + 3) / 4; }
+
+template <int NWV, int METHOD, bool TRUE_X>
+hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
+    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
+    const int NZM = nzm_of(a, dae), NZA = dae ? nza_of(a) : 0;
+#define PSNODE_LAUNCH(NZM_, NZA_, DAE_)                                                                                    \
+    {                                                                                                                      \
+        auto kern = &integrate_mfma_kernel<METHOD, kNXc, NZM_, NZA_, TRUE_X, DAE_, NWV>;                                  \
+        const size_t lds = ae_weights_in_lds(DAE_, NWV) ? ae_lds_bytes(NWV) : 0;                                           \
+        if (lds) {                                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+            if (e != hipSuccess) return e;                                                                                 \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, NA);                                                    \
+        return hipGetLastError();                                                                                          \
+    }
+    if (!dae) {
+        switch (NZM) {
+            case 0: PSNODE_LAUNCH(0, 0, false)
+            case 1: PSNODE_LAUNCH(1, 0, false)
+            case 2: PSNODE_LAUNCH(2, 0, false)
+            default: return hipErrorNotSupported;
+        }
+    }
+    switch (NZM * 10 + NZA) {
+        case 11: PSNODE_LAUNCH(1, 1, true)
+        case 21: PSNODE_LAUNCH(2, 1, true)
+        case 31: PSNODE_LAUNCH(3, 1, true)
+        case 41: PSNODE_LAUNCH(4, 1, true)
+        case 32: PSNODE_LAUNCH(3, 2, true)
+        case 42: PSNODE_LAUNCH(4, 2, true)
+        default: return hipErrorNotSupported;
+    }
+#undef PSNODE_LAUNCH
+}
+
+template <int NWV, int METHOD>
+hipError_t launch_method(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
+    if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_shape<NWV, METHOD, true>(a, dae, pde, pae, NA, s);
+    return launch_shape<NWV, METHOD, false>(a, dae, pde, pae, NA, s);
+}
+
+// pack the weights into the register images, then run the integrator (both on `stream`)
+template <int NWV>
+hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
+    const int NZM = nzm_of(a, dae), NA = na_of(a, dae);
+    const int ne = a.zd + (dae ? a.vd + a.id : 0);
+    PackMfma p;
+    p.ae = 0; p.nw = NWV; p.xd = a.xd; p.ne = ne; p.n = a.xd + ne; p.nzv = a.zd + (dae ? a.vd : 0);
+    p.NX = kNXc; p.NB = kNXc; p.NE = NZM; p.NA = NA;
+    p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
+    p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
+    p.out_dim = a.xd;
+    p.out = pack;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, p);
+    float* pack_ae = pack + (size_t)NWV * (max_regs(NWV) + NA) * 64;
+    if (dae) {
+        PackMfma q = p;
+        q.ae = 1; q.NB = 0; q.NE = nza_of(a);
+        q.w1 = a.ae.w[0]; q.b1 = a.ae.bias[0]; q.w2 = a.ae.w[1]; q.b2 = a.ae.bias[1];
+        q.w3 = a.ae.w[2]; q.b3 = a.ae.bias[2]; q.w4 = a.ae.w[3]; q.b4 = a.ae.bias[3];
+        q.out_dim = a.id;
+        q.out = pack_ae;
+        hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, q);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    switch (a.method) {
+        case PSNODE_EULER: return launch_method<NWV, PSNODE_EULER>(a, dae, pack, pack_ae, NA, stream);
+        case PSNODE_MIDPOINT: return launch_method<NWV, PSNODE_MIDPOINT>(a, dae, pack, pack_ae, NA, stream);
+        default: return launch_method<NWV, PSNODE_RK4_38>(a, dae, pack, pack_ae, NA, stream);
+    }
+}
+
+}  // namespace
+}  // namespace psnode

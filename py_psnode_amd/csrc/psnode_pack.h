@@ -6,8 +6,8 @@
 
 namespace psnode {
 
-constexpr int HID = 64;
-constexpr int NW = HID / 16;   // waves per workgroup
+constexpr int HID = 64;        // hidden width of the backward kernel (the forward kernels take NWV = hidden / 16)
+constexpr int NW = HID / 16;   // waves per workgroup at hidden 64
 constexpr int TBM = 16;        // trajectories per workgroup
 constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8
 constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <= 16
@@ -15,27 +15,29 @@ constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <
 // Forward image of one MLP.
 // DE: W1A = columns of the `s` block (x dims), W1B = columns of the `s-a0` block (x dims), W1E = NE ext registers.
 // AE: W1A = columns of x, W1B unused (count 0), W1E = NE registers of the z|v columns.
-template <int NX, int NB, int NE>
+template <int NX, int NB, int NE, int NWV = NW>
 struct Regs {
     static constexpr int W1A = 0;
     static constexpr int W1B = NX;
     static constexpr int W1E = NX + NB;
     static constexpr int B1 = W1E + NE;
-    static constexpr int W2 = B1 + 4;         // (16) chunk c = source wave (w+c)&3
-    static constexpr int B2 = W2 + 16;
+    static constexpr int W2 = B1 + 4;         // (4*NWV) chunk c = source wave (w+c) % NWV
+    static constexpr int B2 = W2 + 4 * NWV;
     static constexpr int W3 = B2 + 4;
-    static constexpr int B3 = W3 + 16;
-    static constexpr int W4 = B3 + 4;         // (4) this wave's K quarter
+    static constexpr int B3 = W3 + 4 * NWV;
+    static constexpr int W4 = B3 + 4;         // (4) this wave's K slice
     static constexpr int B4 = W4 + 4;
     static constexpr int COUNT = B4 + 4;      // followed by NA registers of the a0 columns of L1
 };
-constexpr int kMaxRegs = 2 * kNXc + kMaxNZM + 52;
+__host__ __device__ constexpr int max_regs(int nw) { return 2 * kNXc + kMaxNZM + 20 + 8 * nw; }
+constexpr int kMaxRegs = max_regs(NW);
 
 // ext slot q -> index into ext = z | v | i, or -1 (padding)
 __host__ __device__ inline int slot_ext(int q, int ne) { return q < ne ? q : (q < 2 * ne ? q - ne : -1); }
 
 struct PackMfma {
     int ae;                 // 0: DE image, 1: AE image
+    int nw;                 // waves per tile = hidden / 16
     int xd, ne, n, nzv;     // ne = z+v+i (DE ext), n = xd+ne, nzv = z+v
     int NX, NB, NE, NA;
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
@@ -43,12 +45,13 @@ struct PackMfma {
     float* out;
 };
 
-__host__ __device__ inline int pack_fwd_count(const PackMfma& p) { return p.NX + p.NB + p.NE + 52 + p.NA; }
+__host__ __device__ inline int pack_fwd_count(const PackMfma& p) { return p.NX + p.NB + p.NE + 20 + 8 * p.nw + p.NA; }
 
 // value of forward-image register `reg` (0 .. pack_fwd_count) for wave w, lane `lane`
 __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int lane) {
-    const int W1B = p.NX, W1E = p.NX + p.NB, B1 = W1E + p.NE, W2 = B1 + 4, B2 = W2 + 16, W3 = B2 + 4, B3 = W3 + 16, W4 = B3 + 4,
-              B4 = W4 + 4, COUNT = B4 + 4;
+    const int H = 16 * p.nw;
+    const int W1B = p.NX, W1E = p.NX + p.NB, B1 = W1E + p.NE, W2 = B1 + 4, B2 = W2 + 4 * p.nw, W3 = B2 + 4, B3 = W3 + 4 * p.nw,
+              W4 = B3 + 4, B4 = W4 + 4, COUNT = B4 + 4;
     const int K1 = p.ae ? p.n + p.xd + p.nzv : 3 * p.n;
     const int i = lane & 15, g = lane >> 4, u = 16 * w + i;
     float v = 0.0f;
@@ -69,13 +72,13 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
     } else if (reg < W2) {
         v = p.b1[16 * w + 4 * g + (reg - B1)];
     } else if (reg < B2) {
-        const int kk = reg - W2, ws = (w + (kk >> 2)) & 3;
-        v = p.w2[u * HID + 16 * ws + 4 * g + (kk & 3)];
+        const int kk = reg - W2, ws = (w + (kk >> 2)) & (p.nw - 1);
+        v = p.w2[u * H + 16 * ws + 4 * g + (kk & 3)];
     } else if (reg < W3) {
         v = p.b2[16 * w + 4 * g + (reg - B2)];
     } else if (reg < B3) {
-        const int kk = reg - W3, ws = (w + (kk >> 2)) & 3;
-        v = p.w3[u * HID + 16 * ws + 4 * g + (kk & 3)];
+        const int kk = reg - W3, ws = (w + (kk >> 2)) & (p.nw - 1);
+        v = p.w3[u * H + 16 * ws + 4 * g + (kk & 3)];
     } else if (reg < W4) {
         v = p.b3[16 * w + 4 * g + (reg - B3)];
     } else if (reg < COUNT) {
@@ -89,7 +92,7 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
         } else {                          // row (gr, rr) <- x-dim 4*rr+gr
             o = 4 * rr + gr;
         }
-        if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * HID + 16 * w + 4 * g + (reg - W4)];
+        if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * H + 16 * w + 4 * g + (reg - W4)];
     } else {
         const int q = 4 * (reg - COUNT) + g;
         if (q < p.n) v = p.w1[u * K1 + q];

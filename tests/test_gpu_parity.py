@@ -141,8 +141,20 @@ def test_other_shapes_generic(xd, zd, H, nh):
 def test_mfma_kernel_shapes(xd, zd, method):
     """Every (x_dim, z_dim) class of the MFMA kernel (NX=2; NZM=0,1,2), forced with kernel='mfma', with events,
     per-trajectory clocks and a ragged last tile."""
+    _check_mfma_ode(xd, zd, method, 64)
+
+
+@pytest.mark.parametrize("H", [32, 128])
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (8, 4)])
+def test_mfma_kernel_hidden_widths(xd, zd, method, H):
+    """--hidden 32 and 128 (the scripts' argparse default, neural_00_ODE_01_no_encode.py:259): 2 and 8 waves per tile."""
+    _check_mfma_ode(xd, zd, method, H)
+
+
+def _check_mfma_ode(xd, zd, method, H):
     B, Tn = 37, 14
-    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=11)
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=11, H=H)
     g = torch.Generator().manual_seed(12)
     t = t * (0.5 + torch.rand(1, B, 1, generator=g))
     t[:, 0] = torch.arange(Tn, dtype=torch.float32).view(Tn, 1) * 0.01      # trajectory 0 = the event clock
@@ -179,8 +191,20 @@ def _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=0, H=64):
 def test_mfma_dae_kernel_shapes(xd, zd, vd, idim, method):
     """Every (NZM, NZA) class of the DAE MFMA kernel, forced with kernel='mfma': events (incl. the i0 recompute),
     all four teacher-forcing combinations, per-trajectory clocks, ragged last tile."""
+    _check_mfma_dae(xd, zd, vd, idim, method, 64)
+
+
+@pytest.mark.parametrize("H", [32, 128])
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd,vd,idim", [(8, 2, 2, 2), (5, 1, 1, 1), (8, 4, 3, 1), (2, 2, 4, 2)])
+def test_mfma_dae_kernel_hidden_widths(xd, zd, vd, idim, method, H):
+    """--hidden 32 / 128 DAE (at 128 the AE's H->H weights sit in LDS, psnode_mfma_impl.h)."""
+    _check_mfma_dae(xd, zd, vd, idim, method, H)
+
+
+def _check_mfma_dae(xd, zd, vd, idim, method, H):
     B, Tn = 21, 11
-    de, ae, t, x, z, v, i, xi, a0, ev, zj, vj = _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=21)
+    de, ae, t, x, z, v, i, xi, a0, ev, zj, vj = _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=21, H=H)
     c = lambda a: a.cuda()
     for tx in (False, True):
         for ti in (False, True):
@@ -333,16 +357,20 @@ def test_auto_picks_mfma_for_reference_shape():
     for k, o in enumerate((64, 64, 64, 8)):
         a.de.out_dim[k] = o
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
-    a.de.out_dim[1] = 32
+    a.de.out_dim[1] = 32                       # mixed widths: no MFMA kernel
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
+    for H in (32, 128):                        # --hidden 32 / 128: the 2- and 8-wave instantiations
+        for k in range(3):
+            a.de.out_dim[k] = H
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
     d = _lib.DaeArgsF32()
     d.method, d.x_dim, d.z_dim, d.v_dim, d.i_dim, d.T, d.B = _lib.RK4_38, 8, 2, 2, 2, 1001, 4096
     d.de.n_layers, d.de.in_dim, d.ae.n_layers, d.ae.in_dim = 4, 42, 4, 26
     for k, (o1, o2) in enumerate(zip((64, 64, 64, 8), (64, 64, 64, 2))):
         d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
     assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA
-    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=32)
-    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel for H=32
+    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=48)
+    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel for H=48
         fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
 
 
