@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
     ap.add_argument("--train", action="store_true", help="time forward + backward (fused autograd route) instead of the forward alone")
+    ap.add_argument("--loss", default="mse-fused", choices=["mse-fused", "mse-torch", "weighted-sum"],
+                    help="with --train: the scripts' masked MSE through the fused loss kernel (default), the same expression in "
+                         "PyTorch ops, or the plain sum(xs * G) of earlier rounds")
     ap.add_argument("--train-baseline-steps", type=int, default=0,
                     help="with --train: also time the unrolled PyTorch-autograd walk on the GPU for this many grid steps")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
@@ -260,6 +263,30 @@ def main():
         train_state["layers"] = pair(train_state["params"][:nde])
         train_state["ae_layers"] = pair(train_state["params"][nde:])
         train_state["G"] = torch.randn(T, B, w["xd"], device=dev)
+        # the scripts' datasets: ODE mask defaults to ones like x (neural_base.py:14-32), DAE mask is [N,T,1]
+        gm = torch.Generator().manual_seed(11)
+        mshape = (B, T, w["xd"]) if w["kind"] == "ode" else (B, T, 1)
+        train_state["mask"] = (torch.rand(mshape, generator=gm) > 0.1).float().to(dev)
+        from py_psnode_amd import loss as ploss
+        mse = torch.nn.functional.mse_loss
+
+    def train_loss(xs, is_=None):
+        """The scripts' loss on the [B,T,D] predictions (neural_00_ODE_01_no_encode.py:353-355, neural_01_DAE_01_no_encode.py:414-419)."""
+        m = train_state["mask"]
+        if args.loss == "weighted-sum":
+            return (xs * train_state["G"]).sum() + (is_.sum() if is_ is not None else 0.0)
+        xp = xs.permute(1, 0, 2)
+        if is_ is None:
+            if args.loss == "mse-fused":
+                return ploss.ode_loss(xp, p["x"], m)[0]
+            return torch.sum(torch.sum(torch.sum(mse(xp, p["x"], reduction="none") * m, dim=1), dim=0) / torch.sum(m))
+        ip = is_.permute(1, 0, 2)
+        if args.loss == "mse-fused":
+            return ploss.dae_loss(xp, p["x"], ip, p["i"], m)[0]
+        x, i = p["x"], p["i"]
+        x_loss = (torch.sum(mse(xp, x, reduction="none") * m) + torch.sum(mse(xp[:, :, 1:2], x[:, :, 1:2], reduction="none") * m) * 9) / torch.sum(m)
+        i_loss = torch.sum(mse(ip, i, reduction="none") * m) / torch.sum(m)
+        return x_loss + i_loss + mse(x[:, 0, :], xp[:, 0, :]) + mse(i[:, 0, :], ip[:, 0, :])
 
     def train_step():
         for q in train_state["params"]:
@@ -267,11 +294,11 @@ def main():
         if w["kind"] == "dae":
             xs, is_ = pag.fused_dae_integrate(args.method, args.kernel, train_state["layers"], train_state["ae_layers"], p["x_init"], tmv(p["t"]),
                                               tmv(p["z"]), tmv(p["v"]), tmv(p["i"]), p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
-            ((xs * train_state["G"]).sum() + is_.sum()).backward()
+            train_loss(xs, is_).backward()
             return (xs.detach(), is_.detach())
         xs = pag.fused_ode_integrate(args.method, args.kernel, train_state["layers"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                      p["event_t"], p["z_jump"])
-        (xs * train_state["G"]).sum().backward()
+        train_loss(xs).backward()
         return (xs.detach(),)
 
     def one_step(ev_pair=None):
@@ -387,7 +414,7 @@ def main():
         }
         if args.train:
             res["metric"] = f"training state-steps/sec (forward + backward), {args.workload} {args.method}, batch {B}"
-            res["config"]["workload"] += " | forward + fused backward (sum-weighted loss)"
+            res["config"]["workload"] += f" | forward + loss ({args.loss}) + fused backward"
             if args.train_baseline_steps > 0 and w["kind"] == "ode":
                 # the route the reference's scripts take: unrolled autograd through the per-step Python loop, on this GPU
                 from py_psnode_amd import models

@@ -155,7 +155,8 @@ int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspac
  * Replaces the forward of the direct_encode encoders/decoders nn.Sequential(Linear, ELU, Linear) applied to every
  * (b,t) row: x_encoder / z_encoder / x_decoder (neural_00_ODE_02_direct_encode.py:64-69,74-88) and
  * v_encoder / i_encoder / i_decoder (neural_01_DAE_02_direct_encode.py:107-118,126-152).
- * Supported: hidden width 16 (the scripts' default hidden_dim), in/out width 1..16 -- see psnode_mlp_rows_supported. */
+ * Supported: hidden width 16 (the scripts' default hidden_dim) or 64 (their debug override), in/out width up to the
+ * hidden width -- see psnode_mlp_rows_supported. */
 int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* mlp);
 int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, float* out,
                             int64_t out_row_stride, void* stream);
@@ -227,6 +228,40 @@ typedef struct {
 int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* args);
 size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* args);
 int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Masked, column-weighted squared-error loss of one (prediction, target) pair and its gradient, in one pass:
+ *
+ *   out[d]   = scale * inv_norm * col_weight[d] * sum_{t,b} mask[t,b,(d)] * (pred[t,b,d] - target[t,b,d])^2     d < D
+ *   out[D]   = t0_coef * sum_{b,d} (pred[0,b,d] - target[0,b,d])^2
+ *   out[D+1] = sum_d out[d] + out[D]                                                  (the scalar the scripts call backward on)
+ *   grad_pred[t,b,d] = d out[D+1] / d pred[t,b,d]                                     (contiguous [T,B,D], optional)
+ *
+ * This is the step right after the path in the training loops:
+ *   `torch.sum(torch.sum(Loss_func(x_pred, x, reduction='none') * mask, dim=1), dim=0) / torch.sum(mask)` summed over d
+ *   (neural_00_ODE_01_no_encode.py:353-355) -> mask = the batch's mask, inv_norm = 1/sum(mask), scale = 1;
+ *   the DAE's weighted form `(sum(se*mask) + 9*sum(se[:,:,1:2]*mask)) / sum(mask)` and `Loss_func(x[:,0,:], x_pred[:,0,:])`
+ *   (neural_01_DAE_01_no_encode.py:414-419) -> col_weight = [1,10,1,...], t0_coef = 1/(B*D);
+ *   the direct_encode reconstruction term `Loss_func(x_re, x)` (neural_00_ODE_02_direct_encode.py:269) -> no mask,
+ *   scale = 1/(T*B*D).
+ * pred/target/mask are logical [T,B,*] views (element strides, last dim contiguous): pred is normally the integrator's
+ * time-major output, target/mask the scripts' B-major tensors.  mask_width: 0 = no mask, 1 = [T,B,1], D = [T,B,D].
+ * inv_norm is a DEVICE scalar (so that sum(mask) -- or its all-reduce over ranks -- never has to visit the host);
+ * NULL = 1.  Deterministic: per-workgroup partial sums are combined in a fixed order (in double). */
+typedef struct {
+    int64_t T, B;
+    int32_t D;
+    int32_t mask_width;
+    psnode_view_f32 pred, target, mask;
+    const float* col_weight;         /* device [D] or NULL (= ones) */
+    const float* inv_norm;           /* device scalar or NULL (= 1) */
+    float scale;
+    float t0_coef;
+    float* out;                      /* device [D+2] */
+    float* grad_pred;                /* device [T,B,D] contiguous, or NULL */
+} psnode_loss_args_f32;
+
+size_t psnode_masked_mse_workspace_bytes(const psnode_loss_args_f32* args);
+int32_t psnode_masked_mse_f32(const psnode_loss_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);

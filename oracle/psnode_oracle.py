@@ -169,3 +169,28 @@ def event_step_table(t: torch.Tensor, event_t: Optional[torch.Tensor]) -> List[i
         sel = (event_t[0] == t[j][0][0]).view(-1).nonzero().view(-1).tolist()
         tab.append(sel[0] if len(sel) else -1)
     return tab
+
+
+# ---- the loss expressions that follow the path in the scripts' training loops (Loss_func = nn.functional.mse_loss,
+#      neural_00_ODE_01_no_encode.py:49).  Tensors in the scripts' [B,T,D] shape.
+def ode_loss(x_pred: torch.Tensor, x: torch.Tensor, mask: torch.Tensor):
+    """neural_00_ODE_01_no_encode.py:354-355 (same lines in neural_00_ODE_02_direct_encode.py:268,270):
+    returns (loss, x_loss[D])."""
+    se = torch.nn.functional.mse_loss(x_pred, x, reduction="none")
+    x_loss = torch.sum(torch.sum(se * mask, dim=1), dim=0) / torch.sum(mask)
+    return torch.sum(x_loss), x_loss
+
+
+def dae_loss(x_pred, x, i_pred, i, mask):
+    """neural_01_DAE_01_no_encode.py:414-419: returns (loss, x_loss, i_loss, x0_term, i0_term)."""
+    mse = torch.nn.functional.mse_loss
+    x_loss = (torch.sum(mse(x_pred, x, reduction="none") * mask)
+              + torch.sum(mse(x_pred[:, :, 1:2], x[:, :, 1:2], reduction="none") * mask) * 9) / torch.sum(mask)
+    i_loss = torch.sum(mse(i_pred, i, reduction="none") * mask) / torch.sum(mask)
+    x0, i0 = mse(x[:, 0, :], x_pred[:, 0, :]), mse(i[:, 0, :], i_pred[:, 0, :])
+    return x_loss + i_loss + x0 + i0, x_loss, i_loss, x0, i0
+
+
+def recon_loss(x_re: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """neural_00_ODE_02_direct_encode.py:269: Loss_func(x_re, x)."""
+    return torch.nn.functional.mse_loss(x_re, x)

@@ -25,6 +25,7 @@ EXPORTS = (
     "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
+    "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
 )
 
 
@@ -86,6 +87,13 @@ class DaeBwdArgsF32(ctypes.Structure):
                 ("grad_v_jump", c_void_p), ("grad_all_initial", c_void_p), ("grad_params_de", c_void_p), ("grad_params_ae", c_void_p)]
 
 
+class LossArgsF32(ctypes.Structure):
+    _fields_ = [("T", c_int64), ("B", c_int64), ("D", c_int32), ("mask_width", c_int32),
+                ("pred", ViewF32), ("target", ViewF32), ("mask", ViewF32),
+                ("col_weight", c_void_p), ("inv_norm", c_void_p), ("scale", ctypes.c_float), ("t0_coef", ctypes.c_float),
+                ("out", c_void_p), ("grad_pred", c_void_p)]
+
+
 _lib = None
 
 
@@ -138,6 +146,10 @@ def load():
     lib.psnode_dae_backward_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdArgsF32)]
     lib.psnode_dae_backward_f32.restype = c_int32
     lib.psnode_dae_backward_f32.argtypes = [ctypes.POINTER(DaeBwdArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_masked_mse_workspace_bytes.restype = c_size_t
+    lib.psnode_masked_mse_workspace_bytes.argtypes = [ctypes.POINTER(LossArgsF32)]
+    lib.psnode_masked_mse_f32.restype = c_int32
+    lib.psnode_masked_mse_f32.argtypes = [ctypes.POINTER(LossArgsF32), c_void_p, c_size_t, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

@@ -123,3 +123,45 @@ def integrate_dae_sharded(method, de_layers, ae_layers, x_init, t, x, z, v, i, a
     if not gather:
         return xs, is_
     return all_gather_batch(xs, group), all_gather_batch(is_, group)
+
+
+def masked_mse_sharded(pred, target, mask, col_weight=None, t0_weight: float = 0.0, global_batch: Optional[int] = None, group=None,
+                       local_fn: Optional[Callable] = None):
+    """The scripts' masked MSE (neural_00_ODE_01_no_encode.py:353-355, neural_01_DAE_01_no_encode.py:414-419) over a batch
+    that is sharded across ranks, WITHOUT gathering the predictions: two scalar-sized all-reduces instead of the
+    [T,B,D] all-gather.
+
+    Each rank passes its shard (pred/target [Bl,T,D], mask [Bl,T,1|D]).  sum(mask) is all-reduced first so that every rank
+    normalises by the GLOBAL mask count; the local kernel then yields this rank's share of the global loss (and, through
+    autograd, exactly the global loss's gradient w.r.t. the local predictions); the per-column terms are all-reduced for
+    logging.  Returns (local_share, global_terms): call .backward() on local_share, then all_reduce_param_grads().
+    t0_weight = coefficient of the mean squared error at t = 0 (`Loss_func(x[:,0,:], x_pred[:,0,:])`), normalised by the
+    GLOBAL batch (global_batch, default world * Bl)."""
+    if local_fn is None:
+        from . import loss
+        local_fn = loss.masked_mse
+    world = dist.get_world_size(group)
+    Bl, _, D = pred.shape
+    msum = torch.sum(mask).reshape(1)
+    dist.all_reduce(msum, group=group)
+    gb = global_batch if global_batch is not None else world * Bl
+    share, terms = local_fn(pred, target, mask, col_weight=col_weight, inv_norm=msum.reciprocal(), t0_coef=t0_weight / (gb * D))
+    terms = terms.detach().clone()
+    dist.all_reduce(terms, group=group)
+    return share, terms
+
+
+def all_reduce_param_grads(params, group=None):
+    """Sum the parameter gradients over ranks in ONE all-reduce of a flat bucket (the ODE_01 DE_Func is 10 824 floats =
+    43 KB, far below any bucketing threshold).  The sharded loss is already a share of the global loss, so the sum -- not
+    the mean -- is the global gradient."""
+    ps = [q for q in params if q.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([q.grad.reshape(-1) for q in ps])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for q in ps:
+        n = q.grad.numel()
+        q.grad.copy_(flat[off:off + n].view_as(q.grad))
+        off += n

@@ -33,6 +33,42 @@ def _oracle_local(method, de, t, x, z, a0, z_jump=None, input_true_x=False, even
     return xs
 
 
+def _torch_masked_mse(pred, target, mask, col_weight=None, inv_norm=None, scale=1.0, t0_coef=0.0):
+    """CPU stand-in for py_psnode_amd.loss.masked_mse (same contract: (total, [per-column..., t0 term, total])), in torch ops."""
+    D = pred.shape[2]
+    se = (pred - target) ** 2
+    w = torch.ones(D) if col_weight is None else torch.as_tensor(col_weight, dtype=torch.float32)
+    cols = torch.sum(se * (mask if mask is not None else 1.0), dim=(0, 1)) * w * scale * (inv_norm if inv_norm is not None else 1.0)
+    t0 = t0_coef * torch.sum(se[:, 0, :])
+    tot = cols.sum() + t0
+    return tot, torch.cat((cols, t0.view(1), tot.view(1)))
+
+
+def _check_sharded_loss(rank, world, sharded):
+    """Sharded loss + gradient all-reduce == the unsharded oracle loss and its autograd gradients (DAE-style weights + t0 term)."""
+    from oracle import psnode_oracle as O
+    g = torch.Generator().manual_seed(7)
+    B, Tn, D = 10, 9, 8
+    lin = torch.nn.Linear(D, D)
+    with torch.no_grad():
+        lin.weight.copy_(0.3 * torch.randn(D, D, generator=g)); lin.bias.copy_(0.1 * torch.randn(D, generator=g))
+    inp, x = torch.randn(B, Tn, D, generator=g), torch.randn(B, Tn, D, generator=g)
+    mask = (torch.rand(B, Tn, 1, generator=g) > 0.3).float()
+    i_dummy = torch.zeros(B, Tn, 1)
+    ref = O.dae_loss(lin(inp), x, i_dummy, i_dummy, mask)          # x part: weights [1,10,1,...] + the t=0 term
+    ref_x = ref[1] + ref[3]
+    gw, gb = torch.autograd.grad(ref_x, (lin.weight, lin.bias))
+    lo, hi = sharded.shard_bounds(B, rank, world)
+    lin.zero_grad()
+    share, terms = sharded.masked_mse_sharded(lin(inp[lo:hi]), x[lo:hi], mask[lo:hi], col_weight=[1.0, 10.0] + [1.0] * (D - 2),
+                                             t0_weight=1.0, global_batch=B, local_fn=_torch_masked_mse)
+    share.backward()
+    sharded.all_reduce_param_grads(lin.parameters())
+    assert abs(float(terms[D + 1]) - float(ref_x)) <= 1e-5 * abs(float(ref_x)), (float(terms[D + 1]), float(ref_x))
+    assert float((lin.weight.grad - gw).abs().max()) <= 1e-5 * float(gw.abs().max())
+    assert float((lin.bias.grad - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
+
+
 def _table(t, event_t):
     from oracle import psnode_oracle as O
     return torch.tensor(O.event_step_table(t, event_t), dtype=torch.int32)
@@ -66,6 +102,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             # trajectory `B/2` (rank 1's first) was integrated with the shifted clock but identical dt -> same result
             q.put((tuple(out.shape), float((out - ref).abs().max())))
+        _check_sharded_loss(rank, world, sharded)
         bounds = [sharded.shard_bounds(10, r, 3) for r in range(3)]
         assert bounds == [(0, 4), (4, 7), (7, 10)]
     finally:
