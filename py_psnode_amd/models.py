@@ -39,15 +39,46 @@ def _rows(seq, inp):
 
 
 class DE_Func(nn.Module):
-    """x_dot MLP over cat(a0, s - a0, s), s = cat(xt, zt[, vt, it]).  `widths` = (in_state_width, hidden..., out)."""
+    """ODE right-hand side: x_dot MLP over cat(a0, s - a0, s), s = cat(xt, zt).  Positional order of forward() as in
+    neural_00_ODE_01_no_encode.py:66 -- the TorchScript export (`save_model`) is called positionally downstream."""
 
     def __init__(self, state_width, hidden_dims, out_dim):
         super().__init__()
         self.x_dot = _elu_mlp(3 * state_width, *hidden_dims, out_dim)
 
-    def forward(self, t0, xt, zt, all_initial, vt=None, it=None):
-        s = torch.cat((xt, zt) if vt is None else (xt, zt, vt, it), dim=-1)
+    def forward(self, t0: torch.Tensor, xt: torch.Tensor, zt: torch.Tensor, all_initial: torch.Tensor):
+        s = torch.cat((xt, zt), dim=-1)
         return self.x_dot(torch.cat((all_initial, s - all_initial, s), dim=-1))
+
+
+class DAE_DE_Func(nn.Module):
+    """DAE right-hand side, s = cat(xt, zt, vt, it); positional order of neural_01_DAE_01_no_encode.py:69."""
+
+    def __init__(self, state_width, hidden_dims, out_dim):
+        super().__init__()
+        self.x_dot = _elu_mlp(3 * state_width, *hidden_dims, out_dim)
+
+    def forward(self, t0: torch.Tensor, xt: torch.Tensor, zt: torch.Tensor, vt: torch.Tensor, it: torch.Tensor, all_initial: torch.Tensor):
+        s = torch.cat((xt, zt, vt, it), dim=-1)
+        return self.x_dot(torch.cat((all_initial, s - all_initial, s), dim=-1))
+
+
+def _export(model, path, names, on_cpu):
+    """torch.jit.script each named sub-module into `path`/<name>.pt -- the files the scripts' save_model / final_save
+    write for the downstream C++ consumer (neural_00_ODE_01_no_encode.py:93-101, neural_01_DAE_02_direct_encode.py:155-203).
+    direct_encode models also write hidden_dim into dim.txt."""
+    import pathlib
+    path = pathlib.Path(path)
+    if not path.exists():
+        path.mkdir()
+    if getattr(model, "direct_encode", False):
+        with open(str(path / "dim.txt"), "w") as f:
+            f.write(str(model.hidden_dim))
+    for name in names:
+        mod = getattr(model, name, None)
+        if mod is None:            # DAE_02 with z_dim == 0 has no z_encoder
+            continue
+        torch.jit.script(mod.to("cpu") if on_cpu else mod).save(str(path / f"{name}.pt"))
 
 
 class AE_Func(nn.Module):
@@ -57,7 +88,7 @@ class AE_Func(nn.Module):
         super().__init__()
         self.i_calculator = _elu_mlp(in_width, *hidden_dims, out_dim)
 
-    def forward(self, xt, zt, vt, all_initial):
+    def forward(self, xt: torch.Tensor, zt: torch.Tensor, vt: torch.Tensor, all_initial: torch.Tensor):
         return self.i_calculator(torch.cat((all_initial, xt, zt, vt), dim=-1))
 
 
@@ -66,7 +97,7 @@ class Init_Func(nn.Module):
         super().__init__()
         self.init_fun = _elu_mlp(z_dim + v_dim + i_dim, hidden_dim, hidden_dim, x_dim)
 
-    def forward(self, z0, v0, i0):
+    def forward(self, z0: torch.Tensor, v0: torch.Tensor, i0: torch.Tensor):
         return self.init_fun(torch.cat([z0, v0, i0], dim=-1))
 
 
@@ -105,6 +136,17 @@ class ODE_Model(nn.Module):
         return _tm(_rows(self.x_decoder, Xh_sol)), _rows(self.x_decoder, Xh_bt)
 
 
+    _EXPORTS = ("x_encoder", "x_decoder", "z_encoder", "de_func")
+
+    def save_model(self, path):
+        """neural_00_ODE_01_no_encode.py:93-96 / neural_00_ODE_02_direct_encode.py:91-102"""
+        _export(self, path, self._EXPORTS if self.direct_encode else ("de_func",), on_cpu=False)
+
+    def final_save(self, path):
+        """as save_model, after moving the sub-modules to the CPU (neural_00_ODE_01_no_encode.py:98-101)"""
+        _export(self, path, self._EXPORTS if self.direct_encode else ("de_func",), on_cpu=True)
+
+
 class DAE_Model(nn.Module):
     def __init__(self, x_dim, z_dim, v_dim, i_dim, hidden_dim, direct_encode=False, solver=None):
         super().__init__()
@@ -121,11 +163,11 @@ class DAE_Model(nn.Module):
         self.init_func = Init_Func(x_dim, z_dim, v_dim, i_dim, H)
         if direct_encode:
             parts = 3 if z_dim == 0 else 4                         # latent blocks in all_initial (x, [z,] v, i)
-            self.de_func = DE_Func(parts * H, (H,), H)             # Linear(12H|9H, H) ELU Linear(H,H)
+            self.de_func = DAE_DE_Func(parts * H, (H,), H)         # Linear(12H|9H, H) ELU Linear(H,H)
             self.ae_func = AE_Func((2 * parts - 1) * H, (H,), H)   # Linear(7H|5H, H) ELU Linear(H,H)
         else:
             n = x_dim + z_dim + v_dim + i_dim
-            self.de_func = DE_Func(n, (H, H, H), x_dim)
+            self.de_func = DAE_DE_Func(n, (H, H, H), x_dim)
             self.ae_func = AE_Func(n + x_dim + z_dim + v_dim, (H, H, H), i_dim)
         self.solver = solver if solver is not None else Euler()
         self.event = DAE_Event()
@@ -152,3 +194,12 @@ class DAE_Model(nn.Module):
         x_pred = _rows(self.x_decoder, Xh_sol)
         x_pred[0] = x0                                             # neural_01_DAE_02_direct_encode.py:150
         return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _rows(self.x_decoder, Xh_bt), _rows(self.i_decoder, Ih_bt)
+
+    _EXPORTS = ("x_encoder", "x_decoder", "z_encoder", "v_encoder", "i_encoder", "i_decoder", "init_func", "de_func", "ae_func")
+
+    def save_model(self, path):
+        """neural_01_DAE_01_no_encode.py:117-124 / neural_01_DAE_02_direct_encode.py:155-177"""
+        _export(self, path, self._EXPORTS if self.direct_encode else self._EXPORTS[6:], on_cpu=False)
+
+    def final_save(self, path):
+        _export(self, path, self._EXPORTS if self.direct_encode else self._EXPORTS[6:], on_cpu=True)
