@@ -100,7 +100,7 @@ def test_step_integrate_matches_reference():
     d = load("g1_single_step.npz")
     de = models.DE_Func(10, (64, 64, 64), 8)
     de.load_state_dict({k[5:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("ode__")})
-    dd = models.DE_Func(14, (64, 64, 64), 8)
+    dd = models.DAE_DE_Func(14, (64, 64, 64), 8)
     dd.load_state_dict({k[5:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("dae__")})
     x0, z0, v0, i0, t0, dt, t1 = (T(d[k]) for k in ("x0", "z0", "v0", "i0", "t0", "dt", "t1"))
     with torch.no_grad():
