@@ -245,7 +245,7 @@ def main():
             mdl.solver.fused, mdl.solver.kernel = "require", args.kernel
     n_out = 1 if w["kind"] == "ode" else 2
     from py_psnode_amd import sharded
-    do_gather = (world > 1 or args.force_dist) and not args.no_gather
+    do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train   # training never gathers (sharded loss)
     pipelined = do_gather and w["kind"] == "ode" and args.chunks > 1
     gathered = None
     if do_gather and not pipelined:
@@ -276,6 +276,13 @@ def main():
         if args.loss == "weighted-sum":
             return (xs * train_state["G"]).sum() + (is_.sum() if is_ is not None else 0.0)
         xp = xs.permute(1, 0, 2)
+        if dist is not None and args.loss == "mse-fused":
+            # data-parallel step: global 1/sum(mask) by a scalar all-reduce, local share of the global loss, no gather
+            if is_ is None:
+                return sharded.masked_mse_sharded(xp, p["x"], m)[0]
+            wx = [10.0 if d == 1 else 1.0 for d in range(w["xd"])]
+            return (sharded.masked_mse_sharded(xp, p["x"], m, col_weight=wx, t0_weight=1.0)[0]
+                    + sharded.masked_mse_sharded(is_.permute(1, 0, 2), p["i"], m, t0_weight=1.0)[0])
         if is_ is None:
             if args.loss == "mse-fused":
                 return ploss.ode_loss(xp, p["x"], m)[0]
@@ -295,10 +302,14 @@ def main():
             xs, is_ = pag.fused_dae_integrate(args.method, args.kernel, train_state["layers"], train_state["ae_layers"], p["x_init"], tmv(p["t"]),
                                               tmv(p["z"]), tmv(p["v"]), tmv(p["i"]), p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
             train_loss(xs, is_).backward()
+            if dist is not None:
+                sharded.all_reduce_param_grads(train_state["params"])
             return (xs.detach(), is_.detach())
         xs = pag.fused_ode_integrate(args.method, args.kernel, train_state["layers"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                      p["event_t"], p["z_jump"])
         train_loss(xs).backward()
+        if dist is not None:
+            sharded.all_reduce_param_grads(train_state["params"])
         return (xs.detach(),)
 
     def one_step(ev_pair=None):
@@ -415,6 +426,8 @@ def main():
         if args.train:
             res["metric"] = f"training state-steps/sec (forward + backward), {args.workload} {args.method}, batch {B}"
             res["config"]["workload"] += f" | forward + loss ({args.loss}) + fused backward"
+            if dist is not None:
+                res["config"]["collective"] = "rccl all_reduce: sum(mask) (1 float), loss terms, flat parameter-gradient bucket; no gather"
             if args.train_baseline_steps > 0 and w["kind"] == "ode":
                 # the route the reference's scripts take: unrolled autograd through the per-step Python loop, on this GPU
                 from py_psnode_amd import models
