@@ -202,6 +202,7 @@ int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* works
  * grad_params_de / grad_params_ae: flat nn.Linear-order vectors (psnode_dae_backward_param_counts). */
 typedef struct {
     int32_t method;
+    int32_t kernel;                  /* PSNODE_KERNEL_AUTO: the MFMA backward (K7) when the shape has one, else the generic one */
     int32_t x_dim, z_dim, v_dim, i_dim;
     int64_t T, B;
     psnode_mlp_f32 de, ae;

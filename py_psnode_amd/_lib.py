@@ -77,7 +77,7 @@ class OdeBwdArgsF32(ctypes.Structure):
 
 
 class DaeBwdArgsF32(ctypes.Structure):
-    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
+    _fields_ = [("method", c_int32), ("kernel", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
                 ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("ae", MlpF32), ("t", ViewF32), ("z", ViewF32), ("v", ViewF32),
                 ("all_initial", c_void_p), ("event_idx", c_void_p),
                 ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),

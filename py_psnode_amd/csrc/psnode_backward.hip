@@ -595,9 +595,15 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
+namespace {
+bool use_mfma_dae_bwd(const psnode_dae_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && dae_mfma_bwd_shape_ok(a); }
+}  // namespace
+
 extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
     if (a->x_dim < 1 || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1) return 0;
+    if (a->kernel == PSNODE_KERNEL_MFMA) return dae_mfma_bwd_shape_ok(a);
+    if (use_mfma_dae_bwd(a)) return 1;
     const int n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
     const psnode_mlp_f32 &d = a->de, &g = a->ae;
     if (d.n_layers < 1 || d.n_layers > kMaxLayers || g.n_layers < 1 || g.n_layers > kMaxLayers) return 0;
@@ -608,6 +614,7 @@ extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* 
 
 extern "C" size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* a) {
     if (!a || !psnode_dae_backward_supported(a)) return 0;
+    if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_workspace_floats(a) * sizeof(float);
     return generic_bwd_workspace_floats(&a->de, &a->ae, a->B) * sizeof(float);
 }
 
@@ -625,6 +632,7 @@ extern "C" int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* a, voi
     if (a->event_idx && ((a->z_dim > 0 && !a->z_jump) || (a->v_dim > 0 && !a->v_jump))) return PSNODE_ERR_NULL;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_dae_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
+    if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     return generic_backward_launch(a->method, a->x_dim, a->z_dim, a->v_dim, a->i_dim, a->T, a->B, &a->de, &a->ae,
                                    ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},
                                    ViewDev{a->v.ptr, a->v.stride_t, a->v.stride_b}, a->all_initial, a->event_idx, a->z_jump, a->zj_stride_b,

@@ -143,6 +143,10 @@ bool mfma_ode_supported(const IntegrateDev& a);
 bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+// K7 (psnode_dae_backward.hip): MFMA backward of the DAE integrator at hidden 64
+bool dae_mfma_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
+size_t dae_mfma_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
+int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
 hipError_t launch_mfma_h32(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);    // psnode_mfma_h32.hip
 hipError_t launch_mfma_h128(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h128.hip
 

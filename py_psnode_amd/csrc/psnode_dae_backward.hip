@@ -1,0 +1,825 @@
+// K7 -- backward (discretise-then-optimise) pass through the fused DAE integrator, K2 shape class at hidden 64
+// (DE: 3n -> 64 -> 64 -> 64 -> x_dim, AE: n+x+z+v -> 64 -> 64 -> 64 -> i_dim, x_dim <= 8, z+v+i <= 8).  Replaces what
+// loss.backward() does when it walks the unrolled autograd graph of integrate_DAE (neural_01_DAE_01_no_encode.py:422-424
+// through my_solvers.py:94-129).  Same decomposition and machinery as K4 (psnode_backward.hip): one workgroup = 4 waves =
+// one tile of 16 trajectories walked from the last grid point to the first, weights as register-resident MFMA operands,
+// transposed-weight MFMAs + reduce-scatter for the delta chain, in-wave transposes for the weight gradients, register
+// accumulators written once as per-workgroup partials (deterministic reduction).
+//
+// Per grid point j = T-1 .. 0:
+//   (1) AE head at j:  i_j = g(x_j; z[j], v[j])  (never jumped, my_solvers.py:95,121).  VJP with the adjoint of i_j
+//       (= upstream dL/dis[j] + what the DE of step j fed back through its algebraic input): adds to the adjoint of x_j,
+//       to dL/dz[j], dL/dv[j], d all_initial and the AE parameter gradients.
+//   (2) step k = j-1 (if j >= 1): DE stages forwards/backwards exactly as K4, with the external input (z|v|i)_k frozen over
+//       the stages.  i_k comes from the saved `is[k]`, or at an event step from a recomputed g(x_k; z_jump, v_jump)
+//       (my_solvers.py:108-110) whose VJP is then chained in as well (its z|v gradients go to the jump arrays).
+// Layout trick (as in the forward kernel): the rows of the DE's W1^T tile that carry the gradient of the algebraic input
+// are packed so that they land in the very lanes/registers the AE's W4^T MFMA reads as its B operand -- the DAE feedback
+// i -> DE input costs no data movement in the backward direction either.
+#include <string.h>
+
+#include "psnode_pack.h"
+
+namespace psnode {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct DaeBwdDev {
+    IntegrateDev a;          // t, z, v, a0, ev, zj, vj (+strides), T, B, xd, zd, vd, id, method
+    const float *xs, *is_;   // forward results [T,B,xd], [T,B,id]
+    const float *gxs, *gis;  // upstream gradients (gis may be null)
+    float *gx0, *gz, *gv, *gzj, *gvj, *ga0;
+    float* wpart;            // [nWG][NP_de + NP_ae]
+    int n_events, NP_de, NP_ae;
+};
+
+// backward registers appended to each forward image
+constexpr int BW4T = 0, BW3T = 2, BW2T = 18, BW1TA = 34, BW1TB = 38, BWC = 42;
+
+struct PackDaeBwd {
+    PackMfma f;              // forward image description of this MLP (ae = 0 / 1)
+    float* out;
+};
+
+// DE: BW4T rows = own units, k-slot g <-> x-dim 4*br+g.  BW1TA = tile 0 (x columns), BW1TB = tile E (ext columns).
+// AE: BW4T[c] k-slot g <-> ext dim e = 4c+g (only the algebraic ones carry weights).  BW1TA = tile X (x | z,v columns),
+//     BW1TB = tile A (all_initial columns).
+__global__ void pack_dae_bwd_kernel(const PackDaeBwd pb) {
+    const PackMfma& p = pb.f;
+    const int RF = pack_fwd_count(p), R = RF + BWC;
+    const int K1 = p.ae ? p.n + p.xd + p.nzv : 3 * p.n;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NW * R * 64; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, reg = (idx >> 6) % R, w = (idx >> 6) / R;
+        if (reg < RF) { pb.out[idx] = pack_fwd_value(p, w, reg, lane); continue; }
+        const int br = reg - RF, i = lane & 15, g = lane >> 4;
+        float v = 0.0f;
+        if (br < BW3T) {
+            if (!p.ae) {
+                const int d = 4 * br + g;
+                if (d < p.xd) v = p.w4[d * HID + 16 * w + i];
+            } else {
+                const int e = 4 * br + g;
+                if (e >= p.nzv && e < p.ne) v = p.w4[(e - p.nzv) * HID + 16 * w + i];
+            }
+        } else if (br < BW1TA) {               // L3^T / L2^T: chunk c <-> output tile of wave (w+c)&3, k-slot g <-> own unit 4g+r
+            const bool l3 = br < BW2T;
+            const int kk = br - (l3 ? BW3T : BW2T), mt = (w + (kk >> 2)) & 3, r = kk & 3;
+            v = (l3 ? p.w3 : p.w2)[(16 * w + 4 * g + r) * HID + 16 * mt + i];
+        } else {
+            const bool tb = br >= BW1TB;
+            const int r = br - (tb ? BW1TB : BW1TA), u = 16 * w + 4 * g + r;
+            const int gr = i >> 2, rr = i & 3;
+            const float* row = p.w1 + u * K1;
+            if (!p.ae) {
+                if (!tb) {                     // tile 0: rows (gr, 0..1) -> gx[d], rows (gr, 2..3) -> g all_initial[x dim d]
+                    const int d = 4 * (rr & 1) + gr;
+                    if (d < p.xd) v = rr < 2 ? row[2 * p.n + d] + row[p.n + d] : row[d] - row[p.n + d];
+                } else {                       // tile E: ext dim e = 4*(rr>>1)+gr; even rr -> g ext[e], odd rr -> g all_initial[xd+e]
+                    const int e = 4 * (rr >> 1) + gr;
+                    if (e < p.ne) v = (rr & 1) ? row[p.xd + e] - row[p.n + p.xd + e] : row[p.n + p.xd + e] + row[2 * p.n + p.xd + e];
+                }
+            } else {
+                if (!tb) {                     // tile X: rows (gr, 0..1) -> gx[d]; rows (gr, 2..3) -> g (z|v)[q = 4(rr-2)+gr]
+                    if (rr < 2) { const int d = 4 * rr + gr; if (d < p.xd) v = row[p.n + d]; }
+                    else { const int q = 4 * (rr - 2) + gr; if (q < p.nzv) v = row[p.n + p.xd + q]; }
+                } else {                       // tile A: all_initial columns, x dims in rows rr < 2, ext dims in rows rr >= 2
+                    if (rr < 2) { const int d = 4 * rr + gr; if (d < p.xd) v = row[d]; }
+                    else { const int e = 4 * (rr - 2) + gr; if (e < p.ne) v = row[p.xd + e]; }
+                }
+            }
+        }
+        pb.out[idx] = v;
+    }
+}
+
+__device__ __forceinline__ f4 bm(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 elu4d(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+__device__ __forceinline__ f4 dactd(f4 h) {   // ELU'(pre) from h = ELU(pre)
+    return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
+}
+constexpr int SCRD = 64 * 4 + 4 * 8;   // padded transpose tile per wave (floats)
+__device__ __forceinline__ f4 z4() { return f4{0.f, 0.f, 0.f, 0.f}; }
+
+template <int N> struct ArrD { float v[N > 0 ? N : 1]; };
+
+template <int METHOD, int NZM, int NZA>
+__global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, const float* __restrict__ pack_de,
+                                                           const float* __restrict__ pack_ae, const int NA) {
+    constexpr int NX = kNXc, S = rk_stages(METHOD);
+    using RD = Regs<NX, NX, NZM>;
+    using RA = Regs<NX, 0, NZA>;
+    const IntegrateDev& a = d.a;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f4* xbuf = reinterpret_cast<f4*>(lds);                 // [2][4][64]
+    f4* rsbuf = xbuf + 2 * NW * 64;                        // [2][4 dest][4 src][64]
+    f4* hTb = rsbuf + 2 * NW * NW * 64;                    // [S + 1][2][4][64]   (slot S = the AE head)
+    f4* aew = hTb + (S + 1) * 2 * NW * 64;                 // [4 arrays: W2, W3, W3^T, W2^T][4 chunks][4 waves][64]: AE 64x64 weights
+    float* scr_all = reinterpret_cast<float*>(aew + 4 * 4 * NW * 64);
+
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = l >> 4, j = l & 15, i = l & 15;
+    float* scr = scr_all + w * SCRD;
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const int xd = a.xd, zd = a.zd, vd = a.vd, idim = a.id;
+    const int nzv = zd + vd, ne = nzv + idim, n = xd + ne;
+
+    // ---- DE weights -> registers
+    const int RFD = RD::COUNT + NA;
+    const float* pw = pack_de + (size_t)w * (RFD + BWC) * 64 + l;
+    float w1xs[NX], w1xd[NX], w2[16], w3[16], w4[4], w4t[2], w3t[16], w2t[16], w1t0[4], w1te[4];
+    ArrD<NZM> w1z;
+    f4 b1r, b2r, b3r, b4r;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) { w1xs[r] = pw[(RD::W1A + r) * 64]; w1xd[r] = pw[(RD::W1B + r) * 64]; }
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) w1z.v[m] = pw[(RD::W1E + m) * 64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        w2[k] = pw[(RD::W2 + k) * 64]; w3[k] = pw[(RD::W3 + k) * 64];
+        w3t[k] = pw[(RFD + BW3T + k) * 64]; w2t[k] = pw[(RFD + BW2T + k) * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w4[r] = pw[(RD::W4 + r) * 64];
+        b1r[r] = pw[(RD::B1 + r) * 64]; b2r[r] = pw[(RD::B2 + r) * 64]; b3r[r] = pw[(RD::B3 + r) * 64]; b4r[r] = pw[(RD::B4 + r) * 64];
+        w1t0[r] = pw[(RFD + BW1TA + r) * 64]; w1te[r] = pw[(RFD + BW1TB + r) * 64];
+    }
+    w4t[0] = pw[(RFD + BW4T) * 64]; w4t[1] = pw[(RFD + BW4T + 1) * 64];
+
+    // ---- AE weights -> registers
+    const int RFA = RA::COUNT + NA;
+    const float* pa = pack_ae + (size_t)w * (RFA + BWC) * 64 + l;
+    // The AE's four 64x64 operand sets do not fit next to the DE's in 512 registers: they live in LDS, each lane reading
+    // back exactly the A-operand values it wrote (conflict-free ds_read_b128, no barrier needed).
+    float aw1x[NX], aw4[4], aw4t[2], aw1tx[4], aw1ta[4];
+    f4* aewp = aew + w * 64 + l;
+    constexpr int AW2 = 0, AW3 = 1, AW3T = 2, AW2T = 3;
+    ArrD<NZA> aw1e;
+    f4 ab1r, ab2r, ab3r, ab4r;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) aw1x[r] = pa[(RA::W1A + r) * 64];
+#pragma unroll
+    for (int m = 0; m < NZA; ++m) aw1e.v[m] = pa[(RA::W1E + m) * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f4 q2, q3, q3t, q2t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            q2[r] = pa[(RA::W2 + 4 * c + r) * 64]; q3[r] = pa[(RA::W3 + 4 * c + r) * 64];
+            q3t[r] = pa[(RFA + BW3T + 4 * c + r) * 64]; q2t[r] = pa[(RFA + BW2T + 4 * c + r) * 64];
+        }
+        aewp[(AW2 * 4 + c) * NW * 64] = q2; aewp[(AW3 * 4 + c) * NW * 64] = q3;
+        aewp[(AW3T * 4 + c) * NW * 64] = q3t; aewp[(AW2T * 4 + c) * NW * 64] = q2t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        aw4[r] = pa[(RA::W4 + r) * 64];
+        ab1r[r] = pa[(RA::B1 + r) * 64]; ab2r[r] = pa[(RA::B2 + r) * 64]; ab3r[r] = pa[(RA::B3 + r) * 64]; ab4r[r] = pa[(RA::B4 + r) * 64];
+        aw1tx[r] = pa[(RFA + BW1TA + r) * 64]; aw1ta[r] = pa[(RFA + BW1TB + r) * 64];
+    }
+    aw4t[0] = pa[(RFA + BW4T) * 64]; aw4t[1] = pa[(RFA + BW4T + 1) * 64];
+
+    // ---- per-trajectory constants
+    float a0x[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) a0x[r] = 4 * r + g < xd ? a.a0[b * n + 4 * r + g] : 0.0f;
+    // DE ext slots of this lane (q = 4m+g): kind 0 = z column, 1 = v column, 2 = algebraic variable, 3 = padding
+    int ekind[NZM], ecol[NZM];
+    ArrD<NZM> a0e;
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) {
+        const int q = 4 * m + g, e = slot_ext(q, ne);
+        ekind[m] = e < 0 ? 3 : (e < zd ? 0 : (e < nzv ? 1 : 2));
+        ecol[m] = e < 0 ? 0 : (e < zd ? e : (e < nzv ? e - zd : e - nzv));
+        a0e.v[m] = q < ne ? a.a0[b * n + xd + q] : 0.0f;
+    }
+    f4 c0 = b1r, c0a = ab1r;   // bias + W1[:, a0 columns] . a0
+    for (int m = 0; m < NA; ++m) {
+        const int q = 4 * m + g;
+        const float av = q < n ? a.a0[b * n + q] : 0.0f;
+        c0 = bm(pw[(RD::COUNT + m) * 64], av, c0);
+        c0a = bm(pa[(RA::COUNT + m) * 64], av, c0a);
+    }
+    // rows of the padded transpose tile that hold column i of the DE `s` vector (x dims, ext dims) / of the AE (x | z,v) vector
+    const int srow = i < xd ? 4 * (i & 3) + (i >> 2) : (i < n ? (i - xd < 4 ? 4 * (i - xd) + 2 : 4 * (i - xd - 4) + 3) : -1);
+    const int arow = i < xd ? 4 * (i & 3) + (i >> 2) : (i < xd + nzv ? (i - xd < 4 ? 4 * (i - xd) + 2 : 4 * (i - xd - 4) + 3) : -1);
+    // z|v dims this lane group stores gradients for: q = g (lo) and q = 4+g (hi)
+    const int qlo = g, qhi = 4 + g;
+
+    const long long tst = a.t.st, nT = a.T, zst = a.z.st, zje = a.zje, vst = a.v.st, vje = a.vje;
+    const float* tp = a.t.p + b * a.t.sb;
+    const float* zp = a.z.p + b * a.z.sb;
+    const float* zjp = a.zj + b * a.zjb;
+    const float* vp = a.v.p + b * a.v.sb;
+    const float* vjp = a.vj + b * a.vjb;
+
+    // D-layout tile (rows 4g+r, col j) of this wave -> o[kk] = M[row][col 4kk+g]   (A/B operand layout), via LDS
+    auto put_tile = [&](const f4 v) { *reinterpret_cast<f4*>(scr + 4 * l + 8 * g) = v; };
+    auto get_row = [&](const int row) -> f4 {
+        const float* s = scr + 4 * (16 * (row >> 2) + g) + 8 * (row >> 2) + (row & 3);
+        return f4{s[0], s[16], s[32], s[48]};
+    };
+    auto transpose = [&](const f4 v) -> f4 { put_tile(v); return get_row(i); };
+
+    int p = 0, q = 0;   // parities of the all-gather/all-reduce buffer and of the reduce-scatter buffer
+    auto mid = [&](const float (&wm)[16], const f4 bias, const f4 h) -> f4 {
+        xbuf[(p * NW + w) * 64 + l] = h;
+        f4 accA = bias, accB = z4();
+        accA = bm(wm[0], h[0], accA); accB = bm(wm[1], h[1], accB);
+        accA = bm(wm[2], h[2], accA); accB = bm(wm[3], h[3], accB);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f4 v = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+            accA = bm(wm[4 * c + 0], v[0], accA); accB = bm(wm[4 * c + 1], v[1], accB);
+            accA = bm(wm[4 * c + 2], v[2], accA); accB = bm(wm[4 * c + 3], v[3], accB);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+    auto mid_lds = [&](const int arr, const f4 bias, const f4 h) -> f4 {
+        xbuf[(p * NW + w) * 64 + l] = h;
+        f4 wq = aewp[(arr * 4) * NW * 64];
+        f4 accA = bias, accB = z4();
+        accA = bm(wq[0], h[0], accA); accB = bm(wq[1], h[1], accB);
+        accA = bm(wq[2], h[2], accA); accB = bm(wq[3], h[3], accB);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f4 v = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+            wq = aewp[(arr * 4 + c) * NW * 64];
+            accA = bm(wq[0], v[0], accA); accB = bm(wq[1], v[1], accB);
+            accA = bm(wq[2], v[2], accA); accB = bm(wq[3], v[3], accB);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+    // all-reduce over the four waves (fixed order): rows r < 2 only / all four rows
+    auto allreduce2 = [&](const f4 part, const f4 init) -> f2 {
+        f2* xb2 = reinterpret_cast<f2*>(xbuf + p * NW * 64);
+        xb2[w * 64 + l] = f2{part[0], part[1]};
+        lds_barrier();
+        f2 out = f2{init[0], init[1]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out += xb2[c * 64 + l];
+        p ^= 1;
+        return out;
+    };
+    auto allreduce4 = [&](const f4 part, const f4 init) -> f4 {
+        xbuf[(p * NW + w) * 64 + l] = part;
+        lds_barrier();
+        f4 out = init;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out += xbuf[(p * NW + c) * 64 + l];
+        p ^= 1;
+        return out;
+    };
+    auto reduce_scatter = [&](const f4 (&part)[4]) -> f4 {
+#pragma unroll
+        for (int c = 1; c < 4; ++c) rsbuf[((q * NW + ((w + c) & 3)) * NW + w) * 64 + l] = part[c];
+        lds_barrier();
+        f4 out = part[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) out += rsbuf[((q * NW + w) * NW + ((w + c) & 3)) * 64 + l];
+        q ^= 1;
+        return out;
+    };
+    auto layer_T = [&](const float (&wt)[16], const f4 dl, f4 (&part)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f4 acc = bm(wt[4 * c], dl[0], z4());
+            acc = bm(wt[4 * c + 1], dl[1], acc);
+            acc = bm(wt[4 * c + 2], dl[2], acc);
+            part[c] = bm(wt[4 * c + 3], dl[3], acc);
+        }
+    };
+
+    auto layer_T_lds = [&](const int arr, const f4 dl, f4 (&part)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f4 wq = aewp[(arr * 4 + c) * NW * 64];
+            f4 acc = bm(wq[0], dl[0], z4());
+            acc = bm(wq[1], dl[1], acc);
+            acc = bm(wq[2], dl[2], acc);
+            part[c] = bm(wq[3], dl[3], acc);
+        }
+    };
+
+    // ---- accumulators (whole launch)
+    f4 accW4 = z4(), accW1s = z4(), S1 = z4(), S2 = z4(), S3 = z4();
+    f4 accW3[4], accW2[4];
+    f4 aaccW4 = z4(), aaccW1 = z4(), AS1 = z4(), AS2 = z4(), AS3 = z4();
+    f4 aaccW3[4], aaccW2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { accW3[c] = z4(); accW2[c] = z4(); aaccW3[c] = z4(); aaccW2[c] = z4(); }
+    f2 db4 = {0.f, 0.f}, adb4 = {0.f, 0.f};
+    f4 GA0 = z4();            // per-wave partial of d all_initial: rows r < 2 x dims 4r+g, rows r >= 2 ext dims 4(r-2)+g
+
+    // ---- hidden layers of the AE head at (xa; zv), activations kept; transposed h1, h2 published in slot S
+    f4 ah1, ah2, ah3;
+    auto ae_hidden = [&](const float (&xa)[NX], const ArrD<NZA>& zv) {
+        f4 acc = c0a;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) acc = bm(aw1x[r], xa[r], acc);
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) acc = bm(aw1e.v[m], zv.v[m], acc);
+        ah1 = elu4d(acc);
+        hTb[((S * 2 + 0) * NW + w) * 64 + l] = transpose(ah1);
+        ah2 = elu4d(mid_lds(AW2, ab2r, ah1));
+        hTb[((S * 2 + 1) * NW + w) * 64 + l] = transpose(ah2);
+        ah3 = elu4d(mid_lds(AW3, ab3r, ah2));
+    };
+    // output of the AE head from ah3: rows (g, m) carry the i-dim DE ext slot (m, g) consumes (forward packing)
+    auto ae_output = [&]() -> f4 {
+        f4 pa_ = bm(aw4[0], ah3[0], z4()), pb_ = bm(aw4[1], ah3[1], z4());
+        pa_ = bm(aw4[2], ah3[2], pa_);
+        pb_ = bm(aw4[3], ah3[3], pb_);
+        return allreduce4(pa_ + pb_, ab4r);
+    };
+    // VJP of the AE head at (xa; zv) with output gradient gi (tile-E layout: row 0 <-> ext dim g, row 2 <-> ext dim 4+g).
+    // Accumulates the AE parameter gradients and GA0; returns the all-reduced tile X: rows 0..1 = gx, rows 2..3 = g(z|v).
+    auto ae_vjp = [&](const float (&xa)[NX], const ArrD<NZA>& zv, const f4 gi) -> f4 {
+        ae_hidden(xa, zv);
+        adb4 += f2{gi[0], gi[2]};
+        f4 t3 = bm(aw4t[0], gi[0], z4());
+        t3 = bm(aw4t[1], gi[2], t3);
+        const f4 d3 = t3 * dactd(ah3);
+        AS3 += d3;
+        {
+            const f4 gT = transpose(f4{gi[0], 0.f, gi[2], 0.f});
+            const f4 hT = transpose(ah3);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) aaccW4 = bm(gT[kk], hT[kk], aaccW4);
+        }
+        f4 part[4];
+        layer_T_lds(AW3T, d3, part);
+        const f4 d2 = reduce_scatter(part) * dactd(ah2);
+        AS2 += d2;
+        {
+            const f4 dT = transpose(d3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 hT = hTb[((S * 2 + 1) * NW + ((w + c) & 3)) * 64 + l];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) aaccW3[c] = bm(dT[kk], hT[kk], aaccW3[c]);
+            }
+        }
+        layer_T_lds(AW2T, d2, part);
+        const f4 d1 = reduce_scatter(part) * dactd(ah1);
+        AS1 += d1;
+        {
+            const f4 dT = transpose(d2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f4 hT = hTb[((S * 2 + 0) * NW + ((w + c) & 3)) * 64 + l];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) aaccW2[c] = bm(dT[kk], hT[kk], aaccW2[c]);
+            }
+        }
+        f4 tx = bm(aw1tx[0], d1[0], z4()), ta = bm(aw1ta[0], d1[0], z4());
+#pragma unroll
+        for (int r = 1; r < 4; ++r) { tx = bm(aw1tx[r], d1[r], tx); ta = bm(aw1ta[r], d1[r], ta); }
+        GA0 += ta;
+        {   // dW1 (x | z,v columns) += delta1^T (x) in^T
+            const f4 dT = transpose(d1);
+            put_tile(f4{xa[0], xa[1], (NZA > 0 && qlo < nzv) ? zv.v[0] : 0.0f, (NZA > 1 && qhi < nzv) ? zv.v[NZA > 1 ? 1 : 0] : 0.0f});
+            const f4 sT = arow >= 0 ? get_row(arow) : z4();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) aaccW1 = bm(dT[kk], sT[kk], aaccW1);
+        }
+        return allreduce4(tx, z4());
+    };
+    // store the z|v gradient rows (lo: dim q = g, hi: dim q = 4+g) of one grid point, or of event `ev`'s jump values
+    auto store_zv = [&](const long long grid, const int ev, const float lo, const float hi) {
+        if (w != 0 || !valid) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int qq = h ? qhi : qlo;
+            const float val = h ? hi : lo;
+            if (qq >= nzv) continue;
+            const bool isz = qq < zd;
+            const int dd = isz ? qq : qq - zd, wd = isz ? zd : vd;
+            if (ev >= 0) {
+                float* dst = isz ? d.gzj : d.gvj;
+                if (dst) dst[(b * d.n_events + ev) * wd + dd] = val;
+            } else {
+                float* dst = isz ? d.gz : d.gv;
+                if (dst) dst[(grid * a.B + b) * wd + dd] = val;
+            }
+        }
+    };
+
+    // ---- loads
+    // z or v column of grid point k (ev >= 0: of event ev's jump values) for a slot of kind 0 (z) / 1 (v).  Both sources are
+    // read with a clamped column and the VALUE is selected: selecting between the two base pointers per lane makes the
+    // compiler build a pointer table in scratch.
+    auto zv_at = [&](const long long k, const int ev, const int kind, const int col) -> float {
+        float zval = 0.0f, vval = 0.0f;
+        if (zd > 0) zval = (ev >= 0 ? zjp + ev * zje : zp + k * zst)[kind == 0 ? col : 0];
+        if (vd > 0) vval = (ev >= 0 ? vjp + ev * vje : vp + k * vst)[kind == 1 ? col : 0];
+        return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
+    };
+    // DE ext of step k: z|v (jumped at an event step), algebraic slots from the saved is[k] unless an event recomputes them
+    auto load_ext = [&](const long long k, const int ev, ArrD<NZM>& dst) {
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) {
+            if (ekind[m] == 2) dst.v[m] = ev >= 0 ? 0.0f : d.is_[(k * a.B + b) * idim + ecol[m]];
+            else dst.v[m] = zv_at(k, ev, ekind[m], ecol[m]);
+        }
+    };
+    // AE ext of grid point k: raw z|v; AE slot (m, g) <-> q = 4m+g < nzv -- the DE's first-block slot of the same (m, g)
+    auto load_zva = [&](const long long k, ArrD<NZA>& dst) {
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) dst.v[m] = 4 * m + g < nzv ? zv_at(k, -1, ekind[m], ecol[m]) : 0.0f;
+    };
+    auto load_x = [&](const long long k, float (&xk)[NX]) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xk[r] = 4 * r + g < xd ? d.xs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
+    };
+    auto load_gx = [&](const long long k, float (&gk)[NX]) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) gk[r] = (4 * r + g < xd && valid) ? d.gxs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
+    };
+    // upstream dL/dis[k] in tile-E layout (row 0 <-> ext dim g, row 2 <-> ext dim 4+g; only the algebraic dims)
+    auto load_gi = [&](const long long k) -> f2 {
+        f2 o = {0.f, 0.f};
+        if (d.gis && valid) {
+            if (qlo >= nzv && qlo < ne) o[0] = d.gis[(k * a.B + b) * idim + qlo - nzv];
+            if (qhi >= nzv && qhi < ne) o[1] = d.gis[(k * a.B + b) * idim + qhi - nzv];
+        }
+        return o;
+    };
+
+    // ---- state of the sweep
+    f2 gcarry = {0.f, 0.f};      // adjoint of x at the current grid point, before its own upstream gradient is added
+    f2 gicarry = {0.f, 0.f};     // what the DE of the step starting at the current grid point fed into i (rows 0, 2)
+    f2 dezv = {0.f, 0.f};        // DE part of dL/d(z|v) at the current grid point (rows 0, 2), 0 if that step took a jump
+
+    for (long long jg = nT - 1; jg >= 0; --jg) {
+        // ================= (1) AE head at grid point jg
+        float xj[NX], gxj[NX];
+        ArrD<NZA> zvj;
+        load_x(jg, xj);
+        load_gx(jg, gxj);
+        load_zva(jg, zvj);
+        const f2 giu = load_gi(jg);
+        const f4 gi = f4{gicarry[0] + giu[0], 0.f, gicarry[1] + giu[1], 0.f};
+        const f4 tX = ae_vjp(xj, zvj, gi);
+        store_zv(jg, -1, dezv[0] + tX[2], dezv[1] + tX[3]);
+        f2 g1 = gcarry + f2{gxj[0], gxj[1]} + f2{tX[0], tX[1]};     // adjoint of x_jg, complete
+        if (jg == 0) { gcarry = g1; break; }
+
+        // ================= (2) step k = jg-1
+        const long long k = jg - 1;
+        const int ev = a.ev ? a.ev[k] : -1;
+        const float h_ = tp[jg * tst] - tp[k * tst];
+        float x0[NX];
+        ArrD<NZM> extv;
+        load_x(k, x0);
+        load_ext(k, ev, extv);
+        if (ev >= 0) {   // i_in = g(x_k; z_jump, v_jump) with the state of grid point k (my_solvers.py:108-110)
+            ArrD<NZA> zvq;
+#pragma unroll
+            for (int m = 0; m < NZA; ++m) zvq.v[m] = extv.v[m];
+            ae_hidden(x0, zvq);
+            const f4 iv = ae_output();
+#pragma unroll
+            for (int m = 0; m < NZM; ++m) if (ekind[m] == 2) extv.v[m] = iv[m];
+        }
+        f4 cz = c0;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) cz = bm(w1z.v[m], extv.v[m] - a0e.v[m], cz);
+
+        // ---- phase A: stage evaluations, activations kept
+        f4 h1[S], h2[S], h3[S];
+        f2 ks[S];
+        float xst[S][NX];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj][r];
+                xst[s][r] = s == 0 ? x0[r] : x0[r] + h_ * acc;
+            }
+            f4 accA = cz, accB = z4();
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                accA = bm(w1xs[r], xst[s][r], accA);
+                accB = bm(w1xd[r], xst[s][r] - a0x[r], accB);
+            }
+            h1[s] = elu4d(accA + accB);
+            hTb[((s * 2 + 0) * NW + w) * 64 + l] = transpose(h1[s]);
+            h2[s] = elu4d(mid(w2, b2r, h1[s]));
+            hTb[((s * 2 + 1) * NW + w) * 64 + l] = transpose(h2[s]);
+            h3[s] = elu4d(mid(w3, b3r, h2[s]));
+            f4 pa_ = bm(w4[0], h3[s][0], z4()), pb_ = bm(w4[1], h3[s][1], z4());
+            pa_ = bm(w4[2], h3[s][2], pa_);
+            pb_ = bm(w4[3], h3[s][3], pb_);
+            ks[s] = allreduce2(pa_ + pb_, b4r);
+        }
+
+        // ---- phase B: stages backwards
+        f2 gks[S], gx0 = g1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) gks[s] = (h_ * rk_b(METHOD, s)) * g1;
+        f4 l1te = z4();   // ext rows of W1^T delta1, this wave's partial, summed over the stages
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            const f2 gk = gks[s];
+            db4 += gk;
+            f4 t3 = bm(w4t[0], gk[0], z4());
+            t3 = bm(w4t[1], gk[1], t3);
+            const f4 d3 = t3 * dactd(h3[s]);
+            S3 += d3;
+            {
+                const f4 gT = transpose(f4{gk[0], gk[1], 0.f, 0.f});
+                const f4 hT = transpose(h3[s]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW4 = bm(gT[kk], hT[kk], accW4);
+            }
+            f4 part[4];
+            layer_T(w3t, d3, part);
+            const f4 d2 = reduce_scatter(part) * dactd(h2[s]);
+            S2 += d2;
+            {
+                const f4 dT = transpose(d3);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f4 hT = hTb[((s * 2 + 1) * NW + ((w + c) & 3)) * 64 + l];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accW3[c] = bm(dT[kk], hT[kk], accW3[c]);
+                }
+            }
+            layer_T(w2t, d2, part);
+            const f4 d1 = reduce_scatter(part) * dactd(h1[s]);
+            S1 += d1;
+            {
+                const f4 dT = transpose(d2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f4 hT = hTb[((s * 2 + 0) * NW + ((w + c) & 3)) * 64 + l];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accW2[c] = bm(dT[kk], hT[kk], accW2[c]);
+                }
+            }
+            f4 t0 = bm(w1t0[0], d1[0], z4());
+            t0 = bm(w1t0[1], d1[1], t0); t0 = bm(w1t0[2], d1[2], t0); t0 = bm(w1t0[3], d1[3], t0);
+            l1te = bm(w1te[0], d1[0], l1te); l1te = bm(w1te[1], d1[1], l1te);
+            l1te = bm(w1te[2], d1[2], l1te); l1te = bm(w1te[3], d1[3], l1te);
+            GA0[0] += t0[2]; GA0[1] += t0[3];
+            const f2 gx = allreduce2(t0, z4());
+            {   // dW1 (`s` columns: x dims, ext dims) += delta1^T (x) s^T
+                const f4 dT = transpose(d1);
+                put_tile(f4{xst[s][0], xst[s][1], qlo < ne ? extv.v[0] : 0.0f, (NZM > 1 && qhi < ne) ? extv.v[NZM > 1 ? 1 : 0] : 0.0f});
+                const f4 sT = srow >= 0 ? get_row(srow) : z4();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW1s = bm(dT[kk], sT[kk], accW1s);
+            }
+            gx0 += gx;
+#pragma unroll
+            for (int jj = 0; jj < s; ++jj) gks[jj] += (h_ * rk_a(METHOD, s, jj)) * gx;
+        }
+        // ---- gradient of this step's external input
+        GA0[2] += l1te[1]; GA0[3] += l1te[3];
+        const f4 gext = allreduce4(l1te, z4());      // rows 0 / 2: ext dims g / 4+g
+        if (ev >= 0) {
+            // the algebraic input was g(x_k; jumps): chain its VJP in; z|v gradients (DE + AE part) go to the jump arrays
+            ArrD<NZA> zvq;
+#pragma unroll
+            for (int m = 0; m < NZA; ++m) zvq.v[m] = extv.v[m];
+            const f4 gie = f4{(qlo >= nzv && qlo < ne) ? gext[0] : 0.f, 0.f, (qhi >= nzv && qhi < ne) ? gext[2] : 0.f, 0.f};
+            const f4 tE = ae_vjp(x0, zvq, gie);
+            store_zv(k, ev, gext[0] + tE[2], gext[2] + tE[3]);
+            gx0 += f2{tE[0], tE[1]};
+            dezv = f2{0.f, 0.f};
+            gicarry = f2{0.f, 0.f};
+        } else {
+            dezv = f2{gext[0], gext[2]};
+            gicarry = f2{(qlo >= nzv && qlo < ne) ? gext[0] : 0.f, (qhi >= nzv && qhi < ne) ? gext[2] : 0.f};
+        }
+        gcarry = gx0;
+    }
+
+    // ---- epilogue
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r)
+            if (4 * r + g < xd) d.gx0[b * xd + 4 * r + g] = gcarry[r];
+    }
+    {
+        const f4 ga = allreduce4(GA0, z4());
+        if (w == 0 && valid) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (4 * r + g < xd) d.ga0[b * n + 4 * r + g] = ga[r];
+                if (4 * r + g < ne) d.ga0[b * n + xd + 4 * r + g] = ga[2 + r];
+            }
+        }
+    }
+    // ---- parameter-gradient partials of this workgroup: [DE | AE], each in nn.Linear order
+    float* wp = d.wpart + (size_t)blockIdx.x * (d.NP_de + d.NP_ae);
+    auto write_mlp = [&](float* o, const int K1, const int a0cols, const int scol0, const int out_dim, const bool is_ae, const f4 s1v,
+                         const f4 s2v, const f4 s3v, const f4 w1acc, const f4 (&w2acc)[4], const f4 (&w3acc)[4], const f4 w4acc,
+                         const f2 b4v) __attribute__((always_inline)) {
+        const int oB1 = HID * K1, oW2 = oB1 + HID, oB2 = oW2 + HID * HID, oW3 = oB2 + HID, oB3 = oW3 + HID * HID, oW4 = oB3 + HID,
+                  oB4 = oW4 + out_dim * HID;
+        {
+            // all_initial columns of dW1: sum_t(delta1)^T (x) a0^T (a0 is constant over time)
+            const f4 sT = transpose(s1v);
+            f4 ca0 = z4();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const long long tb = b0 + 4 * kk + g;
+                const float av = (i < n && tb < a.B) ? a.a0[tb * n + i] : 0.0f;
+                ca0 = bm(sT[kk], av, ca0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* row = o + (16 * w + 4 * g + r) * K1;
+                if (!is_ae) {
+                    if (j < n) { row[j] = ca0[r]; row[n + j] = w1acc[r] - ca0[r]; row[2 * n + j] = w1acc[r]; }
+                } else {
+                    if (j < n) row[j] = ca0[r];
+                    if (j < scol0) row[a0cols + j] = w1acc[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int nt = (w + c) & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[oW2 + (16 * w + 4 * g + r) * HID + 16 * nt + j] = w2acc[c][r];
+                o[oW3 + (16 * w + 4 * g + r) * HID + 16 * nt + j] = w3acc[c][r];
+            }
+        }
+        if (!is_ae) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
+                const int dd = 4 * r + g;
+                if (dd < out_dim) o[oW4 + dd * HID + 16 * w + j] = w4acc[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {   // rows (g, 0) / (g, 2) <-> ext dims g / 4+g; only the algebraic ones
+                const int e = 4 * (r >> 1) + g;
+                if (e >= nzv && e < ne) o[oW4 + (e - nzv) * HID + 16 * w + j] = w4acc[r];
+            }
+        }
+        f4 sb1 = s1v, sb2 = s2v, sb3 = s3v;
+        f2 sb4 = b4v;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sb1[r] += __shfl_xor(sb1[r], m, 64); sb2[r] += __shfl_xor(sb2[r], m, 64); sb3[r] += __shfl_xor(sb3[r], m, 64);
+            }
+            sb4[0] += __shfl_xor(sb4[0], m, 64); sb4[1] += __shfl_xor(sb4[1], m, 64);
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[oB1 + 16 * w + 4 * g + r] = sb1[r]; o[oB2 + 16 * w + 4 * g + r] = sb2[r]; o[oB3 + 16 * w + 4 * g + r] = sb3[r];
+            }
+            if (w == 0) {
+                if (!is_ae) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) if (4 * r + g < out_dim) o[oB4 + 4 * r + g] = sb4[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int e = 4 * r + g;
+                        if (e >= nzv && e < ne) o[oB4 + e - nzv] = sb4[r];
+                    }
+                }
+            }
+        }
+    };
+    write_mlp(wp, 3 * n, 0, 0, xd, false, S1, S2, S3, accW1s, accW2, accW3, accW4, db4);
+    write_mlp(wp + d.NP_de, n + xd + nzv, n, xd + nzv, idim, true, AS1, AS2, AS3, aaccW1, aaccW2, aaccW3, aaccW4, adb4);
+}
+
+// out[p] = sum over workgroups, fixed order; [0, np_de) -> out_de, the rest -> out_ae
+__global__ void reduce_partials_dae(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
+                                    int np_ae, int nwg) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
+    if (pidx >= np) return;
+    float acc = 0.0f;
+    for (int gq = 0; gq < nwg; ++gq) acc += part[(size_t)gq * np + pidx];
+    if (pidx < np_de) out_de[pidx] = acc;
+    else out_ae[pidx - np_de] = acc;
+}
+
+int np_of(int k1, int out) { return HID * k1 + HID + 2 * (HID * HID + HID) + out * HID + out; }
+
+bool mlp64(const psnode_mlp_f32& m, int in_dim, int out_dim) {
+    return m.n_layers == 4 && m.in_dim == in_dim && m.out_dim[0] == HID && m.out_dim[1] == HID && m.out_dim[2] == HID &&
+           m.out_dim[3] == out_dim;
+}
+
+template <int METHOD>
+hipError_t launch_k7(const DaeBwdDev& d, const float* pde, const float* pae, int NA, int NZM, int NZA, size_t lds, hipStream_t s) {
+    const dim3 grid((unsigned)((d.a.B + TBM - 1) / TBM)), block(256);
+#define PSNODE_K7(NZM_, NZA_)                                                                                              \
+    {                                                                                                                      \
+        auto kern = &dae_backward_kernel<METHOD, NZM_, NZA_>;                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds);                                                                      \
+        if (e != hipSuccess) return e;                                                                                     \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, d, pde, pae, NA);                                                    \
+        return hipGetLastError();                                                                                          \
+    }
+    switch (NZM * 10 + NZA) {
+        case 11: PSNODE_K7(1, 1)
+        case 21: PSNODE_K7(2, 1)
+        case 31: PSNODE_K7(3, 1)
+        case 41: PSNODE_K7(4, 1)
+        case 32: PSNODE_K7(3, 2)
+        case 42: PSNODE_K7(4, 2)
+        default: return hipErrorNotSupported;
+    }
+#undef PSNODE_K7
+}
+
+int k7_nzm(const psnode_dae_bwd_args_f32* a) { return (2 * (a->z_dim + a->v_dim + a->i_dim) + 3) / 4; }
+int k7_nza(const psnode_dae_bwd_args_f32* a) { return (a->z_dim + a->v_dim + 3) / 4; }
+size_t k7_pack_floats(int n) { return (size_t)2 * NW * (kMaxRegs + (n + 3) / 4 + BWC) * 64; }
+
+}  // namespace
+
+bool dae_mfma_bwd_shape_ok(const psnode_dae_bwd_args_f32* a) {
+    const int nzv = a->z_dim + a->v_dim, ne = nzv + a->i_dim, n = a->x_dim + ne;
+    if (a->x_dim < 1 || a->x_dim > 4 * kNXc || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1 || ne > 8 || nzv < 1) return false;
+    if (!mlp64(a->de, 3 * n, a->x_dim) || !mlp64(a->ae, n + a->x_dim + nzv, a->i_dim)) return false;
+    switch (k7_nzm(a) * 10 + k7_nza(a)) {
+        case 11: case 21: case 31: case 41: case 32: case 42: return true;
+        default: return false;
+    }
+}
+
+size_t dae_mfma_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a) {
+    const int nzv = a->z_dim + a->v_dim, n = a->x_dim + nzv + a->i_dim;
+    const size_t nwg = (size_t)((a->B + TBM - 1) / TBM);
+    return k7_pack_floats(n) + nwg * (size_t)(np_of(3 * n, a->x_dim) + np_of(n + a->x_dim + nzv, a->i_dim)) + 64;
+}
+
+int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s) {
+    const int xd = a->x_dim, zd = a->z_dim, vd = a->v_dim, id = a->i_dim, nzv = zd + vd, ne = nzv + id, n = xd + ne;
+    const int NZM = k7_nzm(a), NZA = k7_nza(a), NA = (n + 3) / 4;
+    float* pack_de = workspace;
+    float* pack_ae = workspace + k7_pack_floats(n) / 2;
+    float* wpart = workspace + k7_pack_floats(n);
+    DaeBwdDev d;
+    memset(&d, 0, sizeof(d));
+    d.a.method = a->method; d.a.xd = xd; d.a.zd = zd; d.a.vd = vd; d.a.id = id; d.a.T = a->T; d.a.B = a->B;
+    d.a.t = ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b};
+    d.a.z = ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b};
+    d.a.v = ViewDev{a->v.ptr, a->v.stride_t, a->v.stride_b};
+    d.a.a0 = a->all_initial; d.a.ev = a->event_idx;
+    d.a.zj = a->z_jump; d.a.zjb = a->zj_stride_b; d.a.zje = a->zj_stride_e;
+    d.a.vj = a->v_jump; d.a.vjb = a->vj_stride_b; d.a.vje = a->vj_stride_e;
+    d.xs = a->xs; d.is_ = a->is; d.gxs = a->grad_xs; d.gis = a->grad_is;
+    d.gx0 = a->grad_x_init; d.gz = a->grad_z; d.gv = a->grad_v; d.gzj = a->grad_z_jump; d.gvj = a->grad_v_jump; d.ga0 = a->grad_all_initial;
+    d.wpart = wpart; d.n_events = a->n_events;
+    d.NP_de = np_of(3 * n, xd); d.NP_ae = np_of(n + xd + nzv, id);
+
+    PackDaeBwd pd;
+    pd.f.ae = 0; pd.f.nw = NW; pd.f.xd = xd; pd.f.ne = ne; pd.f.n = n; pd.f.nzv = nzv;
+    pd.f.NX = kNXc; pd.f.NB = kNXc; pd.f.NE = NZM; pd.f.NA = NA;
+    pd.f.w1 = a->de.weight[0]; pd.f.b1 = a->de.bias[0]; pd.f.w2 = a->de.weight[1]; pd.f.b2 = a->de.bias[1];
+    pd.f.w3 = a->de.weight[2]; pd.f.b3 = a->de.bias[2]; pd.f.w4 = a->de.weight[3]; pd.f.b4 = a->de.bias[3];
+    pd.f.out_dim = xd; pd.f.out = nullptr;
+    pd.out = pack_de;
+    hipLaunchKernelGGL(pack_dae_bwd_kernel, dim3(32), dim3(256), 0, s, pd);
+    PackDaeBwd pq = pd;
+    pq.f.ae = 1; pq.f.NB = 0; pq.f.NE = NZA;
+    pq.f.w1 = a->ae.weight[0]; pq.f.b1 = a->ae.bias[0]; pq.f.w2 = a->ae.weight[1]; pq.f.b2 = a->ae.bias[1];
+    pq.f.w3 = a->ae.weight[2]; pq.f.b3 = a->ae.bias[2]; pq.f.w4 = a->ae.weight[3]; pq.f.b4 = a->ae.bias[3];
+    pq.f.out_dim = id;
+    pq.out = pack_ae;
+    hipLaunchKernelGGL(pack_dae_bwd_kernel, dim3(32), dim3(256), 0, s, pq);
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    const int S = a->method == PSNODE_EULER ? 1 : (a->method == PSNODE_MIDPOINT ? 2 : 4);
+    const size_t lds = (size_t)(2 * NW * 64 + 2 * NW * NW * 64 + (S + 1) * 2 * NW * 64 + 4 * 4 * NW * 64) * sizeof(f4) +
+                       (size_t)NW * SCRD * sizeof(float);
+    hipError_t e;
+    switch (a->method) {
+        case PSNODE_EULER: e = launch_k7<PSNODE_EULER>(d, pack_de, pack_ae, NA, NZM, NZA, lds, s); break;
+        case PSNODE_MIDPOINT: e = launch_k7<PSNODE_MIDPOINT>(d, pack_de, pack_ae, NA, NZM, NZA, lds, s); break;
+        default: e = launch_k7<PSNODE_RK4_38>(d, pack_de, pack_ae, NA, NZM, NZA, lds, s); break;
+    }
+    if (e != hipSuccess) return e == hipErrorNotSupported ? PSNODE_ERR_UNSUPPORTED : PSNODE_ERR_HIP;
+    const int nwg = (int)((a->B + TBM - 1) / TBM), np = d.NP_de + d.NP_ae;
+    hipLaunchKernelGGL(reduce_partials_dae, dim3((np + 255) / 256), dim3(256), 0, s, wpart, a->grad_params_de, a->grad_params_ae, d.NP_de,
+                       d.NP_ae, nwg);
+    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+}  // namespace psnode

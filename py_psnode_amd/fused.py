@@ -309,8 +309,9 @@ def dae_backward_supported(method: str, de_layers: Layers, ae_layers: Layers, x_
 
 
 def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
-                 z_jump=None, v_jump=None):
-    """Backward pass of `dae_integrate` (no teacher forcing) in one launch (generic backward kernel).
+                 z_jump=None, v_jump=None, kernel: str = "auto"):
+    """Backward pass of `dae_integrate` (no teacher forcing) in one launch: the MFMA backward (K7) for the DAE_01 shape class
+    at hidden 64, else the generic backward kernel (K5); `kernel` = "auto" | "mfma" | "generic".
     Returns dict(x_init, z, v, z_jump, v_jump, all_initial, de=[...], ae=[...]) of gradients."""
     lib = _lib.load()
     dev = xs.device
@@ -319,6 +320,7 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
     keep: list = []
     a = _lib.DaeBwdArgsF32()
     a.method = METHOD_ID[method]
+    a.kernel = KERNEL_ID[kernel]
     a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = xd, zd, vd, idim, T, B
     a.de, a.ae = _mlp(de_layers, dev, "de", keep), _mlp(ae_layers, dev, "ae", keep)
     a.t, a.z, a.v = _view(t, dev, "t", keep), _view(z, dev, "z", keep), _view(v, dev, "v", keep)

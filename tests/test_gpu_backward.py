@@ -273,3 +273,67 @@ def test_dae_backward_without_z_and_odd_widths():
         _close(a, b, f"grad de {k}")
     for k, (a, b) in enumerate(zip(gr["ae"], [q.grad for wb in ae64 for q in wb])):
         _close(a, b, f"grad ae {k}")
+
+
+def _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    n = xd + zd + vd + idim
+    mk = lambda dims: [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
+    de, ae = mk([3 * n, 64, 64, 64, xd]), mk([n + xd + zd + vd, 64, 64, 64, idim])
+    r = lambda *s: (0.1 * torch.randn(*s, generator=g)).cuda()
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1)
+    if B > 1:
+        t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g))      # per-trajectory clocks
+    z, v, xi, i0 = r(Tn, B, zd), r(Tn, B, vd), r(B, xd), r(B, idim)
+    a0 = torch.cat((xi, z[0], v[0], i0), -1)
+    ev = zj = vj = None
+    if events and Tn > 3:
+        ev = torch.stack([t[1, :, :], t[Tn - 2, :, :]], dim=1).contiguous().cuda()
+        zj, vj = r(B, 2, zd), r(B, 2, vd)
+    Gx, Gi = torch.randn(Tn, B, xd, generator=g).cuda(), torch.randn(Tn, B, idim, generator=g).cuda()
+    return de, ae, t.cuda(), z, v, xi, a0, ev, zj, vj, Gx, Gi
+
+
+def _dae_both_kernels(method, B, Tn, xd, zd, vd, idim, seed, events, with_gi=True):
+    from py_psnode_amd import fused
+    de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events)
+    xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, idim, device="cuda")
+    xs, is_ = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj)
+    tab = fused.event_table(t, ev) if ev is not None else None
+    out = {}
+    for kern in ("mfma", "generic"):
+        out[kern] = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, Gi if with_gi else None, event_idx=tab, z_jump=zj,
+                                       v_jump=vj, kernel=kern)
+    a, b = out["mfma"], out["generic"]
+    for key in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial"):
+        if b[key] is None:
+            assert a[key] is None, key
+            continue
+        _close(a[key], b[key].double().cpu(), f"{key} (K7 vs K5)")
+    for grp in ("de", "ae"):
+        for k, (p, q) in enumerate(zip(a[grp], b[grp])):
+            _close(p, q.double().cpu(), f"grad {grp} {k} (K7 vs K5)")
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("xd,zd,vd,idim", [(8, 2, 2, 2), (8, 0, 2, 2), (5, 1, 1, 1), (8, 2, 2, 4), (3, 1, 0, 1), (8, 4, 3, 1), (2, 2, 4, 2)])
+def test_dae_mfma_backward_matches_generic_every_shape_class(xd, zd, vd, idim, method):
+    """K7 (MFMA DAE backward) against K5 (generic backward, itself checked against fp64 autograd above) on every (NZM, NZA)
+    register class, with two event steps, per-trajectory clocks and a ragged tile."""
+    _dae_both_kernels(method, 21, 9, xd, zd, vd, idim, seed=40 + xd + zd, events=True)
+
+
+@pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3), (16, 5)])
+def test_dae_mfma_backward_edge_sizes(B, Tn):
+    _dae_both_kernels("rk4", B, Tn, 8, 2, 2, 2, seed=70 + B, events=False)
+    _dae_both_kernels("rk4", B, Tn, 8, 2, 2, 2, seed=71 + B, events=False, with_gi=False)
+
+
+def test_dae_backward_kernel_selection():
+    from py_psnode_amd import fused
+    de, ae, t, z, v, xi, a0, _, _, _, Gx, Gi = _dae_raw_case(4, 3, 8, 2, 2, 2, 5, False)
+    wide = [(torch.zeros(32, 42, device="cuda"), torch.zeros(32, device="cuda")), (torch.zeros(8, 32, device="cuda"), torch.zeros(8, device="cuda"))]
+    xs, is_ = torch.zeros(3, 4, 8, device="cuda"), torch.zeros(3, 4, 2, device="cuda")
+    with pytest.raises(ValueError):     # PSNODE_ERR_UNSUPPORTED: no MFMA backward for a 2-layer hidden-32 DE
+        fused.dae_backward("rk4", wide, ae, t, z, v, a0, xs, is_, Gx, Gi, kernel="mfma")
