@@ -401,7 +401,7 @@ def main():
         kname = args.kernel if args.kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.hidden and not args.train:
             try:
                 traffic = json.load(open(tpath)).get(f"{args.workload}:{args.method}:{kname}:B{B}:T{T}")
             except Exception:
