@@ -518,12 +518,16 @@ bool ode_generic_ok(const psnode_ode_bwd_args_f32* a) {
     return generic_bwd_fits(&a->de, nullptr, a->x_dim, a->z_dim, 0, 0) != 0;
 }
 bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && bwd_shape_ok(a); }
+// K8 needs 16-byte aligned rows; with pointers not yet known (dims-only queries) the shape decides
+bool use_latent_bwd(const psnode_ode_bwd_args_f32* a) {
+    return a->kernel != PSNODE_KERNEL_GENERIC && latent_bwd_shape_ok(a) && (!a->xs || latent_bwd_ptrs_ok(a));
+}
 }  // namespace
 
 extern "C" int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a);
-    return use_mfma_bwd(a) || ode_generic_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a) || use_latent_bwd(a);
+    return use_mfma_bwd(a) || use_latent_bwd(a) || ode_generic_ok(a);
 }
 
 extern "C" int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* a) {
@@ -532,7 +536,8 @@ extern "C" int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32
 
 extern "C" size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* a) {
     if (!a || !psnode_ode_backward_supported(a)) return 0;
-    size_t floats = generic_bwd_workspace_floats(&a->de, nullptr, a->B);
+    size_t floats = ode_generic_ok(a) ? generic_bwd_workspace_floats(&a->de, nullptr, a->B) : 0;
+    if (latent_bwd_shape_ok(a)) floats = latent_bwd_workspace_floats(a->B) > floats ? latent_bwd_workspace_floats(a->B) : floats;
     if (bwd_shape_ok(a)) {
         const int n = a->x_dim + a->z_dim;
         const size_t pack = (size_t)NW * (kMaxRegs + (n + 3) / 4 + BWCOUNT) * 64;
@@ -555,6 +560,8 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
+    if (a->kernel == PSNODE_KERNEL_MFMA && !bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;   // latent shape, unaligned views
     if (!use_mfma_bwd(a)) {
         return generic_backward_launch(a->method, a->x_dim, a->z_dim, 0, 0, a->T, a->B, &a->de, nullptr,
                                        ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},

@@ -337,3 +337,40 @@ def test_dae_backward_kernel_selection():
     xs, is_ = torch.zeros(3, 4, 8, device="cuda"), torch.zeros(3, 4, 2, device="cuda")
     with pytest.raises(ValueError):     # PSNODE_ERR_UNSUPPORTED: no MFMA backward for a 2-layer hidden-32 DE
         fused.dae_backward("rk4", wide, ae, t, z, v, a0, xs, is_, Gx, Gi, kernel="mfma")
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("B,Tn,events", [(21, 9, True), (16, 5, False), (1, 2, False), (3, 1, False), (37, 12, True)])
+def test_latent16_ode_backward_kernel_matches_generic(method, B, Tn, events):
+    """K8 (single-wave MFMA backward of the hidden-16 latent ODE, kernel='mfma') against K5 (generic, checked against fp64
+    autograd in test_generic_backward_kernel_ode) with events, per-trajectory clocks, ragged tiles and T in {1, 2}; AUTO picks K8."""
+    from py_psnode_amd import fused
+    H = 16
+    g = torch.Generator().manual_seed(300 + B)
+    torch.manual_seed(300 + B)
+    lin = [nn.Linear(6 * H, H), nn.Linear(H, H)]
+    layers = [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1)
+    if B > 1:
+        t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g))
+    r = lambda *s: (0.1 * torch.randn(*s, generator=g)).cuda()
+    x_in, z = torch.zeros(Tn, B, H, device="cuda"), r(Tn, B, H)
+    x_in[0] = r(B, H)
+    a0 = torch.cat((x_in[0], z[0]), -1)
+    ev = zj = tab = None
+    if events:
+        ev = torch.stack([t[1, :, :], t[Tn - 2, :, :]], dim=1).contiguous().cuda()
+        zj = r(B, 2, H)
+        tab = fused.event_table(t.cuda(), ev)
+    G = torch.randn(Tn, B, H, generator=g).cuda()
+    xs = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj)
+    out = {k: fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel=k) for k in ("mfma", "generic", "auto")}
+    names = ["grad x0", "grad z", "grad z_jump", "grad all_initial"]
+    for nme, a, b, c in zip(names, out["mfma"][:4], out["generic"][:4], out["auto"][:4]):
+        if b is None:
+            assert a is None
+            continue
+        _close(a, b.double().cpu(), nme + " (K8 vs K5)")
+        assert torch.equal(a, c), nme + ": AUTO must run K8 on this shape"
+    for k, (a, b) in enumerate(zip(out["mfma"][4], out["generic"][4])):
+        _close(a, b.double().cpu(), f"grad param {k} (K8 vs K5)")
