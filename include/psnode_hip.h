@@ -161,6 +161,15 @@ int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* mlp);
 int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, float* out,
                             int64_t out_row_stride, void* stream);
 
+/* Backward of psnode_mlp_rows_f32: grad_in[r,:] (optional) and the parameter gradients as ONE flat vector in nn.Linear order
+ * [W1 (H x in), b1 (H), W2 (out x H), b2 (out)], from the saved input rows and grad_out.  What loss.backward() does for the
+ * encoders/decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:267-275 through :74-88).
+ * Deterministic (per-wave partials in `workspace`, summed in a fixed order). */
+size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32* mlp, int64_t rows);
+int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride,
+                                     const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
+                                     float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward (discretise-then-optimise) pass through psnode_ode_integrate_f32: what loss.backward() computes when it
  * walks the unrolled T-step autograd graph of integrate_ODE (neural_00_ODE_01_no_encode.py:358-360 through
  * my_solvers.py:66-78), in one launch.  Inputs: the forward arguments, the forward result xs and dL/dxs.

@@ -26,6 +26,7 @@ EXPORTS = (
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
+    "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
 )
 
 
@@ -146,6 +147,11 @@ def load():
     lib.psnode_dae_backward_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdArgsF32)]
     lib.psnode_dae_backward_f32.restype = c_int32
     lib.psnode_dae_backward_f32.argtypes = [ctypes.POINTER(DaeBwdArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_mlp_rows_backward_workspace_bytes.restype = c_size_t
+    lib.psnode_mlp_rows_backward_workspace_bytes.argtypes = [ctypes.POINTER(MlpF32), c_int64]
+    lib.psnode_mlp_rows_backward_f32.restype = c_int32
+    lib.psnode_mlp_rows_backward_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                                 c_void_p, c_void_p, c_size_t, c_void_p]
     lib.psnode_masked_mse_workspace_bytes.restype = c_size_t
     lib.psnode_masked_mse_workspace_bytes.argtypes = [ctypes.POINTER(LossArgsF32)]
     lib.psnode_masked_mse_f32.restype = c_int32

@@ -116,6 +116,260 @@ void launch_rows(int NM, dim3 grid, dim3 block, hipStream_t s, const RowsArgs& a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K3b backward: d in, dW1, db1, dW2, db2 of the same row MLP, one pass over (in, grad_out).  Training the direct_encode
+// models runs the encoders/decoders over all B*T rows under autograd (neural_00_ODE_02_direct_encode.py:74-88,267-275):
+// skinny GEMM pairs with M = 4.1 M that rocBLAS handles poorly (28 of the 34 ms of an ODE_02 training step).  Same
+// stream structure as the forward: one wave per 16-row tile, h recomputed (L2's forward is not needed), delta1 =
+// (W2^T g) * ELU'(pre1) and d in = W1^T delta1 on MFMA with register-resident transposed weights; the weight gradients
+// contract over the tile's 16 rows (operands transposed through private padded LDS tiles) and accumulate in registers
+// over all of the wave's tiles; per-wave partials are summed by a second kernel in a fixed order (deterministic).
+struct RowsBwdArgs {
+    const float *w1, *b1, *w2, *in, *gout;
+    float *gin, *wpart;
+    long long rows, in_stride, gout_stride, gin_stride;
+    int in_dim, out_dim, np;
+};
+
+constexpr int RSCR = 64 * 4 + 4 * 8;   // padded transpose tile (floats)
+
+template <int NM, int HT, int OT>
+__global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
+    constexpr int HID = 16 * HT;
+    constexpr int IT = NM > 4 ? NM / 4 : 1;      // input column tiles
+    constexpr int NC = NM > 4 ? 4 : NM;          // columns per lane per tile
+    __shared__ __attribute__((aligned(16))) float scr_all[4][2][RSCR];
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, g = l >> 4, j = l & 15, i = l & 15;
+    float* scrA = scr_all[wv][0];
+    float* scrB = scr_all[wv][1];
+    // column of the input a tile row (gr, rr) of tile q stands for, or -1
+    auto col_of = [&](const int gr, const int rr, const int q) -> int {
+        const int c = NM > 4 ? NM * gr + 4 * q + rr : (rr < NC ? NM * gr + rr : -1);
+        return (c >= 0 && c < a.in_dim) ? c : -1;
+    };
+    // ---- weights -> registers
+    float w1[HT][NM], w2t[HT][OT * 4], w1t[IT][HT * 4];
+    f4 b1r[HT];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int c = NM * g + m;
+            w1[ht][m] = c < a.in_dim ? a.w1[(16 * ht + i) * a.in_dim + c] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1r[ht][r] = a.b1[16 * ht + 4 * g + r];
+#pragma unroll
+        for (int q = 0; q < OT * 4; ++q) {            // delta = W2^T g: rows = units of tile ht, k-slot g <-> out dim 16*ot + 4g + r
+            const int o = 16 * (q >> 2) + 4 * g + (q & 3);
+            w2t[ht][q] = o < a.out_dim ? a.w2[o * HID + 16 * ht + i] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int c = col_of(i >> 2, i & 3, q);
+#pragma unroll
+        for (int k = 0; k < HT * 4; ++k)               // d in = W1^T delta1: rows = input columns, k-slot g <-> unit 16*ht + 4g + r
+            w1t[q][k] = c >= 0 ? a.w1[(16 * (k >> 2) + 4 * g + (k & 3)) * a.in_dim + c] : 0.0f;
+    }
+    f4 accW1[HT][IT], accW2[OT][HT], sb1[HT], sb2[OT];
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+        sb1[ht] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < IT; ++q) accW1[ht][q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) accW2[ot][ht] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) sb2[ot] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // D-layout tile (rows 4g+r, col j) -> o[kk] = M[row i][col 4kk+g], through a private padded LDS tile
+    auto transpose = [&](float* scr, const f4 v) -> f4 {
+        *reinterpret_cast<f4*>(scr + 4 * l + 8 * g) = v;
+        const float* s = scr + 4 * (16 * (i >> 2) + g) + 8 * (i >> 2) + (i & 3);
+        return f4{s[0], s[16], s[32], s[48]};
+    };
+
+    const long long tiles = (a.rows + 15) / 16;
+    const long long wave = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
+    constexpr int VB = NM == 2 ? 8 : 16;
+    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
+    const bool vec_gin = a.gin && (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.gin_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.gin) % VB) == 0;
+    const bool vec_go = a.out_dim % 4 == 0 && a.gout_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.gout) & 15) == 0;
+    for (long long t = wave; t < tiles; t += nwaves) {
+        const long long row = t * 16 + j;
+        const bool valid = row < a.rows;
+        const long long rc = valid ? row : a.rows - 1;
+        const float* src = a.in + rc * a.in_stride + NM * g;
+        float v[NM];
+        if (vec_in) {
+            if constexpr (NM % 4 == 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < NM / 4; ++c4) {
+                    const f4 q = reinterpret_cast<const f4*>(src)[c4];
+                    v[4 * c4] = q[0]; v[4 * c4 + 1] = q[1]; v[4 * c4 + 2] = q[2]; v[4 * c4 + 3] = q[3];
+                }
+            } else if constexpr (NM == 2) {
+                const float2 q = *reinterpret_cast<const float2*>(src);
+                v[0] = q.x; v[1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) v[m] = NM * g + m < a.in_dim ? src[m] : 0.0f;
+        }
+        f4 go[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            go[ot] = f4{0.f, 0.f, 0.f, 0.f};
+            if (valid && 16 * ot + 4 * g < a.out_dim) {
+                const float* gs = a.gout + row * a.gout_stride + 16 * ot + 4 * g;
+                if (vec_go) go[ot] = *reinterpret_cast<const f4*>(gs);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (16 * ot + 4 * g + r < a.out_dim) go[ot][r] = gs[r];
+                }
+            }
+            sb2[ot] += go[ot];
+        }
+        // hidden activations and delta1
+        f4 h[HT], d1[HT];
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            f4 acc = b1r[ht];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc = rmfma(w1[ht][m], v[m], acc);
+            h[ht] = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
+            f4 tA = {0.f, 0.f, 0.f, 0.f}, tB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                tA = rmfma(w2t[ht][4 * ot + 0], go[ot][0], tA); tB = rmfma(w2t[ht][4 * ot + 1], go[ot][1], tB);
+                tA = rmfma(w2t[ht][4 * ot + 2], go[ot][2], tA); tB = rmfma(w2t[ht][4 * ot + 3], go[ot][3], tB);
+            }
+            const f4 tt = tA + tB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[ht][r] = valid ? tt[r] * (h[ht][r] > 0.f ? 1.f : h[ht][r] + 1.f) : 0.0f;
+            sb1[ht] += d1[ht];
+        }
+        // d in
+        if (a.gin) {
+#pragma unroll
+            for (int q = 0; q < IT; ++q) {
+                f4 gA = {0.f, 0.f, 0.f, 0.f}, gB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) {
+                    gA = rmfma(w1t[q][4 * ht + 0], d1[ht][0], gA); gB = rmfma(w1t[q][4 * ht + 1], d1[ht][1], gB);
+                    gA = rmfma(w1t[q][4 * ht + 2], d1[ht][2], gA); gB = rmfma(w1t[q][4 * ht + 3], d1[ht][3], gB);
+                }
+                const f4 gi = gA + gB;                      // lane (g, j): columns NM*g + 4q + r of row j
+                if (valid) {
+                    float* dst = a.gin + row * a.gin_stride + NM * g + 4 * q;
+                    if (vec_gin && NC == 4) *reinterpret_cast<f4*>(dst) = gi;
+                    else if (vec_gin && NM == 2) *reinterpret_cast<float2*>(dst) = float2{gi[0], gi[1]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < NC; ++r) if (NM * g + 4 * q + r < a.in_dim) dst[r] = gi[r];
+                    }
+                }
+            }
+        }
+        // weight gradients: contraction over the tile's 16 rows
+        f4 hT[HT], vT[IT];
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) hT[ht] = transpose((ht & 1) ? scrB : scrA, h[ht]);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            const f4 gT = transpose((ot & 1) ? scrA : scrB, go[ot]);
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW2[ot][ht] = rmfma(gT[kk], hT[ht][kk], accW2[ot][ht]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            f4 vt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < NC; ++r) vt[r] = valid ? v[4 * q + r] : 0.0f;
+            vT[q] = transpose((q & 1) ? scrB : scrA, vt);
+        }
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            const f4 dT = transpose((ht & 1) ? scrA : scrB, d1[ht]);
+#pragma unroll
+            for (int q = 0; q < IT; ++q) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW1[ht][q] = rmfma(dT[kk], vT[q][kk], accW1[ht][q]);
+            }
+        }
+    }
+    // ---- per-wave partial, nn.Linear order [W1 (H x in), b1, W2 (out x H), b2]
+    float* wp = a.wpart + (size_t)wave * a.np;
+    const int oB1 = HID * a.in_dim, oW2 = oB1 + HID, oB2 = oW2 + a.out_dim * HID;
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int c = col_of(j >> 2, j & 3, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c >= 0) wp[(16 * ht + 4 * g + r) * a.in_dim + c] = accW1[ht][q][r];
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ot + 4 * g + r;
+                if (o < a.out_dim) wp[oW2 + o * HID + 16 * ht + j] = accW2[ot][ht][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) sb1[ht][r] += __shfl_xor(sb1[ht][r], m, 64);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) sb2[ot][r] += __shfl_xor(sb2[ot][r], m, 64);
+        }
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) wp[oB1 + 16 * ht + 4 * g + r] = sb1[ht][r];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) if (16 * ot + 4 * g + r < a.out_dim) wp[oB2 + 16 * ot + 4 * g + r] = sb2[ot][r];
+        }
+    }
+}
+
+__global__ void rows_reduce_partials(const float* __restrict__ part, float* __restrict__ out, int np, int nparts) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= np) return;
+    float acc = 0.0f;
+    for (int q = 0; q < nparts; ++q) acc += part[(size_t)q * np + pidx];
+    out[pidx] = acc;
+}
+
+template <int HT, int OT>
+void launch_rows_bwd(int NM, dim3 grid, dim3 block, hipStream_t s, const RowsBwdArgs& a) {
+    switch (NM) {
+        case 1: hipLaunchKernelGGL((rows_bwd_kernel<1, HT, OT>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((rows_bwd_kernel<2, HT, OT>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((rows_bwd_kernel<3, HT, OT>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((rows_bwd_kernel<4, HT, OT>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((rows_bwd_kernel<16, HT, OT>), grid, block, 0, s, a); break;
+    }
+}
+
+int rows_np(const psnode_mlp_f32* m) { return m->out_dim[0] * (m->in_dim + 1) + m->out_dim[1] * (m->out_dim[0] + 1); }
+long long rows_bwd_blocks(long long rows) {
+    const long long tiles = (rows + 15) / 16;
+    long long blocks = (tiles + 3) / 4;
+    return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+}
+
 }  // namespace
 }  // namespace psnode
 
@@ -148,5 +402,35 @@ extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, co
     if (H == 16) launch_rows<1, 1>(NM, grid, block, s, a);
     else if (OT == 1) launch_rows<4, 1>(NM, grid, block, s, a);
     else launch_rows<4, 4>(NM, grid, block, s, a);
+    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+extern "C" size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32* m, int64_t rows) {
+    if (!m || !psnode_mlp_rows_supported(m) || rows < 0) return 0;
+    return (size_t)rows_bwd_blocks(rows) * 4 * rows_np(m) * sizeof(float);
+}
+
+extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride,
+                                                const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
+                                                float* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !in || !grad_out || !grad_params) return PSNODE_ERR_NULL;
+    if (!psnode_mlp_rows_supported(m)) return PSNODE_ERR_UNSUPPORTED;
+    if (!m->weight[0] || !m->weight[1] || !m->bias[0]) return PSNODE_ERR_NULL;
+    if (rows < 0 || in_row_stride < m->in_dim || gout_row_stride < m->out_dim[1] || (grad_in && gin_row_stride < m->in_dim)) return PSNODE_ERR_DIMS;
+    const size_t need = psnode_mlp_rows_backward_workspace_bytes(m, rows);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PSNODE_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = rows_np(m);
+    const long long blocks = rows_bwd_blocks(rows);
+    RowsBwdArgs a{m->weight[0], m->bias[0], m->weight[1], in, grad_out, grad_in, static_cast<float*>(workspace), rows, in_row_stride,
+                  gout_row_stride, gin_row_stride, m->in_dim, m->out_dim[1], np};
+    const dim3 grid((unsigned)blocks), block(256);
+    const int NM = (m->in_dim + 3) / 4, H = m->out_dim[0], OT = (m->out_dim[1] + 15) / 16;
+    if (H == 16) launch_rows_bwd<1, 1>(NM, grid, block, s, a);
+    else if (OT == 1) launch_rows_bwd<4, 1>(NM, grid, block, s, a);
+    else launch_rows_bwd<4, 4>(NM, grid, block, s, a);
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    hipLaunchKernelGGL(rows_reduce_partials, dim3((np + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), grad_params, np,
+                       (int)(blocks * 4));
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }

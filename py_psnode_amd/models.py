@@ -31,11 +31,15 @@ def _tm(a):
 
 
 def _rows(seq, inp):
-    """Encoder / decoder over every (b,t) row: the fused HIP row kernel when the call is fusable (fp32 HIP tensor,
-    Linear-ELU-Linear with hidden 16, no autograd), otherwise the module itself (training, CPU, other widths)."""
+    """Encoder / decoder over every (b,t) row on the fused HIP row kernels when the call is fusable (fp32 HIP tensor,
+    Linear-ELU-Linear with hidden 16 / 64): forward kernel alone without autograd, forward + fused backward kernel under it;
+    otherwise the module itself (CPU, other widths)."""
     from . import fused
-    layers = fused.rows_layers_of(seq, inp)
-    return fused.mlp_rows(layers, inp) if layers is not None else seq(inp)
+    layers = fused.rows_layers_of(seq, inp, allow_grad=True)
+    if layers is None:
+        return seq(inp)
+    needs_grad = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in seq.parameters()))
+    return fused.mlp_rows_autograd(seq, inp) if needs_grad else fused.mlp_rows(layers, inp)
 
 
 class DE_Func(nn.Module):

@@ -1,0 +1,109 @@
+"""GPU parity of the row-MLP backward kernel (K3b backward, psnode_mlp_rows_backward_f32) against fp64 autograd of the same
+nn.Sequential(Linear, ELU, Linear): grad of the input rows and of all four parameter tensors, every (in, hidden, out)
+class the direct_encode models use (encoders in<=16 -> H -> H, decoders H -> H -> out<=16, H in {16, 64}), ragged row
+counts, strided 3-D inputs; and the model-level route (ODE_02 / DAE_02 training steps take it).
+
+Tolerance: parameter gradients are fp32 sums over up to 4100 rows with a different summation order: 2e-5 of each
+tensor's max; input gradients (no reduction over rows) 2e-6."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= rtol * max(scale, 1e-12), f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+SHAPES = [(8, 16, 16), (2, 16, 16), (16, 16, 8), (16, 16, 2), (3, 16, 5), (1, 16, 16), (6, 16, 16),
+          (8, 64, 64), (2, 64, 64), (64, 64, 8), (64, 64, 2), (5, 64, 64)]
+
+
+@pytest.mark.parametrize("rows", [1, 17, 4100])
+@pytest.mark.parametrize("din,H,dout", SHAPES)
+def test_rows_backward_matches_fp64_autograd(din, H, dout, rows):
+    from py_psnode_amd import fused
+    torch.manual_seed(din * 100 + dout)
+    seq = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout))
+    inp, gout = torch.randn(rows, din), torch.randn(rows, dout)
+    seq64 = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout)).double()
+    seq64.load_state_dict({k: v.double() for k, v in seq.state_dict().items()})
+    x64 = inp.double().requires_grad_(True)
+    (seq64(x64) * gout.double()).sum().backward()
+    layers = [(seq[0].weight.detach().cuda(), seq[0].bias.detach().cuda()), (seq[2].weight.detach().cuda(), seq[2].bias.detach().cuda())]
+    gin, gp = fused.mlp_rows_backward(layers, inp.cuda(), gout.cuda())
+    _close(gin, x64.grad, 2e-6, "grad in")
+    for k, (a, p) in enumerate(zip(gp, [seq64[0].weight, seq64[0].bias, seq64[2].weight, seq64[2].bias])):
+        _close(a, p.grad, 2e-5, f"grad param {k}")
+    gin2, gp2 = fused.mlp_rows_backward(layers, inp.cuda(), gout.cuda(), need_grad_in=False)
+    assert gin2 is None and all(torch.equal(a, b) for a, b in zip(gp, gp2)), "deterministic, grad_in optional"
+
+
+def test_rows_autograd_function_on_strided_3d_input():
+    """The route models._rows takes under autograd: [B,T,D] input that is a permuted view, gradient through input and parameters."""
+    from py_psnode_amd import fused
+    torch.manual_seed(5)
+    seq = nn.Sequential(nn.Linear(8, 16), nn.ELU(), nn.Linear(16, 16)).cuda()
+    ref = nn.Sequential(nn.Linear(8, 16), nn.ELU(), nn.Linear(16, 16)).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in seq.state_dict().items()})
+    base = torch.randn(37, 11, 8)
+    G = torch.randn(11, 37, 16)
+    xg = base.cuda().requires_grad_(True)
+    out = fused.mlp_rows_autograd(seq, xg.permute(1, 0, 2))
+    assert type(out.grad_fn).__name__.startswith("_RowsMlp")
+    (out * G.cuda()).sum().backward()
+    x64 = base.double().requires_grad_(True)
+    (ref(x64.permute(1, 0, 2)) * G.double()).sum().backward()
+    _close(xg.grad, x64.grad, 2e-6, "grad in")
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 2e-5, n)
+
+
+@pytest.mark.parametrize("tag", ["ode02", "dae02_h16"])
+def test_direct_encode_training_step_uses_row_kernels_and_matches_fp64(tag):
+    """ODE_02 / DAE_02 (hidden 16) model: loss.backward() through encoders -> fused latent integrator -> decoders vs the fp64
+    autograd walk on the CPU; the encoders/decoders must have gone through the row kernels."""
+    from py_psnode_amd import models, neural_dae as nd
+    torch.manual_seed(11)
+    B, T = 19, 9
+    g = torch.Generator().manual_seed(12)
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
+    x, z, v, i = r(B, T, 8), r(B, T, 2), r(B, T, 2), r(B, T, 2)
+    ev, zj, vj = -torch.ones(B, 1, 1), torch.zeros(B, 1, 2), torch.zeros(B, 1, 2)
+    if tag == "ode02":
+        mk = lambda: models.ODE_Model(8, 2, 16, direct_encode=True, solver=nd.RK4())
+    else:
+        mk = lambda: models.DAE_Model(8, 2, 2, 2, 16, direct_encode=True, solver=nd.RK4())
+    m32, m64 = mk(), mk().double()
+    m64.load_state_dict({k: v_.double() for k, v_ in m32.state_dict().items()})
+    m64.solver.fused = "off"
+    m32 = m32.cuda()
+    m32.solver.fused = "require"
+
+    def run(model, cast, dev):
+        c = lambda a: cast(a).to(dev)
+        if tag == "ode02":
+            outs = model(t=c(t), x=c(x), z=c(z), event_t=c(ev), z_jump=c(zj))
+        else:
+            outs = model(t=c(t), x=c(x), z=c(z), v=c(v), i=c(i), event_t=c(ev), z_jump=c(zj), v_jump=c(vj))
+        loss = sum(((o - 0.05) ** 2).sum() for o in outs)
+        loss.backward()
+        return [o.detach() for o in outs], outs[-1].grad_fn
+
+    ref, _ = run(m64, lambda a: a.double(), "cpu")
+    out, gfn = run(m32, lambda a: a, "cuda")
+    assert type(gfn).__name__.startswith("_RowsMlp"), type(gfn).__name__
+    for a, b in zip(out, ref):
+        _close(a, b, 1e-5, "model output")
+    for (n, p), (_, q) in zip(m32.named_parameters(), m64.named_parameters()):
+        _close(p.grad, q.grad, 5e-4, n)
