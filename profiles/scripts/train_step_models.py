@@ -1,6 +1,5 @@
 """Whole training step of the four scripts' models as shipped (hidden 64 / 16 / 64 / 64), B=4096 x T=1001 on one MI355X:
-model forward (fused integrator inside) + the script's loss (fused K6) + backward + Adam step.  Reports which route the
-solver took (fused autograd Function or the per-step walk)."""
+model forward (fused integrator inside) + the script's loss (fused K6) + backward + Adam step."""
 import json
 import os
 import sys
@@ -34,7 +33,7 @@ for tag in sys.argv[1:] or ["ode01", "ode02", "dae01", "dae02"]:
             m = models.DAE_Model(8, 2, 2, 2, 64, direct_encode=True, solver=solver)
         m = m.to(dev)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-        steps_T = T if (tag != "dae02") else min(T, int(os.environ.get("T_WALK", 51)))   # dae02@64 trains through the walk: short grid
+        steps_T = min(T, int(os.environ.get("T_CAP", T)))
 
         def step():
             opt.zero_grad()

@@ -522,12 +522,15 @@ bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE
 bool use_latent_bwd(const psnode_ode_bwd_args_f32* a) {
     return a->kernel != PSNODE_KERNEL_GENERIC && latent_bwd_shape_ok(a) && (!a->xs || latent_bwd_ptrs_ok(a));
 }
+bool use_latent64_bwd(const psnode_ode_bwd_args_f32* a) {   // K9: the only fused backward for this shape (K5's LDS budget is too small)
+    return a->kernel != PSNODE_KERNEL_GENERIC && latent64_ode_bwd_shape_ok(a) && (!a->xs || latent64_ode_bwd_ptrs_ok(a));
+}
 }  // namespace
 
 extern "C" int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a) || use_latent_bwd(a);
-    return use_mfma_bwd(a) || use_latent_bwd(a) || ode_generic_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a) || use_latent_bwd(a) || use_latent64_bwd(a);
+    return use_mfma_bwd(a) || use_latent_bwd(a) || use_latent64_bwd(a) || ode_generic_ok(a);
 }
 
 extern "C" int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* a) {
@@ -538,6 +541,7 @@ extern "C" size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_
     if (!a || !psnode_ode_backward_supported(a)) return 0;
     size_t floats = ode_generic_ok(a) ? generic_bwd_workspace_floats(&a->de, nullptr, a->B) : 0;
     if (latent_bwd_shape_ok(a)) floats = latent_bwd_workspace_floats(a->B) > floats ? latent_bwd_workspace_floats(a->B) : floats;
+    if (latent64_ode_bwd_shape_ok(a)) floats = latent64_ode_bwd_workspace_floats(a->B) > floats ? latent64_ode_bwd_workspace_floats(a->B) : floats;
     if (bwd_shape_ok(a)) {
         const int n = a->x_dim + a->z_dim;
         const size_t pack = (size_t)NW * (kMaxRegs + (n + 3) / 4 + BWCOUNT) * 64;
@@ -561,6 +565,7 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
         return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
+    if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);
     if (a->kernel == PSNODE_KERNEL_MFMA && !bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;   // latent shape, unaligned views
     if (!use_mfma_bwd(a)) {
         return generic_backward_launch(a->method, a->x_dim, a->z_dim, 0, 0, a->T, a->B, &a->de, nullptr,
@@ -604,13 +609,16 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
 
 namespace {
 bool use_mfma_dae_bwd(const psnode_dae_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && dae_mfma_bwd_shape_ok(a); }
+bool use_latent64_dae_bwd(const psnode_dae_bwd_args_f32* a) {
+    return a->kernel != PSNODE_KERNEL_GENERIC && latent64_dae_bwd_shape_ok(a) && (!a->xs || latent64_dae_bwd_ptrs_ok(a));
+}
 }  // namespace
 
 extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
     if (a->x_dim < 1 || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA) return dae_mfma_bwd_shape_ok(a);
-    if (use_mfma_dae_bwd(a)) return 1;
+    if (a->kernel == PSNODE_KERNEL_MFMA) return dae_mfma_bwd_shape_ok(a) || use_latent64_dae_bwd(a);
+    if (use_mfma_dae_bwd(a) || use_latent64_dae_bwd(a)) return 1;
     const int n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
     const psnode_mlp_f32 &d = a->de, &g = a->ae;
     if (d.n_layers < 1 || d.n_layers > kMaxLayers || g.n_layers < 1 || g.n_layers > kMaxLayers) return 0;
@@ -622,6 +630,7 @@ extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* 
 extern "C" size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* a) {
     if (!a || !psnode_dae_backward_supported(a)) return 0;
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_workspace_floats(a) * sizeof(float);
+    if (latent64_dae_bwd_shape_ok(a) && a->kernel != PSNODE_KERNEL_GENERIC) return latent64_dae_bwd_workspace_floats(a) * sizeof(float);
     return generic_bwd_workspace_floats(&a->de, &a->ae, a->B) * sizeof(float);
 }
 
@@ -640,6 +649,7 @@ extern "C" int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* a, voi
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_dae_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    if (use_latent64_dae_bwd(a)) return latent64_dae_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     return generic_backward_launch(a->method, a->x_dim, a->z_dim, a->v_dim, a->i_dim, a->T, a->B, &a->de, &a->ae,
                                    ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},
                                    ViewDev{a->v.ptr, a->v.stride_t, a->v.stride_b}, a->all_initial, a->event_idx, a->z_jump, a->zj_stride_b,

@@ -148,6 +148,15 @@ bool latent_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
 bool latent_bwd_ptrs_ok(const psnode_ode_bwd_args_f32* a);
 size_t latent_bwd_workspace_floats(long long B);
 int latent_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
+// K9 (psnode_latent64_bwd.hip): backward of the latent ODE / DAE integrators at hidden 64
+bool latent64_ode_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
+bool latent64_ode_bwd_ptrs_ok(const psnode_ode_bwd_args_f32* a);
+size_t latent64_ode_bwd_workspace_floats(long long B);
+int latent64_ode_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
+bool latent64_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
+bool latent64_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);
+size_t latent64_dae_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
+int latent64_dae_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
 // K7 (psnode_dae_backward.hip): MFMA backward of the DAE integrator at hidden 64
 bool dae_mfma_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 size_t dae_mfma_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);

@@ -68,22 +68,27 @@ def test_rows_autograd_function_on_strided_3d_input():
         _close(p.grad, q.grad, 2e-5, n)
 
 
-@pytest.mark.parametrize("tag", ["ode02", "dae02_h16"])
-def test_direct_encode_training_step_uses_row_kernels_and_matches_fp64(tag):
-    """ODE_02 / DAE_02 (hidden 16) model: loss.backward() through encoders -> fused latent integrator -> decoders vs the fp64
-    autograd walk on the CPU; the encoders/decoders must have gone through the row kernels."""
+@pytest.mark.parametrize("events", [False, True])
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+@pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])
+def test_direct_encode_training_step_uses_row_kernels_and_matches_fp64(tag, H, zd, method, events):
+    """ODE_02 / DAE_02 models (hidden 16 and the shipped hidden 64, with and without z): loss.backward() through encoders ->
+    fused latent integrator (forward K3a/K3c, backward K8 / K5 / K9) -> decoders vs the fp64 autograd walk on the CPU; the
+    solver must have taken the fused route and the encoders/decoders the row kernels."""
     from py_psnode_amd import models, neural_dae as nd
     torch.manual_seed(11)
     B, T = 19, 9
     g = torch.Generator().manual_seed(12)
     r = lambda *s: 0.1 * torch.randn(*s, generator=g)
     t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
-    x, z, v, i = r(B, T, 8), r(B, T, 2), r(B, T, 2), r(B, T, 2)
-    ev, zj, vj = -torch.ones(B, 1, 1), torch.zeros(B, 1, 2), torch.zeros(B, 1, 2)
+    x, z, v, i = r(B, T, 8), r(B, T, zd), r(B, T, 2), r(B, T, 2)
+    ev = t[:, [2, 6], :].contiguous() if events else -torch.ones(B, 2, 1)
+    zj, vj = r(B, 2, zd), r(B, 2, 2)
+    cls = {"euler": nd.Euler, "rk4": nd.RK4}[method]
     if tag == "ode02":
-        mk = lambda: models.ODE_Model(8, 2, 16, direct_encode=True, solver=nd.RK4())
+        mk = lambda: models.ODE_Model(8, zd, H, direct_encode=True, solver=cls())
     else:
-        mk = lambda: models.DAE_Model(8, 2, 2, 2, 16, direct_encode=True, solver=nd.RK4())
+        mk = lambda: models.DAE_Model(8, zd, 2, 2, H, direct_encode=True, solver=cls())
     m32, m64 = mk(), mk().double()
     m64.load_state_dict({k: v_.double() for k, v_ in m32.state_dict().items()})
     m64.solver.fused = "off"
