@@ -344,11 +344,21 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
     }
 }
 
-__global__ void rows_reduce_partials(const float* __restrict__ part, float* __restrict__ out, int np, int nparts) {
+// Two-stage fixed-order sum of the per-wave partials: stage 1 sums slices of the partial sets (grid.y slices), stage 2 the slices.
+constexpr int kRedSlices = 32;
+__global__ void rows_reduce_stage1(const float* __restrict__ part, float* __restrict__ mid, int np, int nparts) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= np) return;
+    const int per = (nparts + kRedSlices - 1) / kRedSlices, q0 = blockIdx.y * per, q1 = q0 + per < nparts ? q0 + per : nparts;
+    float acc = 0.0f;
+    for (int q = q0; q < q1; ++q) acc += part[(size_t)q * np + pidx];
+    mid[(size_t)blockIdx.y * np + pidx] = acc;
+}
+__global__ void rows_reduce_stage2(const float* __restrict__ mid, float* __restrict__ out, int np) {
     const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (pidx >= np) return;
     float acc = 0.0f;
-    for (int q = 0; q < nparts; ++q) acc += part[(size_t)q * np + pidx];
+    for (int q = 0; q < kRedSlices; ++q) acc += mid[(size_t)q * np + pidx];
     out[pidx] = acc;
 }
 
@@ -407,7 +417,7 @@ extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, co
 
 extern "C" size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32* m, int64_t rows) {
     if (!m || !psnode_mlp_rows_supported(m) || rows < 0) return 0;
-    return (size_t)rows_bwd_blocks(rows) * 4 * rows_np(m) * sizeof(float);
+    return ((size_t)rows_bwd_blocks(rows) * 4 + kRedSlices) * rows_np(m) * sizeof(float);
 }
 
 extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride,
@@ -430,7 +440,9 @@ extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t
     else if (OT == 1) launch_rows_bwd<4, 1>(NM, grid, block, s, a);
     else launch_rows_bwd<4, 4>(NM, grid, block, s, a);
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    hipLaunchKernelGGL(rows_reduce_partials, dim3((np + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), grad_params, np,
+    float* mid = static_cast<float*>(workspace) + (size_t)blocks * 4 * np;
+    hipLaunchKernelGGL(rows_reduce_stage1, dim3((np + 255) / 256, kRedSlices), dim3(256), 0, s, static_cast<const float*>(workspace), mid, np,
                        (int)(blocks * 4));
+    hipLaunchKernelGGL(rows_reduce_stage2, dim3((np + 255) / 256), dim3(256), 0, s, mid, grad_params, np);
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
