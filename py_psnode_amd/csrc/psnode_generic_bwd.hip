@@ -48,6 +48,7 @@ struct GBwd {
     const float *xs, *is_, *gxs, *gis;
     float *gx0, *gz, *gv, *gzj, *gvj, *ga0, *wpart;
     int maxw, act_rows;
+    int gacc_global;   // parameter-gradient accumulators in this workgroup's slice of wpart (global, L2) instead of LDS
 };
 
 __device__ __forceinline__ float delu(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }   // ELU'(pre) from h = ELU(pre)
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     float* gic = gxc + nx;                        // [id][TP]  carried dL/di_{k+1}
     float* dts = gic + id * TP;                   // [TP]
     float* wbuf = dts + TP;                       // [kWBuf] staged weights
-    float* gacc = wbuf + kWBuf;                   // [np_de + np_ae]
+    // [np_de + np_ae]: in LDS when it fits, else this workgroup's partial slice in global memory (each element is owned by
+    // one thread either way, so the read-modify-write needs no atomics)
+    float* gacc = a.gacc_global ? a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0)) : wbuf + kWBuf;
     float* gacc_ae = gacc + a.de.np;
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
-    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc[e];
+    if (!a.gacc_global)
+        for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc[e];
 #undef TILE_LOOP
 }
 
@@ -422,7 +426,15 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + kWBuf + a.de.np + (a.dae ? a.ae.np : 0);
+           (size_t)id * TP + TP + kWBuf + (a.gacc_global ? 0 : a.de.np + (a.dae ? a.ae.np : 0));
+}
+// 1: everything in LDS; 2: only with the parameter-gradient accumulators in global memory; 0: does not fit
+int gbwd_mode(GBwd& a) {
+    a.gacc_global = 0;
+    if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
+    a.gacc_global = 1;
+    if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
+    return 0;
 }
 
 int mlp_maxw(const psnode_mlp_f32& m) {
@@ -469,7 +481,7 @@ int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd,
         a.maxw = mlp_maxw(*ae) > a.maxw ? mlp_maxw(*ae) : a.maxw;
     }
     a.act_rows = rows;
-    return gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024;
+    return gbwd_mode(a);
 }
 
 // launches pack (transpose), the backward kernel and the partial reduction
@@ -497,8 +509,8 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     a.t = t; a.z = z; a.v = v; a.a0 = a0; a.ev = ev; a.zj = zj; a.zjb = zjb; a.zje = zje; a.vj = vj; a.vjb = vjb; a.vje = vje;
     a.n_events = n_events; a.xs = xs; a.is_ = is_; a.gxs = gxs; a.gis = gis; a.gx0 = gx0; a.gz = gz; a.gv = gv; a.gzj = gzj; a.gvj = gvj;
     a.ga0 = ga0; a.wpart = ws;
+    if (!gbwd_mode(a)) return PSNODE_ERR_UNSUPPORTED;
     const size_t lds = gbwd_lds_floats(a) * sizeof(float);
-    if (lds > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
     // transposed weights for the forward recomputation
     MlpDev mde, mae;
     memset(&mde, 0, sizeof(mde));

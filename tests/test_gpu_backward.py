@@ -123,9 +123,10 @@ def _param_grads(seq):
 
 
 @pytest.mark.parametrize("method", ["euler", "rk4"])
-@pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2)])
+@pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2), (8, 2, 128, 3), (8, 2, 32, 3)])
 def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
-    """K5 (kernel='generic') on the MFMA shape, the direct_encode latent shape and an odd shape, raw-tensor API."""
+    """K5 (kernel='generic') on the MFMA shape, the direct_encode latent shape, an odd shape, and the --hidden 128 / 32 shapes
+    (at 128 the parameter-gradient accumulators no longer fit LDS and live in the workgroup's global partial slice), raw-tensor API."""
     from py_psnode_amd import fused
     B, Tn = 19, 9
     g = torch.Generator().manual_seed(7)
@@ -374,3 +375,35 @@ def test_latent16_ode_backward_kernel_matches_generic(method, B, Tn, events):
         assert torch.equal(a, c), nme + ": AUTO must run K8 on this shape"
     for k, (a, b) in enumerate(zip(out["mfma"][4], out["generic"][4])):
         _close(a, b.double().cpu(), f"grad param {k} (K8 vs K5)")
+
+
+@pytest.mark.parametrize("H", [128, 32])
+def test_dae_model_training_at_other_hidden_widths_runs_fused(H):
+    """DAE_Model at --hidden 128 (the argparse default) and 32: fused forward (K2) + generic backward (K5, accumulators in global
+    memory at 128) vs the fp64 autograd walk."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    B, Tn = 7, 5
+    g = torch.Generator().manual_seed(8)
+    torch.manual_seed(8)
+    m32 = models.DAE_Model(8, 2, 2, 2, H, solver=nd.RK4())
+    m64 = models.DAE_Model(8, 2, 2, 2, H, solver=nd.RK4()).double()
+    m64.load_state_dict({k: v.double() for k, v in m32.state_dict().items()})
+    m64.solver.fused = "off"
+    m32 = m32.cuda(); m32.solver.fused = "require"
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    x, z, v, i = r(B, Tn, 8), r(B, Tn, 2), r(B, Tn, 2), r(B, Tn, 2)
+    ev, zj, vj = t[:, [2], :].contiguous(), r(B, 1, 2), r(B, 1, 2)
+
+    def run(model, cast, dev):
+        c = lambda a: cast(a).to(dev)
+        xs, is_ = model(t=c(t), x=c(x), z=c(z), v=c(v), i=c(i), event_t=c(ev), z_jump=c(zj), v_jump=c(vj))
+        ((xs ** 2).sum() + (is_ ** 2).sum()).backward()
+        return xs.detach(), is_.detach(), [p.grad for p in model.parameters()]
+
+    ref = run(m64, lambda a: a.double(), "cpu")
+    out = run(m32, lambda a: a, "cuda")
+    _close(out[0], ref[0], "xs"); _close(out[1], ref[1], "is")
+    for k, (a, b) in enumerate(zip(out[2], ref[2])):
+        _close(a, b, f"grad param {k}")
