@@ -13,6 +13,7 @@ from py_psnode_amd import neural_dae as nd  # noqa: E402
 
 dev = torch.device("cuda", 0)
 B, T = int(os.environ.get("B", 4096)), int(os.environ.get("T", 1001))
+H_OVERRIDE = int(os.environ.get("HIDDEN", 0))      # 0 = the widths the scripts ship with
 g = torch.Generator().manual_seed(0)
 r = lambda *s: (0.1 * torch.randn(*s, generator=g)).to(dev)
 t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1).to(dev)
@@ -24,13 +25,13 @@ for tag in sys.argv[1:] or ["ode01", "ode02", "dae01", "dae02"]:
     for method in ("rk4", "euler"):
         solver = {"rk4": nd.RK4, "euler": nd.Euler}[method]()
         if tag == "ode01":
-            m = models.ODE_Model(8, 2, 64, solver=solver)
+            m = models.ODE_Model(8, 2, H_OVERRIDE or 64, solver=solver)
         elif tag == "ode02":
-            m = models.ODE_Model(8, 2, 16, direct_encode=True, solver=solver)
+            m = models.ODE_Model(8, 2, H_OVERRIDE or 16, direct_encode=True, solver=solver)
         elif tag == "dae01":
-            m = models.DAE_Model(8, 2, 2, 2, 64, solver=solver)
+            m = models.DAE_Model(8, 2, 2, 2, H_OVERRIDE or 64, solver=solver)
         else:
-            m = models.DAE_Model(8, 2, 2, 2, 64, direct_encode=True, solver=solver)
+            m = models.DAE_Model(8, 2, 2, 2, H_OVERRIDE or 64, direct_encode=True, solver=solver)
         m = m.to(dev)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
         steps_T = min(T, int(os.environ.get("T_CAP", T)))

@@ -609,6 +609,9 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
 
 namespace {
 bool use_mfma_dae_bwd(const psnode_dae_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && dae_mfma_bwd_shape_ok(a); }
+bool use_latent16_dae_bwd(const psnode_dae_bwd_args_f32* a) {
+    return a->kernel != PSNODE_KERNEL_GENERIC && latent16_dae_bwd_shape_ok(a) && (!a->xs || latent16_dae_bwd_ptrs_ok(a));
+}
 bool use_latent64_dae_bwd(const psnode_dae_bwd_args_f32* a) {
     return a->kernel != PSNODE_KERNEL_GENERIC && latent64_dae_bwd_shape_ok(a) && (!a->xs || latent64_dae_bwd_ptrs_ok(a));
 }
@@ -617,8 +620,8 @@ bool use_latent64_dae_bwd(const psnode_dae_bwd_args_f32* a) {
 extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
     if (a->x_dim < 1 || a->z_dim < 0 || a->v_dim < 0 || a->i_dim < 1) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA) return dae_mfma_bwd_shape_ok(a) || use_latent64_dae_bwd(a);
-    if (use_mfma_dae_bwd(a) || use_latent64_dae_bwd(a)) return 1;
+    if (a->kernel == PSNODE_KERNEL_MFMA) return dae_mfma_bwd_shape_ok(a) || use_latent64_dae_bwd(a) || use_latent16_dae_bwd(a);
+    if (use_mfma_dae_bwd(a) || use_latent64_dae_bwd(a) || use_latent16_dae_bwd(a)) return 1;
     const int n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
     const psnode_mlp_f32 &d = a->de, &g = a->ae;
     if (d.n_layers < 1 || d.n_layers > kMaxLayers || g.n_layers < 1 || g.n_layers > kMaxLayers) return 0;
@@ -631,6 +634,10 @@ extern "C" size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_
     if (!a || !psnode_dae_backward_supported(a)) return 0;
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_workspace_floats(a) * sizeof(float);
     if (latent64_dae_bwd_shape_ok(a) && a->kernel != PSNODE_KERNEL_GENERIC) return latent64_dae_bwd_workspace_floats(a) * sizeof(float);
+    if (latent16_dae_bwd_shape_ok(a)) {      // K8 (DAE) or, for unaligned views / kernel = generic, K5: the larger of the two
+        const size_t k8 = latent16_dae_bwd_workspace_floats(a), k5 = generic_bwd_workspace_floats(&a->de, &a->ae, a->B);
+        return (k8 > k5 ? k8 : k5) * sizeof(float);
+    }
     return generic_bwd_workspace_floats(&a->de, &a->ae, a->B) * sizeof(float);
 }
 
@@ -650,6 +657,8 @@ extern "C" int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* a, voi
         return PSNODE_ERR_WORKSPACE;
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     if (use_latent64_dae_bwd(a)) return latent64_dae_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    if (use_latent16_dae_bwd(a)) return latent16_dae_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    if (a->kernel == PSNODE_KERNEL_MFMA) return PSNODE_ERR_UNSUPPORTED;
     return generic_backward_launch(a->method, a->x_dim, a->z_dim, a->v_dim, a->i_dim, a->T, a->B, &a->de, &a->ae,
                                    ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b}, ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b},
                                    ViewDev{a->v.ptr, a->v.stride_t, a->v.stride_b}, a->all_initial, a->event_idx, a->z_jump, a->zj_stride_b,

@@ -144,6 +144,10 @@ bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 // K8 (psnode_latent_bwd.hip): backward of the latent ODE integrator at hidden 16
+bool latent16_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
+bool latent16_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);
+size_t latent16_dae_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
+int latent16_dae_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
 bool latent_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
 bool latent_bwd_ptrs_ok(const psnode_ode_bwd_args_f32* a);
 size_t latent_bwd_workspace_floats(long long B);

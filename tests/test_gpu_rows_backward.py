@@ -70,7 +70,7 @@ def test_rows_autograd_function_on_strided_3d_input():
 
 @pytest.mark.parametrize("events", [False, True])
 @pytest.mark.parametrize("method", ["euler", "rk4"])
-@pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])
+@pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("dae02", 16, 0), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])
 def test_direct_encode_training_step_uses_row_kernels_and_matches_fp64(tag, H, zd, method, events):
     _direct_encode_case(tag, H, zd, method, events, 19, 9)
 
