@@ -460,28 +460,45 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
     f2 gicarry = {0.f, 0.f};     // what the DE of the step starting at the current grid point fed into i (rows 0, 2)
     f2 dezv = {0.f, 0.f};        // DE part of dL/d(z|v) at the current grid point (rows 0, 2), 0 if that step took a jump
 
+    // inputs of grid point jg (AE head) -- loaded one iteration ahead; x_jg is the previous iteration's x_k
+    float xj[NX], gxj[NX];
+    ArrD<NZA> zvj;
+    f2 giu = {0.f, 0.f};
+    if (nT >= 1) {
+        load_x(nT - 1, xj);
+        load_gx(nT - 1, gxj);
+        load_zva(nT - 1, zvj);
+        giu = load_gi(nT - 1);
+    }
     for (long long jg = nT - 1; jg >= 0; --jg) {
+        // ---- issue every load of this iteration's step and of the next grid point now: they are consumed after the AE head
+        const long long k = jg - 1;
+        int ev = -1;
+        float h_ = 0.0f, x0[NX], gxn[NX];
+        ArrD<NZM> extv;
+        ArrD<NZA> zvn;
+        f2 gin = {0.f, 0.f};
+        if (jg >= 1) {
+            ev = a.ev ? a.ev[k] : -1;
+            h_ = tp[jg * tst] - tp[k * tst];
+            load_x(k, x0);
+            load_ext(k, ev, extv);
+            load_gx(k, gxn);
+            load_zva(k, zvn);
+            gin = load_gi(k);
+        }
         // ================= (1) AE head at grid point jg
-        float xj[NX], gxj[NX];
-        ArrD<NZA> zvj;
-        load_x(jg, xj);
-        load_gx(jg, gxj);
-        load_zva(jg, zvj);
-        const f2 giu = load_gi(jg);
         const f4 gi = f4{gicarry[0] + giu[0], 0.f, gicarry[1] + giu[1], 0.f};
         const f4 tX = ae_vjp(xj, zvj, gi);
         store_zv(jg, -1, dezv[0] + tX[2], dezv[1] + tX[3]);
         f2 g1 = gcarry + f2{gxj[0], gxj[1]} + f2{tX[0], tX[1]};     // adjoint of x_jg, complete
         if (jg == 0) { gcarry = g1; break; }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { xj[r] = x0[r]; gxj[r] = gxn[r]; }
+        zvj = zvn;
+        giu = gin;
 
         // ================= (2) step k = jg-1
-        const long long k = jg - 1;
-        const int ev = a.ev ? a.ev[k] : -1;
-        const float h_ = tp[jg * tst] - tp[k * tst];
-        float x0[NX];
-        ArrD<NZM> extv;
-        load_x(k, x0);
-        load_ext(k, ev, extv);
         if (ev >= 0) {   // i_in = g(x_k; z_jump, v_jump) with the state of grid point k (my_solvers.py:108-110)
             ArrD<NZA> zvq;
 #pragma unroll
