@@ -458,15 +458,6 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     }
 }
 
-// out[p] = sum over workgroups, fixed order
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int NP, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pidx >= NP) return;
-    float acc = 0.0f;
-    for (int g = 0; g < nwg; ++g) acc += part[(size_t)g * NP + pidx];
-    out[pidx] = acc;
-}
-
 int bwd_np(int xd, int zd) {
     const int n = xd + zd;
     return HID * 3 * n + HID + 2 * (HID * HID + HID) + xd * HID + xd;
@@ -603,8 +594,7 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     }
     if (e != hipSuccess) return e == hipErrorNotSupported ? PSNODE_ERR_UNSUPPORTED : PSNODE_ERR_HIP;
     const int nwg = (int)((a->B + TBM - 1) / TBM);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((d.NP + 255) / 256), dim3(256), 0, s, wpart, a->grad_params, d.NP, nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    return launch_reduce_partials(wpart, a->grad_params, nullptr, d.NP, 0, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 namespace {

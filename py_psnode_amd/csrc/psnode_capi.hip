@@ -259,3 +259,24 @@ int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {
 }
 
 }  // extern "C"
+
+// ---- shared by every backward kernel: out[p] = sum over the per-workgroup partial vectors, in a fixed order (deterministic).
+//      The first np_a entries go to out_a, the remaining np_b to out_b (out_b may be null when np_b == 0).
+namespace psnode {
+namespace {
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out_a, float* __restrict__ out_b, int np_a,
+                                       int np_b, int nparts) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_a + np_b;
+    if (pidx >= np) return;
+    float acc = 0.0f;
+    for (int q = 0; q < nparts; ++q) acc += part[(size_t)q * np + pidx];
+    if (pidx < np_a) out_a[pidx] = acc;
+    else out_b[pidx - np_a] = acc;
+}
+}  // namespace
+hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s) {
+    const int np = np_a + np_b;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np + 255) / 256), dim3(256), 0, s, part, out_a, out_b, np_a, np_b, nparts);
+    return hipGetLastError();
+}
+}  // namespace psnode

@@ -143,6 +143,8 @@ bool mfma_ode_supported(const IntegrateDev& a);
 bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+// psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
+hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
 // K8 (psnode_latent_bwd.hip): backward of the latent ODE integrator at hidden 16
 bool latent16_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 bool latent16_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);

@@ -723,17 +723,6 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
     write_mlp(wp + d.NP_de, n + xd + nzv, n, xd + nzv, idim, true, AS1, AS2, AS3, aaccW1, aaccW2, aaccW3, aaccW4, adb4);
 }
 
-// out[p] = sum over workgroups, fixed order; [0, np_de) -> out_de, the rest -> out_ae
-__global__ void reduce_partials_dae(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
-                                    int np_ae, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
-    if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int gq = 0; gq < nwg; ++gq) acc += part[(size_t)gq * np + pidx];
-    if (pidx < np_de) out_de[pidx] = acc;
-    else out_ae[pidx - np_de] = acc;
-}
-
 int np_of(int k1, int out) { return HID * k1 + HID + 2 * (HID * HID + HID) + out * HID + out; }
 
 bool mlp64(const psnode_mlp_f32& m, int in_dim, int out_dim) {
@@ -833,10 +822,8 @@ int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipS
         default: e = launch_k7<PSNODE_RK4_38>(d, pack_de, pack_ae, NA, NZM, NZA, lds, s); break;
     }
     if (e != hipSuccess) return e == hipErrorNotSupported ? PSNODE_ERR_UNSUPPORTED : PSNODE_ERR_HIP;
-    const int nwg = (int)((a->B + TBM - 1) / TBM), np = d.NP_de + d.NP_ae;
-    hipLaunchKernelGGL(reduce_partials_dae, dim3((np + 255) / 256), dim3(256), 0, s, wpart, a->grad_params_de, a->grad_params_ae, d.NP_de,
-                       d.NP_ae, nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    const int nwg = (int)((a->B + TBM - 1) / TBM);
+    return launch_reduce_partials(wpart, a->grad_params_de, a->grad_params_ae, d.NP_de, d.NP_ae, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // namespace psnode

@@ -391,16 +391,6 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
 #undef TILE_LOOP
 }
 
-__global__ void reduce_partials_g(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
-                                  int np_ae, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
-    if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int g = 0; g < nwg; ++g) acc += part[(size_t)g * np + pidx];
-    if (pidx < np_de) out_de[pidx] = acc;
-    else out_ae[pidx - np_de] = acc;
-}
-
 int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
     g.L = m.n_layers;
     g.in_dim = m.in_dim;
@@ -527,10 +517,7 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     const unsigned nwg = (unsigned)((B + TB - 1) / TB);
     hipLaunchKernelGGL(generic_backward_kernel, dim3(nwg), dim3(NT), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    const int np = a.de.np + (dae ? a.ae.np : 0);
-    hipLaunchKernelGGL(reduce_partials_g, dim3((np + 255) / 256), dim3(256), 0, stream, a.wpart, gparams_de, gparams_ae, a.de.np,
-                       dae ? a.ae.np : 0, (int)nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    return launch_reduce_partials(a.wpart, gparams_de, gparams_ae, a.de.np, dae ? a.ae.np : 0, (int)nwg, stream) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // namespace psnode

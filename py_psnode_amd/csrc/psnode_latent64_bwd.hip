@@ -529,16 +529,6 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     if constexpr (DAE) write_mlp(wp + d.NP_de, n + H9 * NAE, std::true_type{}, std::integral_constant<int, NAE>{}, AS1, ASB2, accAF, accW2a);
 }
 
-__global__ void reduce_partials9(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
-                                 int np_ae, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
-    if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int gq = 0; gq < nwg; ++gq) acc += part[(size_t)gq * np + pidx];
-    if (pidx < np_de) out_de[pidx] = acc;
-    else out_ae[pidx - np_de] = acc;
-}
-
 int np9(int k1) { return H9 * k1 + H9 + H9 * H9 + H9; }
 bool two9(const psnode_mlp_f32& m, int in_dim) { return m.n_layers == 2 && m.in_dim == in_dim && m.out_dim[0] == H9 && m.out_dim[1] == H9; }
 bool mis9(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
@@ -590,9 +580,8 @@ int run9(Bwd9Dev& d, bool dae, int nblk, const psnode_mlp_f32& de, const psnode_
         default: e = launch9_method<PSNODE_RK4_38>(d, dae, pack_de, pack_ae, s); break;
     }
     if (e != hipSuccess) return PSNODE_ERR_HIP;
-    const int nwg = (int)((d.a.B + 15) / 16), np = d.NP_de + d.NP_ae;
-    hipLaunchKernelGGL(reduce_partials9, dim3((np + 255) / 256), dim3(256), 0, s, d.wpart, gp_de, gp_ae, d.NP_de, d.NP_ae, nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    const int nwg = (int)((d.a.B + 15) / 16);
+    return launch_reduce_partials(d.wpart, gp_de, gp_ae, d.NP_de, d.NP_ae, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // namespace

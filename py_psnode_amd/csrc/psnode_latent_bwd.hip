@@ -285,14 +285,6 @@ __global__ __launch_bounds__(64) void latent_ode_backward_kernel(const LatentBwd
     }
 }
 
-__global__ void reduce_partials_latent(const float* __restrict__ part, float* __restrict__ out, int np, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int q = 0; q < nwg; ++q) acc += part[(size_t)q * np + pidx];
-    out[pidx] = acc;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // K8 (DAE): the same single-wave scheme for the latent DAE at hidden 16 (K3a's DAE shapes: blocks x | [z] | v | i of width 16,
 // DE = Linear(12H|9H,H) ELU Linear(H,H), AE = Linear(7H|5H,H) ELU Linear(H,H)).  Every matrix is a set of 16x16 blocks held in
@@ -574,16 +566,6 @@ __global__ __launch_bounds__(64) void latent16_dae_backward_kernel(const LatentD
     }
 }
 
-__global__ void reduce_partials_latent_dae(const float* __restrict__ part, float* __restrict__ out_de, float* __restrict__ out_ae, int np_de,
-                                           int np_ae, int nwg) {
-    const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_de + np_ae;
-    if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int q = 0; q < nwg; ++q) acc += part[(size_t)q * np + pidx];
-    if (pidx < np_de) out_de[pidx] = acc;
-    else out_ae[pidx - np_de] = acc;
-}
-
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -626,8 +608,7 @@ int latent_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStr
         default: hipLaunchKernelGGL((latent_ode_backward_kernel<PSNODE_RK4_38>), grid, block, 0, s, d, pack); break;
     }
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    hipLaunchKernelGGL(reduce_partials_latent, dim3((LNP + 255) / 256), dim3(256), 0, s, wpart, a->grad_params, LNP, nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    return launch_reduce_partials(wpart, a->grad_params, nullptr, LNP, 0, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 // ---- DAE entry points
@@ -685,9 +666,7 @@ int latent16_dae_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, 
     }
 #undef PSNODE_L16
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    hipLaunchKernelGGL(reduce_partials_latent_dae, dim3((npd + npa + 255) / 256), dim3(256), 0, s, workspace, a->grad_params_de,
-                       a->grad_params_ae, npd, npa, nwg);
-    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    return launch_reduce_partials(workspace, a->grad_params_de, a->grad_params_ae, npd, npa, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // namespace psnode
