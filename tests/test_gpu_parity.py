@@ -545,3 +545,27 @@ def test_shapes_beyond_every_kernel_fall_back_to_the_walk():
         s.fused = "require"
         with pytest.raises((_lib.UnsupportedShapeError, ValueError)):
             s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
+
+
+def test_fused_call_is_capturable_in_a_hip_graph():
+    """Nothing in a fused call synchronises the host, so the 3-launch sequence (pack, event table, integrator) can be captured in a
+    HIP graph by the caller and replayed on new data in the same buffers."""
+    B, Tn = 64, 40
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, seed=77)
+    layers = dl(ls)
+    tc, xc, zc, ac = t.cuda(), x.cuda(), z.cuda(), a0.cuda()
+    out = torch.empty(Tn, B, 8, device="cuda")
+    fused().ode_integrate("rk4", layers, tc, xc, zc, ac, out=out)            # warm-up outside the capture (workspace sizing etc.)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            fused().ode_integrate("rk4", layers, tc, xc, zc, ac, out=out)
+    ls2, t2, x2, z2, a02 = _synthetic_ode(B, Tn, seed=78)
+    xc.copy_(x2.cuda()); zc.copy_(z2.cuda()); ac.copy_(a02.cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = fused().ode_integrate("rk4", layers, tc, xc, zc, ac)
+    assert torch.equal(out, ref)
+    assert rel_err(out.cpu(), O.integrate_ode("rk4", ls, t, x2, z2, a02)) <= TOL_GPU
