@@ -3,15 +3,18 @@
 `integrate_ODE` / `integrate_DAE` keep the reference's keyword names, tensor layout (time-major views in,
 fresh contiguous [T,B,D] out) and error behaviour (my_solvers.py:11-29, 52-131).  When the right-hand
 sides are the reference's ELU-MLPs on a HIP device the whole time loop runs in ONE fused HIP launch
-(py_psnode_amd.fused -> libpsnode_hip.so).  Arbitrary Python callbacks -- which no kernel can execute --
-and calls that need autograd are stepped through the user's own callables by `_walk_*` below.
+(py_psnode_amd.fused -> libpsnode_hip.so); with autograd in play the call becomes a torch.autograd.Function
+(fused forward kernel + one fused backward kernel, py_psnode_amd/autograd.py).  Arbitrary Python callbacks --
+which no kernel can execute -- teacher-forced training and shapes no backward kernel covers are stepped through
+the user's own callables by `_walk_*` below.
 
 `solver.fused` selects the route: "auto" (default; fused whenever the call is fusable, and it then FAILS
-LOUDLY if libpsnode_hip.so is missing -- never a silent substitute), "require" (raise if the call is not
-fusable), "off" (always the callback walk).
+LOUDLY if libpsnode_hip.so is missing -- never a silent substitute; a call on a HIP device that has to walk
+says so once with a RuntimeWarning), "require" (raise if the call is not fusable), "off" (always the walk).
 """
 import abc
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -57,6 +60,14 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
             return grid
         return _grid_constructor
 
+    def _note_walk(self, what, tensor):
+        """The walk is the reference's own route, but on a HIP device it is ~100x slower than the fused one: never silent."""
+        if self.fused == "auto" and tensor.device.type == "cuda" and not getattr(self, "_walk_warned", False):
+            self._walk_warned = True
+            warnings.warn(f"{what}: this call is not fusable (needs fp32 HIP tensors, DE_Func/AE_Func-style ELU-MLPs, "
+                          "ODE_Event/DAE_Event callbacks; under autograd also a shape with a backward kernel and no teacher "
+                          "forcing) -- stepping through the Python callables instead", RuntimeWarning, stacklevel=3)
+
     @abc.abstractmethod
     def _step_func(self, func, t0, dt, t1, x0, z0=None, v0=None, i0=None, all_initial=None):
         """-> (dx, f0)"""
@@ -84,7 +95,8 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump)
             if self.fused == "require":
                 raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style ELU-MLP "
-                                      "`x_dot`, ODE_Event callbacks; with autograd: the 3n-64-64-64-x shape class, no teacher forcing)")
+                                      "`x_dot`, ODE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
+            self._note_walk("integrate_ODE", x)
         return self._walk_ode(x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x)
 
     def _walk_ode(self, x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x):
@@ -122,7 +134,8 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump)
             if self.fused == "require":
                 raise NotFusableError("integrate_DAE: call is not fusable (needs fp32 HIP tensors, DE_Func/AE_Func-style "
-                                      "ELU-MLPs, DAE_Event callbacks and no autograd)")
+                                      "ELU-MLPs, DAE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
+            self._note_walk("integrate_DAE", z if z.numel() else v)
         return self._walk_dae(x_init, x_func, i_func, t, x, z, v, i, all_initial, event_fn, jump_change_fn,
                               input_true_x, input_true_i)
 

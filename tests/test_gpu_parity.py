@@ -540,7 +540,8 @@ def test_shapes_beyond_every_kernel_fall_back_to_the_walk():
     a0 = torch.cat((x[0], z[0]), -1)
     s = nd.Euler()
     with torch.no_grad():
-        out = s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
+        with pytest.warns(RuntimeWarning, match="not fusable"):          # the walk on a HIP device is never silent
+            out = s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
         assert out.shape == x.shape and torch.isfinite(out).all()
         s.fused = "require"
         with pytest.raises((_lib.UnsupportedShapeError, ValueError)):
