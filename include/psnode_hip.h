@@ -176,9 +176,10 @@ int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* mlp, int64_t rows, co
  * Outputs: dL/dx[0], dL/dz (per grid point; steps that took a jump put their gradient into grad_z_jump instead),
  * dL/dall_initial and dL/d(parameters) as ONE flat vector in nn.Linear order
  * [W1 (64 x 3n), b1, W2, b2, W3, b3, W4 (x_dim x 64), b4] (psnode_ode_backward_param_count floats).
- * Kernels: the MFMA backward for the shape class 3n -> 64 -> 64 -> 64 -> x_dim (x_dim <= 8, z_dim <= 4), the generic
- * backward for any MLP whose activations + parameter gradients fit the 160 KB LDS.  No teacher forcing; t carries no
- * gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
+ * Kernels: MFMA backwards for the shape classes 3n -> 64 -> 64 -> 64 -> x_dim (x_dim <= 8, z_dim <= 4) and the latent
+ * 6H -> H -> H with x_dim = z_dim = H in {16, 64} (16-byte aligned rows); the generic backward for any MLP whose activations
+ * fit the 160 KB LDS (its parameter-gradient accumulators move to the workspace when they do not).  No teacher forcing;
+ * t carries no gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
 typedef struct {
     int32_t method;
     int32_t kernel;                  /* psnode_kernel: AUTO = MFMA backward when the shape has one, else generic */
@@ -211,7 +212,8 @@ int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* works
  * grad_params_de / grad_params_ae: flat nn.Linear-order vectors (psnode_dae_backward_param_counts). */
 typedef struct {
     int32_t method;
-    int32_t kernel;                  /* PSNODE_KERNEL_AUTO: the MFMA backward (K7) when the shape has one, else the generic one */
+    int32_t kernel;                  /* PSNODE_KERNEL_AUTO: an MFMA backward when the shape has one (3n-64-64-64 DE + AE with
+                                        x <= 8, z+v+i <= 8; the latent blocks-of-H shapes, H in {16, 64}), else the generic one */
     int32_t x_dim, z_dim, v_dim, i_dim;
     int64_t T, B;
     psnode_mlp_f32 de, ae;
