@@ -175,13 +175,20 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     const float* vp = a.v.p + b * a.v.sb;
     const float* vjp = a.vj + b * a.vjb;
 
-    // z|v column of grid point k for one slot (ev >= 0: the batch takes the jump values for this step)
+    // z|v column of grid point k for one slot (ev >= 0: the batch takes the jump values for this step).  In the DAE a lane's slot
+    // may be a z or a v column: both sources are read with a clamped column and the VALUE is selected -- selecting between the
+    // two base pointers per lane makes the compiler spill a pointer table to scratch and chase it with flat loads and full
+    // vmcnt(0) waits inside the time loop (3-4 k cycles per step on K2 before this change).
     auto load_zv = [&](long long k, int ev, int kind, int col) -> float {
-        if (kind == 0) return (ev >= 0 ? zjp + ev * zje : zp + k * zst)[col];
-        if constexpr (DAE) {
-            if (kind == 1) return (ev >= 0 ? vjp + ev * vje : vp + k * vst)[col];
+        if constexpr (!DAE) {
+            if (kind == 0) return (ev >= 0 ? zjp + ev * zje : zp + k * zst)[col];
+            return 0.0f;
+        } else {
+            float zval = 0.0f, vval = 0.0f;
+            if (zd > 0) zval = (ev >= 0 ? zjp + ev * zje : zp + k * zst)[kind == 0 ? col : 0];
+            if (vd > 0) vval = (ev >= 0 ? vjp + ev * vje : vp + k * vst)[kind == 1 ? col : 0];
+            return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
         }
-        return 0.0f;
     };
     auto load_de_ext = [&](long long k, int ev, Arr<NZM>& dst) {
 #pragma unroll
