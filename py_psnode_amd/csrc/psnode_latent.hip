@@ -124,7 +124,11 @@ __global__ __launch_bounds__(64) void latent_kernel(const IntegrateDev a, const 
 #pragma unroll
         for (int s = 0; s < NZV; ++s) {
             const long long off = ev >= 0 ? ev * jse[s] : k * sst[s];
+#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 8)   // timing experiment: no per-step input loads (WRONG results)
+            dst.v[s] = f4{0.01f * (float)k, 0.f, 0.f, 0.f} + 0.0f * (float)off;
+#else
             dst.v[s] = *reinterpret_cast<const f4*>((ev >= 0 ? jp[s] : sp[s]) + off + 4 * g);
+#endif
         }
     };
 
