@@ -147,3 +147,105 @@ def test_dataset_npz_roundtrip(tmp_path):
     assert len(ds) == 4 and ds[0][1].shape == (3, 3) and ds.mask.shape == ds.x.shape
     idx = np.random.default_rng(42).choice(np.arange(N), 4, replace=False)
     assert np.array_equal(ds.x.numpy(), np.load(p)["x"][idx][:, :3])
+
+
+# ----------------------------------------------------------------------------- rows a15 / a16 / f4: G6 (tests/golden/make_goldens_r2.py)
+def _sd(d, prefix):
+    return {k[len(prefix):].replace("__", "."): T(v) for k, v in d.items() if k.startswith(prefix)}
+
+
+def test_legacy_per_variable_blocks_match_reference():
+    """neural_base.DE_Func / AE_Func (neural_base.py:68-115,199-229), standalone with [B,n,1] inputs: golden G6."""
+    d = load("g6_legacy_blocks.npz")
+    xd, zd, vd, idim, H = (int(v) for v in d["dims"])
+    de, ae = nd.DE_Func(xd, zd, H), nd.AE_Func(xd, vd, idim, H)
+    sd_de, sd_ae = _sd(d, "de__"), _sd(d, "ae__")
+    assert set(sd_de) == set(de.state_dict()) and set(sd_ae) == set(ae.state_dict()), "state-dict keys differ from the reference's"
+    de.load_state_dict(sd_de)
+    ae.load_state_dict(sd_ae)
+    with torch.no_grad():
+        assert rel_err(de.set_initial(T(d["x0"]), T(d["z0"])), d["de_set_initial"]) <= TOL_ORACLE
+        assert rel_err(de.f_XZh0_H, d["de_f_XZh0_H"]) <= TOL_ORACLE
+        assert rel_err(de.get_decode_x(T(d["Xht"])), d["de_decode"]) <= TOL_ORACLE
+        assert rel_err(de(torch.zeros(5, 1), T(d["Xht"]), T(d["zt"])), d["de_forward"]) <= TOL_ORACLE
+        assert rel_err(ae(T(d["Xht"]), T(d["vt"])), d["ae_forward"]) <= TOL_ORACLE
+
+
+def _ode_base_case(d, method, dev):
+    rhs = models.DE_Func(10, (64, 64, 64), 8)
+    rhs.load_state_dict(_sd(d, "base_de__"))
+    base = nd.ODE_Base(rhs.to(dev), SOLVERS[method]())
+    c = lambda k: T(d[k]).to(dev)
+    event = nd.ODE_Event()
+    event.set_event(c("base_event_t"), c("base_z_jump"))
+    P = lambda a: a.permute(1, 0, 2)
+    return base, event, (P(c("base_t")), P(c("base_x")), P(c("base_z")), c("base_all_initial"))
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_ode_base_forward_matches_reference(method):
+    """ODE_Base.forward (neural_base.py:118-133) is a pass-through to integrate_ODE without input_true_x."""
+    d = load("g6_legacy_blocks.npz")
+    base, event, args = _ode_base_case(d, method, "cpu")
+    assert base.de_function is not None and isinstance(base.solver, nd.FixedGridODESolver)
+    with torch.no_grad():
+        assert rel_err(base(*args, event.event_fn, event.jump_change_fn), d[f"base_{method}"]) <= TOL_ORACLE
+        assert rel_err(base(*args), d[f"base_{method}_noev"]) <= TOL_ORACLE
+        assert rel_err(base(t=args[0], x=args[1], z=args[2], all_initial=args[3], event_fn=event.event_fn,
+                            jump_change_fn=event.jump_change_fn), d[f"base_{method}"]) <= TOL_ORACLE
+
+
+def _dae_base_case(d, dev, tx, ti):
+    de = models.DAE_DE_Func(14, (64, 64, 64), 8)
+    ae = models.AE_Func(26, (64, 64, 64), 2)
+    de.load_state_dict(_sd(d, "de__"))
+    ae.load_state_dict(_sd(d, "ae__"))
+    c = lambda k: T(d[k]).to(dev)
+    P = lambda a: a.permute(1, 0, 2)
+    event = nd.DAE_Event()
+    event.set_event(c("event_t"), c("z_jump"), c("v_jump"))
+    args = dict(t=P(c("t")), x=P(c("x")), z=P(c("z")), v=P(c("v")), i=P(c("i")))
+    return de.to(dev), ae.to(dev), event, args, c("x_init"), c("all_initial")
+
+
+@pytest.mark.parametrize("tx,ti", [(False, False), (True, False), (False, True), (True, True)])
+def test_dae_base_stores_fields_and_forwards_flags(tx, ti):
+    """DAE_Base (neural_base.py:232-255): the ctor's fields as upstream; upstream's forward cannot run, this one is
+    a superset taking x_init / all_initial -- checked against the reference's integrate_DAE goldens (G3) for every
+    teacher-forcing combination the stored flags select."""
+    d = load("g3_dae.npz")
+    de, ae, event, args, x_init, a0 = _dae_base_case(d, "cpu", tx, ti)
+    base = nd.DAE_Base(de, ae, nd.RK4(), flg_encode_x=False, flg_input_true_x=tx, flg_input_true_i=ti)
+    assert (base.de_function, base.ae_function, base.flg_encode_x, base.flg_input_true_x, base.flg_input_true_i) == (de, ae, False, tx, ti)
+    with pytest.raises(TypeError):
+        base(**args)                                # upstream's call shape: TypeError there too (SURVEY D8)
+    with torch.no_grad():
+        xs, is_ = base(**args, event_fn=event.event_fn, jump_change_fn=event.jump_change_fn, x_init=x_init, all_initial=a0)
+    key = f"rk4_tx{int(tx)}_ti{int(ti)}_ev1"
+    assert rel_err(xs, d[key + "_x"]) <= TOL_ORACLE and rel_err(is_, d[key + "_i"]) <= TOL_ORACLE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_ode_base_takes_the_fused_route_on_gpu(method):
+    from helpers import TOL_GPU, traj_rel_err
+    d = load("g6_legacy_blocks.npz")
+    base, event, args = _ode_base_case(d, method, "cuda")
+    base.solver.fused = "require"
+    with torch.no_grad():
+        assert traj_rel_err(base(*args, event.event_fn, event.jump_change_fn).cpu(), d[f"base_{method}"]) <= TOL_GPU
+        assert traj_rel_err(base(*args).cpu(), d[f"base_{method}_noev"]) <= TOL_GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tx,ti", [(False, False), (True, False), (False, True), (True, True)])
+def test_dae_base_takes_the_fused_route_on_gpu(tx, ti):
+    from helpers import TOL_GPU, traj_rel_err
+    d = load("g3_dae.npz")
+    de, ae, event, args, x_init, a0 = _dae_base_case(d, "cuda", tx, ti)
+    base = nd.DAE_Base(de, ae, nd.RK4(), flg_input_true_x=tx, flg_input_true_i=ti)
+    base.solver.fused = "require"
+    with torch.no_grad():
+        xs, is_ = base(**args, event_fn=event.event_fn, jump_change_fn=event.jump_change_fn, x_init=x_init, all_initial=a0)
+    key = f"rk4_tx{int(tx)}_ti{int(ti)}_ev1"
+    assert traj_rel_err(xs.cpu(), d[key + "_x"]) <= TOL_GPU and traj_rel_err(is_.cpu(), d[key + "_i"]) <= TOL_GPU
