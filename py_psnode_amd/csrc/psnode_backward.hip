@@ -81,7 +81,7 @@ __global__ void pack_bwd_kernel(const PackBwd pb) {
 }
 
 __device__ __forceinline__ f4 bmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f4 elu4b(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+__device__ __forceinline__ f4 elu4b(f4 v) { return elu_quad(v); }
 // ELU'(pre) from h = ELU(pre): 1 for pre > 0 (h > 0), exp(pre) = h + 1 otherwise
 __device__ __forceinline__ f4 dact(f4 h) {
     return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};

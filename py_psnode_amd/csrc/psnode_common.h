@@ -51,41 +51,75 @@ struct IntegrateDev {
 // libm flavour, used by the generic kernel:
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
-// Inline flavour for the MFMA kernels (no libm call, branch free):
-//   xn = min(x, 0);  q(xn) = degree-7 Taylor of expm1 for xn > -0.25 (truncation 1.5e-9 relative),
-//   exp2(xn*log2e) - 1 below (result in (-1, -0.22]: absolute error ~1 ulp of exp, <= 1.4e-7 relative);
-//   ELU(x) = max(x, 0) + q(xn)   (one of the two terms is exactly 0).
-// This min / max+add form measured 2 % faster than a v_med3 form and 6 % faster than a sign select on K1
-// (profiles/scripts/k1_elu_ab.sh, interleaved A/B on one MI355X: 4.998 / 5.110 / 5.298 ms).
-// PSNODE_ELU=1 (experiments only) is the exp2-only form: same trajectory-level error on the goldens but only ABSOLUTE
-// 2^-24 accuracy near 0-, i.e. no relative accuracy for tiny activations -- not used.
-#ifndef PSNODE_ELU
-#define PSNODE_ELU 0
+// Inline flavour for the MFMA kernels (no libm call, branch free, no select), written on float PAIRS so that the
+// arithmetic lowers to v_pk_{mul,fma,add}_f32 (one instruction for two values; the same 5 issue cycles as the scalar form --
+// profiles/r02a_ubench_valu.txt).  On gfx950 the fp32 MFMA shares the fp32 datapath with the VALU: VALU work next to
+// v_mfma_f32_16x16x4_f32 is ADDITIVE (32 cycles per MFMA + 5 per VALU instruction + 12 per v_exp, one wave per SIMD;
+// profiles/r02a_ubench_mfma.txt), so the ELU's instruction count is wall time of every kernel in this library.
+//   xc = med3(x, knee, 0)  in [knee, 0]      knee = -0.25
+//   xe = min(x, knee)      in (-inf, knee]
+//   ELU(x) = max(x, 0) + [ xc * q(xc) + (exp2(xe * log2e) - t0) ],   t0 = exp2(knee * log2e) evaluated by the same instructions
+//   * x >= knee: xe = knee, the exp term is EXACTLY 0 and xc * q(xc) is expm1 with q the degree-4 near-minimax of expm1(x)/x
+//     on [-0.25, 0] (max relative error 9.1e-8 in fp32 evaluation -- the fp32 rounding floor, same as the degree-7 Taylor form
+//     it replaces; relative accuracy is kept down to denormal x because the leading coefficient is exactly 1);
+//   * x <  knee: xc = knee, result = expm1(knee)[poly] + (e^x - e^knee): absolute error <= 2 ulp of exp on a value <= -0.22.
+//   * x >  0   : xc = 0, xe = knee: both terms are exactly 0, ELU(x) = x.
+// 3 clamps + 1 v_exp per value and 8 pack-able operations per value (4 instructions): 8 issue slots per value where the
+// round-1 form (min, degree-7 Horner, exp2 - 1, compare + select, max + add) took 14.5.  K1: 4.91 -> see DESIGN.md.
+// The knee is made opaque to the compiler so that t0 is produced by the hardware v_exp_f32 (not constant-folded by a host
+// libm whose last bit may differ): exp2(xe * log2e) - t0 must cancel EXACTLY for x >= knee.
+typedef float elu_f2 __attribute__((ext_vector_type(2)));
+typedef float elu_f4 __attribute__((ext_vector_type(4)));
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ float elu_knee() {
+    float c = -0.25f;
+    asm("" : "+v"(c));          // not volatile: loop-invariant, the compiler hoists it and the exp2 below out of the time loop
+    return c;
+}
+// Polynomial coefficients as register PAIRS: with literal operands the compiler splits about a fifth of the packed FMAs back
+// into two scalar v_fmaak/v_fmamk (literal forms exist only for the scalar opcode).  Translation units whose kernels are
+// register-bound (K7, K9) define PSNODE_ELU_LITERALS before including this header and keep the literals.
+struct EluK {
+    float knee, neg_t0;
+    elu_f2 c4, c3, c2, c1;
+};
+__device__ __forceinline__ elu_f2 elu_splat(float c) {
+    elu_f2 r = elu_f2{c, c};
+#ifndef PSNODE_ELU_LITERALS
+    asm("" : "+v"(r));
 #endif
-__device__ __forceinline__ float elu_fast(float x) {
-#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 1)   // timing experiment: ELU -> one max (WRONG results)
-    return fmaxf(x, -0.5f);
-#elif PSNODE_ELU == 1
-    return fmaxf(x, __builtin_amdgcn_exp2f(fminf(x, 0.0f) * 1.44269504088896340736f) - 1.0f);
-#else
-    const float xn = fminf(x, 0.0f);
-#if PSNODE_ELU == 5     // A/B: Estrin evaluation of the same polynomial (shorter dependency chain, 2 more ops)
-    const float x2 = xn * xn, x4 = x2 * x2;
-    const float qa = fmaf(xn, 0.5f, 1.0f), qb = fmaf(xn, 1.0f / 24.0f, 1.0f / 6.0f), qc = fmaf(xn, 1.0f / 720.0f, 1.0f / 120.0f);
-    const float lo = fmaf(qb, x2, qa), hi = fmaf(x2, 1.0f / 5040.0f, qc);
-    float p = xn * fmaf(hi, x4, lo);
-#else
-    float p = fmaf(xn, 1.0f / 5040.0f, 1.0f / 720.0f);
-    p = fmaf(xn, p, 1.0f / 120.0f);
-    p = fmaf(xn, p, 1.0f / 24.0f);
-    p = fmaf(xn, p, 1.0f / 6.0f);
-    p = fmaf(xn, p, 0.5f);
-    p = fmaf(xn, p, 1.0f);
-    p = xn * p;
-#endif
-    const float e = __builtin_amdgcn_exp2f(xn * 1.44269504088896340736f) - 1.0f;
-    return fmaxf(x, 0.0f) + (xn > -0.25f ? p : e);
-#endif
+    return r;
+}
+__device__ __forceinline__ EluK elu_consts() {
+    EluK k;
+    k.knee = elu_knee();
+    k.neg_t0 = -__builtin_amdgcn_exp2f(k.knee * kLog2e);
+    k.c4 = elu_splat(0.007513605989515781f);
+    k.c3 = elu_splat(0.04149065539240837f);
+    k.c2 = elu_splat(0.16665108501911163f);
+    k.c1 = elu_splat(0.4999995231628418f);
+    return k;
+}
+__device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const EluK& k) {
+    const elu_f2 xc = elu_f2{__builtin_amdgcn_fmed3f(x[0], k.knee, 0.0f), __builtin_amdgcn_fmed3f(x[1], k.knee, 0.0f)};
+    const elu_f2 xe = elu_f2{fminf(x[0], k.knee), fminf(x[1], k.knee)};
+    const elu_f2 xp = elu_f2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    const elu_f2 y = xe * kLog2e;
+    const elu_f2 t = elu_f2{__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+    const elu_f2 u = t + k.neg_t0;
+    elu_f2 q = __builtin_elementwise_fma(xc, k.c4, k.c3);
+    q = __builtin_elementwise_fma(xc, q, k.c2);
+    q = __builtin_elementwise_fma(xc, q, k.c1);
+    q = __builtin_elementwise_fma(xc, q, elu_f2{1.0f, 1.0f});
+    return xp + __builtin_elementwise_fma(xc, q, u);
+}
+__device__ __forceinline__ elu_f4 elu_quad(const elu_f4 v) {
+    const EluK k = elu_consts();     // loop-invariant: hoisted out of the time loop by the compiler
+    const elu_f2 a = elu_pair(elu_f2{v[0], v[1]}, k), b = elu_pair(elu_f2{v[2], v[3]}, k);
+    return elu_f4{a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ float elu_fast(const float x) {   // scalar form of the same function (bit-identical to elu_quad)
+    return elu_pair(elu_f2{x, x}, elu_consts())[0];
 }
 
 // Cooperative copy of `count` floats global -> LDS by a 256-thread workgroup (float4 when both sides are 16-B aligned),

@@ -20,7 +20,7 @@ constexpr int LTB = 16;    // trajectories per wave
 
 __device__ __forceinline__ f4 lmfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ f4 lelu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+__device__ __forceinline__ f4 lelu4(f4 v) { return elu_quad(v); }
 
 // Packed image per lane (identical for every wave): pack[reg][lane]
 //   DE: S[blk][m] (NBLK*4) | D[blk][m] (NBLK*4) | B1 (4) | W2 (4) | B2 (4) | A0[m] (n/4)          NBLK = 1 + NBE
@@ -124,11 +124,7 @@ __global__ __launch_bounds__(64) void latent_kernel(const IntegrateDev a, const 
 #pragma unroll
         for (int s = 0; s < NZV; ++s) {
             const long long off = ev >= 0 ? ev * jse[s] : k * sst[s];
-#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 8)   // timing experiment: no per-step input loads (WRONG results)
-            dst.v[s] = f4{0.01f * (float)k, 0.f, 0.f, 0.f} + 0.0f * (float)off;
-#else
             dst.v[s] = *reinterpret_cast<const f4*>((ev >= 0 ? jp[s] : sp[s]) + off + 4 * g);
-#endif
         }
     };
 

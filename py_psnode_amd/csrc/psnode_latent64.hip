@@ -21,7 +21,7 @@ constexpr int H64 = 64;
 constexpr int NW64 = 4;
 
 __device__ __forceinline__ f4 mf(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f4 elu4l(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+__device__ __forceinline__ f4 elu4l(f4 v) { return elu_quad(v); }
 // pack[wave][reg][lane]; every 64x64 block takes 16 registers: reg 4c+r = Blk[16w + i][16((w+c)&3) + 4g + r]
 //   DE: F[NBLK] | B1(4) | W2(16) | B2(4) | A0[NBLK]            F_b = Ws_b + Wd_b,  A0_b = Wa0_b - Wd_b
 //   AE: W[NBE]  | B1(4) | W2(16) | B2(4) | A0[NBLK]            blocks x | [z] | v right after the a0 group

@@ -46,7 +46,7 @@ __global__ void pack_mfma_kernel(const PackMfma p) {
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ f4 elu4(f4 v) { return f4{elu_fast(v[0]), elu_fast(v[1]), elu_fast(v[2]), elu_fast(v[3])}; }
+__device__ __forceinline__ f4 elu4(f4 v) { return elu_quad(v); }
 
 // layers 2..4 of one MLP, in registers (NWV = waves per tile = hidden / 16)
 template <int NWV>
@@ -213,11 +213,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         lds_barrier();
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
-#if defined(PSNODE_ABLATE) && (PSNODE_ABLATE & 4)   // timing experiment: no LDS read (WRONG results)
-            const f4 v = h * (float)c;
-#else
             const f4 v = xbuf[p][(w + c) & (NWV - 1)][l];
-#endif
             accA = mfma4(wm[4 * c + 0], v[0], accA);
             accB = mfma4(wm[4 * c + 1], v[1], accB);
             accA = mfma4(wm[4 * c + 2], v[2], accA);

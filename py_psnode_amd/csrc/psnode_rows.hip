@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
             f4 acc = b1r[ht];
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc = rmfma(w1[ht][m], v[m], acc);
-            h[ht] = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
+            h[ht] = elu_quad(acc);
         }
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
             f4 acc = b1r[ht];
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc = rmfma(w1[ht][m], v[m], acc);
-            h[ht] = f4{elu_fast(acc[0]), elu_fast(acc[1]), elu_fast(acc[2]), elu_fast(acc[3])};
+            h[ht] = elu_quad(acc);
             f4 tA = {0.f, 0.f, 0.f, 0.f}, tB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {

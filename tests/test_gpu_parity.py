@@ -570,3 +570,28 @@ def test_fused_call_is_capturable_in_a_hip_graph():
     ref = fused().ode_integrate("rk4", layers, tc, xc, zc, ac)
     assert torch.equal(out, ref)
     assert rel_err(out.cpu(), O.integrate_ode("rk4", ls, t, x2, z2, a02)) <= TOL_GPU
+
+
+def test_inline_elu_has_expm1_relative_accuracy():
+    """The MFMA kernels' inline ELU (psnode_common.h:elu_pair) seen through the row kernel with identity weights
+    (Linear(16,16)=I, ELU, Linear(16,16)=I: fp32 MFMA products with 1.0 and sums with 0.0 are exact, so out == ELU(in) bit for bit).
+    ATen's CPU ELU is expm1 on the negative side (what the reference runs): relative error vs fp64 expm1 must stay at the
+    few-ulp level over the whole range, including denormal-small arguments (no absolute-only accuracy near 0-)."""
+    eye = torch.eye(16)
+    ls = [(eye.cuda(), torch.zeros(16).cuda()), (eye.cuda(), torch.zeros(16).cuda())]
+    mags = torch.cat((torch.logspace(-38, 2, 16 * 4096, dtype=torch.float64), torch.linspace(0.2, 0.3, 16 * 256, dtype=torch.float64),
+                      torch.tensor([0.25, 0.2500001, 0.2499999, 17.0, 88.0, 104.0, 1e4, 0.0] * 2, dtype=torch.float64)))
+    x = torch.cat((-mags, mags)).float()
+    out = fused().mlp_rows(ls, x.view(-1, 16).cuda()).cpu().view(-1).double()
+    xd = x.double()
+    ref = torch.where(xd > 0, xd, torch.expm1(xd))
+    pos = xd > 0
+    assert torch.equal(out[pos], xd[pos]), "ELU(x) must be exactly x for x > 0"
+    neg = ~pos & (xd != 0)
+    rel = ((out[neg] - ref[neg]).abs() / ref[neg].abs())
+    worst = float(rel.max())
+    print(f"inline ELU: max relative error vs fp64 expm1 {worst:.3e} at x = {float(xd[neg][rel.argmax()]):.6g}")
+    assert worst <= 6e-7, worst                                  # <= ~5 ulp (worst case just below the knee at -0.25)
+    small = neg & (xd.abs() < 1e-3)
+    assert float(((out[small] - ref[small]).abs() / ref[small].abs()).max()) <= 1.2e-7   # 1 ulp near 0-: relative, not absolute
+    assert float(out[xd == 0].abs().max()) == 0.0
