@@ -15,6 +15,7 @@
 //            order (deterministic).  The a0- and (s-a0)-columns of dW1 are reconstructed at the end from the s-columns and
 //            sum(delta_1), because a0 is constant over time.
 //   RK adjoint: g_k[s] = h b_s g1 + h sum_{s'>s} a_{s's} gx[s'],  gx[s] = (df/dx)(x_s)^T g_k[s],  g0 = g1 + sum_s gx[s].
+#define PSNODE_ELU_LITERALS   // register-bound kernels: ELU coefficients as literals, not as 8 resident VGPRs (psnode_common.h)
 #include <string.h>
 
 #include "psnode_pack.h"
@@ -172,9 +173,13 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
         accA = bmfma(wm[0], h[0], accA); accB = bmfma(wm[1], h[1], accB);
         accA = bmfma(wm[2], h[2], accA); accB = bmfma(wm[3], h[3], accB);
         lds_barrier();
+        f4 vq[4];      // all three reads in flight before the first dependent MFMA (K1: -5 % launch time)
+#pragma unroll
+        for (int c = 1; c < 4; ++c) vq[c] = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
-            const f4 v = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+            const f4 v = vq[c];
             accA = bmfma(wm[4 * c + 0], v[0], accA); accB = bmfma(wm[4 * c + 1], v[1], accB);
             accA = bmfma(wm[4 * c + 2], v[2], accA); accB = bmfma(wm[4 * c + 3], v[3], accB);
         }

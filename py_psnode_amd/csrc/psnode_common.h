@@ -78,11 +78,7 @@ __device__ __forceinline__ float elu_knee() {
 }
 // Polynomial coefficients as register PAIRS: with literal operands the compiler splits about a fifth of the packed FMAs back
 // into two scalar v_fmaak/v_fmamk (literal forms exist only for the scalar opcode).  Translation units whose kernels are
-// register-bound (K7, K9) define PSNODE_ELU_LITERALS before including this header and keep the literals.
-struct EluK {
-    float knee, neg_t0;
-    elu_f2 c4, c3, c2, c1;
-};
+// register-bound (the backward kernels, hidden 128) define PSNODE_ELU_LITERALS before including this header and keep the literals.
 __device__ __forceinline__ elu_f2 elu_splat(float c) {
     elu_f2 r = elu_f2{c, c};
 #ifndef PSNODE_ELU_LITERALS
@@ -90,37 +86,37 @@ __device__ __forceinline__ elu_f2 elu_splat(float c) {
 #endif
     return r;
 }
-__device__ __forceinline__ EluK elu_consts() {
-    EluK k;
-    k.knee = elu_knee();
-    k.neg_t0 = -__builtin_amdgcn_exp2f(k.knee * kLog2e);
-    k.c4 = elu_splat(0.007513605989515781f);
-    k.c3 = elu_splat(0.04149065539240837f);
-    k.c2 = elu_splat(0.16665108501911163f);
-    k.c1 = elu_splat(0.4999995231628418f);
-    return k;
-}
-__device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const EluK& k) {
-    const elu_f2 xc = elu_f2{__builtin_amdgcn_fmed3f(x[0], k.knee, 0.0f), __builtin_amdgcn_fmed3f(x[1], k.knee, 0.0f)};
-    const elu_f2 xe = elu_f2{fminf(x[0], k.knee), fminf(x[1], k.knee)};
+__device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const float knee, const float neg_t0, const elu_f2 c4, const elu_f2 c3,
+                                           const elu_f2 c2, const elu_f2 c1) {
+    const elu_f2 xc = elu_f2{__builtin_amdgcn_fmed3f(x[0], knee, 0.0f), __builtin_amdgcn_fmed3f(x[1], knee, 0.0f)};
+    const elu_f2 xe = elu_f2{fminf(x[0], knee), fminf(x[1], knee)};
     const elu_f2 xp = elu_f2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
     const elu_f2 y = xe * kLog2e;
     const elu_f2 t = elu_f2{__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
-    const elu_f2 u = t + k.neg_t0;
-    elu_f2 q = __builtin_elementwise_fma(xc, k.c4, k.c3);
-    q = __builtin_elementwise_fma(xc, q, k.c2);
-    q = __builtin_elementwise_fma(xc, q, k.c1);
+    const elu_f2 u = t + neg_t0;
+    elu_f2 q = __builtin_elementwise_fma(xc, c4, c3);
+    q = __builtin_elementwise_fma(xc, q, c2);
+    q = __builtin_elementwise_fma(xc, q, c1);
     q = __builtin_elementwise_fma(xc, q, elu_f2{1.0f, 1.0f});
     return xp + __builtin_elementwise_fma(xc, q, u);
 }
+// everything up to the first elu_pair is loop-invariant: the compiler hoists it out of the time loop
+#define PSNODE_ELU_CONSTS                                                                   \
+    const float knee = elu_knee();                                                          \
+    const float neg_t0 = -__builtin_amdgcn_exp2f(knee * kLog2e);                            \
+    const elu_f2 c4 = elu_splat(0.007513605989515781f), c3 = elu_splat(0.04149065539240837f), \
+                 c2 = elu_splat(0.16665108501911163f), c1 = elu_splat(0.4999995231628418f);
 __device__ __forceinline__ elu_f4 elu_quad(const elu_f4 v) {
-    const EluK k = elu_consts();     // loop-invariant: hoisted out of the time loop by the compiler
-    const elu_f2 a = elu_pair(elu_f2{v[0], v[1]}, k), b = elu_pair(elu_f2{v[2], v[3]}, k);
+    PSNODE_ELU_CONSTS
+    const elu_f2 a = elu_pair(elu_f2{v[0], v[1]}, knee, neg_t0, c4, c3, c2, c1);
+    const elu_f2 b = elu_pair(elu_f2{v[2], v[3]}, knee, neg_t0, c4, c3, c2, c1);
     return elu_f4{a[0], a[1], b[0], b[1]};
 }
 __device__ __forceinline__ float elu_fast(const float x) {   // scalar form of the same function (bit-identical to elu_quad)
-    return elu_pair(elu_f2{x, x}, elu_consts())[0];
+    PSNODE_ELU_CONSTS
+    return elu_pair(elu_f2{x, x}, knee, neg_t0, c4, c3, c2, c1)[0];
 }
+#undef PSNODE_ELU_CONSTS
 
 // Cooperative copy of `count` floats global -> LDS by a 256-thread workgroup (float4 when both sides are 16-B aligned),
 // followed by a barrier.  Used by the generic kernels to stage one layer's weights (or a chunk of it) per use.

@@ -16,6 +16,7 @@
 // Layout trick (as in the forward kernel): the rows of the DE's W1^T tile that carry the gradient of the algebraic input
 // are packed so that they land in the very lanes/registers the AE's W4^T MFMA reads as its B operand -- the DAE feedback
 // i -> DE input costs no data movement in the backward direction either.
+#define PSNODE_ELU_LITERALS   // register-bound kernels: ELU coefficients as literals, not as 8 resident VGPRs (psnode_common.h)
 #include <string.h>
 
 #include "psnode_pack.h"
@@ -233,9 +234,13 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
         accA = bm(wm[0], h[0], accA); accB = bm(wm[1], h[1], accB);
         accA = bm(wm[2], h[2], accA); accB = bm(wm[3], h[3], accB);
         lds_barrier();
+        f4 vq[4];      // all three reads in flight before the first dependent MFMA
+#pragma unroll
+        for (int c = 1; c < 4; ++c) vq[c] = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
-            const f4 v = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+            const f4 v = vq[c];
             accA = bm(wm[4 * c + 0], v[0], accA); accB = bm(wm[4 * c + 1], v[1], accB);
             accA = bm(wm[4 * c + 2], v[2], accA); accB = bm(wm[4 * c + 3], v[3], accB);
         }

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         o.v[0] = own;
 #pragma unroll
         for (int c = 1; c < 4; ++c) o.v[c] = xbuf[p][(w + c) & 3][l];
+        __builtin_amdgcn_sched_barrier(0);
         p ^= 1;
         return o;
     };
@@ -175,9 +176,13 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         accA = mf(wr[2], own[2], accA); accB = mf(wr[3], own[3], accB);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
+        f4 vq[4];      // all three reads in flight before the first dependent MFMA
+#pragma unroll
+        for (int c = 1; c < 4; ++c) vq[c] = xbuf[p][(w + c) & 3][l];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
-            const f4 v = xbuf[p][(w + c) & 3][l];
+            const f4 v = vq[c];
             accA = mf(wr[4 * c + 0], v[0], accA); accB = mf(wr[4 * c + 1], v[1], accB);
             accA = mf(wr[4 * c + 2], v[2], accA); accB = mf(wr[4 * c + 3], v[3], accB);
         }

@@ -20,6 +20,7 @@
 // 160 accumulators stay in VGPR/AGPRs; the AE's transposed blocks and the DE's transposed z|v blocks (up to 96 KB) live
 // in LDS, each lane reading back the A-operand values it wrote; W2 of the AE (event steps only) and the a0 blocks (epilogue
 // only) are streamed from the packed image.
+#define PSNODE_ELU_LITERALS   // register-bound kernels: ELU coefficients as literals, not as 8 resident VGPRs (psnode_common.h)
 #include <string.h>
 
 #include <type_traits>

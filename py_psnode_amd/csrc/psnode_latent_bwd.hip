@@ -14,6 +14,7 @@
 // Layout: D row 4g+r of every tile is unit/dim 4g+r and the K order of a 16-wide block is column 4g+m for MFMA m
 // (K3a's convention): a lane's four D registers are its four B operands of the next product, and every global access of
 // a lane (state, z block, gradients) is one aligned float4.
+#define PSNODE_ELU_LITERALS   // register-bound kernels: ELU coefficients as literals, not as 8 resident VGPRs (psnode_common.h)
 #include <string.h>
 
 #include "psnode_common.h"

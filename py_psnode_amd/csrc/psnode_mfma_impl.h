@@ -200,20 +200,32 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     };
 
     int p = 0;   // exchange buffer parity
+    // 4 waves per tile = one per SIMD: nothing else hides the exchange latency, so all reads are put in flight at once (12 VGPRs).
+    // 8 waves (hidden 128) have a second wave per SIMD to hide it and no registers to spare.
+    constexpr bool PREFETCH_ALL = NWV <= 4;
 
     // one H->H layer: publish own activations, multiply own K slice, barrier, multiply the other NWV-1 slices
     auto mid = [&](const float (&wm)[4 * NWV], const f4 bias, const f4 h) -> f4 {
         xbuf[p][w][l] = h;
         f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        // the wave's own K quarter goes in front of the barrier (covers the LDS write); behind it ALL reads are issued before the
+        // first dependent MFMA (sched_barrier pins that order: left alone, the compiler serialises read -> wait -> 4 MFMAs three
+        // times, +0.25 ms per launch on K1).  Moving own-quarter MFMAs behind the reads instead measured 2.5 % slower.
         accA = mfma4(wm[0], h[0], accA);
         accB = mfma4(wm[1], h[1], accB);
         accA = mfma4(wm[2], h[2], accA);
         accB = mfma4(wm[3], h[3], accB);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
+        f4 vq[NWV];
+        if constexpr (PREFETCH_ALL) {
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) vq[c] = xbuf[p][(w + c) & (NWV - 1)][l];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
-            const f4 v = xbuf[p][(w + c) & (NWV - 1)][l];
+            const f4 v = PREFETCH_ALL ? vq[c] : xbuf[p][(w + c) & (NWV - 1)][l];
             accA = mfma4(wm[4 * c + 0], v[0], accA);
             accB = mfma4(wm[4 * c + 1], v[1], accB);
             accA = mfma4(wm[4 * c + 2], v[2], accA);
