@@ -275,6 +275,36 @@ typedef struct {
 size_t psnode_masked_mse_workspace_bytes(const psnode_loss_args_f32* args);
 int32_t psnode_masked_mse_f32(const psnode_loss_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The WHOLE forward of the direct_encode ODE model in one launch -- replaces ODE_Model.forward of
+ * neural_00_ODE_02_direct_encode.py:74-89 (hidden_dim = 16, the script's default):
+ *
+ *   Xh = x_encoder(x); Zh = z_encoder(z); a0 = cat(Xh[0], Zh[0]); Zh_jump = z_encoder(z_jump)
+ *   Xh_sol = integrate_ODE(de, t, Xh, Zh, a0, events on Zh_jump)                (my_solvers.py:52-80)
+ *   x_pred = x_decoder(Xh_sol);  x_re = x_decoder(Xh)
+ *
+ * t, x, z are the scripts' RAW tensors as time-major views (permute(1,0,2) of [B,T,*]); z_jump is the RAW [B,nE,z_dim] tensor
+ * (encoded in the kernel at the steps that take a jump); event_idx as produced by psnode_event_table_f32.
+ * Every MLP is Linear(in,16) ELU Linear(16,out): x_encoder x_dim->16->16, z_encoder z_dim->16->16, x_decoder 16->16->x_dim,
+ * de 96->16->16 (x_dim, z_dim <= 16).  Xh, Zh and Xh_sol never reach memory (108 B of HBM traffic per state-step instead of ~490);
+ * xh_out (optional) receives the latent trajectory [T,B,16] for callers that want it.  No workspace. */
+typedef struct {
+    int32_t method;                  /* psnode_method */
+    int32_t x_dim, z_dim;
+    int64_t T, B;
+    psnode_mlp_f32 x_encoder, z_encoder, x_decoder, de;
+    psnode_view_f32 t, x, z;         /* [T,B,1], [T,B,x_dim], [T,B,z_dim] */
+    const int32_t* event_idx;        /* int32[T-1] or NULL */
+    const float* z_jump;             /* raw [B,nE,z_dim] */
+    int64_t zj_stride_b, zj_stride_e;
+    float* x_pred;                   /* [T,B,x_dim] contiguous */
+    float* x_re;                     /* x_re[t*xre_stride_t + b*xre_stride_b + d], or NULL to skip the reconstruction */
+    int64_t xre_stride_t, xre_stride_b;
+    float* xh_out;                   /* [T,B,16] contiguous or NULL */
+} psnode_ode_encoded_args_f32;
+
+int32_t psnode_ode_encoded_supported(const psnode_ode_encoded_args_f32* args);   /* 1 / 0, dims only */
+int32_t psnode_ode_encoded_integrate_f32(const psnode_ode_encoded_args_f32* args, void* stream);
+
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);

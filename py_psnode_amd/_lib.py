@@ -27,6 +27,7 @@ EXPORTS = (
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
+    "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
 )
 
 
@@ -86,6 +87,14 @@ class DaeBwdArgsF32(ctypes.Structure):
                 ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
                 ("grad_x_init", c_void_p), ("grad_z", c_void_p), ("grad_v", c_void_p), ("grad_z_jump", c_void_p),
                 ("grad_v_jump", c_void_p), ("grad_all_initial", c_void_p), ("grad_params_de", c_void_p), ("grad_params_ae", c_void_p)]
+
+
+class OdeEncodedArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64),
+                ("x_encoder", MlpF32), ("z_encoder", MlpF32), ("x_decoder", MlpF32), ("de", MlpF32),
+                ("t", ViewF32), ("x", ViewF32), ("z", ViewF32), ("event_idx", c_void_p), ("z_jump", c_void_p),
+                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_pred", c_void_p), ("x_re", c_void_p),
+                ("xre_stride_t", c_int64), ("xre_stride_b", c_int64), ("xh_out", c_void_p)]
 
 
 class LossArgsF32(ctypes.Structure):
@@ -156,6 +165,10 @@ def load():
     lib.psnode_masked_mse_workspace_bytes.argtypes = [ctypes.POINTER(LossArgsF32)]
     lib.psnode_masked_mse_f32.restype = c_int32
     lib.psnode_masked_mse_f32.argtypes = [ctypes.POINTER(LossArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_ode_encoded_supported.restype = c_int32
+    lib.psnode_ode_encoded_supported.argtypes = [ctypes.POINTER(OdeEncodedArgsF32)]
+    lib.psnode_ode_encoded_integrate_f32.restype = c_int32
+    lib.psnode_ode_encoded_integrate_f32.argtypes = [ctypes.POINTER(OdeEncodedArgsF32), c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

@@ -34,10 +34,10 @@ class _FusedOde(torch.autograd.Function):
         return (None, None, None, None, gx0, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)
 
 
-def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None):
+def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None, check_events=False):
     """Differentiable fused integrate_ODE (no teacher forcing): gradients flow to x[0], z, all_initial, z_jump and the MLP."""
     with torch.no_grad():
-        event_idx = fused.event_table(t, event_t)
+        event_idx = fused.event_table(t, event_t, check_events)
     if event_idx is None:
         z_jump = None
     params = [p for wb in layers for p in wb]
@@ -78,11 +78,12 @@ class _FusedDae(torch.autograd.Function):
                 g["z_jump"] if ctx.needs_input_grad[10] else None, g["v_jump"] if ctx.needs_input_grad[11] else None, *g["de"], *g["ae"])
 
 
-def fused_dae_integrate(method, kernel, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None):
+def fused_dae_integrate(method, kernel, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None,
+                        check_events=False):
     """Differentiable fused integrate_DAE (no teacher forcing): gradients flow to x_init, z, v, all_initial, the jump inputs and
     both MLPs.  `i` only provides the width of the algebraic variable (the dataset values are unused without teacher forcing)."""
     with torch.no_grad():
-        event_idx = fused.event_table(t, event_t)
+        event_idx = fused.event_table(t, event_t, check_events)
     if event_idx is None:
         z_jump = v_jump = None
     else:

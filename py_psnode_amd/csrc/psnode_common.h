@@ -214,6 +214,8 @@ bool latent_shape_ok(const IntegrateDev& a, bool dae);
 bool latent_ptrs_ok(const IntegrateDev& a, bool dae);
 size_t latent_pack_floats();
 hipError_t launch_latent(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+// K3f (psnode_latent_dpp.hip): the latent ODE at hidden 16 on VALU + DPP row broadcasts (any alignment)
+hipError_t launch_latent_dpp(const IntegrateDev& a, hipStream_t stream);
 
 // psnode_latent64.hip (direct_encode latent shapes, hidden_dim 64)
 bool latent64_shape_ok(const IntegrateDev& a, bool dae);

@@ -260,8 +260,8 @@ bool latent_shape_ok(const IntegrateDev& a, bool dae) {
 }
 
 bool latent_ptrs_ok(const IntegrateDev& a, bool dae) {
+    if (!dae) return true;   // K3f reads lane-granular
     if ((reinterpret_cast<uintptr_t>(a.a0) & 15) || (reinterpret_cast<uintptr_t>(a.xo) & 15)) return false;
-    if (!dae) return aligned4(a.x) && aligned4(a.z) && (!a.ev || ((reinterpret_cast<uintptr_t>(a.zj) & 15) == 0 && a.zjb % 4 == 0 && a.zje % 4 == 0));
     if ((reinterpret_cast<uintptr_t>(a.x_init) & 15) || (reinterpret_cast<uintptr_t>(a.io) & 15)) return false;
     if (a.zd && !aligned4(a.z)) return false;
     if (!aligned4(a.v)) return false;
@@ -284,6 +284,7 @@ static hipError_t launch_latent_method(const IntegrateDev& a, bool dae, const fl
 }
 
 hipError_t launch_latent(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
+    if (!dae) return launch_latent_dpp(a, stream);   // ODE: K3f (4 trajectories per wave, every SIMD busy); K3a below serves the DAE
     const int nblk = dae ? (a.zd ? 4 : 3) : 2;
     PackLatent p;
     p.ae = 0; p.nblk = nblk; p.n = nblk * LH; p.k1 = 3 * p.n;

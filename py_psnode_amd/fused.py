@@ -132,7 +132,7 @@ def event_table(t: torch.Tensor, event_t: Optional[torch.Tensor], check_duplicat
     (two events at one time make its `.view(z0.shape)` fail).
     """
     T = t.shape[0]
-    if event_t is None or T < 2:
+    if event_t is None or T < 2 or event_t.shape[1] == 0:      # an empty event list is "no events", as in the reference
         return None
     lib = _lib.load()
     dev = t.device
@@ -430,6 +430,71 @@ def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
                                      torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_mlp_rows_f32")
     return out
+
+
+def ode_encoded_supported(x_encoder: Layers, z_encoder: Layers, x_decoder: Layers, de_layers: Layers) -> bool:
+    """Shapes of the fused direct_encode ODE forward (psnode_ode_encoded_integrate_f32): every MLP 2 layers with hidden 16."""
+    try:
+        shapes = [(l[0][0].shape, l[1][0].shape) for l in (x_encoder, z_encoder, x_decoder, de_layers)]
+    except (IndexError, TypeError):
+        return False
+    if any(len(l) != 2 for l in (x_encoder, z_encoder, x_decoder, de_layers)):
+        return False
+    (xe1, xe2), (ze1, ze2), (xd1, xd2), (de1, de2) = shapes
+    H = 16
+    return (xe1[0] == H and tuple(xe2) == (H, H) and ze1[0] == H and tuple(ze2) == (H, H) and tuple(xd1) == (H, H) and xd2[1] == H
+            and xd2[0] == xe1[1] and tuple(de1) == (H, 6 * H) and tuple(de2) == (H, H) and 1 <= xe1[1] <= H and 1 <= ze1[1] <= H)
+
+
+def ode_encoded_integrate(method: str, x_encoder: Layers, z_encoder: Layers, x_decoder: Layers, de_layers: Layers, t, x, z,
+                          event_t=None, z_jump=None, event_idx=None, want_recon: bool = True, want_latent: bool = False,
+                          check_events: bool = False):
+    """The whole ODE_Model.forward of neural_00_ODE_02_direct_encode.py:74-89 in ONE launch (hidden_dim 16): encoders, latent
+    integrate_ODE, decoder of the solution and the reconstruction x_decoder(x_encoder(x)).  t, x, z are the scripts' B-major
+    tensors [B,T,*] (any strides with a contiguous last dim); z_jump is the RAW [B,nE,z_dim] tensor.  Returns
+    (x_pred [B,T,xd] as the permuted view of a time-major buffer -- like the script --, x_re [B,T,xd] or None, Xh_sol [T,B,16] or None)."""
+    lib = _lib.load()
+    dev = x.device
+    keep: list = []
+    a = _lib.OdeEncodedArgsF32()
+    a.method = METHOD_ID[method]
+    B, T, xd = x.shape
+    zd = z.shape[-1]
+    if t.shape[:2] != (B, T) or z.shape[:2] != (B, T):
+        raise ValueError(f"ode_encoded_integrate: t {tuple(t.shape)}, x {tuple(x.shape)}, z {tuple(z.shape)} disagree on [B,T]")
+    a.x_dim, a.z_dim, a.T, a.B = xd, zd, T, B
+    a.x_encoder = _mlp(x_encoder, dev, "x_encoder", keep)
+    a.z_encoder = _mlp(z_encoder, dev, "z_encoder", keep)
+    a.x_decoder = _mlp(x_decoder, dev, "x_decoder", keep)
+    a.de = _mlp(de_layers, dev, "de", keep)
+    if not lib.psnode_ode_encoded_supported(ctypes.byref(a)):
+        raise _lib.UnsupportedShapeError("ode_encoded_integrate: needs x_encoder xd->16->16, z_encoder zd->16->16, x_decoder 16->16->xd, de 96->16->16")
+    a.t = _view(t.permute(1, 0, 2), dev, "t", keep)
+    a.x = _view(x.permute(1, 0, 2), dev, "x", keep)
+    a.z = _view(z.permute(1, 0, 2), dev, "z", keep)
+    if event_idx is None and event_t is not None and event_t.shape[1] > 0 and T > 1:
+        event_idx = event_table(t.permute(1, 0, 2), event_t, check_duplicates=check_events)
+    if event_idx is not None:
+        if z_jump is None:
+            raise ValueError("ode_encoded_integrate: events need z_jump")
+        if z_jump.shape[0] != B or z_jump.shape[-1] != zd:
+            raise ValueError(f"ode_encoded_integrate: z_jump {tuple(z_jump.shape)} does not match [B={B}, nE, zd={zd}]")
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+    x_pred = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+    a.x_pred = x_pred.data_ptr()
+    x_re = xh = None
+    if want_recon:
+        x_re = torch.empty((B, T, xd), dtype=torch.float32, device=dev)
+        a.x_re, a.xre_stride_t, a.xre_stride_b = x_re.data_ptr(), xd, T * xd
+    if want_latent:
+        xh = torch.empty((T, B, 16), dtype=torch.float32, device=dev)
+        a.xh_out = xh.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.psnode_ode_encoded_integrate_f32(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_ode_encoded_integrate_f32")
+    return x_pred.permute(1, 0, 2), x_re, xh
 
 
 def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor, need_grad_in: bool = True):

@@ -128,6 +128,9 @@ class ODE_Model(nn.Module):
             xs = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=_tm(x), z=_tm(z), all_initial=a0,
                                            event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
             return _tm(xs)
+        fused_out = self._forward_encoded(t, x, z, event_t, z_jump)
+        if fused_out is not None:
+            return fused_out
         Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view
         Xh = _tm(Xh_bt)
         Zh = _tm(_rows(self.z_encoder, z))
@@ -139,6 +142,32 @@ class ODE_Model(nn.Module):
         # x_decoder(Xh).permute(1,0,2) without first materialising the permuted view
         return _tm(_rows(self.x_decoder, Xh_sol)), _rows(self.x_decoder, Xh_bt)
 
+
+    def _forward_encoded(self, t, x, z, event_t, z_jump):
+        """The whole direct_encode forward in ONE HIP launch (psnode_ode_encoded_integrate_f32: encoders, latent integration,
+        decoder, reconstruction -- Xh / Zh / Xh_solution never reach memory) when nothing needs autograd, the tensors are fp32 on a
+        HIP device, hidden_dim is 16 and the solver is one of this package's with fusing allowed; None otherwise (the caller then
+        takes the row kernels + solver route, which is also the training route)."""
+        from . import fused
+        from .neural_dae.my_solvers import FixedGridODESolver
+        solver = self.solver
+        if not isinstance(solver, FixedGridODESolver) or getattr(solver, "fused", "off") == "off" or not solver.method:
+            return None
+        if x.device.type != "cuda" or any(a.dtype != torch.float32 for a in (t, x, z)) or x.dim() != 3 or x.shape[1] < 1:
+            return None
+        if not getattr(type(self.event), "_psnode_event", False) or type(self.de_func) is not DE_Func:
+            return None
+        mlps = [fused.sequential_layers(m) for m in (self.x_encoder, self.z_encoder, self.x_decoder, self.de_func.x_dot)]
+        if any(m is None for m in mlps) or not fused.ode_encoded_supported(*mlps):
+            return None
+        if fused._needs_autograd([x, z, z_jump] + [p for m in mlps for wb in m for p in wb]):
+            return None
+        if event_t is not None and (event_t.dtype != torch.float32 or z_jump is None or z_jump.dtype != torch.float32):
+            return None
+        self.event.set_event(t=event_t, z=z_jump)                 # state as upstream leaves it (raw jumps: nothing reads Zh_jump)
+        x_pred, x_re, _ = fused.ode_encoded_integrate(solver.method, *mlps, t, x, z, event_t=event_t, z_jump=z_jump,
+                                                      check_events=solver._check_events_now(event_t))
+        return x_pred, x_re
 
     _EXPORTS = ("x_encoder", "x_decoder", "z_encoder", "de_func")
 

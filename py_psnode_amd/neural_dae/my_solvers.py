@@ -41,6 +41,10 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
         self.total_time = 0
         self.fused = os.environ.get("PSNODE_FUSED", "auto")
         self.kernel = os.environ.get("PSNODE_KERNEL", "auto")
+        # Two events at one time stamp make the reference's jump_change_fn raise (neural_base.py:61); the fused event table would
+        # take the first.  True: read the table kernel's duplicate flag back (one 4-byte D2H per call, skipped when the event list
+        # has fewer than two entries or the stream is being captured into a HIP graph) and raise like the reference.
+        self.check_events = os.environ.get("PSNODE_CHECK_EVENTS", "1") != "0"
         if step_size is not None and grid_constructor is not None:
             raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
         if grid_constructor is not None:
@@ -68,6 +72,10 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                           "ODE_Event/DAE_Event callbacks; under autograd also a shape with a backward kernel and no teacher "
                           "forcing) -- stepping through the Python callables instead", RuntimeWarning, stacklevel=3)
 
+    def _check_events_now(self, event_t):
+        return (self.check_events and event_t is not None and event_t.dim() == 3 and event_t.shape[1] > 1
+                and not torch.cuda.is_current_stream_capturing())
+
     @abc.abstractmethod
     def _step_func(self, func, t0, dt, t1, x0, z0=None, v0=None, i0=None, all_initial=None):
         """-> (dx, f0)"""
@@ -85,14 +93,16 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                 if not needs_grad:
                     try:
                         return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
-                                                    input_true_x=input_true_x, kernel=self.kernel)
+                                                    input_true_x=input_true_x, kernel=self.kernel,
+                                                    check_events=self._check_events_now(event_t))
                     except UnsupportedShapeError:      # no kernel covers the shape (too wide for LDS): user callables it is
                         if self.fused == "require":
                             raise
                 # training: fused forward + fused backward when the backward kernel covers the shape
                 elif not input_true_x and _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1]):
                     from ..autograd import fused_ode_integrate
-                    return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump)
+                    return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
+                                               check_events=self._check_events_now(event_t))
             if self.fused == "require":
                 raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style ELU-MLP "
                                       "`x_dot`, ODE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
@@ -124,14 +134,16 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     try:
                         return _fused.dae_integrate(self.method, de, ae, x_init, t, x, z, v, i, all_initial, event_t=event_t,
                                                     z_jump=z_jump, v_jump=v_jump, input_true_x=input_true_x,
-                                                    input_true_i=input_true_i, kernel=self.kernel)
+                                                    input_true_i=input_true_i, kernel=self.kernel,
+                                                    check_events=self._check_events_now(event_t))
                     except UnsupportedShapeError:
                         if self.fused == "require":
                             raise
                 elif not (input_true_x or input_true_i) and _fused.dae_backward_supported(
                         self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]):
                     from ..autograd import fused_dae_integrate
-                    return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump)
+                    return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump,
+                                               check_events=self._check_events_now(event_t))
             if self.fused == "require":
                 raise NotFusableError("integrate_DAE: call is not fusable (needs fp32 HIP tensors, DE_Func/AE_Func-style "
                                       "ELU-MLPs, DAE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")

@@ -1,0 +1,147 @@
+"""K3f: the whole direct_encode ODE forward in one launch (psnode_ode_encoded_integrate_f32, neural_00_ODE_02_direct_encode.py:74-89)
+and the DPP latent integrator behind psnode_ode_integrate_f32 at hidden 16 -- against the CPU oracle (encoders/decoders as
+plain fp32 nn.functional ops, oracle.integrate_ode for the latent loop) and the golden model forwards G4-ode02."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import TOL_GPU, T, load, traj_rel_err
+from oracle import psnode_oracle as O
+
+pytestmark = pytest.mark.gpu
+METHODS = ["euler", "midpoint", "rk4"]
+
+
+def fused():
+    from py_psnode_amd import fused as f
+    return f
+
+
+def _mlp2(din, dout, H=16):
+    l1, l2 = nn.Linear(din, H), nn.Linear(H, dout)
+    return [(l1.weight.detach(), l1.bias.detach()), (l2.weight.detach(), l2.bias.detach())]
+
+
+def _apply(ls, a):
+    return F.linear(F.elu(F.linear(a, *ls[0])), *ls[1])
+
+
+def _case(B, Tn, xd, zd, seed, events=True, ragged_clock=True):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    H = 16
+    xe, ze, xdec, de = _mlp2(xd, H), _mlp2(zd, H), _mlp2(H, xd), _mlp2(6 * H, H)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    if ragged_clock and B > 1:
+        t[1:] = t[1:] * (0.5 + torch.rand(B - 1, 1, 1, generator=g))
+    x, z = 0.3 * torch.randn(B, Tn, xd, generator=g), 0.3 * torch.randn(B, Tn, zd, generator=g)
+    ev = zj = None
+    if events and Tn > 4:
+        ev = t[:, [1, Tn - 2], :].contiguous()
+        zj = 0.3 * torch.randn(B, 2, zd, generator=g)
+    return xe, ze, xdec, de, t, x, z, ev, zj
+
+
+def _oracle(method, xe, ze, xdec, de, t, x, z, ev, zj):
+    P = lambda a: a.permute(1, 0, 2)
+    Xh, Zh = _apply(xe, x), _apply(ze, z)
+    a0 = torch.cat((Xh[:, 0], Zh[:, 0]), -1)
+    Zhj = _apply(ze, zj) if zj is not None else None
+    Xs = O.integrate_ode(method, de, P(t), P(Xh), P(Zh), a0, ev, Zhj)
+    return _apply(xdec, Xs).permute(1, 0, 2), _apply(xdec, Xh), Xs
+
+
+def _dev(ls):
+    return [(w.cuda(), b.cuda()) for w, b in ls]
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("B,Tn,xd,zd", [(37, 23, 8, 2), (16, 9, 5, 3), (1, 2, 1, 1), (21, 1, 8, 2), (64, 12, 16, 16), (3, 40, 12, 9)])
+def test_encoded_forward_matches_oracle(method, B, Tn, xd, zd):
+    xe, ze, xdec, de, t, x, z, ev, zj = _case(B, Tn, xd, zd, seed=B * 100 + Tn)
+    ref_pred, ref_re, ref_xs = _oracle(method, xe, ze, xdec, de, t, x, z, ev, zj)
+    c = lambda a: None if a is None else a.cuda()
+    pred, re, xh = fused().ode_encoded_integrate(method, _dev(xe), _dev(ze), _dev(xdec), _dev(de), c(t), c(x), c(z), event_t=c(ev),
+                                                 z_jump=c(zj), want_latent=True)
+    assert pred.shape == (B, Tn, xd) and re.shape == (B, Tn, xd) and xh.shape == (Tn, B, 16)
+    assert traj_rel_err(pred.cpu(), ref_pred, bdim=0) <= TOL_GPU
+    assert traj_rel_err(re.cpu(), ref_re, bdim=0) <= TOL_GPU
+    assert traj_rel_err(xh.cpu(), ref_xs, bdim=1) <= TOL_GPU
+
+
+def test_encoded_forward_strided_inputs_and_no_recon():
+    """Inputs as non-contiguous slices of wider tensors (element strides travel through the C ABI); reconstruction skipped."""
+    B, Tn, xd, zd = 19, 15, 8, 2
+    xe, ze, xdec, de, t, x, z, ev, zj = _case(B, Tn, xd, zd, seed=5)
+    ref_pred, _, _ = _oracle("rk4", xe, ze, xdec, de, t, x, z, ev, zj)
+    big = torch.zeros(B, Tn + 3, xd + zd + 5).cuda()
+    big[:, 1:Tn + 1, 2:2 + xd] = x.cuda()
+    big[:, 1:Tn + 1, 2 + xd:2 + xd + zd] = z.cuda()
+    xv, zv = big[:, 1:Tn + 1, 2:2 + xd], big[:, 1:Tn + 1, 2 + xd:2 + xd + zd]
+    assert not xv.is_contiguous()
+    pred, re, xh = fused().ode_encoded_integrate("rk4", _dev(xe), _dev(ze), _dev(xdec), _dev(de), t.cuda(), xv, zv, event_t=ev.cuda(),
+                                                 z_jump=zj.cuda(), want_recon=False)
+    assert re is None and xh is None
+    assert traj_rel_err(pred.cpu(), ref_pred, bdim=0) <= TOL_GPU
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_model_forward_takes_the_single_launch_route(method):
+    """models.ODE_Model(direct_encode) under no_grad: one fused launch, equal (to tolerance) to the row-kernel + solver route that
+    training uses, and to the reference's golden forward G4-ode02."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    d = load("g4_model_ode02.npz")
+    m = models.ODE_Model(8, 2, 16, direct_encode=True)
+    m.load_state_dict({k[4:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("sd__")})
+    m = m.cuda()
+    m.solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+    m.solver.fused = "require"
+    g = lambda k: T(d[k]).cuda()
+    calls = []
+    orig = fused().ode_encoded_integrate
+    try:
+        fused().ode_encoded_integrate = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        with torch.no_grad():
+            pred, re = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+    finally:
+        fused().ode_encoded_integrate = orig
+    assert calls == [1], "the no-grad direct_encode forward must be ONE fused launch"
+    assert traj_rel_err(pred.cpu(), d[f"{method}_out0"], bdim=0) <= TOL_GPU
+    assert traj_rel_err(re.cpu(), d[f"{method}_out1"], bdim=0) <= TOL_GPU
+    # the training route (autograd on): row kernels + latent integrator + row kernels -- same numbers to tolerance
+    pred2, re2 = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+    assert pred2.requires_grad
+    assert traj_rel_err(pred2.detach().cpu(), pred.cpu(), bdim=0) <= TOL_GPU and traj_rel_err(re2.detach().cpu(), re.cpu(), bdim=0) <= TOL_GPU
+
+
+def test_encoded_forward_full_size_matches_unfused_route():
+    """BASELINE config 3 size (B=4096, T=1001): the single launch against the round-1 route (row kernels + latent integrator) on the
+    GPU, and 32 of the trajectories against the CPU oracle."""
+    B, Tn, xd, zd = 4096, 1001, 8, 2
+    xe, ze, xdec, de, t, x, z, ev, zj = _case(B, Tn, xd, zd, seed=77, ragged_clock=False)
+    f = fused()
+    c = lambda a: a.cuda()
+    pred, re, xh = f.ode_encoded_integrate("rk4", _dev(xe), _dev(ze), _dev(xdec), _dev(de), c(t), c(x), c(z), event_t=c(ev), z_jump=c(zj),
+                                           want_latent=True)
+    Xh, Zh = f.mlp_rows(_dev(xe), c(x)), f.mlp_rows(_dev(ze), c(z))
+    a0 = torch.cat((Xh[:, 0], Zh[:, 0]), -1)
+    Xs = f.ode_integrate("rk4", _dev(de), c(t).permute(1, 0, 2), Xh.permute(1, 0, 2), Zh.permute(1, 0, 2), a0, event_t=c(ev),
+                         z_jump=f.mlp_rows(_dev(ze), c(zj)))
+    assert traj_rel_err(xh.cpu(), Xs.cpu(), bdim=1) <= TOL_GPU
+    assert traj_rel_err(pred.cpu(), f.mlp_rows(_dev(xdec), Xs).permute(1, 0, 2).cpu(), bdim=0) <= TOL_GPU
+    assert traj_rel_err(re.cpu(), f.mlp_rows(_dev(xdec), Xh).cpu(), bdim=0) <= TOL_GPU
+    sel = torch.arange(0, B, B // 32)
+    ref_pred, ref_re, _ = _oracle("rk4", xe, ze, xdec, de, t[sel], x[sel], z[sel], ev[sel], zj[sel])
+    # events are decided by GLOBAL trajectory 0, which is in `sel`
+    assert traj_rel_err(pred.cpu()[sel], ref_pred, bdim=0) <= TOL_GPU and traj_rel_err(re.cpu()[sel], ref_re, bdim=0) <= TOL_GPU
+
+
+def test_encoded_unsupported_shape_raises():
+    from py_psnode_amd import _lib
+    xe, ze, xdec, de, t, x, z, ev, zj = _case(4, 5, 8, 2, seed=1, events=False)
+    bad = _mlp2(6 * 16, 16, H=32)
+    assert not fused().ode_encoded_supported(_dev(xe), _dev(ze), _dev(xdec), _dev(bad))
+    with pytest.raises(_lib.UnsupportedShapeError):
+        fused().ode_encoded_integrate("rk4", _dev(xe), _dev(ze), _dev(xdec), _dev(bad), t.cuda(), x.cuda(), z.cuda())
