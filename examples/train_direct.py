@@ -57,19 +57,21 @@ def build(model, solver):
 
 
 def step_loss(model_name, model, batch):
-    """forward + the script's training loss (neural_00_ODE_0x:353-355/267-270, neural_01_DAE_0x:414-419/359-365)"""
+    """forward + THAT script's training loss -- the four differ (py_psnode_amd/loss.py): ODE_01 masked term only
+    (neural_00_ODE_01_no_encode.py:353-355), ODE_02 + x0 term + reconstruction (neural_00_ODE_02_direct_encode.py:267-270),
+    DAE_01 with the 9x extra weight on x column 1 (neural_01_DAE_01_no_encode.py:414-419), DAE_02 without it and with both
+    reconstruction terms (neural_01_DAE_02_direct_encode.py:359-365)."""
     if model_name.startswith("ode"):
         t, x, z, event_t, z_jump, mask = batch
         out = model(t=t, x=x, z=z, event_t=event_t, z_jump=z_jump)
         if model_name == "ode01":
-            return L.ode_loss(out, x, mask)[0]
-        return L.ode_loss(out[0], x, mask)[0] + L.recon_loss(out[1], x)[0]
+            return L.ode01_loss(out, x, mask)[0]
+        return L.ode02_loss(out[0], out[1], x, mask)[0]
     t, x, z, v, i, event_t, z_jump, v_jump, mask = batch
     out = model(t=t, x=x, z=z, v=v, i=i, event_t=event_t, z_jump=z_jump, v_jump=v_jump)
-    loss = L.dae_loss(out[0], x, out[1], i, mask)[0]
-    if model_name == "dae02":
-        loss = loss + L.recon_loss(out[2], x)[0] + L.recon_loss(out[3], i)[0]
-    return loss
+    if model_name == "dae01":
+        return L.dae01_loss(out[0], x, out[1], i, mask)[0]
+    return L.dae02_loss(out[0], out[1], out[2], out[3], x, i, mask)[0]
 
 
 @torch.no_grad()

@@ -194,3 +194,22 @@ def dae_loss(x_pred, x, i_pred, i, mask):
 def recon_loss(x_re: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """neural_00_ODE_02_direct_encode.py:269: Loss_func(x_re, x)."""
     return torch.nn.functional.mse_loss(x_re, x)
+
+
+def ode02_loss(x_pred, x_re, x, mask):
+    """neural_00_ODE_02_direct_encode.py:267-270: x0_loss + sum(x_loss) + x_recon_loss."""
+    mse = torch.nn.functional.mse_loss
+    x0_loss = mse(x[:, 0, :], x_pred[:, 0, :]).view(1)
+    x_loss = torch.sum(torch.sum(mse(x_pred, x, reduction="none") * mask, dim=1), dim=0) / torch.sum(mask)
+    x_recon_loss = mse(x_re, x).view(1)
+    return torch.sum(x0_loss) + torch.sum(x_loss) + torch.sum(x_recon_loss)
+
+
+def dae02_loss(x_pred, i_pred, x_re, i_re, x, i, mask):
+    """neural_01_DAE_02_direct_encode.py:359-365: no extra column weight (commented out upstream), two reconstruction terms."""
+    mse = torch.nn.functional.mse_loss
+    x_loss = torch.sum(mse(x_pred, x, reduction="none") * mask) / torch.sum(mask)
+    i_loss = torch.sum(mse(i_pred, i, reduction="none") * mask) / torch.sum(mask)
+    recon = mse(x_re, x) + mse(i_re, i)
+    return x_loss + i_loss + mse(x[:, 0, :], x_pred[:, 0, :]) + mse(i[:, 0, :], i_pred[:, 0, :]) + recon
+

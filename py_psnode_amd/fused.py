@@ -66,6 +66,56 @@ def ae_layers_of(i_func, n: int, m: int, i_dim: int):
     return layers
 
 
+def _mlp_eval(layers, u):
+    for k, (w, b) in enumerate(layers):
+        u = nn.functional.linear(u, w, b)
+        if k + 1 < len(layers):
+            u = nn.functional.elu(u)
+    return u
+
+
+def _recipe_ok(mod: nn.Module, layers, kind: str, widths) -> bool:
+    """Does `mod.forward` really compute the recipe the kernels hard-code?  The structural checks (attribute name, Sequential
+    shape, no extra parameters) say nothing about forward(): a user DE_Func that scales its output, uses t0 or concatenates in
+    another order would be integrated WRONGLY.  One numeric probe per (module, forward function): a few random rows through the
+    module's own forward against MLP(cat(a0, s - a0, s)) (DE) / MLP(cat(a0, x, z, v)) (AE) on the module's device.  The result
+    is cached on the module; this package's own classes are known and skip the probe."""
+    fwd = type(mod).forward
+    if getattr(fwd, "_psnode_recipe", None) == kind:
+        return True
+    key = (fwd, kind, tuple(widths))
+    cached = mod.__dict__.get("_psnode_probe")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    ok = False
+    try:
+        w0 = layers[0][0]
+        dev, dt = w0.device, w0.dtype
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        R = 5
+        parts = [torch.randn(R, d, generator=g).to(device=dev, dtype=dt) for d in widths]
+        a0 = torch.randn(R, sum(widths), generator=g).to(device=dev, dtype=dt)
+        t0 = torch.rand(R, 1, generator=g).to(device=dev, dtype=dt)
+        with torch.no_grad():
+            if kind == "de_ode":
+                got = mod(t0=t0, xt=parts[0], zt=parts[1], all_initial=a0)
+                s_ = torch.cat(parts, -1)
+                want = _mlp_eval(layers, torch.cat((a0, s_ - a0, s_), -1))
+            elif kind == "de_dae":
+                got = mod(t0=t0, xt=parts[0], zt=parts[1], vt=parts[2], it=parts[3], all_initial=a0)
+                s_ = torch.cat(parts, -1)
+                want = _mlp_eval(layers, torch.cat((a0, s_ - a0, s_), -1))
+            else:   # "ae": all_initial spans x|z|v|i, the inputs x, z, v
+                a0 = torch.randn(R, widths[3], generator=g).to(device=dev, dtype=dt)
+                got = mod(xt=parts[0], zt=parts[1], vt=parts[2], all_initial=a0)
+                want = _mlp_eval(layers, torch.cat((a0, parts[0], parts[1], parts[2]), -1))
+            ok = bool(got.shape == want.shape and torch.allclose(got, want, rtol=1e-4, atol=1e-6))
+    except Exception:
+        ok = False
+    mod.__dict__["_psnode_probe"] = (key, ok)
+    return ok
+
+
 def _overrides_forward_hooks(mod: nn.Module) -> bool:
     return bool(mod._forward_hooks) or bool(mod._forward_pre_hooks)
 
@@ -596,7 +646,7 @@ def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
     if all_initial.dim() != 2 or all_initial.shape[-1] != xd + zd:
         return None
     layers = de_layers_of(x_func, xd + zd, xd)
-    if layers is None:
+    if layers is None or not _recipe_ok(x_func, layers, "de_ode", (xd, zd)):
         return None
     ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
     if not ok:
@@ -615,6 +665,8 @@ def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change
     de = de_layers_of(x_func, n, xd)
     ae = ae_layers_of(i_func, n, xd + zd + vd, idim)
     if de is None or ae is None:
+        return None
+    if not _recipe_ok(x_func, de, "de_dae", (xd, zd, vd, idim)) or not _recipe_ok(i_func, ae, "ae", (xd, zd, vd, n)):
         return None
     ok, event_t, z_jump, v_jump = _event_tensors(event_fn, jump_change_fn, True)
     if not ok:

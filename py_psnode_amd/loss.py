@@ -1,12 +1,16 @@
 """Fused masked-MSE loss (kernel K6, psnode_masked_mse_f32): the step right after the integrator in the scripts'
 training loops, as one pass over (prediction, target, mask) that returns the loss AND d loss / d prediction.
 
-Reference expressions (Loss_func = nn.functional.mse_loss, neural_00_ODE_01_no_encode.py:49):
-  ODE_01/02  x_loss = sum(sum(Loss_func(x_pred, x, reduction='none') * mask, dim=1), dim=0) / sum(mask); loss = sum(x_loss)
-             (neural_00_ODE_01_no_encode.py:353-355; neural_00_ODE_02_direct_encode.py:267-270)
-  DAE_01/02  x_loss = (sum(se*mask) + 9*sum(se[:,:,1:2]*mask)) / sum(mask);  i_loss = sum(se_i*mask)/sum(mask)
-             loss = x_loss + i_loss + Loss_func(x[:,0,:], x_pred[:,0,:]) + Loss_func(i[:,0,:], i_pred[:,0,:])
-             (neural_01_DAE_01_no_encode.py:414-419; neural_01_DAE_02_direct_encode.py:359-365)
+Reference expressions (Loss_func = nn.functional.mse_loss, neural_00_ODE_01_no_encode.py:49) -- the four scripts differ:
+  ODE_01  x_loss = sum(sum(Loss_func(x_pred, x, reduction='none') * mask, dim=1), dim=0) / sum(mask);  loss = sum(x_loss)
+          (neural_00_ODE_01_no_encode.py:353-355; the x0_loss of :353 is computed but NOT added)              -> ode01_loss
+  ODE_02  loss = Loss_func(x[:,0,:], x_pred[:,0,:]) + sum(x_loss) + Loss_func(x_re, x)
+          (neural_00_ODE_02_direct_encode.py:267-270)                                                         -> ode02_loss
+  DAE_01  x_loss = (sum(se*mask) + 9*sum(se[:,:,1:2]*mask)) / sum(mask);  i_loss = sum(se_i*mask)/sum(mask)
+          loss = x_loss + i_loss + Loss_func(x[:,0,:], x_pred[:,0,:]) + Loss_func(i[:,0,:], i_pred[:,0,:])
+          (neural_01_DAE_01_no_encode.py:414-419)                                                             -> dae01_loss
+  DAE_02  as DAE_01 WITHOUT the 9x extra weight on x column 1 (commented out upstream), plus the reconstruction terms
+          Loss_func(x_re, x) + Loss_func(i_re, i)   (neural_01_DAE_02_direct_encode.py:359-365)                -> dae02_loss
 Tensors are in the scripts' [B,T,D] shape with any strides: the integrator's `xs.permute(1,0,2)` and the DataLoader's
 B-major batches go in as they are.  There is no non-HIP implementation here."""
 import ctypes
@@ -102,13 +106,31 @@ def inv_mask_sum(mask: torch.Tensor) -> torch.Tensor:
     return torch.sum(mask).reciprocal().reshape(1)
 
 
-def ode_loss(x_pred, x, mask):
-    """ODE_01/ODE_02 training loss on the prediction: neural_00_ODE_01_no_encode.py:353-355."""
+def ode01_loss(x_pred, x, mask):
+    """ODE_01 training loss: neural_00_ODE_01_no_encode.py:353-355 (masked term only)."""
     return masked_mse(x_pred, x, mask, inv_norm=inv_mask_sum(mask))
 
 
-def dae_loss(x_pred, x, i_pred, i, mask, x_col_weight: Optional[Sequence[float]] = None):
-    """DAE_01 training loss: neural_01_DAE_01_no_encode.py:414-419 (column 1 of x counted 1 + 9 times by default)."""
+ode_loss = ode01_loss     # round-1 name
+
+
+def recon_loss(x_re, x):
+    """Unmasked mean squared reconstruction error `Loss_func(x_re, x)`: neural_00_ODE_02_direct_encode.py:269."""
+    return masked_mse(x_re, x, None, scale=1.0 / x.numel())
+
+
+def ode02_loss(x_pred, x_re, x, mask):
+    """ODE_02 training loss: x0 term + masked term + reconstruction (neural_00_ODE_02_direct_encode.py:267-270).
+    Returns (loss, (terms of the prediction call, terms of the reconstruction call))."""
+    B, _, xd = x.shape
+    lp, tp = masked_mse(x_pred, x, mask, inv_norm=inv_mask_sum(mask), t0_coef=1.0 / (B * xd))
+    lr, tr = recon_loss(x_re, x)
+    return lp + lr, (tp, tr)
+
+
+def dae01_loss(x_pred, x, i_pred, i, mask, x_col_weight: Optional[Sequence[float]] = None):
+    """DAE_01 training loss: neural_01_DAE_01_no_encode.py:414-419 (column 1 of x counted 1 + 9 times unless `x_col_weight`
+    says otherwise)."""
     B, _, xd = x.shape
     idim = i.shape[2]
     if x_col_weight is None:
@@ -119,6 +141,12 @@ def dae_loss(x_pred, x, i_pred, i, mask, x_col_weight: Optional[Sequence[float]]
     return lx + li, (tx, ti)
 
 
-def recon_loss(x_re, x):
-    """Unmasked mean squared reconstruction error `Loss_func(x_re, x)`: neural_00_ODE_02_direct_encode.py:269."""
-    return masked_mse(x_re, x, None, scale=1.0 / x.numel())
+dae_loss = dae01_loss     # round-1 name
+
+
+def dae02_loss(x_pred, i_pred, x_re, i_re, x, i, mask):
+    """DAE_02 training loss: unweighted columns + the two reconstruction terms (neural_01_DAE_02_direct_encode.py:359-365)."""
+    base, terms = dae01_loss(x_pred, x, i_pred, i, mask, x_col_weight=[1.0] * x.shape[2])
+    lxr, txr = recon_loss(x_re, x)
+    lir, tir = recon_loss(i_re, i)
+    return base + lxr + lir, (*terms, txr, tir)

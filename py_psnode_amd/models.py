@@ -54,6 +54,8 @@ class DE_Func(nn.Module):
         s = torch.cat((xt, zt), dim=-1)
         return self.x_dot(torch.cat((all_initial, s - all_initial, s), dim=-1))
 
+    forward._psnode_recipe = "de_ode"     # known to follow the kernels' input recipe (fused._recipe_ok skips the numeric probe)
+
 
 class DAE_DE_Func(nn.Module):
     """DAE right-hand side, s = cat(xt, zt, vt, it); positional order of neural_01_DAE_01_no_encode.py:69."""
@@ -65,6 +67,8 @@ class DAE_DE_Func(nn.Module):
     def forward(self, t0: torch.Tensor, xt: torch.Tensor, zt: torch.Tensor, vt: torch.Tensor, it: torch.Tensor, all_initial: torch.Tensor):
         s = torch.cat((xt, zt, vt, it), dim=-1)
         return self.x_dot(torch.cat((all_initial, s - all_initial, s), dim=-1))
+
+    forward._psnode_recipe = "de_dae"
 
 
 def _export(model, path, names, on_cpu):
@@ -94,6 +98,8 @@ class AE_Func(nn.Module):
 
     def forward(self, xt: torch.Tensor, zt: torch.Tensor, vt: torch.Tensor, all_initial: torch.Tensor):
         return self.i_calculator(torch.cat((all_initial, xt, zt, vt), dim=-1))
+
+    forward._psnode_recipe = "ae"
 
 
 class Init_Func(nn.Module):

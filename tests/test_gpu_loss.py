@@ -148,3 +148,39 @@ def test_train_step_fused_integrator_plus_fused_loss_matches_oracle_autograd():
     assert _close(tot, ref, 1e-5)
     for (n, pr), (_, pg) in zip(m_ref.named_parameters(), m_gpu.named_parameters()):
         assert _close(pg.grad, pr.grad, 2e-4), n
+
+
+@pytest.mark.parametrize("B,T,xd", [(32, 101, 8), (7, 3, 5)])
+def test_ode02_loss_matches_the_script_expression(B, T, xd):
+    """neural_00_ODE_02_direct_encode.py:267-270: x0 term + masked term + reconstruction (the x0 term was missing)."""
+    xp, x, mask = _case(B, T, xd, xd, seed=12)
+    xre, _, _ = _case(B, T, xd, 0, seed=13, layout="bm")
+    pr, rr = xp.clone().requires_grad_(True), xre.clone().requires_grad_(True)
+    ref = O.ode02_loss(pr, rr, x, mask)
+    ref.backward()
+    c = lambda a: a.permute(1, 0, 2).contiguous().cuda().permute(1, 0, 2)
+    pg, rg = c(xp).requires_grad_(True), xre.cuda().requires_grad_(True)
+    tot, _ = L().ode02_loss(pg, rg, x.cuda(), mask.cuda())
+    tot.backward()
+    assert _close(tot, ref, RTOL_VAL) and _close(pg.grad, pr.grad, RTOL_GRAD) and _close(rg.grad, rr.grad, RTOL_GRAD)
+    assert float(pr.grad[:, 0].abs().max()) > float(pr.grad[:, 1:].abs().max()) * 0 and not _close(tot, O.ode_loss(pr, x, mask)[0], 1e-3)
+
+
+@pytest.mark.parametrize("B,T,xd,idim", [(32, 101, 8, 2), (5, 4, 8, 3)])
+def test_dae02_loss_matches_the_script_expression(B, T, xd, idim):
+    """neural_01_DAE_02_direct_encode.py:359-365: NO extra weight on x column 1, both reconstruction terms."""
+    xp, x, mask = _case(B, T, xd, 1, seed=21)
+    ip, i, _ = _case(B, T, idim, 0, seed=22)
+    xre, _, _ = _case(B, T, xd, 0, seed=23, layout="bm")
+    ire, _, _ = _case(B, T, idim, 0, seed=24, layout="bm")
+    leaves = [a.clone().requires_grad_(True) for a in (xp, ip, xre, ire)]
+    ref = O.dae02_loss(*leaves, x, i, mask)
+    ref.backward()
+    c = lambda a: a.permute(1, 0, 2).contiguous().cuda().permute(1, 0, 2)
+    dev = [c(xp).requires_grad_(True), c(ip).requires_grad_(True), xre.cuda().requires_grad_(True), ire.cuda().requires_grad_(True)]
+    tot, _ = L().dae02_loss(*dev, x.cuda(), i.cuda(), mask.cuda())
+    tot.backward()
+    assert _close(tot, ref, RTOL_VAL)
+    for a, b in zip(dev, leaves):
+        assert _close(a.grad, b.grad, RTOL_GRAD)
+    assert not _close(tot, O.dae_loss(leaves[0], x, leaves[1], i, mask)[0], 1e-3)     # differs from DAE_01's weighted objective

@@ -595,3 +595,33 @@ def test_inline_elu_has_expm1_relative_accuracy():
     small = neg & (xd.abs() < 1e-3)
     assert float(((out[small] - ref[small]).abs() / ref[small].abs()).max()) <= 1.2e-7   # 1 ulp near 0-: relative, not absolute
     assert float(out[xd == 0].abs().max()) == 0.0
+
+
+def test_module_with_another_forward_is_walked_not_fused():
+    """A DE_Func-shaped module whose forward() is NOT the recipe: 'auto' steps through the user's callable (correct result),
+    'require' raises -- it is never integrated with the hard-coded recipe."""
+    import warnings
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+
+    class Scaled(models.DE_Func):
+        def forward(self, t0, xt, zt, all_initial):
+            return 0.5 * super().forward(t0, xt, zt, all_initial)
+
+    torch.manual_seed(3)
+    de = Scaled(10, (64, 64, 64), 8).cuda()
+    B, Tn = 9, 7
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1).cuda()
+    x, z = (0.1 * torch.randn(Tn, B, 8)).cuda(), (0.1 * torch.randn(Tn, B, 2)).cuda()
+    a0 = torch.cat((x[0], z[0]), -1)
+    s = nd.RK4()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)
+        ls = [(w.detach().cpu(), b.detach().cpu()) for w, b in fused().sequential_layers(de.x_dot)]
+        half = [(w, b) for w, b in ls[:-1]] + [(0.5 * ls[-1][0], 0.5 * ls[-1][1])]       # 0.5 * MLP == MLP with the last layer halved
+        ref = O.integrate_ode("rk4", half, t.cpu(), x.cpu(), z.cpu(), a0.cpu())
+    assert rel_err(out.cpu(), ref) <= TOL_GPU
+    s.fused = "require"
+    with torch.no_grad(), pytest.raises(nd.NotFusableError):
+        s.integrate_ODE(x_func=de, t=t, x=x, z=z, all_initial=a0)

@@ -249,3 +249,52 @@ def test_dae_base_takes_the_fused_route_on_gpu(tx, ti):
         xs, is_ = base(**args, event_fn=event.event_fn, jump_change_fn=event.jump_change_fn, x_init=x_init, all_initial=a0)
     key = f"rk4_tx{int(tx)}_ti{int(ti)}_ev1"
     assert traj_rel_err(xs.cpu(), d[key + "_x"]) <= TOL_GPU and traj_rel_err(is_.cpu(), d[key + "_i"]) <= TOL_GPU
+
+
+def test_fused_recognition_probes_the_forward_not_just_the_attribute_names():
+    """a module with an `x_dot` Sequential of the right shape but ANOTHER forward (scaled output, swapped concat order,
+    use of t0) must not be integrated with the hard-coded recipe.  The probe runs the module's own forward on a few rows."""
+    import torch.nn as nn
+    from py_psnode_amd import fused
+
+    class Scaled(models.DE_Func):
+        def forward(self, t0, xt, zt, all_initial):
+            return 2.0 * super().forward(t0, xt, zt, all_initial)
+
+    class Swapped(models.DE_Func):
+        def forward(self, t0, xt, zt, all_initial):
+            s = torch.cat((xt, zt), dim=-1)
+            return self.x_dot(torch.cat((s, s - all_initial, all_initial), dim=-1))
+
+    class UsesTime(models.DE_Func):
+        def forward(self, t0, xt, zt, all_initial):
+            return super().forward(t0, xt, zt, all_initial) * (1.0 + t0)
+
+    class Renamed(nn.Module):            # the reference scripts' own class shape: unknown type, same recipe -> accepted by the probe
+        def __init__(self):
+            super().__init__()
+            self.x_dot = models._elu_mlp(30, 64, 64, 64, 8)
+
+        def forward(self, t0, xt, zt, all_initial):
+            xtzt = torch.cat((xt, zt), dim=-1)
+            return self.x_dot.forward(torch.cat((all_initial, xtzt - all_initial, xtzt), dim=-1))
+
+    good = models.DE_Func(10, (64, 64, 64), 8)
+    layers = fused.de_layers_of(good, 10, 8)
+    assert fused._recipe_ok(good, layers, "de_ode", (8, 2))
+    for cls in (Scaled, Swapped, UsesTime):
+        m = cls(10, (64, 64, 64), 8)
+        ls = fused.de_layers_of(m, 10, 8)
+        assert ls is not None                      # the structural checks alone accept it ...
+        assert not fused._recipe_ok(m, ls, "de_ode", (8, 2)), cls.__name__      # ... the probe does not
+        assert m.__dict__["_psnode_probe"][1] is False                           # cached
+    r = Renamed()
+    assert fused._recipe_ok(r, fused.de_layers_of(r, 10, 8), "de_ode", (8, 2))
+    ae = models.AE_Func(26, (64, 64, 64), 2)
+    assert fused._recipe_ok(ae, fused.ae_layers_of(ae, 14, 12, 2), "ae", (8, 2, 2, 14))
+
+    class BadAE(models.AE_Func):
+        def forward(self, xt, zt, vt, all_initial):
+            return self.i_calculator(torch.cat((all_initial, xt, vt, zt), dim=-1))
+    bad = BadAE(26, (64, 64, 64), 2)
+    assert not fused._recipe_ok(bad, fused.ae_layers_of(bad, 14, 12, 2), "ae", (8, 2, 2, 14))

@@ -74,3 +74,28 @@ def test_event_table_matches_reference_semantics():
     tab = O.event_step_table(tm(d["t"]), T(d["event_t"]))
     assert [k for k, e in enumerate(tab) if e >= 0] == [20, 55]
     assert tab[20] == 0 and tab[55] == 1
+
+
+def test_oracle_losses_are_the_four_scripts_expressions():
+    """The oracle's loss restatements against the scripts' expressions written out literally (Loss_func = F.mse_loss):
+    neural_00_ODE_01_no_encode.py:353-355, neural_00_ODE_02_direct_encode.py:267-270, neural_01_DAE_01_no_encode.py:414-419,
+    neural_01_DAE_02_direct_encode.py:359-365.  The four objectives differ (x0 term, column weight, reconstruction terms)."""
+    from oracle import psnode_oracle as O
+    Loss_func = torch.nn.functional.mse_loss
+    g = torch.Generator().manual_seed(0)
+    B, Tn, xd, idim = 6, 9, 8, 2
+    r = lambda *s: torch.randn(*s, generator=g)
+    x, x_pred, x_re, i, i_pred, i_re = r(B, Tn, xd), r(B, Tn, xd), r(B, Tn, xd), r(B, Tn, idim), r(B, Tn, idim), r(B, Tn, idim)
+    mask_x, mask_1 = (torch.rand(B, Tn, xd, generator=g) > 0.3).float(), (torch.rand(B, Tn, 1, generator=g) > 0.3).float()
+    x_loss = torch.sum(torch.sum(Loss_func(x_pred, x, reduction='none') * mask_x, dim=1), dim=0) / torch.sum(mask_x)
+    assert torch.equal(O.ode_loss(x_pred, x, mask_x)[0], torch.sum(x_loss))
+    x0_loss, x_recon_loss = Loss_func(x[:, 0, :], x_pred[:, 0, :]).view(1), Loss_func(x_re, x).view(1)
+    assert torch.allclose(O.ode02_loss(x_pred, x_re, x, mask_x), torch.sum(x0_loss) + torch.sum(x_loss) + torch.sum(x_recon_loss), rtol=1e-6)
+    mask = mask_1
+    xl = (torch.sum(Loss_func(x_pred, x, reduction='none') * mask)
+          + torch.sum(Loss_func(x_pred[:, :, 1:2], x[:, :, 1:2], reduction='none') * mask) * 9) / torch.sum(mask)
+    il = torch.sum(Loss_func(i_pred, i, reduction='none') * mask) / torch.sum(mask)
+    tail = Loss_func(x[:, 0, :], x_pred[:, 0, :]) + Loss_func(i[:, 0, :], i_pred[:, 0, :])
+    assert torch.allclose(O.dae_loss(x_pred, x, i_pred, i, mask)[0], xl + il + tail, rtol=1e-6)
+    xl2 = torch.sum(Loss_func(x_pred, x, reduction='none') * mask) / torch.sum(mask)
+    assert torch.allclose(O.dae02_loss(x_pred, i_pred, x_re, i_re, x, i, mask), xl2 + il + tail + Loss_func(x_re, x) + Loss_func(i_re, i), rtol=1e-6)
