@@ -246,7 +246,7 @@ def main():
     n_out = 1 if w["kind"] == "ode" else 2
     from py_psnode_amd import sharded
     do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train   # training never gathers (sharded loss)
-    pipelined = do_gather and w["kind"] == "ode" and args.chunks > 1
+    pipelined = do_gather and w["kind"] in ("ode", "dae") and args.chunks > 1
     gathered = None
     if do_gather and not pipelined:
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
@@ -323,14 +323,20 @@ def main():
             return outs
         if pipelined:
             tab = fused.event_table(tmv(p["t"]), p["event_t"])
-            xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
-                                                           event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
-                                                           kernel=args.kernel)
+            if w["kind"] == "ode":
+                xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
+                                                               event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
+                                                               kernel=args.kernel)
+                outs = (xs,)
+            else:
+                outs, _, works = sharded.integrate_dae_pipelined(args.method, p["de"], p["ae"], p["x_init"], tmv(p["t"]), tmv(p["z"]),
+                                                                 tmv(p["v"]), tmv(p["i"]), p["a0"], event_idx=tab, z_jump=p["z_jump"],
+                                                                 v_jump=p["v_jump"], chunks=args.chunks, wait=False, kernel=args.kernel)
             if ev_pair:
                 ev_pair[1].record()
             for wk in works:
                 wk.wait()
-            return (xs,)
+            return outs
         outs = run_fused(fused, w, p, args.method, args.kernel)
         if ev_pair:
             ev_pair[1].record()
@@ -362,17 +368,20 @@ def main():
         elapsed, kern_avg_ms = float(tt[0]), float(tt[1])
 
     gather_only_ms = None
-    if do_gather and w["kind"] == "ode":
-        # config 5 also wants the gather alone: one un-pipelined all-gather of a full [T,B,xd] shard, after the timed region
-        flat = torch.empty((world * T, B, w["xd"]), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(flat, outs[0])
+    if do_gather and w["kind"] in ("ode", "dae"):
+        # config 5 also wants the gather alone: un-pipelined all-gathers of the full [T,B,D] shards, after the timed region
+        flats = [torch.empty((world * T, B, o.shape[-1]), dtype=torch.float32, device=dev) for o in outs]
+        srcs = [o.contiguous() for o in outs]
+        for f_, o in zip(flats, srcs):
+            dist.all_gather_into_tensor(f_, o)
         fence()
         tg = time.perf_counter()
         for _ in range(3):
-            dist.all_gather_into_tensor(flat, outs[0])
+            for f_, o in zip(flats, srcs):
+                dist.all_gather_into_tensor(f_, o)
         fence()
         gather_only_ms = (time.perf_counter() - tg) / 3 * 1e3
-        del flat
+        del flats, srcs
 
     finite = bool(torch.isfinite(outs[0]).all())
     state_steps_launch = B * (T - 1)
@@ -399,6 +408,8 @@ def main():
             a.ae = fused._mlp(p["ae"], dev, "ae", [])
             auto_kernel = lib.psnode_dae_kernel_for(a)
         kname = args.kernel if args.kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
+        if kname == "mfma" and w["H"] == 16 and w["kind"] in ("ode", "ode02_model"):
+            kname = "valu_dpp"       # K3f: the hidden-16 latent ODE runs on VALU + DPP row broadcasts (psnode_latent_dpp.hip)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and not args.hidden and not args.train:
@@ -415,8 +426,8 @@ def main():
             "config": {"workload": f"{args.workload} {args.method}: B={B} trajectories/GPU x {T - 1} steps, x{w['xd']} z{w['zd']}"
                                    + (f" v{w['vd']} i{w['id']}" if w["kind"] == "dae" else "") + f" H{w['H']}, fp32, h=0.01, no events",
                        "kernel": kname, "trajectories_total": world * B,
-                       "collective": ((f"rccl all_gather of xs shards [T,B,xd], {args.chunks} time chunks overlapped with the integration"
-                                       if pipelined else "rccl all_gather of xs shards [T,B,xd]") if do_gather else "none"),
+                       "collective": ((f"rccl all_gather of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration"
+                                       if pipelined else "rccl all_gather of the output shards [T,B,D]") if do_gather else "none"),
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel_ms": kern_avg_ms, "flop_per_state_step": flops,

@@ -18,3 +18,11 @@ def install_as_neural_dae():
     sys.modules["neural_dae.my_solvers"] = my_solvers
     sys.modules["neural_dae.my_fixed_grid"] = my_fixed_grid
     return nd
+
+
+def accelerate(model):
+    """Encoders / decoders of a direct_encode model (the reference's own script classes included) onto the fused HIP row kernels;
+    see py_psnode_amd.models.accelerate."""
+    from .models import accelerate as _acc
+    return _acc(model)
+

@@ -42,6 +42,46 @@ def _rows(seq, inp):
     return fused.mlp_rows_autograd(seq, inp) if needs_grad else fused.mlp_rows(layers, inp)
 
 
+class RowsSequential(nn.Sequential):
+    """An `nn.Sequential(Linear, ELU, Linear)` -- same children, same parameters, same state-dict keys -- whose forward runs on the
+    fused HIP row kernels (psnode_mlp_rows_f32 / _backward_f32) whenever the call is fusable (fp32 HIP tensor, hidden 16 / 64), and
+    is the plain Sequential otherwise (CPU, other widths, TorchScript export: `torch.jit.script` compiles only the plain loop)."""
+
+    def forward(self, input):
+        if not torch.jit.is_scripting():
+            return _rows_of_accelerated(self, input)
+        for module in self:
+            input = module(input)
+        return input
+
+
+@torch.jit.unused
+def _rows_of_accelerated(seq, inp):
+    from . import fused
+    layers = fused.rows_layers_of(seq, inp, allow_grad=True)
+    if layers is None:
+        return nn.Sequential.forward(seq, inp)
+    needs_grad = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in seq.parameters()))
+    return fused.mlp_rows_autograd(seq, inp) if needs_grad else fused.mlp_rows(layers, inp)
+
+
+def accelerate(model: nn.Module, names=("_encoder", "_decoder")) -> nn.Module:
+    """Put the encoders / decoders of a direct_encode model -- the REFERENCE'S OWN ODE_Model / DAE_Model of
+    neural_00_ODE_02_direct_encode.py:64-69 / neural_01_DAE_02_direct_encode.py:107-118 included -- on the fused row kernels:
+    every direct child whose name ends in `_encoder` / `_decoder` and that is exactly `nn.Sequential(Linear, ELU(1), Linear)` has
+    its class swapped in place to `RowsSequential`.  Parameters, buffers, state-dict keys, optimizer references and the
+    TorchScript export (`save_model`) are unchanged; `accelerate` is idempotent and returns the model."""
+    from . import fused
+    for name, child in model.named_children():
+        if not name.endswith(tuple(names)) or type(child) is not nn.Sequential:
+            continue
+        layers = fused.sequential_layers(child)
+        if layers is None or len(layers) != 2:
+            continue
+        child.__class__ = RowsSequential
+    return model
+
+
 class DE_Func(nn.Module):
     """ODE right-hand side: x_dot MLP over cat(a0, s - a0, s), s = cat(xt, zt).  Positional order of forward() as in
     neural_00_ODE_01_no_encode.py:66 -- the TorchScript export (`save_model`) is called positionally downstream."""

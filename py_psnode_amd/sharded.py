@@ -37,12 +37,32 @@ def broadcast_event_table(t_local: torch.Tensor, event_t_local: Optional[torch.T
     return tab
 
 
+_EQUAL_SHARDS_OK = set()
+
+
+def _require_equal_shards(Bl: int, device, group=None):
+    """all_gather_into_tensor needs the same shard size on every rank; with unequal shards (B not a multiple of the world size)
+    it hangs or fails inside RCCL.  One tiny max-reduce the first time a (group, shard size) is seen -- every rank makes the same
+    sequence of collective calls -- raises a clear error on all ranks instead."""
+    key = (id(group), Bl, str(device))
+    if key in _EQUAL_SHARDS_OK:
+        return
+    sizes = torch.tensor([Bl, -Bl], device=device)
+    dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(sizes[0]), int(-sizes[1])
+    if hi != lo:
+        raise ValueError(f"the all-gather needs equal shards on every rank (this rank {Bl}, range {lo}..{hi} trajectories): "
+                         "pad the batch or shard a multiple of the world size")
+    _EQUAL_SHARDS_OK.add(key)
+
+
 def all_gather_batch(shard: torch.Tensor, group=None) -> torch.Tensor:
     """[T, Bl, D] shards (equal Bl on every rank) -> [T, G*Bl, D] view in rank order, one all_gather_into_tensor.
     The gathered storage is rank-major [G, T, Bl, D]; the result is its [T, G*Bl, D] rearrangement (one device copy)."""
     world = dist.get_world_size(group)
     shard = shard.contiguous()
     T, Bl, D = shard.shape
+    _require_equal_shards(Bl, shard.device, group)
     flat = torch.empty((world * T, Bl, D), dtype=shard.dtype, device=shard.device)   # rank-major concatenation
     dist.all_gather_into_tensor(flat, shard, group=group)
     return flat.view(world, T, Bl, D).permute(1, 0, 2, 3).reshape(T, world * Bl, D)
@@ -54,40 +74,93 @@ def chunk_bounds(T: int, chunks: int):
     return [round(c * T / chunks) for c in range(chunks + 1)]
 
 
+def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, group, gather: bool, wait: bool, want_local: bool):
+    """Shared driver of the time-chunked integrate / all-gather pipeline.  `launch(s, r1, starts, outs)` integrates grid points
+    s..r1-1 from the state rows `starts` (None for the first chunk) into the buffers `outs` ([r1-s, Bl, D] each).
+
+    Every chunk writes into ITS OWN buffer: a launch stores its first row too (= the previous chunk's last row), and that row
+    must not land in memory an in-flight all-gather of the previous chunk is reading (round-1 ADVICE: formal write/read race
+    across streams when the chunks shared one [T,Bl,D] tensor)."""
+    b = chunk_bounds(T, chunks)
+    world = dist.get_world_size(group) if gather else 1
+    if gather:
+        _require_equal_shards(Bl, device, group)
+    works, gathered, local_rows = [], [[] for _ in widths], [[] for _ in widths]
+    prev = None
+    for c in range(len(b) - 1):
+        r0, r1 = b[c], b[c + 1]
+        s = max(r0 - 1, 0)                      # first grid point of this launch (= last row of the previous chunk)
+        outs = [torch.empty((r1 - s, Bl, d), dtype=dtype, device=device) for d in widths]
+        launch(s, r1, prev, outs)
+        prev = [o[-1:] for o in outs]
+        for k, o in enumerate(outs):
+            rows = o[r0 - s:]                   # rows r0..r1-1 of output k (contiguous view of the chunk buffer)
+            if want_local:
+                local_rows[k].append(rows)
+            if gather:
+                buf = torch.empty((world * (r1 - r0), Bl, widths[k]), dtype=dtype, device=device)
+                works.append(dist.all_gather_into_tensor(buf, rows, group=group, async_op=True))
+                gathered[k].append((r0, r1, buf.view(world, r1 - r0, Bl, widths[k])))
+    local = [torch.cat(r) if want_local else None for r in local_rows]
+    if wait:
+        for wk in works:
+            wk.wait()
+    return local, gathered, works
+
+
 def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=None, z_jump=None, chunks: int = 4, group=None,
-                            local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, **kw):
+                            local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, want_local: bool = True, **kw):
     """Time-chunked integrate with the all-gather of finished chunks overlapped with the integration of later ones.
 
     The all-gather of one [T, Bl, xd] shard set at 8 GPUs moves ~0.9 GB into every GPU -- about as long as the
     integration itself -- so it has to be hidden.  Chunk c restarts from the last row of chunk c-1 (the
     kernels read only x[0]), which is bit-identical to one long launch.  Each finished chunk is all-gathered with
     async_op=True: RCCL runs it on its own stream after the chunk's kernel, concurrently with the next chunk's kernel.
-    Returns (xs_local[T,Bl,xd], gathered) where `gathered` is a list of per-chunk rank-major buffers
-    [(r0, r1, buf[G, r1-r0, Bl, xd])] -- the reassembled batch in time-chunk-major order (no extra copy).
+    Returns (xs_local[T,Bl,xd] or None, gathered) where `gathered` is a list of per-chunk rank-major buffers
+    [(r0, r1, buf[G, r1-r0, Bl, xd])] -- the reassembled batch in time-chunk-major order (no extra copy).  `want_local=False`
+    skips the concatenation of the local chunks (this rank's rows are in `gathered` anyway).
     """
     if local_fn is None:
         from . import fused
         local_fn = fused.ode_integrate
     T, Bl, xd = t.shape[0], x.shape[1], x.shape[2]
-    xs = torch.empty((T, Bl, xd), dtype=x.dtype, device=x.device)
-    b = chunk_bounds(T, chunks)
-    works, gathered = [], []
-    world = dist.get_world_size(group) if gather else 1
-    for c in range(len(b) - 1):
-        r0, r1 = b[c], b[c + 1]
-        s = max(r0 - 1, 0)                      # first grid point of this launch (= last row of the previous chunk)
-        x_start = x[0:1] if c == 0 else xs[s:s + 1]
+
+    def launch(s, r1, starts, outs):
+        x_start = x[0:1] if starts is None else starts[0]
         ev = None if event_idx is None else event_idx[s:r1 - 1]
-        local_fn(method, de_layers, t[s:r1], x_start, z[s:r1], all_initial, z_jump=z_jump, event_idx=ev, out=xs[s:r1], **kw)
-        if gather:
-            buf = torch.empty((world * (r1 - r0), Bl, xd), dtype=xs.dtype, device=xs.device)
-            works.append(dist.all_gather_into_tensor(buf, xs[r0:r1], group=group, async_op=True))
-            gathered.append((r0, r1, buf.view(world, r1 - r0, Bl, xd)))
+        local_fn(method, de_layers, t[s:r1], x_start, z[s:r1], all_initial, z_jump=z_jump, event_idx=ev, out=outs[0], **kw)
+
+    local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local)
     if not wait:
-        return xs, gathered, works      # caller waits (bench.py brackets the compute stream before waiting)
-    for wk in works:
-        wk.wait()
-    return xs, gathered
+        return local[0], gathered[0], works      # caller waits (bench.py brackets the compute stream before waiting)
+    return local[0], gathered[0]
+
+
+def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_idx=None, z_jump=None, v_jump=None,
+                            chunks: int = 4, group=None, local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True,
+                            want_local: bool = True, **kw):
+    """integrate_DAE (no teacher forcing) as integrate_ode_pipelined: xs AND is shards gathered chunk by chunk behind the next
+    chunk's kernel.  A chunk restarts from x_init = xs[s]; the launch recomputes i0 = g(xs[s]; z[s], v[s]) itself, which is exactly
+    how is[s] was produced (my_solvers.py:121 uses the un-jumped z, v of the right grid point), so the restart is bit-identical
+    to one long launch -- including an event at step s, whose i0 recomputation with the jumped inputs happens inside the loop.
+    Returns ((xs_local, is_local), (gathered_x, gathered_i))."""
+    if local_fn is None:
+        from . import fused
+        local_fn = fused.dae_integrate
+    T, Bl = t.shape[0], t.shape[1]
+    xd, idim = x_init.shape[-1], i.shape[-1]
+    x_dummy = x_init.new_zeros((1, Bl, 0))          # dataset x is only read under teacher forcing
+
+    def launch(s, r1, starts, outs):
+        xi = x_init if starts is None else starts[0][0]
+        ev = None if event_idx is None else event_idx[s:r1 - 1]
+        local_fn(method, de_layers, ae_layers, xi, t[s:r1], x_dummy, z[s:r1], v[s:r1], i[s:r1], all_initial, z_jump=z_jump,
+                 v_jump=v_jump, event_idx=ev, out=(outs[0], outs[1]), **kw)
+
+    local, gathered, works = _pipelined(launch, T, Bl, [xd, idim], x_init.dtype, x_init.device, chunks, group, gather, wait, want_local)
+    if not wait:
+        return tuple(local), tuple(gathered), works
+    return tuple(local), tuple(gathered)
 
 
 def assemble(gathered, T: int) -> torch.Tensor:

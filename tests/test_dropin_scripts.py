@@ -74,3 +74,34 @@ def test_script_classes_are_recognised_for_fusion(swapped):
     assert len(fused.ae_layers_of(m.ae_func, 14, 12, 2)) == 4
     ok, ev_t, zj, vj = fused._event_tensors(m.event.event_fn, m.event.jump_change_fn, True)
     assert ok and ev_t is None
+
+
+@pytest.mark.parametrize("tag", ["ode02", "dae02"])
+def test_accelerate_keeps_the_reference_models_intact(swapped, tag, tmp_path):
+    """py_psnode_amd.accelerate() on the REFERENCE'S OWN direct_encode classes: encoders/decoders become RowsSequential (fused row
+    kernels on a HIP device), state-dict keys / parameters / outputs / TorchScript export (`save_model`) unchanged."""
+    import py_psnode_amd
+    from py_psnode_amd.models import RowsSequential
+    mod = importlib.import_module(SCRIPTS[tag])
+    d = load(f"g4_model_{tag}.npz")
+    m = mod.ODE_Model(8, 2, 16) if tag == "ode02" else mod.DAE_Model(8, 2, 2, 2, 16)
+    keys = list(m.state_dict().keys())
+    params = [id(p) for p in m.parameters()]
+    assert py_psnode_amd.accelerate(m) is m and py_psnode_amd.accelerate(m) is m        # idempotent
+    swapped_names = [n for n, c in m.named_children() if isinstance(c, RowsSequential)]
+    assert swapped_names == [n for n, c in m.named_children() if n.endswith(("_encoder", "_decoder"))] and len(swapped_names) >= 3
+    assert list(m.state_dict().keys()) == keys and [id(p) for p in m.parameters()] == params
+    m.load_state_dict({k[4:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("sd__")})
+    m.solver = swapped.RK4()
+    with torch.no_grad():
+        if tag == "ode02":
+            out = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), event_t=T(d["event_t"]), z_jump=T(d["z_jump"]))
+        else:
+            out = m(t=T(d["t"]), x=T(d["x"]), z=T(d["z"]), v=T(d["v"]), i=T(d["i"]), event_t=T(d["event_t"]),
+                    z_jump=T(d["z_jump"]), v_jump=T(d["v_jump"]))
+    for k, o in enumerate(out):
+        assert rel_err(o, d[f"rk4_out{k}"]) <= TOL_ORACLE, (tag, k)
+    m.save_model(tmp_path / "saved")                       # the script's own TorchScript export still works
+    enc = torch.jit.load(str(tmp_path / "saved" / "x_encoder.pt"))
+    x = T(d["x"])
+    assert torch.equal(enc(x), torch.nn.Sequential.forward(m.x_encoder, x))

@@ -145,3 +145,72 @@ def test_encoded_unsupported_shape_raises():
     assert not fused().ode_encoded_supported(_dev(xe), _dev(ze), _dev(xdec), _dev(bad))
     with pytest.raises(_lib.UnsupportedShapeError):
         fused().ode_encoded_integrate("rk4", _dev(xe), _dev(ze), _dev(xdec), _dev(bad), t.cuda(), x.cuda(), z.cuda())
+
+
+class _ScriptStyleOde02(nn.Module):
+    """The shape of the reference's ODE_Model (neural_00_ODE_02_direct_encode.py:60-89) restated for the GPU box, where the
+    reference's files do not exist: plain nn.Sequential encoders/decoder called as modules, the script's forward order."""
+
+    def __init__(self, xd, zd, H, nd_):
+        super().__init__()
+        from py_psnode_amd import models
+        self.x_encoder = nn.Sequential(nn.Linear(xd, H), nn.ELU(), nn.Linear(H, H))
+        self.x_decoder = nn.Sequential(nn.Linear(H, H), nn.ELU(), nn.Linear(H, xd))
+        self.z_encoder = nn.Sequential(nn.Linear(zd, H), nn.ELU(), nn.Linear(H, H))
+        self.de_func = models.DE_Func(2 * H, (H,), H)
+        self.solver = nd_.Euler()
+        self.event = nd_.ODE_Event()
+
+    def forward(self, t, x, z, event_t, z_jump):
+        Xh = self.x_encoder(x).permute(1, 0, 2)
+        Zh = self.z_encoder(z).permute(1, 0, 2)
+        all_initial = torch.cat((Xh[0], Zh[0]), dim=-1)
+        self.event.set_event(t=event_t, z=self.z_encoder(z_jump))
+        sol = self.solver.integrate_ODE(x_func=self.de_func, t=t.permute(1, 0, 2), x=Xh, z=Zh, all_initial=all_initial,
+                                        event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
+        return self.x_decoder(sol).permute(1, 0, 2), self.x_decoder(Xh).permute(1, 0, 2)
+
+
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_accelerate_puts_script_style_encoders_on_the_row_kernels(method):
+    """accelerate(model) on a model written like the reference's script class: forward equals golden G4-ode02, gradients equal the
+    reference's (G7-ode02), and the row kernels really take the encoder / decoder calls (forward and backward)."""
+    import py_psnode_amd
+    from py_psnode_amd import neural_dae as nd
+    from py_psnode_amd.models import RowsSequential
+    cls = {"euler": nd.Euler, "rk4": nd.RK4}[method]
+    d, dg = load("g4_model_ode02.npz"), load("g7_grad_ode02.npz")
+    f = fused()
+    calls = {"fwd": 0, "bwd": 0}
+    of, ob = f.mlp_rows, f.mlp_rows_backward
+
+    def run(dd, grad):
+        m = _ScriptStyleOde02(8, 2, 16, nd)
+        m.load_state_dict({k[4:].replace("__", "."): T(v) for k, v in dd.items() if k.startswith("sd__")})
+        m = py_psnode_amd.accelerate(m.cuda())
+        assert all(isinstance(getattr(m, n), RowsSequential) for n in ("x_encoder", "x_decoder", "z_encoder"))
+        m.solver = cls()
+        m.solver.fused = "require"
+        g = lambda k: T(dd[k]).cuda()
+        if not grad:
+            with torch.no_grad():
+                return m, m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+        out = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+        sum((o * g(f"G{k}")).sum() for k, o in enumerate(out)).backward()
+        return m, out
+
+    try:
+        f.mlp_rows = lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), of(*a, **k))[1]
+        f.mlp_rows_backward = lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), ob(*a, **k))[1]
+        m, out = run(d, grad=False)
+        assert calls["fwd"] == 5                        # enc x, enc z, enc z_jump, dec solution, dec reconstruction
+        for k, o in enumerate(out):
+            assert traj_rel_err(o.cpu(), d[f"{method}_out{k}"], bdim=0) <= TOL_GPU
+        m, out = run(dg, grad=True)
+        assert calls["bwd"] == 5
+    finally:
+        f.mlp_rows, f.mlp_rows_backward = of, ob
+    for name, p in m.named_parameters():
+        ref = torch.as_tensor(dg[f"{method}_gp__" + name.replace(".", "__")], dtype=torch.float64)
+        err = float((p.grad.double().cpu() - ref).abs().max())
+        assert err <= 2e-4 * max(float(ref.abs().max()), 1e-6), (name, err)

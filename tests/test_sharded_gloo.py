@@ -69,6 +69,47 @@ def _check_sharded_loss(rank, world, sharded):
     assert float((lin.bias.grad - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
 
 
+def _oracle_dae_local(method, de, ae, x_init, t, x, z, v, i, a0, z_jump=None, v_jump=None, event_idx=None, out=None):
+    """DAE oracle driven by an explicit per-step event table (no teacher forcing)."""
+    from oracle import psnode_oracle as O
+    Tn, B = t.shape[0], t.shape[1]
+    xs, is_ = torch.zeros(Tn, B, x_init.shape[-1]), torch.zeros(Tn, B, i.shape[-1])
+    cx = x_init
+    ci = O.ae_rhs(ae, cx, z[0], v[0], a0)
+    xs[0], is_[0] = cx, ci
+    for k in range(Tn - 1):
+        zk, vk = z[k], v[k]
+        if event_idx is not None and int(event_idx[k]) >= 0:
+            zk, vk = z_jump[:, int(event_idx[k])], v_jump[:, int(event_idx[k])]
+            ci = O.ae_rhs(ae, cx, zk, vk, a0)
+        cx, _ = O.step(method, lambda xx: O.de_rhs(de, xx, (zk, vk, ci), a0), t[k], t[k + 1] - t[k], t[k + 1], cx)
+        ci = O.ae_rhs(ae, cx, z[k + 1], v[k + 1], a0)
+        xs[k + 1], is_[k + 1] = cx, ci
+    if out is not None:
+        out[0].copy_(xs); out[1].copy_(is_)
+        return out
+    return xs, is_
+
+
+def _check_dae_pipelined(rank, world, sharded):
+    """integrate_dae_pipelined (time chunks restarted from xs[s], is recomputed by the launch) == the reference's one-shot
+    integrate_DAE golden (G3, events on), xs and is reassembled from the chunk-major gathers."""
+    from helpers import T, layers, load, tm
+    d = load("g3_dae.npz")
+    de, ae = layers(d, "de__x_dot"), layers(d, "ae__i_calculator")
+    t, z, v, i = tm(d["t"]), tm(d["z"]), tm(d["v"]), tm(d["i"])
+    xi, a0, ev, zj, vj = T(d["x_init"]), T(d["all_initial"]), T(d["event_t"]), T(d["z_jump"]), T(d["v_jump"])
+    lo, hi = sharded.shard_bounds(t.shape[1], rank, world)
+    tab = sharded.broadcast_event_table(t[:, lo:hi], ev[lo:hi], table_fn=_table)
+    (xl, il), (gx, gi) = sharded.integrate_dae_pipelined("rk4", de, ae, xi[lo:hi], t[:, lo:hi], z[:, lo:hi], v[:, lo:hi], i[:, lo:hi],
+                                                          a0[lo:hi], event_idx=tab, z_jump=zj[lo:hi], v_jump=vj[lo:hi], chunks=4,
+                                                          local_fn=_oracle_dae_local)
+    X, I = sharded.assemble(gx, t.shape[0]), sharded.assemble(gi, t.shape[0])
+    rx, ri = T(d["rk4_tx0_ti0_ev1_x"]), T(d["rk4_tx0_ti0_ev1_i"])
+    assert float((X - rx).abs().max()) <= 2e-6 and float((I - ri).abs().max()) <= 2e-6
+    assert torch.equal(xl, X[:, lo:hi]) and torch.equal(il, I[:, lo:hi])
+
+
 def _table(t, event_t):
     from oracle import psnode_oracle as O
     return torch.tensor(O.event_step_table(t, event_t), dtype=torch.int32)
@@ -99,6 +140,14 @@ def _worker(rank, world, port, q):
                                                          z_jump=zj[lo:hi], chunks=3, local_fn=_oracle_local)
         assert torch.equal(sharded.assemble(gathered, tl.shape[0]), out), "pipelined gather differs from the one-shot gather"
         assert sharded.chunk_bounds(1001, 4) == [0, 250, 500, 751, 1001] and sharded.chunk_bounds(2, 4) == [0, 1, 2]
+        assert torch.equal(xs_l, out[:, lo:hi]), "local rows of the pipelined run differ from this rank's slice of the gather"
+        _check_dae_pipelined(rank, world, sharded)
+        # unequal shards must raise on every rank instead of hanging inside the collective
+        try:
+            sharded.all_gather_batch(torch.zeros(3, 4 + rank, 2))
+            raise AssertionError("unequal shards were accepted")
+        except ValueError as e:
+            assert "equal shards" in str(e)
         if rank == 0:
             # trajectory `B/2` (rank 1's first) was integrated with the shifted clock but identical dt -> same result
             q.put((tuple(out.shape), float((out - ref).abs().max())))
