@@ -42,14 +42,15 @@ for tag in sys.argv[1:] or ["ode01", "ode02", "dae01", "dae02"]:
             if tag.startswith("ode"):
                 o = m(t=t[:, sl], x=x[:, sl], z=z[:, sl], event_t=ev, z_jump=zj)
                 if tag == "ode01":
-                    loss = L.ode_loss(o, x[:, sl], mask8[:, sl])[0]
+                    loss = L.ode01_loss(o, x[:, sl], mask8[:, sl])[0]
                 else:
-                    loss = L.ode_loss(o[0], x[:, sl], mask8[:, sl])[0] + L.recon_loss(o[1], x[:, sl])[0]
+                    loss = L.ode02_loss(o[0], o[1], x[:, sl], mask8[:, sl])[0]
             else:
                 o = m(t=t[:, sl], x=x[:, sl], z=z[:, sl], v=v[:, sl], i=i[:, sl], event_t=ev, z_jump=zj, v_jump=vj)
-                loss = L.dae_loss(o[0], x[:, sl], o[1], i[:, sl], mask1[:, sl])[0]
-                if tag == "dae02":
-                    loss = loss + L.recon_loss(o[2], x[:, sl])[0] + L.recon_loss(o[3], i[:, sl])[0]
+                if tag == "dae01":
+                    loss = L.dae01_loss(o[0], x[:, sl], o[1], i[:, sl], mask1[:, sl])[0]
+                else:
+                    loss = L.dae02_loss(o[0], o[1], o[2], o[3], x[:, sl], i[:, sl], mask1[:, sl])[0]
             route = type(o[0].grad_fn if isinstance(o, tuple) else o.grad_fn).__name__
             loss.backward()
             opt.step()

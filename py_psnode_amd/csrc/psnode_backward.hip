@@ -628,7 +628,15 @@ extern "C" int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* 
 extern "C" size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* a) {
     if (!a || !psnode_dae_backward_supported(a)) return 0;
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_workspace_floats(a) * sizeof(float);
-    if (latent64_dae_bwd_shape_ok(a) && a->kernel != PSNODE_KERNEL_GENERIC) return latent64_dae_bwd_workspace_floats(a) * sizeof(float);
+    if (latent64_dae_bwd_shape_ok(a) && a->kernel != PSNODE_KERNEL_GENERIC) {
+        // sized for every kernel this launch can end up on: K9, or K5 when the pointers turn out unaligned and K5 fits the shape
+        size_t f = latent64_dae_bwd_workspace_floats(a);
+        if (generic_bwd_fits(&a->de, &a->ae, a->x_dim, a->z_dim, a->v_dim, a->i_dim)) {
+            const size_t k5 = generic_bwd_workspace_floats(&a->de, &a->ae, a->B);
+            f = k5 > f ? k5 : f;
+        }
+        return f * sizeof(float);
+    }
     if (latent16_dae_bwd_shape_ok(a)) {      // K8 (DAE) or, for unaligned views / kernel = generic, K5: the larger of the two
         const size_t k8 = latent16_dae_bwd_workspace_floats(a), k5 = generic_bwd_workspace_floats(&a->de, &a->ae, a->B);
         return (k8 > k5 ? k8 : k5) * sizeof(float);

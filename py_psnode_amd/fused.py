@@ -147,6 +147,17 @@ def _view(t: Optional[torch.Tensor], dev, name: str, keep: list) -> _lib.ViewF32
     return _lib.ViewF32(t.data_ptr(), t.stride(0), t.stride(1))
 
 
+def _aligned16(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The MFMA backward kernels of the latent shapes read rows as float4: a view whose base or strides are not 16-byte aligned
+    would make the library report 'unsupported' AFTER the fused forward has run (the generic backward does not fit those shapes).
+    Such a view -- rare: torch allocations are 256-byte aligned, widths there are multiples of 16 -- is copied once."""
+    if t is None or t.shape[-1] < 4:
+        return t
+    if t.data_ptr() % 16 or t.stride(-1) != 1 or any(st % 4 for st in t.stride()[:-1]):
+        return t.contiguous()
+    return t
+
+
 def _mlp(layers: Layers, dev, name: str, keep: list) -> _lib.MlpF32:
     m = _lib.MlpF32()
     if not 1 <= len(layers) <= _lib.MAX_LAYERS:
@@ -161,6 +172,24 @@ def _mlp(layers: Layers, dev, name: str, keep: list) -> _lib.MlpF32:
         m.weight[k] = w.data_ptr()
         m.bias[k] = b.data_ptr()
     return m
+
+
+def _check_tb(name: str, a: Optional[torch.Tensor], T: int, B: int, min_T: Optional[int] = None):
+    """Leading dims of a time-major input against the call's (T, B): a mismatch would be an out-of-bounds device read."""
+    if a is None or a.shape[-1] == 0:
+        return
+    need_T = T if min_T is None else min_T
+    if a.dim() != 3 or a.shape[1] != B or a.shape[0] < need_T:
+        raise ValueError(f"{name}: shape {tuple(a.shape)} does not cover [T={need_T}, B={B}, D]")
+
+
+def _check_jump(name: str, j: Optional[torch.Tensor], B: int, width: int, event_idx):
+    if event_idx is None or width == 0:
+        return
+    if j is None:
+        raise ValueError(f"{name}: events need the jump values")
+    if j.dim() != 3 or j.shape[0] != B or j.shape[2] != width or j.shape[1] < 1:
+        raise ValueError(f"{name}: shape {tuple(j.shape)}, expected [B={B}, nE>=1, {width}]")
 
 
 def _jump(j: Optional[torch.Tensor], dev, name: str, keep: list):
@@ -229,6 +258,10 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
     if x.shape[0] < (T if input_true_x else 1):
         raise ValueError("x has fewer grid points than t")
     zd = z.shape[-1]
+    _check_tb("t", t, T, B)
+    _check_tb("z", z, T, B)
+    if event_idx is not None and (event_idx.numel() < T - 1 or event_idx.dtype != torch.int32):
+        raise ValueError(f"event_idx must be int32[T-1={T - 1}], got {event_idx.dtype}[{event_idx.numel()}]")
     keep: list = []
     a = _lib.OdeArgsF32()
     a.method = METHOD_ID[method]
@@ -248,6 +281,7 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
         if event_idx is None:
             event_idx = event_table(t, event_t, check_events)
         if event_idx is not None:
+            _check_jump("z_jump", z_jump, B, zd, event_idx)
             keep.append(event_idx)
             a.event_idx = event_idx.data_ptr()
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
@@ -275,6 +309,17 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
         raise ValueError("fused integrator needs tensors on a HIP device")
     T, B = t.shape[0], t.shape[1]
     xd, zd, vd, idim = x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]
+    if x_init.dim() != 2 or x_init.shape[0] != B:
+        raise ValueError(f"x_init: shape {tuple(x_init.shape)}, expected [B={B}, x_dim]")
+    _check_tb("t", t, T, B)
+    _check_tb("z", z, T, B)
+    _check_tb("v", v, T, B)
+    if input_true_x:
+        _check_tb("x", x, T, B)
+    if input_true_i:
+        _check_tb("i", i, T, B)
+    if event_idx is not None and (event_idx.numel() < T - 1 or event_idx.dtype != torch.int32):
+        raise ValueError(f"event_idx must be int32[T-1={T - 1}], got {event_idx.dtype}[{event_idx.numel()}]")
     keep: list = []
     a = _lib.DaeArgsF32()
     a.method = METHOD_ID[method]
@@ -300,6 +345,8 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
         if event_idx is None:
             event_idx = event_table(t, event_t, check_events)
         if event_idx is not None:
+            _check_jump("z_jump", z_jump, B, zd, event_idx)
+            _check_jump("v_jump", v_jump, B, vd, event_idx)
             keep.append(event_idx)
             a.event_idx = event_idx.data_ptr()
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
@@ -373,6 +420,7 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
     a.kernel = KERNEL_ID[kernel]
     a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = xd, zd, vd, idim, T, B
     a.de, a.ae = _mlp(de_layers, dev, "de", keep), _mlp(ae_layers, dev, "ae", keep)
+    z, v, z_jump, v_jump = _aligned16(z), _aligned16(v), _aligned16(z_jump), _aligned16(v_jump)
     a.t, a.z, a.v = _view(t, dev, "t", keep), _view(z, dev, "z", keep), _view(v, dev, "v", keep)
     a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
     xs_c, is_c = _f32_dev(xs, dev, "xs").contiguous(), _f32_dev(is_, dev, "is").contiguous()
@@ -427,6 +475,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     zd = z.shape[-1]
     keep: list = []
     a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep, kernel)
+    z, z_jump = _aligned16(z), _aligned16(z_jump)
     a.t = _view(t, dev, "t", keep)
     a.z = _view(z, dev, "z", keep)
     a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
@@ -638,9 +687,15 @@ def _needs_autograd(tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
+def _all_f32_on(dev, *tensors) -> bool:
+    return all(a is None or (torch.is_tensor(a) and a.dtype == torch.float32 and a.device == dev) for a in tensors)
+
+
+def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=None):
     """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump, needs_autograd)."""
     if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 3 or z.dim() != 3:
+        return None
+    if not _all_f32_on(x.device, z, all_initial, t):      # mixed dtypes / devices: 'auto' promises the walk, not a TypeError
         return None
     xd, zd = x.shape[-1], z.shape[-1]
     if all_initial.dim() != 2 or all_initial.shape[-1] != xd + zd:
@@ -649,14 +704,16 @@ def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn):
     if layers is None or not _recipe_ok(x_func, layers, "de_ode", (xd, zd)):
         return None
     ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
-    if not ok:
+    if not ok or not _all_f32_on(x.device, event_t, z_jump):
         return None
     needs_grad = _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb])
     return layers, event_t, z_jump, needs_grad
 
 
-def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn):
+def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn, t=None):
     if x_init.device.type != "cuda" or x_init.dtype != torch.float32 or z.dim() != 3:
+        return None
+    if not _all_f32_on(x_init.device, z, v, all_initial, t):
         return None
     xd, zd, vd, idim = x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]
     n = xd + zd + vd + idim
@@ -669,7 +726,7 @@ def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change
     if not _recipe_ok(x_func, de, "de_dae", (xd, zd, vd, idim)) or not _recipe_ok(i_func, ae, "ae", (xd, zd, vd, n)):
         return None
     ok, event_t, z_jump, v_jump = _event_tensors(event_fn, jump_change_fn, True)
-    if not ok:
+    if not ok or not _all_f32_on(x_init.device, event_t, z_jump, v_jump):
         return None
     needs_grad = _needs_autograd([x_init, z, v, all_initial, z_jump, v_jump] + [p for wb in list(de) + list(ae) for p in wb])
     return de, ae, event_t, z_jump, v_jump, needs_grad

@@ -87,7 +87,7 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
     # ------------------------------------------------------------------ ODE
     def integrate_ODE(self, x_func, t, x, z, all_initial, event_fn=None, jump_change_fn=None, input_true_x=False):
         if self.fused != "off":
-            plan = _fused.plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn)
+            plan = _fused.plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=t)
             if plan is not None:
                 layers, event_t, z_jump, needs_grad = plan
                 if not needs_grad:
@@ -127,7 +127,7 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
     def integrate_DAE(self, x_init, x_func, i_func, t, x, z, v, i, all_initial, event_fn=None, jump_change_fn=None,
                       input_true_x=False, input_true_i=False):
         if self.fused != "off":
-            plan = _fused.plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn)
+            plan = _fused.plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn, t=t)
             if plan is not None:
                 de, ae, event_t, z_jump, v_jump, needs_grad = plan
                 if not needs_grad:
