@@ -27,7 +27,7 @@ bash profiles/scripts/pmc_sq.sh r02_dae01 integrate_mfma --workload dae01 > /dev
 bash profiles/scripts/pmc_sq.sh r02_ode02 latent_dpp --workload ode02 > /dev/null
 rm -f $O/pmc_r02_*.log
 python profiles/scripts/accuracy_report.py > $O/r02_accuracy_report.txt 2>&1
-bash profiles/scripts/r01d_batch_sweep.sh > $O/r02_batch_sweep.txt 2>&1
+bash profiles/scripts/batch_sweep.sh > $O/r02_batch_sweep.txt 2>&1
 python profiles/scripts/train_step_models.py > $O/r02_train_step_models.txt 2>&1; cp $O/train_step_models.json $O/r02_train_step_models.json
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/r02_bench_ode01_n1.json
 python bench.py --steps 10 --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_dae01_n1.json
