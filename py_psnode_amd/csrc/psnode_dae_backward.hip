@@ -802,7 +802,7 @@ int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipS
     d.NP_de = np_of(3 * n, xd); d.NP_ae = np_of(n + xd + nzv, id);
 
     PackDaeBwd pd;
-    pd.f.ae = 0; pd.f.nw = NW; pd.f.xd = xd; pd.f.ne = ne; pd.f.n = n; pd.f.nzv = nzv;
+    pd.f.fold = 0; pd.f.ae = 0; pd.f.nw = NW; pd.f.xd = xd; pd.f.ne = ne; pd.f.n = n; pd.f.nzv = nzv;
     pd.f.NX = kNXc; pd.f.NB = kNXc; pd.f.NE = NZM; pd.f.NA = NA;
     pd.f.w1 = a->de.weight[0]; pd.f.b1 = a->de.bias[0]; pd.f.w2 = a->de.weight[1]; pd.f.b2 = a->de.bias[1];
     pd.f.w3 = a->de.weight[2]; pd.f.b3 = a->de.bias[2]; pd.f.w4 = a->de.weight[3]; pd.f.b4 = a->de.bias[3];
@@ -810,7 +810,7 @@ int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipS
     pd.out = pack_de;
     hipLaunchKernelGGL(pack_dae_bwd_kernel, dim3(32), dim3(256), 0, s, pd);
     PackDaeBwd pq = pd;
-    pq.f.ae = 1; pq.f.NB = 0; pq.f.NE = NZA;
+    pq.f.fold = 0; pq.f.ae = 1; pq.f.NB = 0; pq.f.NE = NZA;
     pq.f.w1 = a->ae.weight[0]; pq.f.b1 = a->ae.bias[0]; pq.f.w2 = a->ae.weight[1]; pq.f.b2 = a->ae.bias[1];
     pq.f.w3 = a->ae.weight[2]; pq.f.b3 = a->ae.bias[2]; pq.f.w4 = a->ae.weight[3]; pq.f.b4 = a->ae.bias[3];
     pq.f.out_dim = id;

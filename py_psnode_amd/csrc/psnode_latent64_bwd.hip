@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         o.v[0] = ownv;
 #pragma unroll
         for (int c = 1; c < 4; ++c) o.v[c] = xbuf[(p * NW9 + ((w + c) & 3)) * 64 + l];
+        __builtin_amdgcn_sched_barrier(0);      // all three reads in flight before the first dependent MFMA (as K1)
         p ^= 1;
         return o;
     };

@@ -77,7 +77,7 @@ template <int N> struct Arr { float v[N > 0 ? N : 1]; };
 template <int METHOD, int NX, int NZM, int NZA, bool TRUE_X, bool DAE, int NWV>
 __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const IntegrateDev a, const float* __restrict__ pack_de,
                                                                   const float* __restrict__ pack_ae, const int NA) {
-    using RD = Regs<NX, NX, NZM, NWV>;
+    using RD = Regs<NX, 0, NZM, NWV>;     // folded DE image: no `s - a0` registers for the x dims (psnode_pack.h)
     using RA = Regs<NX, 0, NZA, NWV>;
     __shared__ f4 xbuf[2][NWV][64];
     // 8 waves of 64 lanes leave 256 VGPRs per lane: the DAE's second weight set does not fit next to the DE's, so the
@@ -97,17 +97,17 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 
     // ---- weights -> registers (once per launch)
     const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
-    float w1xs[NX], w1xd[NX];
+    float w1xs[NX];
     Arr<NZM> w1z;
     f4 b1r;
     Tail<NWV> de;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) { w1xs[r] = pw[(RD::W1A + r) * 64]; w1xd[r] = pw[(RD::W1B + r) * 64]; }
+    for (int r = 0; r < NX; ++r) w1xs[r] = pw[(RD::W1A + r) * 64];
 #pragma unroll
     for (int m = 0; m < NZM; ++m) w1z.v[m] = pw[(RD::W1E + m) * 64];
 #pragma unroll
     for (int r = 0; r < 4; ++r) b1r[r] = pw[(RD::B1 + r) * 64];
-    load_tail<NX, NX, NZM, NWV>(pw, de);
+    load_tail<NX, 0, NZM, NWV>(pw, de);
 
     const float* pwa = pack_ae + (size_t)w * (RA::COUNT + NA) * 64 + l;
     float aw1x[NX];
@@ -294,13 +294,14 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     };
     // DE right-hand side at xs with this step's constant part cz
     auto rhs = [&](const float (&xs)[NX], const f4 cz) -> f4 {
+        // folded L1: (Ws + Wd) . xs, the -Wd . a0x term lives in c0 (two accumulator chains for NX = 2)
         f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-            accA = mfma4(w1xs[r], xs[r], accA);
-            accB = mfma4(w1xd[r], xs[r] - a0x[r], accB);
+            if (r & 1) accB = mfma4(w1xs[r], xs[r], accB);
+            else accA = mfma4(w1xs[r], xs[r], accA);
         }
-        return tail(accA + accB, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{});
+        return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{});
     };
     // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
     auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv) -> f4 {
@@ -492,7 +493,7 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     const int ne = a.zd + (dae ? a.vd + a.id : 0);
     PackMfma p;
     p.ae = 0; p.nw = NWV; p.xd = a.xd; p.ne = ne; p.n = a.xd + ne; p.nzv = a.zd + (dae ? a.vd : 0);
-    p.NX = kNXc; p.NB = kNXc; p.NE = NZM; p.NA = NA;
+    p.NX = kNXc; p.NB = 0; p.NE = NZM; p.NA = NA; p.fold = 1;
     p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
     p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
     p.out_dim = a.xd;
@@ -501,7 +502,7 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     float* pack_ae = pack + (size_t)NWV * (max_regs(NWV) + NA) * 64;
     if (dae) {
         PackMfma q = p;
-        q.ae = 1; q.NB = 0; q.NE = nza_of(a);
+        q.ae = 1; q.NB = 0; q.NE = nza_of(a); q.fold = 0;
         q.w1 = a.ae.w[0]; q.b1 = a.ae.bias[0]; q.w2 = a.ae.w[1]; q.b2 = a.ae.bias[1];
         q.w3 = a.ae.w[2]; q.b3 = a.ae.bias[2]; q.w4 = a.ae.w[3]; q.b4 = a.ae.bias[3];
         q.out_dim = a.id;

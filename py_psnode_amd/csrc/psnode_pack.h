@@ -14,6 +14,9 @@ constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <
 
 // Forward image of one MLP.
 // DE: W1A = columns of the `s` block (x dims), W1B = columns of the `s-a0` block (x dims), W1E = NE ext registers.
+//     The forward kernels use the FOLDED image (PackMfma::fold, NB = 0): W1A = Ws + Wd on the x dims and the a0 columns carry
+//     Wa - Wd there, so a stage multiplies 2*NX fewer MFMAs (one extra rounding of the summed weights, 6e-8 relative, as K3c/K3f).
+//     The backward kernels keep the unfolded image (they need Ws and Wd separately for the weight gradients).
 // AE: W1A = columns of x, W1B unused (count 0), W1E = NE registers of the z|v columns.
 template <int NX, int NB, int NE, int NWV = NW>
 struct Regs {
@@ -40,6 +43,7 @@ struct PackMfma {
     int nw;                 // waves per tile = hidden / 16
     int xd, ne, n, nzv;     // ne = z+v+i (DE ext), n = xd+ne, nzv = z+v
     int NX, NB, NE, NA;
+    int fold;               // DE forward image only: W1A = Ws + Wd on the x dims, no W1B registers (NB = 0), a0 columns = Wa - Wd there
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
     int out_dim;            // x_dim (DE) or i_dim (AE)
     float* out;
@@ -57,7 +61,10 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
     float v = 0.0f;
     if (reg < W1B) {                      // x columns: DE `s` block / AE x block
         const int d = 4 * reg + g;
-        if (d < p.xd) v = p.w1[u * K1 + (p.ae ? p.n : 2 * p.n) + d];
+        if (d < p.xd) {
+            v = p.w1[u * K1 + (p.ae ? p.n : 2 * p.n) + d];
+            if (p.fold) v += p.w1[u * K1 + p.n + d];      // W.cat(a0, s-a0, s) = (Ws+Wd).s + (Wa-Wd).a0 on the x dims
+        }
     } else if (reg < W1E) {               // DE `s - a0` block, x dims
         const int d = 4 * (reg - W1B) + g;
         if (d < p.xd) v = p.w1[u * K1 + p.n + d];
@@ -95,7 +102,10 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
         if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * H + 16 * w + 4 * g + (reg - W4)];
     } else {
         const int q = 4 * (reg - COUNT) + g;
-        if (q < p.n) v = p.w1[u * K1 + q];
+        if (q < p.n) {
+            v = p.w1[u * K1 + q];
+            if (p.fold && q < p.xd) v -= p.w1[u * K1 + p.n + q];
+        }
     }
     return v;
 }
