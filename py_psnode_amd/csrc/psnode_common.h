@@ -216,6 +216,9 @@ size_t latent_pack_floats();
 hipError_t launch_latent(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 // K3f (psnode_latent_dpp.hip): the latent ODE at hidden 16 on VALU + DPP row broadcasts (any alignment)
 hipError_t launch_latent_dpp(const IntegrateDev& a, hipStream_t stream);
+// K8f: backward through the hidden-16 latent ODE, same mapping (any alignment); workspace = per-wave parameter-gradient partials
+size_t latent_bwd_dpp_workspace_floats(long long B);
+int latent_bwd_dpp_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
 
 // psnode_latent64.hip (direct_encode latent shapes, hidden_dim 64)
 bool latent64_shape_ok(const IntegrateDev& a, bool dae);

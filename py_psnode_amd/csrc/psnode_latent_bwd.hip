@@ -24,7 +24,6 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int LH = 16, LTB = 16, LN = 2 * LH, LK1 = 3 * LN;   // hidden, tile, all_initial width, in_features
-constexpr int LNP = LH * LK1 + LH + LH * LH + LH;              // parameters: W1, b1, W2, b2
 constexpr int LSCR = 64 * 4 + 4 * 8;                           // padded transpose tile (floats)
 
 __device__ __forceinline__ f4 km(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -34,257 +33,8 @@ __device__ __forceinline__ f4 kdact(f4 h) {
 }
 __device__ __forceinline__ f4 kz4() { return f4{0.f, 0.f, 0.f, 0.f}; }
 
-// pack[reg][lane], lane l: i = l&15, g = l>>4
-//   WS[blk][m] (8)  W1[i][2n + 16 blk + 4g+m]            forward, `s` group, blk 0 = x, 1 = z
-//   WD[blk][m] (8)  W1[i][ n + 16 blk + 4g+m]            forward, `s - a0` group
-//   B1 (4) b1[4g+r]   W2 (4) W2[i][4g+m]   B2 (4) b2[4g+r]
-//   A0[blk][m] (8)  W1[i][16 blk + 4g+m]                 forward, a0 columns (folded into c0)
-//   W2T[m] (4)      W2[4g+m][i]                          delta1 = W2^T gk
-//   WXT[blk][m] (8) (W1s + W1d)[4g+m][16 blk + i]        gx / gz = (dpre1/ds)^T delta1
-//   WAT[blk][m] (8) (W1a - W1d)[4g+m][16 blk + i]        d all_initial
-constexpr int PWS = 0, PWD = 8, PB1 = 16, PW2 = 20, PB2 = 24, PA0 = 28, PW2T = 36, PWXT = 40, PWAT = 48, PCOUNT = 56;
-
-struct PackLatentBwd {
-    const float *w1, *b1, *w2, *b2;
-    float* out;
-};
-
-__global__ void pack_latent_bwd_kernel(const PackLatentBwd p) {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < PCOUNT * 64; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, reg = idx >> 6, i = lane & 15, g = lane >> 4;
-        float v;
-        if (reg < PWD) { const int blk = reg >> 2, m = reg & 3; v = p.w1[i * LK1 + 2 * LN + LH * blk + 4 * g + m]; }
-        else if (reg < PB1) { const int blk = (reg - PWD) >> 2, m = reg & 3; v = p.w1[i * LK1 + LN + LH * blk + 4 * g + m]; }
-        else if (reg < PW2) v = p.b1[4 * g + (reg - PB1)];
-        else if (reg < PB2) v = p.w2[i * LH + 4 * g + (reg - PW2)];
-        else if (reg < PA0) v = p.b2[4 * g + (reg - PB2)];
-        else if (reg < PW2T) { const int blk = (reg - PA0) >> 2, m = reg & 3; v = p.w1[i * LK1 + LH * blk + 4 * g + m]; }
-        else if (reg < PWXT) v = p.w2[(4 * g + (reg - PW2T)) * LH + i];
-        else {
-            const bool at = reg >= PWAT;
-            const int q = reg - (at ? PWAT : PWXT), blk = q >> 2, m = q & 3;
-            const float* row = p.w1 + (4 * g + m) * LK1 + LH * blk + i;
-            v = at ? row[0] - row[LN] : row[2 * LN] + row[LN];
-        }
-        p.out[idx] = v;
-    }
-}
-
-struct LatentBwdDev {
-    IntegrateDev a;          // t, z, a0, ev, zj (+strides), T, B, method
-    const float *xs, *gout;  // [T,B,16]
-    float *gx0, *gz, *gzj, *ga0, *wpart;
-    int n_events;
-};
-
-template <int METHOD>
-__global__ __launch_bounds__(64) void latent_ode_backward_kernel(const LatentBwdDev d, const float* __restrict__ pack) {
-    constexpr int S = rk_stages(METHOD);
-    const IntegrateDev& a = d.a;
-    __shared__ __attribute__((aligned(16))) float scr[4][LSCR];   // four private transpose tiles
-    const int l = threadIdx.x, g = l >> 4, j = l & 15, i = j;
-    const long long b0 = (long long)blockIdx.x * LTB;
-    const bool valid = b0 + j < a.B;
-    const long long b = valid ? b0 + j : a.B - 1;
-
-    const float* pw = pack + l;
-    float wsx[4], wdx[4], wsz[4], wdz[4], w2[4], w2t[4], wxt[4], wzt[4];
-    f4 b1r, b2r;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        wsx[m] = pw[(PWS + m) * 64]; wdx[m] = pw[(PWD + m) * 64]; w2[m] = pw[(PW2 + m) * 64]; w2t[m] = pw[(PW2T + m) * 64];
-        wxt[m] = pw[(PWXT + m) * 64]; wzt[m] = pw[(PWXT + 4 + m) * 64];
-        wsz[m] = pw[(PWS + 4 + m) * 64]; wdz[m] = pw[(PWD + 4 + m) * 64];
-        b1r[m] = pw[(PB1 + m) * 64]; b2r[m] = pw[(PB2 + m) * 64];
-    }
-    // a0 blocks of this lane (columns 4g..4g+3), a0 columns of L1 folded into c0
-    const f4 a0x = *reinterpret_cast<const f4*>(a.a0 + b * LN + 4 * g);
-    const f4 a0z = *reinterpret_cast<const f4*>(a.a0 + b * LN + LH + 4 * g);
-    f4 c0 = b1r;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        c0 = km(pw[(PA0 + m) * 64], a0x[m], c0);
-        c0 = km(pw[(PA0 + 4 + m) * 64], a0z[m], c0);
-    }
-
-    // D-layout tile (rows 4g+r, col j) -> o[kk] = M[row i][col 4kk+g]  (A/B operand layout), through private tile q
-    auto put_tile = [&](const int q, const f4 v) { *reinterpret_cast<f4*>(scr[q] + 4 * l + 8 * g) = v; };
-    auto get_tile = [&](const int q) -> f4 {
-        const float* s = scr[q] + 4 * (16 * (i >> 2) + g) + 8 * (i >> 2) + (i & 3);
-        return f4{s[0], s[16], s[32], s[48]};
-    };
-    auto outer = [&](const f4 aT, const f4 bT, f4 acc) -> f4 {   // acc[row][col] += sum_traj A[row][traj] B[col][traj]
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = km(aT[kk], bT[kk], acc);
-        return acc;
-    };
-    auto mat4 = [&](const float (&wq)[4], const f4 v, const f4 init) -> f4 {
-        f4 accA = km(wq[0], v[0], init), accB = km(wq[1], v[1], kz4());
-        accA = km(wq[2], v[2], accA);
-        accB = km(wq[3], v[3], accB);
-        return accA + accB;
-    };
-
-    const long long tst = a.t.st, nT = a.T;
-    const float* tp = a.t.p + b * a.t.sb;
-    const float* zp = a.z.p + b * a.z.sb;
-    const float* zjp = a.zj + b * a.zjb;
-    auto load_z = [&](long long k, int ev) -> f4 {
-        return *reinterpret_cast<const f4*>((ev >= 0 ? zjp + ev * a.zje : zp + k * a.z.st) + 4 * g);
-    };
-    auto load_row = [&](const float* base, long long k) -> f4 {
-        return *reinterpret_cast<const f4*>(base + (k * a.B + b) * LH + 4 * g);
-    };
-
-    f4 accW2 = kz4(), accW1x = kz4(), accW1z = kz4(), S1 = kz4(), SB2 = kz4();
-    f4 gcarry = kz4();
-
-    // inputs of a step, prefetched one iteration ahead (the sweep runs k = T-2 .. 0)
-    int lane_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const int* evp = a.ev + lane_zero;
-    float t_hi = nT >= 2 ? tp[(nT - 1) * tst] : 0.0f, t_lo = nT >= 2 ? tp[(nT - 2) * tst] : 0.0f;
-    int ev_cur = (a.ev && nT >= 2) ? a.ev[nT - 2] : -1;
-    int ev_n1 = (a.ev && nT >= 3) ? evp[nT - 3] : -1;
-    f4 z_n = kz4(), x_n = kz4(), g_n = kz4();
-    if (nT >= 2) {
-        z_n = load_z(nT - 2, ev_cur);
-        x_n = load_row(d.xs, nT - 2);
-        g_n = valid ? load_row(d.gout, nT - 1) : kz4();
-    }
-
-    for (long long k = nT - 2; k >= 0; --k) {
-        const float h_ = t_hi - t_lo;
-        const int ev = ev_cur;
-        const f4 zk = z_n, x0 = x_n;
-        const f4 g1 = gcarry + g_n;
-        if (k >= 1) {
-            t_hi = t_lo;
-            t_lo = tp[(k - 1) * tst];
-            z_n = load_z(k - 1, ev_n1);
-            x_n = load_row(d.xs, k - 1);
-            g_n = valid ? load_row(d.gout, k) : kz4();
-            ev_cur = ev_n1;
-            ev_n1 = (a.ev && k >= 2) ? evp[k - 2] : -1;
-        }
-        // per-step constant of L1: c0 + W1[:, z columns].(z - a0 | z)
-        f4 cz;
-        {
-            const f4 zd_ = zk - a0z;
-            f4 accA = c0, accB = kz4();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { accA = km(wsz[m], zk[m], accA); accB = km(wdz[m], zd_[m], accB); }
-            cz = accA + accB;
-        }
-        put_tile(3, zk);                       // z^T for the dW1 columns of the external block (read after phase B)
-
-        // ---- phase A: stage evaluations
-        f4 xst[S], h1[S], ks[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            f4 acc = kz4();
-#pragma unroll
-            for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj];
-            xst[s] = s == 0 ? x0 : x0 + h_ * acc;
-            const f4 xdf = xst[s] - a0x;
-            f4 accA = cz, accB = kz4();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { accA = km(wsx[m], xst[s][m], accA); accB = km(wdx[m], xdf[m], accB); }
-            h1[s] = kelu4(accA + accB);
-            ks[s] = mat4(w2, h1[s], b2r);
-        }
-
-        // ---- phase B: stages backwards
-        f4 gks[S], gx0 = g1, D1 = kz4();
-#pragma unroll
-        for (int s = 0; s < S; ++s) gks[s] = (h_ * rk_b(METHOD, s)) * g1;
-#pragma unroll
-        for (int s = S - 1; s >= 0; --s) {
-            const f4 gk = gks[s];
-            SB2 += gk;
-            put_tile(0, gk);
-            put_tile(1, h1[s]);
-            put_tile(2, xst[s]);
-            const f4 d1 = mat4(w2t, gk, kz4()) * kdact(h1[s]);
-            D1 += d1;
-            const f4 gT = get_tile(0), hT = get_tile(1), xT = get_tile(2);
-            accW2 = outer(gT, hT, accW2);                     // dW2[o][u] += gk[o] h1[u]
-            put_tile(0, d1);
-            const f4 gx = mat4(wxt, d1, kz4());
-            const f4 dT = get_tile(0);
-            accW1x = outer(dT, xT, accW1x);                   // dW1[u][2n + c] += delta1[u] xs[c]
-            gx0 += gx;
-#pragma unroll
-            for (int jj = 0; jj < s; ++jj) gks[jj] += (h_ * rk_a(METHOD, s, jj)) * gx;
-        }
-        S1 += D1;
-        // ---- external block: frozen over the stages
-        {
-            const f4 gz = mat4(wzt, D1, kz4());
-            put_tile(0, D1);
-            const f4 dT = get_tile(0), zT = get_tile(3);
-            accW1z = outer(dT, zT, accW1z);
-            if (valid) {
-                if (ev >= 0) { if (d.gzj) *reinterpret_cast<f4*>(d.gzj + (b * d.n_events + ev) * LH + 4 * g) = gz; }
-                if (d.gz) *reinterpret_cast<f4*>(d.gz + (k * a.B + b) * LH + 4 * g) = ev >= 0 ? kz4() : gz;
-            }
-        }
-        gcarry = gx0;
-    }
-
-    // ---- epilogue
-    if (valid) {
-        const f4 g0 = load_row(d.gout, 0);
-        *reinterpret_cast<f4*>(d.gx0 + b * LH + 4 * g) = gcarry + g0;
-        if (d.gz && nT >= 1) *reinterpret_cast<f4*>(d.gz + ((nT - 1) * a.B + b) * LH + 4 * g) = kz4();   // z[T-1] is never read
-    }
-    {   // d all_initial = (W1a - W1d)^T sum_t(delta1)
-        float wat[4];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) wat[m] = pw[(PWAT + 4 * blk + m) * 64];
-            const f4 ga = mat4(wat, S1, kz4());
-            if (valid) *reinterpret_cast<f4*>(d.ga0 + b * LN + LH * blk + 4 * g) = ga;
-        }
-    }
-    // ---- parameter-gradient partials of this workgroup, nn.Linear order [W1 (16 x 96), b1, W2 (16 x 16), b2]
-    float* wp = d.wpart + (size_t)blockIdx.x * LNP;
-    {
-        put_tile(0, S1);
-        const f4 sT = get_tile(0);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            f4 ca0 = kz4();      // sum_t(delta1)^T (x) a0^T  for the columns of this block
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const long long tb = b0 + 4 * kk + g;
-                const float av = tb < a.B ? a.a0[tb * LN + LH * blk + j] : 0.0f;
-                ca0 = km(sT[kk], av, ca0);
-            }
-            const f4 ws_ = blk == 0 ? accW1x : accW1z;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* row = wp + (4 * g + r) * LK1 + LH * blk + j;
-                row[0] = ca0[r];
-                row[LN] = ws_[r] - ca0[r];
-                row[2 * LN] = ws_[r];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wp[LH * LK1 + LH + (4 * g + r) * LH + j] = accW2[r];
-    f4 sb1 = S1, sb2 = SB2;
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sb1[r] += __shfl_xor(sb1[r], m, 64); sb2[r] += __shfl_xor(sb2[r], m, 64); }
-    }
-    if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { wp[LH * LK1 + 4 * g + r] = sb1[r]; wp[LH * LK1 + LH + LH * LH + 4 * g + r] = sb2[r]; }
-    }
-}
+// The ODE case (Linear(96,16) ELU Linear(16,16)) moved to K8f in psnode_latent_dpp.hip (lane = (trajectory, unit), VALU + DPP
+// row broadcasts, 4 trajectories per wave): this file keeps the single-wave MFMA backward of the latent DAE.
 
 // ---------------------------------------------------------------------------------------------------------------
 // K8 (DAE): the same single-wave scheme for the latent DAE at hidden 16 (K3a's DAE shapes: blocks x | [z] | v | i of width 16,
@@ -576,41 +326,11 @@ bool latent_bwd_shape_ok(const psnode_ode_bwd_args_f32* a) {
     return a->x_dim == LH && a->z_dim == LH && m.n_layers == 2 && m.in_dim == LK1 && m.out_dim[0] == LH && m.out_dim[1] == LH;
 }
 
-// float4 accesses: every per-trajectory row must be 16-byte aligned
-bool latent_bwd_ptrs_ok(const psnode_ode_bwd_args_f32* a) {
-    if (!al16(a->all_initial) || !al16(a->xs) || !al16(a->grad_xs) || !al16(a->grad_x0) || !al16(a->grad_all_initial)) return false;
-    if (!al16(a->z.ptr) || (a->z.stride_t & 3) || (a->z.stride_b & 3)) return false;
-    if (a->grad_z && !al16(a->grad_z)) return false;
-    if (a->event_idx && (!al16(a->z_jump) || (a->zj_stride_b & 3) || (a->zj_stride_e & 3) || (a->grad_z_jump && !al16(a->grad_z_jump))))
-        return false;
-    return true;
-}
+bool latent_bwd_ptrs_ok(const psnode_ode_bwd_args_f32*) { return true; }   // K8f reads lane-granular: any alignment
 
-size_t latent_bwd_workspace_floats(long long B) { return (size_t)PCOUNT * 64 + (size_t)((B + LTB - 1) / LTB) * LNP + 64; }
+size_t latent_bwd_workspace_floats(long long B) { return latent_bwd_dpp_workspace_floats(B); }
 
-int latent_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s) {
-    float* pack = workspace;
-    float* wpart = workspace + PCOUNT * 64;
-    PackLatentBwd p{a->de.weight[0], a->de.bias[0], a->de.weight[1], a->de.bias[1], pack};
-    hipLaunchKernelGGL(pack_latent_bwd_kernel, dim3(4), dim3(256), 0, s, p);
-    LatentBwdDev d;
-    memset(&d, 0, sizeof(d));
-    d.a.method = a->method; d.a.xd = LH; d.a.zd = LH; d.a.T = a->T; d.a.B = a->B;
-    d.a.t = ViewDev{a->t.ptr, a->t.stride_t, a->t.stride_b};
-    d.a.z = ViewDev{a->z.ptr, a->z.stride_t, a->z.stride_b};
-    d.a.a0 = a->all_initial; d.a.ev = a->event_idx; d.a.zj = a->z_jump; d.a.zjb = a->zj_stride_b; d.a.zje = a->zj_stride_e;
-    d.xs = a->xs; d.gout = a->grad_xs; d.gx0 = a->grad_x0; d.gz = a->grad_z; d.gzj = a->grad_z_jump; d.ga0 = a->grad_all_initial;
-    d.wpart = wpart; d.n_events = a->n_events;
-    const int nwg = (int)((a->B + LTB - 1) / LTB);
-    const dim3 grid((unsigned)nwg), block(64);
-    switch (a->method) {
-        case PSNODE_EULER: hipLaunchKernelGGL((latent_ode_backward_kernel<PSNODE_EULER>), grid, block, 0, s, d, pack); break;
-        case PSNODE_MIDPOINT: hipLaunchKernelGGL((latent_ode_backward_kernel<PSNODE_MIDPOINT>), grid, block, 0, s, d, pack); break;
-        default: hipLaunchKernelGGL((latent_ode_backward_kernel<PSNODE_RK4_38>), grid, block, 0, s, d, pack); break;
-    }
-    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    return launch_reduce_partials(wpart, a->grad_params, nullptr, LNP, 0, nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
-}
+int latent_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s) { return latent_bwd_dpp_launch(a, workspace, s); }
 
 // ---- DAE entry points
 static bool two16(const psnode_mlp_f32& m, int in_dim) { return m.n_layers == 2 && m.in_dim == in_dim && m.out_dim[0] == LH && m.out_dim[1] == LH; }

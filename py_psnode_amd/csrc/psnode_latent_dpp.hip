@@ -62,6 +62,18 @@ __device__ __forceinline__ float dot16(const float init, const float src, const 
           "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
     return acc;
 }
+// acc[j] += src[row lane j] * own, j < 16: the rank-1 update of a lane's row of a weight-gradient block (backward kernel).
+// Two v_nop = the DPP hazard's two wait states (no initialisation to hide them behind here).
+#define PSNODE_DPP_RANK1(N) "v_fmac_f32_dpp %" #N ", %16, %17 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void outer16(float (&acc)[16], const float src, const float own) {
+    asm("v_nop\n\tv_nop\n\t" PSNODE_DPP_RANK1(0) PSNODE_DPP_RANK1(1) PSNODE_DPP_RANK1(2) PSNODE_DPP_RANK1(3) PSNODE_DPP_RANK1(4)
+        PSNODE_DPP_RANK1(5) PSNODE_DPP_RANK1(6) PSNODE_DPP_RANK1(7) PSNODE_DPP_RANK1(8) PSNODE_DPP_RANK1(9) PSNODE_DPP_RANK1(10)
+        PSNODE_DPP_RANK1(11) PSNODE_DPP_RANK1(12) PSNODE_DPP_RANK1(13) PSNODE_DPP_RANK1(14) PSNODE_DPP_RANK1(15)
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]),
+          "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+        : "v"(src), "v"(own));
+}
+#undef PSNODE_DPP_RANK1
 #undef PSNODE_DPP_FMAC
 #undef PSNODE_DPP_HEAD
 // first layer of an encoder: in-features `quads`*4 <= 16 (the weights beyond in_dim are zero), wave-uniform choice
@@ -306,6 +318,212 @@ __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const Laten
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// K8f -- backward (discretise-then-optimise) through the hidden-16 latent ODE, same lane = (trajectory, unit) mapping: what
+// loss.backward() computes through integrate_ODE between the encoders and the decoder of neural_00_ODE_02_direct_encode.py:74-89.
+// Replaces K8 (one MFMA wave per 16 trajectories = one wave per CU at B = 4096, 3.85 ms) -- 1024 waves instead of 256.
+//   forward recompute per stage  pre = cz + F_x . X_s ; h = ELU(pre) ; k_s = b2 + W2 . h                       (dot16 x2 + ELU)
+//   backward per stage           dW2[u][:] += gk[u] * h[:]              (outer16: the lane's row of the gradient block)
+//                                d1 = (W2^T gk) * ELU'(pre)             (dot16 with the lane's COLUMN of W2)
+//                                dF_x[u][:] += d1[u] * X_s[:] ;  gX_s = F_x^T d1
+//   per step                     dF_z[u][:] += D1[u] * z[:] ; gz = F_z^T D1 ,  D1 = sum_s d1 (the external block is frozen)
+//   per launch                   d all_initial = (Wa - Wd)^T sum_t D1 ;  dWa = sum_t D1 (x) a0 ;  dWd = dF - dWa ;  dWs = dF
+// Every lane accumulates the gradient of ITS row of each block for ITS trajectory in registers over the whole launch; the four
+// trajectories of a wave are summed with two xor-shuffles at the end, one partial vector per wave, summed by reduce_partials in
+// a fixed order (deterministic).  No LDS, no barrier, any alignment.
+struct LatentBwdDppDev {
+    int method, n_events;
+    long long T, B;
+    const float *de_w1, *de_b1, *de_w2, *de_b2;
+    ViewDev t, z;
+    const float* a0;
+    const int* ev;
+    const float* zj;
+    long long zjb, zje;
+    const float *xs, *gout;
+    float *gx0, *gz, *gzj, *ga0, *wpart;
+};
+constexpr int BK1 = 6 * LH, BNP = LH * BK1 + LH + LH * LH + LH;   // in_features of L1; parameters W1, b1, W2, b2
+
+template <int METHOD>
+__global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const LatentBwdDppDev a) {
+    constexpr int S = rk_stages(METHOD);
+    const int lane = threadIdx.x & 63, u = lane & 15, row = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long b_raw = (long long)blockIdx.x * DTB + wv * 4 + row;
+    const bool valid = b_raw < a.B;
+    const long long b = valid ? b_raw : a.B - 1;
+    const long long nT = a.T;
+    EluS elu;
+    elu.knee = elu_knee();
+    elu.neg_t0 = -__builtin_amdgcn_exp2f(elu.knee * kLog2e);
+    auto dact = [](const float h) -> float { return h > 0.0f ? 1.0f : h + 1.0f; };   // ELU'(pre) from h = ELU(pre)
+
+    // rows (forward) and columns (transposed products) of the folded blocks F = Ws + Wd and of W2
+    float fx[16], fz[16], w2[16], fxT[16], fzT[16], w2T[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float* r = a.de_w1 + (long long)u * BK1;
+        fx[j] = r[4 * LH + j] + r[2 * LH + j];
+        fz[j] = r[5 * LH + j] + r[3 * LH + j];
+        w2[j] = a.de_w2[u * LH + j];
+        const float* c = a.de_w1 + (long long)j * BK1;
+        fxT[j] = c[4 * LH + u] + c[2 * LH + u];
+        fzT[j] = c[5 * LH + u] + c[3 * LH + u];
+        w2T[j] = a.de_w2[j * LH + u];
+    }
+    const float b2 = a.de_b2[u];
+    const float a0x = a.a0[b * 2 * LH + u], a0z = a.a0[b * 2 * LH + LH + u];
+    float c0 = a.de_b1[u];
+    {
+        float wa[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wa[j] = a.de_w1[(long long)u * BK1 + j] - a.de_w1[(long long)u * BK1 + 2 * LH + j];
+        c0 = dot16(c0, a0x, wa);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wa[j] = a.de_w1[(long long)u * BK1 + LH + j] - a.de_w1[(long long)u * BK1 + 3 * LH + j];
+        c0 = dot16(c0, a0z, wa);
+    }
+
+    float aW2[16], aFx[16], aFz[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) aW2[j] = aFx[j] = aFz[j] = 0.0f;
+    float S1 = 0.0f, SB2 = 0.0f, gcarry = 0.0f;
+
+    const float* tp = a.t.p + b * a.t.sb;
+    const long long tst = a.t.st;
+    const float* zp = a.z.p + b * a.z.sb + u;
+    const float* zjp = a.zj ? a.zj + b * a.zjb + u : zp;
+    long long zst = a.z.st, zje = a.zje;
+    asm volatile("" : "+s"(zst), "+s"(zje));
+    auto load_z = [&](const long long k, const int ev) -> float {
+        const long long off = ev >= 0 ? ev * zje : k * zst;
+        return (ev >= 0 ? zjp : zp)[off];
+    };
+    auto load_evb = [&](const long long blk) -> int {      // event indices of steps 64 blk .. 64 blk + 63, one per lane
+        const long long i = blk * 64 + lane;
+        const int v = (a.ev && i + 1 < nT) ? a.ev[i] : -1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        return v;
+    };
+    auto row_of = [&](const float* base, const long long k) -> float { return base[(k * a.B + b) * LH + u]; };
+
+    // The sweep runs k = T-2 .. 0; step inputs PF steps ahead in a register ring (as the forward kernel).
+    float tq[PF], zq_[PF], xq[PF], gq[PF];   // slot j of a chunk: t[k], z of step k, xs[k], dL/dxs[k+1]
+    int evq[PF];
+    int evb = 0;
+    long long evb_blk = -1;
+    auto fetch = [&](const int j, const long long k) {       // k >= 0
+        if ((k >> 6) != evb_blk) { evb_blk = k >> 6; evb = load_evb(evb_blk); }
+        evq[j] = __builtin_amdgcn_readlane(evb, (int)(k & 63));
+        tq[j] = tp[k * tst];
+        zq_[j] = load_z(k, evq[j]);
+        xq[j] = row_of(a.xs, k);
+        gq[j] = valid ? row_of(a.gout, k + 1) : 0.0f;
+    };
+    float t_hi = nT >= 2 ? tp[(nT - 1) * tst] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        tq[j] = zq_[j] = xq[j] = gq[j] = 0.0f; evq[j] = -1;
+        if (nT - 2 - j >= 0) fetch(j, nT - 2 - j);
+    }
+    for (long long kc = nT - 2; kc >= 0; kc -= PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const long long k = kc - j;
+            if (k >= 0) {
+                const float h_ = t_hi - tq[j];
+                t_hi = tq[j];
+                const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
+                const int ev = evq[j];
+                if (k - PF >= 0) fetch(j, k - PF);
+                const float cz = dot16(c0, zk, fz);
+                // ---- phase A: stage evaluations from the saved state
+                float X[S], hh[S], ks[S];
+#pragma unroll
+                for (int st = 0; st < S; ++st) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < st; ++jj) acc += rk_a(METHOD, st, jj) * ks[jj];
+                    X[st] = st == 0 ? x0 : x0 + h_ * acc;
+                    hh[st] = elu(dot16(cz, X[st], fx));
+                    ks[st] = dot16(b2, hh[st], w2);
+                }
+                // ---- phase B: stages backwards
+                float gks[S], gx0 = g1, D1 = 0.0f;
+#pragma unroll
+                for (int st = 0; st < S; ++st) gks[st] = (h_ * rk_b(METHOD, st)) * g1;
+#pragma unroll
+                for (int st = S - 1; st >= 0; --st) {
+                    const float gk = gks[st];
+                    SB2 += gk;
+                    outer16(aW2, hh[st], gk);                              // dW2[u][:] += gk[u] h[:]
+                    const float d1 = dot16(0.0f, gk, w2T) * dact(hh[st]);  // (W2^T gk)[u] ELU'
+                    D1 += d1;
+                    outer16(aFx, X[st], d1);                               // dF_x[u][:] += d1[u] X_s[:]
+                    const float gx = dot16(0.0f, d1, fxT);
+                    gx0 += gx;
+#pragma unroll
+                    for (int jj = 0; jj < st; ++jj) gks[jj] += (h_ * rk_a(METHOD, st, jj)) * gx;
+                }
+                S1 += D1;
+                // ---- external block: frozen over the stages
+                const float gzv = dot16(0.0f, D1, fzT);
+                outer16(aFz, zk, D1);
+                if (valid) {
+                    if (ev >= 0) { if (a.gzj) a.gzj[(b * a.n_events + ev) * LH + u] = gzv; }
+                    if (a.gz) a.gz[(k * a.B + b) * LH + u] = ev >= 0 ? 0.0f : gzv;
+                }
+                gcarry = gx0;
+            }
+        }
+    }
+
+    // ---- epilogue
+    if (valid) {
+        a.gx0[b * LH + u] = gcarry + row_of(a.gout, 0);
+        if (a.gz && nT >= 1) a.gz[((nT - 1) * a.B + b) * LH + u] = 0.0f;      // z[T-1] is never read
+    }
+    float cax[16], caz[16];     // dWa of this trajectory: sum_t(D1)[u] * a0[:]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cax[j] = caz[j] = 0.0f;
+    outer16(cax, a0x, S1);
+    outer16(caz, a0z, S1);
+    {   // d all_initial = (Wa - Wd)^T sum_t(D1): the lane's column of each a0 block
+        float wt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wt[j] = a.de_w1[(long long)j * BK1 + u] - a.de_w1[(long long)j * BK1 + 2 * LH + u];
+        const float gax = dot16(0.0f, S1, wt);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wt[j] = a.de_w1[(long long)j * BK1 + LH + u] - a.de_w1[(long long)j * BK1 + 3 * LH + u];
+        const float gaz = dot16(0.0f, S1, wt);
+        if (valid) { a.ga0[b * 2 * LH + u] = gax; a.ga0[b * 2 * LH + LH + u] = gaz; }
+    }
+    // ---- sum the wave's four trajectories (fixed order), one partial per wave in nn.Linear order [W1 (16 x 96), b1, W2, b2]
+    auto rows4 = [](float v) -> float {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { aW2[j] = rows4(aW2[j]); aFx[j] = rows4(aFx[j]); aFz[j] = rows4(aFz[j]); cax[j] = rows4(cax[j]); caz[j] = rows4(caz[j]); }
+    S1 = rows4(S1);
+    SB2 = rows4(SB2);
+    if (row == 0) {
+        float* wp = a.wpart + ((size_t)blockIdx.x * 4 + wv) * BNP;
+        float* r = wp + u * BK1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            r[j] = cax[j];                       r[LH + j] = caz[j];
+            r[2 * LH + j] = aFx[j] - cax[j];     r[3 * LH + j] = aFz[j] - caz[j];
+            r[4 * LH + j] = aFx[j];              r[5 * LH + j] = aFz[j];
+            wp[LH * BK1 + LH + u * LH + j] = aW2[j];
+        }
+        wp[LH * BK1 + u] = S1;
+        wp[LH * BK1 + LH + LH * LH + u] = SB2;
+    }
+}
+
 template <bool ENC>
 hipError_t launch_dpp(const LatentDppDev& a, hipStream_t s) {
     const dim3 grid((unsigned)((a.B + DTB - 1) / DTB)), block(ENC ? 512 : 256);
@@ -334,6 +552,29 @@ hipError_t launch_latent_dpp(const IntegrateDev& d, hipStream_t stream) {
     a.t = d.t; a.x = d.x; a.z = d.z; a.a0 = d.a0; a.ev = d.ev; a.zj = d.zj; a.zjb = d.zjb; a.zje = d.zje;
     a.xo = d.xo;
     return launch_dpp<false>(a, stream);
+}
+
+size_t latent_bwd_dpp_workspace_floats(long long B) { return (size_t)((B + DTB - 1) / DTB) * 4 * BNP + 64; }
+
+int latent_bwd_dpp_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStream_t s) {
+    LatentBwdDppDev a;
+    memset(&a, 0, sizeof(a));
+    a.method = p->method; a.n_events = p->n_events; a.T = p->T; a.B = p->B;
+    a.de_w1 = p->de.weight[0]; a.de_b1 = p->de.bias[0]; a.de_w2 = p->de.weight[1]; a.de_b2 = p->de.bias[1];
+    a.t = ViewDev{p->t.ptr, p->t.stride_t, p->t.stride_b};
+    a.z = ViewDev{p->z.ptr, p->z.stride_t, p->z.stride_b};
+    a.a0 = p->all_initial; a.ev = p->event_idx; a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
+    a.xs = p->xs; a.gout = p->grad_xs; a.gx0 = p->grad_x0; a.gz = p->grad_z; a.gzj = p->grad_z_jump; a.ga0 = p->grad_all_initial;
+    a.wpart = workspace;
+    const int nwg = (int)((p->B + DTB - 1) / DTB);
+    const dim3 grid((unsigned)nwg), block(256);
+    switch (p->method) {
+        case PSNODE_EULER: hipLaunchKernelGGL((latent_ode_backward_dpp_kernel<PSNODE_EULER>), grid, block, 0, s, a); break;
+        case PSNODE_MIDPOINT: hipLaunchKernelGGL((latent_ode_backward_dpp_kernel<PSNODE_MIDPOINT>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((latent_ode_backward_dpp_kernel<PSNODE_RK4_38>), grid, block, 0, s, a); break;
+    }
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    return launch_reduce_partials(workspace, p->grad_params, nullptr, BNP, 0, nwg * 4, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // namespace psnode
