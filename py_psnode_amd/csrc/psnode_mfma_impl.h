@@ -175,28 +175,63 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     const float* vp = a.v.p + b * a.v.sb;
     const float* vjp = a.vj + b * a.vjb;
 
-    // z|v column of grid point k for one slot (ev >= 0: the batch takes the jump values for this step).  In the DAE a lane's slot
-    // may be a z or a v column: both sources are read with a clamped column and the VALUE is selected -- selecting between the
-    // two base pointers per lane makes the compiler spill a pointer table to scratch and chase it with flat loads and full
-    // vmcnt(0) waits inside the time loop (3-4 k cycles per step on K2 before this change).
-    auto load_zv = [&](long long k, int ev, int kind, int col) -> float {
-        if constexpr (!DAE) {
+    // z|v columns of grid point k for the ext slots (ev >= 0: the batch takes the jump values for this step).  In the DAE a lane's
+    // slot may be a z or a v column: BOTH sources are read with a clamped column and the value is selected WHEN IT IS CONSUMED
+    // (a step later) -- selecting right behind the loads put an s_waitcnt vmcnt(0) behind every prefetch (a full memory round trip
+    // inside every step of K2), and selecting between the two base pointers per lane makes the compiler spill a pointer table to
+    // scratch.  `ev` is wave-uniform (read with v_readlane from a 64-step block of the event table, as K3f): the address of a row is
+    // scalar arithmetic; a per-lane copy of the index cost 64-bit per-lane multiplies for every load.
+    auto raw_z = [&](long long k, int ev, int kind, int col) -> float {
+        if constexpr (!DAE) {      // single source: nothing to select, nothing to clamp
             if (kind == 0) return (ev >= 0 ? zjp + ev * zje : zp + k * zst)[col];
             return 0.0f;
         } else {
-            float zval = 0.0f, vval = 0.0f;
-            if (zd > 0) zval = (ev >= 0 ? zjp + ev * zje : zp + k * zst)[kind == 0 ? col : 0];
-            if (vd > 0) vval = (ev >= 0 ? vjp + ev * vje : vp + k * vst)[kind == 1 ? col : 0];
-            return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
+            if (zd <= 0) return 0.0f;
+            const long long off = ev >= 0 ? (long long)ev * zje : k * zst;
+            return (ev >= 0 ? zjp : zp)[off + (kind == 0 ? col : 0)];
         }
     };
-    auto load_de_ext = [&](long long k, int ev, Arr<NZM>& dst) {
-#pragma unroll
-        for (int m = 0; m < NZM; ++m) dst.v[m] = load_zv(k, ev, ekind[m], ecol[m]);
+    auto raw_v = [&](long long k, int ev, int kind, int col) -> float {
+        if (!DAE || vd <= 0) return 0.0f;
+        const long long off = ev >= 0 ? (long long)ev * vje : k * vst;
+        return (ev >= 0 ? vjp : vp)[off + (kind == 1 ? col : 0)];
     };
-    auto load_ae_ext = [&](long long k, int ev, Arr<NZA>& dst) {
+    // 8 waves per tile (hidden 128) have a second wave per SIMD to hide the wait and no registers for the second copy: they select
+    // at load time (the value travels in the z array).
+    constexpr bool DEFER_PICK = NWV <= 4;
+    auto pick = [&](int kind, float zval, float vval) -> float {
+        if constexpr (!DEFER_PICK || !DAE) return zval;
+        return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
+    };
+    auto pick_now = [&](int kind, float zval, float vval) -> float { return kind == 0 ? zval : (kind == 1 ? vval : 0.0f); };
+    auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>& dv) {
 #pragma unroll
-        for (int m = 0; m < NZA; ++m) dst.v[m] = load_zv(k, ev, akind[m], acol[m]);
+        for (int m = 0; m < NZM; ++m) {
+            const float zr = raw_z(k, ev, ekind[m], ecol[m]), vr = raw_v(k, ev, ekind[m], ecol[m]);
+            if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
+            else dz.v[m] = pick_now(ekind[m], zr, vr);
+        }
+    };
+    auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>& dv) {
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) {
+            const float zr = raw_z(k, ev, akind[m], acol[m]), vr = raw_v(k, ev, akind[m], acol[m]);
+            if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
+            else dz.v[m] = pick_now(akind[m], zr, vr);
+        }
+    };
+    auto pick_ae = [&](const Arr<NZA>& dz, const Arr<NZA>& dv) -> Arr<NZA> {
+        Arr<NZA> o = {};
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) o.v[m] = pick(akind[m], dz.v[m], dv.v[m]);
+        return o;
+    };
+    // Event indices travel 64 steps at a time: lane i holds event_idx[64 blk + i] (one 256-byte load per 64 steps, waited for on the spot)
+    auto load_evb = [&](const long long blk) -> int {
+        const long long i = blk * 64 + l;
+        const int v = (a.ev && i + 1 < a.T) ? a.ev[i] : -1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        return v;
     };
 
     int p = 0;   // exchange buffer parity
@@ -339,37 +374,53 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 
     store_x(0);
     f4 icur = f4{0.f, 0.f, 0.f, 0.f};
-    Arr<NZA> zva_nxt = {};
+    Arr<NZA> zaz_nxt = {}, zav_nxt = {};      // raw z / v reads of grid point k+1 for the AE head (selected at use)
     if constexpr (DAE) {   // my_solvers.py:95
-        Arr<NZA> zv0;
-        load_ae_ext(0, -1, zv0);
+        Arr<NZA> rz, rv;
+        load_ae_raw(0, -1, rz, rv);
         float xa[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) xa[r] = x[r];
         if constexpr (TRUE_X) load_x(0, xa);
-        icur = ae_eval(xa, zv0);
+        icur = ae_eval(xa, pick_ae(rz, rv));
         store_i(0, icur);
-        if (nT > 1) load_ae_ext(1, -1, zva_nxt);
+        if (nT > 1) load_ae_raw(1, -1, zaz_nxt, zav_nxt);
     }
     if (nT < 2) return;
 
     float t_cur = tp[0], t_nxt = tp[tst];
-    // Event index of step k+1, fetched one iteration before the prefetch that needs it.  The address is made
-    // formally per-lane (opaque zero) so the value stays in a VGPR instead of a load -> s_waitcnt -> readfirstlane.
+#ifndef PSNODE_UNIFORM_EV
+#define PSNODE_UNIFORM_EV 1
+#endif
+    // UNIFORM_EV: the event index of a step is wave-uniform (block of 64 steps in a VGPR, read with v_readlane).  Otherwise it is
+    // fetched per step through a formally per-lane address two steps ahead (round 1's scheme: no block reload, but per-lane
+    // address arithmetic for every input row).  Chosen per kernel family by measurement.
+    constexpr bool UNIFORM_EV = (PSNODE_UNIFORM_EV == 1) || (PSNODE_UNIFORM_EV == 2 && DAE);
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     const int* evp = a.ev + lane_zero;
-    int ev_cur = a.ev ? a.ev[0] : -1;
-    int ev_n1 = (a.ev && nT > 2) ? evp[1] : -1;
-    Arr<NZM> ext_nxt = {};
-    load_de_ext(0, ev_cur, ext_nxt);
+    int evb = UNIFORM_EV ? load_evb(0) : 0;
+    int ev_cur = UNIFORM_EV ? __builtin_amdgcn_readlane(evb, 0) : (a.ev ? a.ev[0] : -1);
+    int ev_n1 = (!UNIFORM_EV && a.ev && nT > 2) ? evp[1] : -1;
+    Arr<NZM> exz_nxt = {}, exv_nxt = {};
+    load_de_raw(0, ev_cur, exz_nxt, exv_nxt);
 
     for (long long k = 0; k + 1 < nT; ++k) {
         const float h_ = t_nxt - t_cur;
         t_cur = t_nxt;
-        const Arr<NZM> extv = ext_nxt;
-        const Arr<NZA> zva = zva_nxt;     // raw z|v of grid point k+1 for the AE head at the end of this step
+        Arr<NZM> extv;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) extv.v[m] = pick(ekind[m], exz_nxt.v[m], exv_nxt.v[m]);
+        const Arr<NZA> zva = pick_ae(zaz_nxt, zav_nxt);     // z|v of grid point k+1 for the AE head at the end of this step
         const int ev_now = ev_cur;
+        // Deferred store of the PREVIOUS step's result (still in x / icur): issued behind the consumption of this step's prefetched
+        // inputs and in front of the next prefetch, it has a full step to drain.  Stored at the end of its own step it sat in
+        // front of the loop-top s_waitcnt vmcnt(0) (the only count that is safe on the waves that do not store), and the storing
+        // wave -- hence, through the barriers, the whole tile -- waited out the store's round trip every step.
+        if (k > 0) {
+            store_x(k);
+            if constexpr (DAE) store_i(k, icur);
+        }
 
         float xsrc[NX];
 #pragma unroll
@@ -378,17 +429,22 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         // prefetch the next step's inputs (consumed one full step later)
         if (k + 2 < nT) {
             t_nxt = tp[(k + 2) * tst];
-            load_de_ext(k + 1, ev_n1, ext_nxt);
-            if constexpr (DAE) load_ae_ext(k + 2, -1, zva_nxt);
-            ev_cur = ev_n1;
-            ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+            if constexpr (UNIFORM_EV) {
+                if (((k + 1) & 63) == 0) evb = load_evb((k + 1) >> 6);
+                ev_cur = __builtin_amdgcn_readlane(evb, (int)((k + 1) & 63));
+            } else {
+                ev_cur = ev_n1;
+                ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+            }
+            load_de_raw(k + 1, ev_cur, exz_nxt, exv_nxt);
+            if constexpr (DAE) load_ae_raw(k + 2, -1, zaz_nxt, zav_nxt);
         }
         if constexpr (DAE) {
             // event: i0 = g(x0; z_jump, v_jump) with the RUNNING state (my_solvers.py:108-110)
             if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {
-                Arr<NZA> zvj;
-                load_ae_ext(k, ev_now, zvj);
-                icur = ae_eval(x, zvj);
+                Arr<NZA> rz, rv;
+                load_ae_raw(k, ev_now, rz, rv);
+                icur = ae_eval(x, pick_ae(rz, rv));
             }
         }
         // per-step constant of L1: c0 + W1[:, ext columns] . (ext - a0 | ext)
@@ -428,16 +484,16 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
             for (int r = 0; r < NX; ++r) x[r] = xsrc[r] + (k1[r] + 3.0f * (k2[r] + k3[r]) + k4[r]) * h_ * 0.125f;
         }
-        store_x(k + 1);
         if constexpr (DAE) {   // my_solvers.py:121: i1 at the right grid point, un-jumped inputs
             float xa[NX];
 #pragma unroll
             for (int r = 0; r < NX; ++r) xa[r] = x[r];
             if constexpr (TRUE_X) load_x(k + 1, xa);
             icur = ae_eval(xa, zva);
-            store_i(k + 1, icur);
         }
     }
+    store_x(nT - 1);
+    if constexpr (DAE) store_i(nT - 1, icur);
 }
 
 inline int nzm_of(const IntegrateDev& a, bool dae) { return (2 * (a.zd + (dae ? a.vd + a.id : 0)) + 3) / 4; }
