@@ -206,6 +206,45 @@ int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* args);
 size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* args);
 int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stage adjoints of the ODE integrator for hidden widths the one-launch backward does not cover (hidden 32 and 128: the scripts'
+ * argparse default is --hidden 128, neural_00_ODE_01_no_encode.py:245-246).  At those widths the weights, their transposes and the
+ * parameter-gradient accumulators do not fit the register file + LDS of a CU together, so the backward is split where the algebra
+ * splits: THIS call runs the sequential part of loss.backward() through integrate_ODE (my_solvers.py:66-78) -- the recomputed stage
+ * evaluations and the adjoint recursion through the stages and steps k1-1 .. k0 (MFMA, weights in registers, transposed weights in
+ * LDS) -- and writes, per (step, stage, trajectory), what the parameter gradients contract over:
+ *     act[l]   = h_l      (ELU outputs of hidden layer l = 1..3)            [k1-k0, S, B, H]
+ *     delta[l] = dL/dpre_l (adjoint of the pre-activation of layer l)       [k1-k0, S, B, H]
+ *     gk       = dL/dk_s  (adjoint of the stage derivative = delta of the output layer)   [k1-k0, S, B, x_dim]
+ *     xstage   = X_s      (the stage's state input)                          [k1-k0, S, B, x_dim]
+ * The parameter gradients are then PLAIN GEMMs over those rows (dW_l = delta_l^T . act_{l-1}, library GEMMs on the host side:
+ * py_psnode_amd/fused.py:ode_backward_wide), as are dL/dz = D1 . (Ws+Wd)[:, z] and dL/dall_initial = sum_t D1 . (Wa-Wd), D1 = sum_s delta_1.
+ * `carry` [B, x_dim] holds the adjoint of x[k1] WITHOUT dL/dxs[k1] on entry (zeros for the last chunk) and of x[k0] likewise on exit, so
+ * the sweep can be cut into time chunks to bound the size of the stored rows.  Shape class: de = 3n -> H -> H -> H -> x_dim,
+ * H in {32, 64, 128}, x_dim <= 8, z_dim <= 4. */
+typedef struct {
+    int32_t method;
+    int32_t x_dim, z_dim;
+    int64_t T, B;                    /* grid points / trajectories of the whole call */
+    int64_t k0, k1;                  /* steps k0 <= k < k1 of this chunk (0 <= k0 < k1 <= T-1) */
+    psnode_mlp_f32 de;
+    psnode_view_f32 t, z;
+    const float* all_initial;        /* [B, x+z] */
+    const int32_t* event_idx;        /* int32[T-1] or NULL */
+    const float* z_jump;
+    int64_t zj_stride_b, zj_stride_e;
+    const float* xs;                 /* forward result [T,B,x_dim] contiguous */
+    const float* grad_xs;            /* dL/dxs [T,B,x_dim] contiguous */
+    float* carry;                    /* [B,x_dim] in/out */
+    float* act[3];                   /* [k1-k0, S, B, H] each, S = stages of the method */
+    float* delta[3];
+    float* gk;                       /* [k1-k0, S, B, x_dim] */
+    float* xstage;                   /* [k1-k0, S, B, x_dim] */
+} psnode_ode_bwd_wide_args_f32;
+
+int32_t psnode_ode_backward_wide_supported(const psnode_ode_bwd_wide_args_f32* args);   /* dims only */
+size_t psnode_ode_backward_wide_workspace_bytes(const psnode_ode_bwd_wide_args_f32* args);
+int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward pass through psnode_dae_integrate_f32 (no teacher forcing): loss.backward() through integrate_DAE
  * (neural_01_DAE_01_no_encode.py:422-424 over my_solvers.py:94-129), including the AE head, the feedback of the
  * algebraic variable into the DE input and the event-time recomputation i0 = g(x0; jumps).

@@ -28,6 +28,7 @@ EXPORTS = (
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
+    "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
 )
 
 
@@ -95,6 +96,13 @@ class OdeEncodedArgsF32(ctypes.Structure):
                 ("t", ViewF32), ("x", ViewF32), ("z", ViewF32), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_pred", c_void_p), ("x_re", c_void_p),
                 ("xre_stride_t", c_int64), ("xre_stride_b", c_int64), ("xh_out", c_void_p)]
+
+
+class OdeBwdWideArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64), ("k0", c_int64), ("k1", c_int64),
+                ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
+                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("xs", c_void_p), ("grad_xs", c_void_p), ("carry", c_void_p),
+                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p)]
 
 
 class LossArgsF32(ctypes.Structure):
@@ -169,6 +177,12 @@ def load():
     lib.psnode_ode_encoded_supported.argtypes = [ctypes.POINTER(OdeEncodedArgsF32)]
     lib.psnode_ode_encoded_integrate_f32.restype = c_int32
     lib.psnode_ode_encoded_integrate_f32.argtypes = [ctypes.POINTER(OdeEncodedArgsF32), c_void_p]
+    lib.psnode_ode_backward_wide_supported.restype = c_int32
+    lib.psnode_ode_backward_wide_supported.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
+    lib.psnode_ode_backward_wide_workspace_bytes.restype = c_size_t
+    lib.psnode_ode_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
+    lib.psnode_ode_backward_wide_f32.restype = c_int32
+    lib.psnode_ode_backward_wide_f32.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

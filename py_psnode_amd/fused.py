@@ -412,6 +412,114 @@ def ode_backward_supported(method: str, de_layers: Layers, x_dim: int, z_dim: in
     return bool(lib.psnode_ode_backward_supported(ctypes.byref(a)))
 
 
+def ode_backward_wide_supported(method: str, de_layers: Layers, x_dim: int, z_dim: int) -> bool:
+    """Shapes of the two-part backward (psnode_ode_backward_wide_f32 + GEMMs): 3n -> H -> H -> H -> x, H in {32, 64, 128}."""
+    if de_layers[0][0].device.type != "cuda" or len(de_layers) != 4:
+        return False
+    lib = _lib.load()
+    a = _lib.OdeBwdWideArgsF32()
+    a.method, a.x_dim, a.z_dim, a.T, a.B = METHOD_ID[method], x_dim, z_dim, 2, 1
+    a.de = _mlp(de_layers, de_layers[0][0].device, "de", [])
+    return bool(lib.psnode_ode_backward_wide_supported(ctypes.byref(a)))
+
+
+def _gemm_tn(a2: torch.Tensor, b2: torch.Tensor, groups: int) -> torch.Tensor:
+    """a2^T @ b2 for tall-skinny [N, p], [N, q] (N in the millions): `groups` independent partial products + one sum, so the library
+    GEMM has parallelism over the contraction (one [p,N]x[N,q] call runs on a handful of workgroups: 21 vs 124 TFLOP/s at p=q=128)."""
+    N = a2.shape[0]
+    while groups > 1 and N % groups:
+        groups //= 2
+    return torch.bmm(a2.view(groups, N // groups, -1).transpose(1, 2), b2.view(groups, N // groups, -1)).sum(0)
+
+
+def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None,
+                      chunk_steps: Optional[int] = None, need_grad_z: bool = True):
+    """Backward of `ode_integrate` for hidden widths without a one-launch backward kernel (32, 128; also valid at 64): the sequential
+    adjoint sweep on the MFMA kernel K4w in time chunks (psnode_ode_backward_wide_f32), the parameter gradients and the input
+    gradients that are plain contractions over its stored rows as library GEMMs.  Same return value as `ode_backward`."""
+    lib = _lib.load()
+    dev = xs.device
+    T, B, xd = xs.shape
+    zd = z.shape[-1]
+    n = xd + zd
+    H = de_layers[0][0].shape[0]
+    S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    keep: list = []
+    a = _lib.OdeBwdWideArgsF32()
+    a.method, a.x_dim, a.z_dim, a.T, a.B = METHOD_ID[method], xd, zd, T, B
+    a.de = _mlp(de_layers, dev, "de", keep)
+    a.t, a.z = _view(t, dev, "t", keep), _view(z, dev, "z", keep)
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    xs_c, g_c = _f32_dev(xs, dev, "xs").contiguous(), _f32_dev(grad_xs, dev, "grad_xs").contiguous()
+    keep += [a0, xs_c, g_c]
+    a.all_initial, a.xs, a.grad_xs = a0.data_ptr(), xs_c.data_ptr(), g_c.data_ptr()
+    if event_idx is not None:
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+    W1, W2, W3, W4 = (w.detach() for w, _ in de_layers)
+    gW = [torch.zeros_like(w) for w in (W1, W2, W3, W4)]
+    gb = [torch.zeros(w.shape[0], dtype=torch.float32, device=dev) for w in (W1, W2, W3, W4)]
+    gz = torch.zeros((T, B, zd), dtype=torch.float32, device=dev) if (zd > 0 and need_grad_z) else None
+    gzj = torch.zeros((B, z_jump.shape[1], zd), dtype=torch.float32, device=dev) if (event_idx is not None and zd > 0) else None
+    S1 = torch.zeros((B, H), dtype=torch.float32, device=dev)
+    carry = torch.zeros((B, xd), dtype=torch.float32, device=dev)
+    a.carry = carry.data_ptr()
+    if T >= 2:
+        if chunk_steps is None:      # ~3 GB of stored rows per chunk
+            chunk_steps = max(1, min(T - 1, int(3e9 // (6 * 4 * S * B * H))))
+        Fz = (W1[:, 2 * n + xd:3 * n] + W1[:, n + xd:2 * n]) if zd > 0 else None          # (Ws + Wd)[:, z columns]
+        with torch.cuda.device(dev):
+            nbytes = lib.psnode_ode_backward_wide_workspace_bytes(ctypes.byref(a))
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            wp, wn = _aligned_ptr(ws)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            zt = z.detach() if zd > 0 else None
+            for k1 in range(T - 1, 0, -chunk_steps):
+                k0 = max(0, k1 - chunk_steps)
+                Tc = k1 - k0
+                rows = [torch.empty((Tc, S, B, H), dtype=torch.float32, device=dev) for _ in range(6)]
+                gk = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
+                Xs = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
+                a.k0, a.k1 = k0, k1
+                for q in range(3):
+                    a.act[q], a.delta[q] = rows[q].data_ptr(), rows[3 + q].data_ptr()
+                a.gk, a.xstage = gk.data_ptr(), Xs.data_ptr()
+                _lib.check(lib.psnode_ode_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_ode_backward_wide_f32")
+                h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
+                G = Tc * S
+                gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
+                gW[2] += _gemm_tn(d3, h2, G); gb[2] += d3.sum(0)
+                gW[1] += _gemm_tn(d2, h1, G); gb[1] += d2.sum(0)
+                # input of L1 per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z of the step (jump values at event steps))
+                if zd > 0:
+                    zc = zt[k0:k1]                                                           # [Tc, B, zd] view
+                    if event_idx is not None:
+                        evc = event_idx[k0:k1].long()
+                        hit = (evc >= 0).view(Tc, 1, 1)
+                        zc = torch.where(hit, z_jump.detach()[:, evc.clamp_min(0)].permute(1, 0, 2), zc)
+                    s_in = torch.cat((Xs, zc.unsqueeze(1).expand(Tc, S, B, zd)), -1)
+                else:
+                    s_in = Xs
+                U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
+                gW[0] += _gemm_tn(d1, U, G); gb[0] += d1.sum(0)
+                D1 = rows[3].sum(1)                                                          # [Tc, B, H]: sum over the stages
+                S1 += D1.sum(0)
+                if zd > 0 and (gz is not None or gzj is not None):
+                    gzc = D1.reshape(-1, H) @ Fz                                             # [Tc*B, zd]
+                    gzc = gzc.view(Tc, B, zd)
+                    if event_idx is not None:
+                        if gzj is not None:
+                            gzj.index_add_(1, evc.clamp_min(0), (gzc * hit).permute(1, 0, 2))
+                        gzc = torch.where(hit, torch.zeros_like(gzc), gzc)
+                    if gz is not None:
+                        gz[k0:k1] = gzc
+                del rows, gk, Xs, U, D1
+    gx0 = carry + g_c[0]
+    ga0 = S1 @ (W1[:, 0:n] - W1[:, n:2 * n])                                                # d all_initial = sum_t D1 . (Wa - Wd)
+    return gx0, gz, gzj, ga0, [gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3]]
+
+
 def _split_grads(flat, layers):
     out, off = [], 0
     for w, b in layers:
@@ -500,6 +608,11 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     dev = xs.device
     T, B, xd = xs.shape
     zd = z.shape[-1]
+    # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K4w + library GEMMs instead of the generic K5
+    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64
+                            and ode_backward_wide_supported(method, de_layers, xd, zd)):
+        return ode_backward_wide(method, de_layers, t, z, all_initial, xs, grad_xs, event_idx=event_idx, z_jump=z_jump,
+                                 need_grad_z=need_grad_z)
     keep: list = []
     a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep, kernel)
     z, z_jump = _aligned16(z), _aligned16(z_jump)

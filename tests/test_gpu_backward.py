@@ -122,6 +122,84 @@ def _param_grads(seq):
     return [p.grad for p in seq.parameters()]
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("xd,zd,H", [(8, 2, 128), (8, 2, 32), (8, 2, 64), (5, 3, 128), (3, 0, 32), (8, 4, 128)])
+def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
+    """K4w (psnode_ode_backward_wide_f32: MFMA adjoint sweep in time chunks + library GEMMs for the parameter gradients) at hidden
+    128 / 32 / 64 vs the fp64 autograd walk: ragged tile, per-trajectory clocks, two events, three time chunks, every NZM class."""
+    from py_psnode_amd import fused
+    B, Tn = 21, 12
+    g = torch.Generator().manual_seed(500 + H + xd)
+    torch.manual_seed(500 + H + xd)
+    n = xd + zd
+    dims = [3 * n, H, H, H, xd]
+    lin = [nn.Linear(dims[k], dims[k + 1]) for k in range(4)]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g))
+    x, z = 0.1 * torch.randn(Tn, B, xd, generator=g), 0.1 * torch.randn(Tn, B, zd, generator=g)
+    ev = torch.stack([t[2, :, :], t[Tn - 3, :, :]], dim=1).contiguous() if zd else None
+    zj = 0.1 * torch.randn(B, 2, zd, generator=g) if zd else None
+    G = torch.randn(Tn, B, xd, generator=g)
+    # fp64 truth through this package's walk with a DE_Func of the same width
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    de = models.DE_Func(n, (H, H, H), xd).double()
+    with torch.no_grad():
+        for k, l_ in enumerate(lin):
+            de.x_dot[2 * k].weight.copy_(l_.weight.double()); de.x_dot[2 * k].bias.copy_(l_.bias.double())
+    solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+    solver.fused = "off"
+    xq, zq = x.double().requires_grad_(True), z.double().requires_grad_(True)
+    zjq = zj.double().requires_grad_(True) if zj is not None else None
+    event = nd.ODE_Event()
+    if ev is not None:
+        event.set_event(ev.double(), zjq)
+    a0q = torch.cat((xq[0], zq[0]), -1)
+    xs_ref = solver.integrate_ODE(x_func=de, t=t.double(), x=xq, z=zq, all_initial=a0q, event_fn=event.event_fn if ev is not None else None,
+                                  jump_change_fn=event.jump_change_fn if ev is not None else None)
+    (xs_ref * G.double()).sum().backward()
+    layers = [(l_.weight.detach().cuda(), l_.bias.detach().cuda()) for l_ in lin]
+    a0 = torch.cat((x[0], z[0]), -1).cuda()
+    c = lambda a: None if a is None else a.cuda()
+    xs = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj))
+    tab = fused.event_table(c(t), c(ev)) if ev is not None else None
+    gx0, gz, gzj, ga0, gp = fused.ode_backward_wide(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), chunk_steps=4)
+    _close(xs, xs_ref.detach(), "xs")
+    _close(gx0 + ga0[:, :xd], xq.grad[0], "grad x0")
+    if zd:
+        gz_tot = gz.clone(); gz_tot[0] += ga0[:, xd:]
+        _close(gz_tot, zq.grad, "grad z")
+        _close(gzj, zjq.grad, "grad z_jump")
+    for k, (a_, p_) in enumerate(zip(gp, de.x_dot.parameters())):
+        _close(a_, p_.grad, f"grad param {k}")
+    # the auto route picks K4w at hidden 32 / 128 and the one-launch K4 at 64: same numbers either way
+    auto = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj))
+    for k, (a_, b_) in enumerate(zip(gp, auto[4])):
+        _close(a_, b_.double().cpu(), f"auto vs wide param {k}")
+
+
+def test_hidden128_training_takes_the_wide_backward():
+    """ODE_Model at --hidden 128 (the scripts' argparse default) under autograd with fused='require': forward K1, backward K4w."""
+    from py_psnode_amd import fused, models
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(1)
+    m = models.ODE_Model(8, 2, 128, solver=nd.RK4()).cuda()
+    m.solver.fused = "require"
+    B, Tn = 40, 30
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1).cuda()
+    x, z = (0.1 * torch.randn(B, Tn, 8)).cuda(), (0.1 * torch.randn(B, Tn, 2)).cuda()
+    calls = []
+    orig = fused.ode_backward_wide
+    try:
+        fused.ode_backward_wide = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        pred = m(t=t, x=x, z=z, event_t=torch.full((B, 1, 1), -1.0).cuda(), z_jump=torch.zeros(B, 1, 2).cuda())
+        nn.functional.mse_loss(pred, x).backward()
+    finally:
+        fused.ode_backward_wide = orig
+    assert calls == [1]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in m.parameters())
+
+
 @pytest.mark.parametrize("method", ["euler", "rk4"])
 @pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2), (8, 2, 128, 3), (8, 2, 32, 3)])
 def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
