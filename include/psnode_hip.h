@@ -280,6 +280,57 @@ int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* args);
 size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* args);
 int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The DAE counterpart of psnode_ode_backward_wide_f32 (hidden 32 / 64 / 128): the sequential part of loss.backward() through
+ * integrate_DAE (my_solvers.py:94-129) for steps k1-1 .. k0 -- per grid point the AE head's recompute + adjoint (its output adjoint
+ * = dL/dis of that grid point + what the DE of the step starting there returned through its algebraic inputs), per step the DE stages as
+ * in the ODE call, at event steps the recompute i0 = g(x0; jumps) and its adjoint -- writing the rows the parameter gradients contract
+ * over.  "Slot" layout of an algebraic-variable row [.., 16]: slot q < 2(z+v+i) is the DE's external input q of the `s - a0` block
+ * (q < z+v+i) or of the `s` block; the adjoint / value of i-dim d sits in slots z+v+d and (z+v+i)+z+v+d (values: equal; adjoints: to be
+ * summed by the caller).  Rows:
+ *     act / delta / gk / xstage : the DE's, as in psnode_ode_bwd_wide_args_f32
+ *     ae_act[l], ae_delta[l]    : [k1-k0+1, B, H]  AE head at grid point k0+r (row 0 is written only when k0 == 0)
+ *     ae_gi                     : [k1-k0+1, B, 16] adjoint of the head's output, slot layout
+ *     ev_act[l], ev_delta[l]    : [n_events, B, H] the event-time recompute of event e (written for events taken in [k0,k1))
+ *     ev_gi, ev_i               : [n_events, B, 16] its output adjoint and its value i0, slot layout
+ * carry_x [B,x_dim] / carry_i [B,16] (slot layout): adjoint of x[k1] without dL/dxs[k1] / of is[k1] without dL/dis[k1] on entry (zeros for
+ * the last chunk), of x[k0] / is[k0] likewise on exit -- except that the chunk with k0 == 0 also runs the head at grid point 0, so its
+ * carry_x is dL/dx_init without dL/dxs[0] and its carry_i is zero.  Parameter and input gradients: py_psnode_amd/fused.py:dae_backward_wide.
+ * Shape class: de = 3n -> H -> H -> H -> x_dim, ae = n+x+z+v -> H -> H -> H -> i_dim, x_dim <= 8, z+v+i <= 8. */
+typedef struct {
+    int32_t method;
+    int32_t x_dim, z_dim, v_dim, i_dim;
+    int64_t T, B;
+    int64_t k0, k1;
+    psnode_mlp_f32 de, ae;
+    psnode_view_f32 t, z, v;
+    const float* all_initial;        /* [B, x+z+v+i] */
+    const int32_t* event_idx;        /* int32[T-1] or NULL */
+    const float* z_jump; int64_t zj_stride_b, zj_stride_e;
+    const float* v_jump; int64_t vj_stride_b, vj_stride_e;
+    int32_t n_events;
+    const float* xs;                 /* forward results [T,B,x_dim], [T,B,i_dim] contiguous */
+    const float* is;
+    const float* grad_xs;            /* dL/dxs [T,B,x_dim] */
+    const float* grad_is;            /* dL/dis [T,B,i_dim] or NULL (= zeros) */
+    float* carry_x;                  /* [B,x_dim] in/out */
+    float* carry_i;                  /* [B,16] in/out */
+    float* act[3];
+    float* delta[3];
+    float* gk;
+    float* xstage;
+    float* ae_act[3];
+    float* ae_delta[3];
+    float* ae_gi;
+    float* ev_act[3];
+    float* ev_delta[3];
+    float* ev_gi;
+    float* ev_i;
+} psnode_dae_bwd_wide_args_f32;
+
+int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* args);   /* dims only */
+size_t psnode_dae_backward_wide_workspace_bytes(const psnode_dae_bwd_wide_args_f32* args);
+int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Masked, column-weighted squared-error loss of one (prediction, target) pair and its gradient, in one pass:
  *
  *   out[d]   = scale * inv_norm * col_weight[d] * sum_{t,b} mask[t,b,(d)] * (pred[t,b,d] - target[t,b,d])^2     d < D

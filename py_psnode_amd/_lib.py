@@ -29,6 +29,7 @@ EXPORTS = (
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
     "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
+    "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
 )
 
 
@@ -103,6 +104,19 @@ class OdeBwdWideArgsF32(ctypes.Structure):
                 ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("xs", c_void_p), ("grad_xs", c_void_p), ("carry", c_void_p),
                 ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p)]
+
+
+class DaeBwdWideArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
+                ("T", c_int64), ("B", c_int64), ("k0", c_int64), ("k1", c_int64), ("de", MlpF32), ("ae", MlpF32),
+                ("t", ViewF32), ("z", ViewF32), ("v", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p),
+                ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
+                ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64), ("n_events", c_int32),
+                ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
+                ("carry_x", c_void_p), ("carry_i", c_void_p),
+                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p),
+                ("ae_act", c_void_p * 3), ("ae_delta", c_void_p * 3), ("ae_gi", c_void_p),
+                ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p)]
 
 
 class LossArgsF32(ctypes.Structure):
@@ -183,6 +197,12 @@ def load():
     lib.psnode_ode_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
     lib.psnode_ode_backward_wide_f32.restype = c_int32
     lib.psnode_ode_backward_wide_f32.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_dae_backward_wide_supported.restype = c_int32
+    lib.psnode_dae_backward_wide_supported.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
+    lib.psnode_dae_backward_wide_workspace_bytes.restype = c_size_t
+    lib.psnode_dae_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
+    lib.psnode_dae_backward_wide_f32.restype = c_int32
+    lib.psnode_dae_backward_wide_f32.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
     if lib.psnode_abi_version() != 1:
         raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib

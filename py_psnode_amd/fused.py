@@ -540,15 +540,183 @@ def dae_backward_supported(method: str, de_layers: Layers, ae_layers: Layers, x_
     return bool(lib.psnode_dae_backward_supported(ctypes.byref(a)))
 
 
+def dae_backward_wide_supported(method: str, de_layers: Layers, ae_layers: Layers, x_dim, z_dim, v_dim, i_dim) -> bool:
+    """Shapes of the two-part DAE backward (psnode_dae_backward_wide_f32 + GEMMs): DE 3n -> H -> H -> H -> x and
+    AE n+x+z+v -> H -> H -> H -> i with H in {32, 64, 128}, x <= 8, z+v+i <= 8."""
+    if de_layers[0][0].device.type != "cuda" or len(de_layers) != 4 or len(ae_layers) != 4:
+        return False
+    lib = _lib.load()
+    a = _lib.DaeBwdWideArgsF32()
+    a.method, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = METHOD_ID[method], x_dim, z_dim, v_dim, i_dim, 2, 1
+    dev = de_layers[0][0].device
+    a.de, a.ae = _mlp(de_layers, dev, "de", []), _mlp(ae_layers, dev, "ae", [])
+    return bool(lib.psnode_dae_backward_wide_supported(ctypes.byref(a)))
+
+
+def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
+                      z_jump=None, v_jump=None, chunk_steps: Optional[int] = None):
+    """Backward of `dae_integrate` for hidden widths without a one-launch backward kernel (32, 128; also valid at 64): the sequential
+    adjoint sweep -- DE stages, AE head per grid point, event-time recompute -- on the MFMA kernel K7w in time chunks
+    (psnode_dae_backward_wide_f32); parameter gradients and the input gradients that are plain contractions over its stored rows as
+    library GEMMs.  Same return value as `dae_backward`."""
+    lib = _lib.load()
+    dev = xs.device
+    T, B, xd = xs.shape
+    zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
+    nzv, ne = zd + vd, zd + vd + idim
+    n = xd + ne
+    H = de_layers[0][0].shape[0]
+    S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    keep: list = []
+    a = _lib.DaeBwdWideArgsF32()
+    a.method, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = METHOD_ID[method], xd, zd, vd, idim, T, B
+    a.de, a.ae = _mlp(de_layers, dev, "de", keep), _mlp(ae_layers, dev, "ae", keep)
+    a.t, a.z, a.v = _view(t, dev, "t", keep), _view(z, dev, "z", keep), _view(v, dev, "v", keep)
+    a0 = _f32_dev(all_initial, dev, "all_initial").contiguous()
+    xs_c, is_c = _f32_dev(xs, dev, "xs").contiguous(), _f32_dev(is_, dev, "is").contiguous()
+    gx_c = _f32_dev(grad_xs, dev, "grad_xs").contiguous() if grad_xs is not None else torch.zeros_like(xs_c)
+    gi_c = _f32_dev(grad_is, dev, "grad_is").contiguous() if grad_is is not None else None
+    keep += [a0, xs_c, is_c, gx_c, gi_c]
+    a.all_initial, a.xs, a.is_, a.grad_xs = a0.data_ptr(), xs_c.data_ptr(), is_c.data_ptr(), gx_c.data_ptr()
+    a.grad_is = gi_c.data_ptr() if gi_c is not None else None
+    f32 = dict(dtype=torch.float32, device=dev)
+    n_ev = 0
+    if event_idx is not None:
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+        a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
+        n_ev = (z_jump if z_jump is not None else v_jump).shape[1]
+        a.n_events = n_ev
+        # rows of the event-time heads: zero-initialised, so that events no step takes contribute nothing
+        ev_rows = [torch.zeros((n_ev, B, H), **f32) for _ in range(6)]
+        ev_gi, ev_i = torch.zeros((n_ev, B, 16), **f32), torch.zeros((n_ev, B, 16), **f32)
+        for q in range(3):
+            a.ev_act[q], a.ev_delta[q] = ev_rows[q].data_ptr(), ev_rows[3 + q].data_ptr()
+        a.ev_gi, a.ev_i = ev_gi.data_ptr(), ev_i.data_ptr()
+    W1, W2, W3, W4 = (w.detach() for w, _ in de_layers)
+    A1, A2, A3, A4 = (w.detach() for w, _ in ae_layers)
+    gW = [torch.zeros_like(w) for w in (W1, W2, W3, W4)]
+    gb = [torch.zeros(w.shape[0], **f32) for w in (W1, W2, W3, W4)]
+    gA = [torch.zeros_like(w) for w in (A1, A2, A3, A4)]
+    gab = [torch.zeros(w.shape[0], **f32) for w in (A1, A2, A3, A4)]
+    gzv = torch.zeros((T, B, nzv), **f32)                       # dL/d(z|v) of the un-jumped inputs
+    gjump = torch.zeros((B, n_ev, nzv), **f32) if n_ev else None
+    S1 = torch.zeros((B, H), **f32)                             # sum over steps and stages of the DE's delta_1
+    Sa1 = torch.zeros((B, H), **f32)                            # sum over the heads of the AE's delta_1
+    carry_x, carry_i = torch.zeros((B, xd), **f32), torch.zeros((B, 16), **f32)
+    a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
+    Fe = W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv]       # (Ws + Wd)[:, z|v columns]
+    Ae = A1[:, n + xd:n + xd + nzv]
+    zv_all = torch.cat((z.detach(), v.detach()), -1)            # [T, B, nzv] (one copy of the two input views)
+    jump_all = None
+    if n_ev:
+        parts = ([z_jump.detach()] if zd > 0 else []) + ([v_jump.detach()] if vd > 0 else [])
+        jump_all = torch.cat(parts, -1)                         # [B, n_ev, nzv]
+
+    def head_grads(act, delta, gi_slots, x_rows, zv_rows):
+        """parameter / input gradients of AE heads from their stored rows; all arguments [R, B, .]"""
+        nonlocal Sa1
+        h1, h2, h3, d1, d2, d3 = (r.reshape(-1, H) for r in (*act, *delta))
+        R = act[0].shape[0]
+        gi = (gi_slots[..., nzv:ne] + gi_slots[..., ne + nzv:2 * ne]).reshape(-1, idim)
+        gA[3].add_(_gemm_tn(gi, h3, R)); gab[3].add_(gi.sum(0))
+        gA[2].add_(_gemm_tn(d3, h2, R)); gab[2].add_(d3.sum(0))
+        gA[1].add_(_gemm_tn(d2, h1, R)); gab[1].add_(d2.sum(0))
+        U = torch.cat((a0.view(1, B, n).expand(R, B, n), x_rows, zv_rows), -1).reshape(-1, n + xd + nzv)
+        gA[0].add_(_gemm_tn(d1, U, R)); gab[0].add_(d1.sum(0))
+        Sa1 += delta[0].sum(0)
+        return (d1 @ Ae).view(R, B, nzv)
+
+    if chunk_steps is None:      # ~3 GB of stored rows per chunk
+        chunk_steps = max(1, min(T - 1, int(3e9 // ((6 * S + 6) * 4 * B * H))))
+    with torch.cuda.device(dev):
+        nbytes = lib.psnode_dae_backward_wide_workspace_bytes(ctypes.byref(a))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for k1 in range(T - 1, 0, -chunk_steps):
+            k0 = max(0, k1 - chunk_steps)
+            Tc = k1 - k0
+            rows = [torch.empty((Tc, S, B, H), **f32) for _ in range(6)]
+            arows = [torch.empty((Tc + 1, B, H), **f32) for _ in range(6)]
+            agi = torch.empty((Tc + 1, B, 16), **f32)
+            gk = torch.empty((Tc, S, B, xd), **f32)
+            Xs = torch.empty((Tc, S, B, xd), **f32)
+            a.k0, a.k1 = k0, k1
+            for q in range(3):
+                a.act[q], a.delta[q] = rows[q].data_ptr(), rows[3 + q].data_ptr()
+                a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
+            a.gk, a.xstage, a.ae_gi = gk.data_ptr(), Xs.data_ptr(), agi.data_ptr()
+            _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
+            # ---- DE
+            h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
+            G = Tc * S
+            gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
+            gW[2] += _gemm_tn(d3, h2, G); gb[2] += d3.sum(0)
+            gW[1] += _gemm_tn(d2, h1, G); gb[1] += d2.sum(0)
+            # L1 input per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z|v|i of the step -- jump values and recomputed i0 at events)
+            ext = torch.cat((zv_all[k0:k1], is_c[k0:k1]), -1)                                  # [Tc, B, ne]
+            if n_ev:
+                evc = event_idx[k0:k1].long()
+                hit = (evc >= 0).view(Tc, 1, 1)
+                evi = evc.clamp_min(0)
+                ext_ev = torch.cat((jump_all[:, evi].permute(1, 0, 2), ev_i[evi][..., ne + nzv:2 * ne]), -1)
+                ext = torch.where(hit, ext_ev, ext)
+            s_in = torch.cat((Xs, ext.unsqueeze(1).expand(Tc, S, B, ne)), -1)
+            U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
+            gW[0] += _gemm_tn(d1, U, G); gb[0] += d1.sum(0)
+            D1 = rows[3].sum(1)                                                                  # [Tc, B, H]
+            S1 += D1.sum(0)
+            if nzv > 0:
+                gc = (D1.reshape(-1, H) @ Fe).view(Tc, B, nzv)
+                if n_ev:
+                    gjump.index_add_(1, evi, (gc * hit).permute(1, 0, 2))
+                    gc = torch.where(hit, torch.zeros_like(gc), gc)
+                gzv[k0:k1] += gc
+            del rows, gk, Xs, U, D1, s_in
+            # ---- AE heads at grid points k0+lo .. k1 (row r of the chunk = grid point k0 + r)
+            lo = 0 if k0 == 0 else 1
+            gza = head_grads([r[lo:] for r in arows[:3]], [r[lo:] for r in arows[3:]], agi[lo:], xs_c[k0 + lo:k1 + 1], zv_all[k0 + lo:k1 + 1])
+            if nzv > 0:
+                gzv[k0 + lo:k1 + 1] += gza
+            del arows, agi
+        if n_ev:    # event-time heads g(x_k; jumps): x of the step that takes the event (events no step takes have zero rows)
+            evl = event_idx.long()
+            step_of = torch.zeros(n_ev, dtype=torch.long, device=dev).scatter_reduce_(
+                0, evl.clamp_min(0), torch.arange(T - 1, device=dev) * (evl >= 0), "amax")
+            gza = head_grads(ev_rows[:3], ev_rows[3:], ev_gi, xs_c[step_of], jump_all.permute(1, 0, 2))
+            if nzv > 0:
+                gjump += gza.permute(1, 0, 2)
+    g = {"z_jump": None, "v_jump": None}
+    g["x_init"] = carry_x + gx_c[0]
+    ga0 = S1 @ (W1[:, 0:n] - W1[:, n:2 * n]) + Sa1 @ A1[:, 0:n]
+    g["all_initial"] = ga0
+    g["z"] = gzv[..., :zd].contiguous() if zd > 0 else None
+    g["v"] = gzv[..., zd:].contiguous() if vd > 0 else None
+    if n_ev:
+        g["z_jump"] = gjump[..., :zd].contiguous() if zd > 0 else None
+        g["v_jump"] = gjump[..., zd:].contiguous() if vd > 0 else None
+    g["de"] = [gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3]]
+    g["ae"] = [gA[0], gab[0], gA[1], gab[1], gA[2], gab[2], gA[3], gab[3]]
+    return g
+
+
 def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
                  z_jump=None, v_jump=None, kernel: str = "auto"):
-    """Backward pass of `dae_integrate` (no teacher forcing) in one launch: the MFMA backward (K7) for the DAE_01 shape class
-    at hidden 64, else the generic backward kernel (K5); `kernel` = "auto" | "mfma" | "generic".
+    """Backward pass of `dae_integrate` (no teacher forcing): the one-launch MFMA backward (K7) for the DAE_01 shape class at hidden 64,
+    the adjoint sweep + GEMMs (`dae_backward_wide`) at hidden 32 / 128, else the generic backward kernel (K5);
+    `kernel` = "auto" | "mfma" | "generic" | "wide".
     Returns dict(x_init, z, v, z_jump, v_jump, all_initial, de=[...], ae=[...]) of gradients."""
     lib = _lib.load()
     dev = xs.device
     T, B, xd = xs.shape
     zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
+    # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K7w + library GEMMs instead of the generic K5
+    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
+                            and dae_backward_wide_supported(method, de_layers, ae_layers, xd, zd, vd, idim)):
+        return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
+                                 z_jump=z_jump, v_jump=v_jump)
     keep: list = []
     a = _lib.DaeBwdArgsF32()
     a.method = METHOD_ID[method]

@@ -354,12 +354,12 @@ def test_dae_backward_without_z_and_odd_widths():
         _close(a, b, f"grad ae {k}")
 
 
-def _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events):
+def _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events, H=64):
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     n = xd + zd + vd + idim
     mk = lambda dims: [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
-    de, ae = mk([3 * n, 64, 64, 64, xd]), mk([n + xd + zd + vd, 64, 64, 64, idim])
+    de, ae = mk([3 * n, H, H, H, xd]), mk([n + xd + zd + vd, H, H, H, idim])
     r = lambda *s: (0.1 * torch.randn(*s, generator=g)).cuda()
     t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1)
     if B > 1:
@@ -401,6 +401,47 @@ def test_dae_mfma_backward_matches_generic_every_shape_class(xd, zd, vd, idim, m
     """K7 (MFMA DAE backward) against K5 (generic backward, itself checked against fp64 autograd above) on every (NZM, NZA)
     register class, with two event steps, per-trajectory clocks and a ragged tile."""
     _dae_both_kernels(method, 21, 9, xd, zd, vd, idim, seed=40 + xd + zd, events=True)
+
+
+def _dae_wide_vs_generic(method, H, B, Tn, xd, zd, vd, idim, seed, events, with_gi=True, chunk_steps=None):
+    from py_psnode_amd import fused
+    de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events, H=H)
+    xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, idim, device="cuda")
+    xs, is_ = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj)
+    tab = fused.event_table(t, ev) if ev is not None else None
+    gi = Gi if with_gi else None
+    b = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="generic")
+    if chunk_steps is None:
+        a = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj,
+                               kernel="wide" if H == 64 else "auto")
+    else:
+        a = fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, chunk_steps=chunk_steps)
+    for key in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial"):
+        if b[key] is None:
+            assert a[key] is None, key
+            continue
+        _close(a[key], b[key].double().cpu(), f"{key} (K7w vs K5)")
+    for grp in ("de", "ae"):
+        for k, (p, q) in enumerate(zip(a[grp], b[grp])):
+            _close(p, q.double().cpu(), f"grad {grp} {k} (K7w vs K5)")
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("H", [32, 64, 128])
+@pytest.mark.parametrize("xd,zd,vd,idim", [(8, 2, 2, 2), (8, 0, 2, 2), (5, 1, 1, 1), (8, 2, 2, 4), (3, 1, 0, 1), (8, 4, 3, 1), (2, 2, 4, 2)])
+def test_dae_wide_backward_matches_generic_every_shape_class(xd, zd, vd, idim, H, method):
+    """K7w (adjoint sweep + library GEMMs; `auto` at hidden 32 / 128, forced at 64) against K5 (generic backward, itself checked
+    against fp64 autograd above) on every (NZM, NZA) register class, with two event steps, per-trajectory clocks and a ragged tile."""
+    _dae_wide_vs_generic(method, H, 21, 9, xd, zd, vd, idim, seed=140 + xd + zd, events=True)
+
+
+@pytest.mark.parametrize("H", [32, 128])
+@pytest.mark.parametrize("B,Tn,chunk", [(1, 2, None), (17, 2, None), (33, 3, 1), (16, 12, 4), (37, 12, 5)])
+def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):
+    """single trajectory, T = 2, ragged tiles, time chunks (carried x / algebraic adjoints, events inside and at chunk borders),
+    grad_is = None"""
+    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True, chunk_steps=chunk)
+    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False, chunk_steps=chunk)
 
 
 @pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3), (16, 5)])
@@ -457,8 +498,8 @@ def test_latent16_ode_backward_kernel_matches_generic(method, B, Tn, events):
 
 @pytest.mark.parametrize("H", [128, 32])
 def test_dae_model_training_at_other_hidden_widths_runs_fused(H):
-    """DAE_Model at --hidden 128 (the argparse default) and 32: fused forward (K2) + generic backward (K5, accumulators in global
-    memory at 128) vs the fp64 autograd walk."""
+    """DAE_Model at --hidden 128 (the argparse default) and 32: fused forward (K2) + adjoint sweep K7w with library GEMMs for the
+    parameter gradients vs the fp64 autograd walk."""
     from py_psnode_amd import models
     from py_psnode_amd import neural_dae as nd
     B, Tn = 7, 5
