@@ -68,17 +68,7 @@ __global__ void pack_wide_fwd_kernel(const PackMfma p) {
 
 __host__ __device__ constexpr bool aet_in_lds(int nwv) { return nwv <= 4; }
 
-// Addressing: every global access of the time loop is <uniform row base in SGPRs> + <32-bit per-lane offset>.  The row base is made
-// opaque at each use: left visible, `base + lane offset` is loop-invariant per array, and the compiler keeps one precomputed 64-bit
-// per-lane pointer for each of the ~30 arrays the loop touches (60+ VGPRs, all spilled at 8 waves per tile).
-template <typename T>
-__device__ __forceinline__ T* sbase(T* p) {
-    unsigned lo = (unsigned)reinterpret_cast<uintptr_t>(p), hi = (unsigned)(reinterpret_cast<uintptr_t>(p) >> 32);
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    asm volatile("" : "+s"(lo), "+s"(hi));
-    return reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo);
-}
+// Addressing: every global access of the time loop is sbase(uniform row base) + 32-bit per-lane offset (psnode_common.h).
 
 template <int METHOD, int NZM, int NZA, int NWV>
 __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideDaeDev a, const float* __restrict__ pack_de,

@@ -267,26 +267,31 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     const f4 c0 = c0A + c0B, c0a = caA + caB;
 
     const long long tst = a.t.st, nT = a.T;
-    const float* tp = a.t.p + b * a.t.sb;
+    // addressing: sbase(uniform row base) + 32-bit per-lane offset (psnode_common.h)
+    const unsigned offR = (unsigned)(b * H9) + own;                 // rows of [*, B, 64] tensors
+    const unsigned offT = (unsigned)(b * a.t.sb);
     // streamed block s (0 = z or, when the model has no z, v; 1 = v): sources, jump tables, gradient destinations
     const bool has_z = a.zd > 0;
-    const float* vbase = DAE ? a.v.p + b * a.v.sb : nullptr;
-    const float* vjbase = DAE ? a.vj + b * a.vjb : nullptr;
-    const float* sp[2] = {has_z ? a.z.p + b * a.z.sb : vbase, vbase};
+    const float* spb[2] = {has_z ? a.z.p : (DAE ? a.v.p : nullptr), DAE ? a.v.p : nullptr};
     const long long sst[2] = {has_z ? a.z.st : a.v.st, a.v.st};
-    const float* jp[2] = {has_z ? a.zj + b * a.zjb : vjbase, vjbase};
+    const unsigned spo[2] = {(unsigned)(b * (has_z ? a.z.sb : a.v.sb)) + own, (unsigned)(b * a.v.sb) + own};
+    const float* jpb[2] = {has_z ? a.zj : (DAE ? a.vj : nullptr), DAE ? a.vj : nullptr};
     const long long jse[2] = {has_z ? a.zje : a.vje, a.vje};
+    const unsigned jpo[2] = {(unsigned)(b * (has_z ? a.zjb : a.vjb)) + own, (unsigned)(b * a.vjb) + own};
     float* gdst[2] = {has_z ? d.gz : d.gv, d.gv};
     float* gjdst[2] = {has_z ? d.gzj : d.gvj, d.gvj};
-    auto load_own = [&](const float* rowptr) -> f4 { return *reinterpret_cast<const f4*>(rowptr + own); };
+    const unsigned offJ = (unsigned)(b * d.n_events * H9) + own;
     auto load_zv = [&](const int s, const long long k, const int ev) -> f4 {
-        return load_own(ev >= 0 ? jp[s] + ev * jse[s] : sp[s] + k * sst[s]);
+        if (ev >= 0) return *reinterpret_cast<const f4*>(sbase(jpb[s] + ev * jse[s]) + jpo[s]);
+        return *reinterpret_cast<const f4*>(sbase(spb[s] + k * sst[s]) + spo[s]);
     };
-    auto row_of = [&](const float* base, const long long k) -> f4 { return load_own(base + (k * a.B + b) * H9); };
+    auto row_of = [&](const float* base, const long long k) -> f4 {
+        return *reinterpret_cast<const f4*>(sbase(base + k * a.B * H9) + offR);
+    };
     auto store_zv = [&](const int s, const long long grid, const int ev, const f4 val) {
         if (!valid) return;
-        if (ev >= 0) { if (gjdst[s]) *reinterpret_cast<f4*>(gjdst[s] + (b * d.n_events + ev) * H9 + own) = val; }
-        else if (gdst[s]) *reinterpret_cast<f4*>(gdst[s] + (grid * a.B + b) * H9 + own) = val;
+        if (ev >= 0) { if (gjdst[s]) *reinterpret_cast<f4*>(sbase(gjdst[s] + (long long)ev * H9) + offJ) = val; }
+        else if (gdst[s]) *reinterpret_cast<f4*>(sbase(gdst[s] + grid * a.B * H9) + offR) = val;
     };
 
     // ---- accumulators (whole launch)
@@ -320,10 +325,14 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     auto ae_output = [&]() -> f4 {
         const V9 hg = gather(ah1);
         f4 accA = ab2r, accB = z9();
+        // (opaque pointer: the addresses of these 16 loads are loop-invariant, and hoisted out of the time loop they are 13 VGPR pairs
+        //  that live -- spilled -- across every step for the sake of the event steps)
+        const float* pq = pwa + A_W2 * 64;
+        asm volatile("" : "+v"(pq));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            accA = m9(pwa[(A_W2 + 4 * c + 0) * 64], hg.v[c][0], accA); accB = m9(pwa[(A_W2 + 4 * c + 1) * 64], hg.v[c][1], accB);
-            accA = m9(pwa[(A_W2 + 4 * c + 2) * 64], hg.v[c][2], accA); accB = m9(pwa[(A_W2 + 4 * c + 3) * 64], hg.v[c][3], accB);
+            accA = m9(pq[(4 * c + 0) * 64], hg.v[c][0], accA); accB = m9(pq[(4 * c + 1) * 64], hg.v[c][1], accB);
+            accA = m9(pq[(4 * c + 2) * 64], hg.v[c][2], accA); accB = m9(pq[(4 * c + 3) * 64], hg.v[c][3], accB);
         }
         return accA + accB;
     };
@@ -373,8 +382,8 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 
         // ================= (2) step k = jg-1
         const long long k = jg - 1;
-        const int ev = a.ev ? a.ev[k] : -1;
-        const float h_ = tp[jg * tst] - tp[k * tst];
+        const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
+        const float h_ = sbase(a.t.p + jg * tst)[offT] - sbase(a.t.p + k * tst)[offT];
         const f4 x0 = row_of(d.xs, k);
         f4 ext[NBE];
 #pragma unroll
@@ -460,7 +469,21 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         gcarry = gx0;
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Lane coordinates are re-derived from an opaque copy of the thread index: computed from the prologue's values, the
+    //      epilogue's addresses are live (spilled) across the whole time loop.
+    {
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int l_e = tid_e & 63, g = l_e >> 4, j = l_e & 15, own = 16 * w + 4 * g;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    float* scr = scr_all + w * SCR9;
+    const int l = l_e, i = j;
+    auto transpose = [&](const f4 v) -> f4 {
+        *reinterpret_cast<f4*>(scr + 4 * l + 8 * g) = v;
+        const float* s = scr + 4 * (16 * (i >> 2) + g) + 8 * (i >> 2) + (i & 3);
+        return f4{s[0], s[16], s[32], s[48]};
+    };
     if (valid) *reinterpret_cast<f4*>(d.gx0 + b * H9 + own) = gcarry;
     for (int blk = 0; blk < NBLK; ++blk) {       // d all_initial block = A0_blk^T sum_t(delta1)  (DE + AE)
         f4 part[4];
@@ -529,6 +552,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     };
     write_mlp(wp, 3 * n, std::false_type{}, std::integral_constant<int, NBLK>{}, S1, SB2, accF, accW2);
     if constexpr (DAE) write_mlp(wp + d.NP_de, n + H9 * NAE, std::true_type{}, std::integral_constant<int, NAE>{}, AS1, ASB2, accAF, accW2a);
+    }
 }
 
 int np9(int k1) { return H9 * k1 + H9 + H9 * H9 + H9; }
