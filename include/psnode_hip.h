@@ -216,6 +216,7 @@ int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* works
  *     delta[l] = dL/dpre_l (adjoint of the pre-activation of layer l)       [k1-k0, S, B, H]
  *     gk       = dL/dk_s  (adjoint of the stage derivative = delta of the output layer)   [k1-k0, S, B, x_dim]
  *     xstage   = X_s      (the stage's state input)                          [k1-k0, S, B, x_dim]
+ *     dsum[l]  = sum over the stages of delta[l]                              [k1-k0, B, H]
  * The parameter gradients are then PLAIN GEMMs over those rows (dW_l = delta_l^T . act_{l-1}, library GEMMs on the host side:
  * py_psnode_amd/fused.py:ode_backward_wide), as are dL/dz = D1 . (Ws+Wd)[:, z] and dL/dall_initial = sum_t D1 . (Wa-Wd), D1 = sum_s delta_1.
  * `carry` [B, x_dim] holds the adjoint of x[k1] WITHOUT dL/dxs[k1] on entry (zeros for the last chunk) and of x[k0] likewise on exit, so
@@ -239,6 +240,7 @@ typedef struct {
     float* delta[3];
     float* gk;                       /* [k1-k0, S, B, x_dim] */
     float* xstage;                   /* [k1-k0, S, B, x_dim] */
+    float* dsum[3];                  /* [k1-k0, B, H]: sum over the stages of delta[l] (bias gradients, dL/dz, dL/dall_initial) */
 } psnode_ode_bwd_wide_args_f32;
 
 int32_t psnode_ode_backward_wide_supported(const psnode_ode_bwd_wide_args_f32* args);   /* dims only */
@@ -318,6 +320,7 @@ typedef struct {
     float* delta[3];
     float* gk;
     float* xstage;
+    float* dsum[3];                  /* [k1-k0, B, H]: sum over the stages of delta[l] */
     float* ae_act[3];
     float* ae_delta[3];
     float* ae_gi;

@@ -103,7 +103,7 @@ class OdeBwdWideArgsF32(ctypes.Structure):
     _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64), ("k0", c_int64), ("k1", c_int64),
                 ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("xs", c_void_p), ("grad_xs", c_void_p), ("carry", c_void_p),
-                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p)]
+                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p), ("dsum", c_void_p * 3)]
 
 
 class DaeBwdWideArgsF32(ctypes.Structure):
@@ -114,7 +114,7 @@ class DaeBwdWideArgsF32(ctypes.Structure):
                 ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64), ("n_events", c_int32),
                 ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
                 ("carry_x", c_void_p), ("carry_i", c_void_p),
-                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p),
+                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p), ("dsum", c_void_p * 3),
                 ("ae_act", c_void_p * 3), ("ae_delta", c_void_p * 3), ("ae_gi", c_void_p),
                 ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p)]
 

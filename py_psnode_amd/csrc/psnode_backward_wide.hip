@@ -43,7 +43,7 @@ struct WideDev {
     long long zjb, zje;
     const float *xs, *gout;
     float* carry;
-    float *act[3], *delta[3], *gk, *xst;
+    float *act[3], *delta[3], *gk, *xst, *dsum[3];
 };
 
 // transposed images of W2 / W3 in the order the kernel's LDS array wants: [(layer * NWV + c) * NWV + w][lane] (f4):
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
 #pragma unroll
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
         }
+        f4 D1 = f4{0.f, 0.f, 0.f, 0.f}, D2 = D1, D3 = D1;
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
             const f4 d3 = g3 * wdact(a3);
             const f4 d2 = midT(1, d3) * wdact(a2);
             const f4 d1 = midT(0, d2) * wdact(a1);
+            D1 += d1; D2 += d2; D3 += d3;
             const f2 gx = out2(fT, d1, f4{0.f, 0.f, 0.f, 0.f});
             if (valid) {
                 const size_t off = row_off(s);
@@ -319,6 +321,12 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
 #pragma unroll
                 for (int jj = 0; jj < s; ++jj) gks[jj][r] += (h_ * rk_a(METHOD, s, jj)) * gxr;
             }
+        }
+        if (valid) {     // per-step sums over the stages: what the bias / input gradients contract over (a quarter of the rows at RK4)
+            const size_t off = ((size_t)(k - a.k0) * nrow + b) * H + 16 * w + 4 * g;
+            *reinterpret_cast<f4*>(a.dsum[0] + off) = D1;
+            *reinterpret_cast<f4*>(a.dsum[1] + off) = D2;
+            *reinterpret_cast<f4*>(a.dsum[2] + off) = D3;
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];
@@ -401,7 +409,7 @@ int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* p, void
     if (p->T < 2 || p->B < 1 || p->k0 < 0 || p->k1 <= p->k0 || p->k1 > p->T - 1) return PSNODE_ERR_DIMS;
     for (int l = 0; l < 4; ++l) if (!p->de.weight[l] || !p->de.bias[l]) return PSNODE_ERR_NULL;
     if (!p->t.ptr || !p->all_initial || !p->xs || !p->grad_xs || !p->carry || !p->gk || !p->xstage) return PSNODE_ERR_NULL;
-    for (int l = 0; l < 3; ++l) if (!p->act[l] || !p->delta[l]) return PSNODE_ERR_NULL;
+    for (int l = 0; l < 3; ++l) if (!p->act[l] || !p->delta[l] || !p->dsum[l]) return PSNODE_ERR_NULL;
     if (p->z_dim > 0 && !p->z.ptr) return PSNODE_ERR_NULL;
     if (p->event_idx && p->z_dim > 0 && !p->z_jump) return PSNODE_ERR_NULL;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_wide_workspace_bytes(p))
@@ -429,7 +437,7 @@ int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* p, void
     a.z = ViewDev{p->z.ptr, p->z.stride_t, p->z.stride_b};
     a.a0 = p->all_initial; a.ev = p->event_idx; a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
     a.xs = p->xs; a.gout = p->grad_xs; a.carry = p->carry;
-    for (int l = 0; l < 3; ++l) { a.act[l] = p->act[l]; a.delta[l] = p->delta[l]; }
+    for (int l = 0; l < 3; ++l) { a.act[l] = p->act[l]; a.delta[l] = p->delta[l]; a.dsum[l] = p->dsum[l]; }
     a.gk = p->gk; a.xst = p->xstage;
     hipError_t e;
     switch (nw) {

@@ -37,7 +37,7 @@ struct WideDaeDev {
     long long zjb, zje, vjb, vje;
     const float *xs, *is, *gxs, *gis;
     float *carry_x, *carry_i;
-    float *act[3], *delta[3], *gk, *xst;
+    float *act[3], *delta[3], *gk, *xst, *dsum[3];
     float *aact[3], *adelta[3], *agi;
     float *eact[3], *edelta[3], *egi, *ei;
 };
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
 #pragma unroll
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
         }
-        f4 D1 = f4{0.f, 0.f, 0.f, 0.f};
+        f4 D1 = f4{0.f, 0.f, 0.f, 0.f}, D2 = D1, D3 = D1;
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
             const f4 d3 = g3 * wdact(a3);
             const f4 d2 = midT(NWV * NWV * 64, d3) * wdact(a2);
             const f4 d1 = midT(0, d2) * wdact(a1);
-            D1 += d1;
+            D1 += d1; D2 += d2; D3 += d3;
             const f2 gx = out2(fT, d1, f4{0.f, 0.f, 0.f, 0.f});
             if (valid) {
                 const size_t rb = row_blk(s) * H;
@@ -526,6 +526,12 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
 #pragma unroll
                 for (int jj = 0; jj < s; ++jj) gks[jj][r] += (h_ * rk_a(METHOD, s, jj)) * gxr;
             }
+        }
+        if (valid) {     // per-step sums over the stages: what the bias / input gradients contract over (a quarter of the rows at RK4)
+            const size_t rb = (size_t)(k - a.k0) * nrow * H;
+            *reinterpret_cast<f4*>(sbase(a.dsum[0] + rb) + offH) = D1;
+            *reinterpret_cast<f4*>(sbase(a.dsum[1] + rb) + offH) = D2;
+            *reinterpret_cast<f4*>(sbase(a.dsum[2] + rb) + offH) = D3;
         }
         const f4 gE = out4(fE, D1, f4{0.f, 0.f, 0.f, 0.f});      // adjoint of the algebraic inputs of this step, slot layout
 #pragma unroll
@@ -644,7 +650,7 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
     for (int l = 0; l < 4; ++l) if (!p->de.weight[l] || !p->de.bias[l] || !p->ae.weight[l] || !p->ae.bias[l]) return PSNODE_ERR_NULL;
     if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || !p->carry_i || !p->gk || !p->xstage || !p->ae_gi)
         return PSNODE_ERR_NULL;
-    for (int l = 0; l < 3; ++l) if (!p->act[l] || !p->delta[l] || !p->ae_act[l] || !p->ae_delta[l]) return PSNODE_ERR_NULL;
+    for (int l = 0; l < 3; ++l) if (!p->act[l] || !p->delta[l] || !p->dsum[l] || !p->ae_act[l] || !p->ae_delta[l]) return PSNODE_ERR_NULL;
     if ((p->z_dim > 0 && !p->z.ptr) || (p->v_dim > 0 && !p->v.ptr)) return PSNODE_ERR_NULL;
     if (p->event_idx) {
         if (p->n_events < 1 || (p->z_dim > 0 && !p->z_jump) || (p->v_dim > 0 && !p->v_jump) || !p->ev_gi || !p->ev_i) return PSNODE_ERR_NULL;
@@ -697,7 +703,7 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
     a.xs = p->xs; a.is = p->is; a.gxs = p->grad_xs; a.gis = p->grad_is;
     a.carry_x = p->carry_x; a.carry_i = p->carry_i;
     for (int l = 0; l < 3; ++l) {
-        a.act[l] = p->act[l]; a.delta[l] = p->delta[l];
+        a.act[l] = p->act[l]; a.delta[l] = p->delta[l]; a.dsum[l] = p->dsum[l];
         a.aact[l] = p->ae_act[l]; a.adelta[l] = p->ae_delta[l];
         a.eact[l] = p->ev_act[l]; a.edelta[l] = p->ev_delta[l];
     }

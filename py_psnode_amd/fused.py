@@ -481,16 +481,17 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                 rows = [torch.empty((Tc, S, B, H), dtype=torch.float32, device=dev) for _ in range(6)]
                 gk = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
                 Xs = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
+                dsum = [torch.empty((Tc, B, H), dtype=torch.float32, device=dev) for _ in range(3)]
                 a.k0, a.k1 = k0, k1
                 for q in range(3):
-                    a.act[q], a.delta[q] = rows[q].data_ptr(), rows[3 + q].data_ptr()
+                    a.act[q], a.delta[q], a.dsum[q] = rows[q].data_ptr(), rows[3 + q].data_ptr(), dsum[q].data_ptr()
                 a.gk, a.xstage = gk.data_ptr(), Xs.data_ptr()
                 _lib.check(lib.psnode_ode_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_ode_backward_wide_f32")
                 h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
                 G = Tc * S
                 gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
-                gW[2] += _gemm_tn(d3, h2, G); gb[2] += d3.sum(0)
-                gW[1] += _gemm_tn(d2, h1, G); gb[1] += d2.sum(0)
+                gW[2] += _gemm_tn(d3, h2, G); gb[2] += dsum[2].sum((0, 1))
+                gW[1] += _gemm_tn(d2, h1, G); gb[1] += dsum[1].sum((0, 1))
                 # input of L1 per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z of the step (jump values at event steps))
                 if zd > 0:
                     zc = zt[k0:k1]                                                           # [Tc, B, zd] view
@@ -502,9 +503,10 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                 else:
                     s_in = Xs
                 U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
-                gW[0] += _gemm_tn(d1, U, G); gb[0] += d1.sum(0)
-                D1 = rows[3].sum(1)                                                          # [Tc, B, H]: sum over the stages
-                S1 += D1.sum(0)
+                gW[0] += _gemm_tn(d1, U, G)
+                D1 = dsum[0]                                                                 # [Tc, B, H]: sum over the stages
+                D1s = D1.sum(0)
+                S1 += D1s; gb[0] += D1s.sum(0)
                 if zd > 0 and (gz is not None or gzj is not None):
                     gzc = D1.reshape(-1, H) @ Fz                                             # [Tc*B, zd]
                     gzc = gzc.view(Tc, B, zd)
@@ -514,7 +516,7 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                         gzc = torch.where(hit, torch.zeros_like(gzc), gzc)
                     if gz is not None:
                         gz[k0:k1] = gzc
-                del rows, gk, Xs, U, D1
+                del rows, gk, Xs, U, D1, dsum
     gx0 = carry + g_c[0]
     ga0 = S1 @ (W1[:, 0:n] - W1[:, n:2 * n])                                                # d all_initial = sum_t D1 . (Wa - Wd)
     return gx0, gz, gzj, ga0, [gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3]]
@@ -643,9 +645,10 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
             agi = torch.empty((Tc + 1, B, 16), **f32)
             gk = torch.empty((Tc, S, B, xd), **f32)
             Xs = torch.empty((Tc, S, B, xd), **f32)
+            dsum = [torch.empty((Tc, B, H), **f32) for _ in range(3)]
             a.k0, a.k1 = k0, k1
             for q in range(3):
-                a.act[q], a.delta[q] = rows[q].data_ptr(), rows[3 + q].data_ptr()
+                a.act[q], a.delta[q], a.dsum[q] = rows[q].data_ptr(), rows[3 + q].data_ptr(), dsum[q].data_ptr()
                 a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
             a.gk, a.xstage, a.ae_gi = gk.data_ptr(), Xs.data_ptr(), agi.data_ptr()
             _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
@@ -653,8 +656,8 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
             h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
             G = Tc * S
             gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
-            gW[2] += _gemm_tn(d3, h2, G); gb[2] += d3.sum(0)
-            gW[1] += _gemm_tn(d2, h1, G); gb[1] += d2.sum(0)
+            gW[2] += _gemm_tn(d3, h2, G); gb[2] += dsum[2].sum((0, 1))
+            gW[1] += _gemm_tn(d2, h1, G); gb[1] += dsum[1].sum((0, 1))
             # L1 input per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z|v|i of the step -- jump values and recomputed i0 at events)
             ext = torch.cat((zv_all[k0:k1], is_c[k0:k1]), -1)                                  # [Tc, B, ne]
             if n_ev:
@@ -665,16 +668,17 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 ext = torch.where(hit, ext_ev, ext)
             s_in = torch.cat((Xs, ext.unsqueeze(1).expand(Tc, S, B, ne)), -1)
             U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
-            gW[0] += _gemm_tn(d1, U, G); gb[0] += d1.sum(0)
-            D1 = rows[3].sum(1)                                                                  # [Tc, B, H]
-            S1 += D1.sum(0)
+            gW[0] += _gemm_tn(d1, U, G)
+            D1 = dsum[0]                                                                         # [Tc, B, H]
+            D1s = D1.sum(0)
+            S1 += D1s; gb[0] += D1s.sum(0)
             if nzv > 0:
                 gc = (D1.reshape(-1, H) @ Fe).view(Tc, B, nzv)
                 if n_ev:
                     gjump.index_add_(1, evi, (gc * hit).permute(1, 0, 2))
                     gc = torch.where(hit, torch.zeros_like(gc), gc)
                 gzv[k0:k1] += gc
-            del rows, gk, Xs, U, D1, s_in
+            del rows, gk, Xs, U, D1, s_in, dsum
             # ---- AE heads at grid points k0+lo .. k1 (row r of the chunk = grid point k0 + r)
             lo = 0 if k0 == 0 else 1
             gza = head_grads([r[lo:] for r in arows[:3]], [r[lo:] for r in arows[3:]], agi[lo:], xs_c[k0 + lo:k1 + 1], zv_all[k0 + lo:k1 + 1])
