@@ -198,31 +198,44 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
         return out;
     };
 
-    const long long tst = a.t.st, zst = a.z.st, zje = a.zje;
-    const float* tp = a.t.p + b * a.t.sb;
-    const float* zp = a.z.p + b * a.z.sb;
-    const float* zjp = a.zj ? a.zj + b * a.zjb : zp;
-    auto load_ext = [&](const long long k, const int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
+    // addressing: sbase(uniform row base) + 32-bit per-lane offset (psnode_common.h)
+    const unsigned offH = (unsigned)(b * H) + 16 * w + 4 * g;      // rows of H floats: this lane's 4 units of its trajectory
+    const unsigned offX = (unsigned)(b * xd) + g;                  // rows of x_dim floats (+ 4r)
+    const unsigned offT = (unsigned)(b * a.t.sb), offZ = (unsigned)(b * a.z.sb), offZJ = (unsigned)(b * a.zjb);
+    auto load_ext = [&, offZ, offZJ](const long long k, const int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
+        if constexpr (NZM > 0) {
+            const float* row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
+            const unsigned m_ = ev >= 0 ? ~0u : 0u, zo = (offZJ & m_) | (offZ & ~m_);
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? (ev >= 0 ? zjp + (long long)ev * zje : zp + k * zst)[ecol[m]] : 0.0f;
+            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? row[zo + ecol[m]] : 0.0f;
+        }
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
+        const float* row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? base[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? row[offX + 4 * r] : 0.0f;
     };
+    auto load_dt = [&](const long long k) -> float { return sbase(a.t.p + (k + 1) * a.t.st)[offT] - sbase(a.t.p + k * a.t.st)[offT]; };
 
     float gcar[NX];
 #pragma unroll
     for (int r = 0; r < NX; ++r) gcar[r] = (valid && 4 * r + g < xd) ? a.carry[b * xd + 4 * r + g] : 0.0f;
 
     const long long nrow = a.B;           // rows per (step, stage) in the stored tensors
+    auto event_of = [&](const long long k) -> int { return a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1; };
+    // inputs of a step are requested one step ahead (at the top of the previous step's backward half)
+    float x0n[NX], ginn[NX], extn[NZM > 0 ? NZM : 1], hn;
+    load_x2(a.xs, a.k1 - 1, x0n);
+    load_x2(a.gout, a.k1, ginn);
+    load_ext(a.k1 - 1, event_of(a.k1 - 1), extn);
+    hn = load_dt(a.k1 - 1);
     for (long long k = a.k1 - 1; k >= a.k0; --k) {
-        const int ev = a.ev ? a.ev[k] : -1;
         float x0[NX], gin[NX], ext[NZM > 0 ? NZM : 1];
-        load_x2(a.xs, k, x0);
-        load_x2(a.gout, k + 1, gin);
-        load_ext(k, ev, ext);
-        const float h_ = tp[(k + 1) * tst] - tp[k * tst];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { x0[r] = x0n[r]; gin[r] = ginn[r]; }
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) ext[m] = extn[m];
+        const float h_ = hn;
         f4 cz = c0;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) cz = wm4(w1z[m], ext[m] - a0e[m], cz);
@@ -230,7 +243,8 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
         // ---- phase A: stage evaluations (K1's plan; pre-activations are not kept, the ELU outputs are)
         float X[S][NX], ks[S][NX];
         f4 h1[STREAM ? 1 : S], h2[STREAM ? 1 : S], h3[STREAM ? 1 : S];
-        auto row_off = [&](const int s) -> size_t { return ((size_t)((k - a.k0) * S + s) * nrow + b) * H + 16 * w + 4 * g; };
+        auto row_blk = [&](const int s) -> size_t { return (size_t)((k - a.k0) * S + s) * nrow; };   // uniform
+        f4 la1, la2, la3;    // ELU outputs of the last stage evaluated (the first one the backward half needs)
         {
             float w2s[STREAM ? 4 * NWV : 1], w3s[STREAM ? 4 * NWV : 1];
             if constexpr (STREAM) {
@@ -257,19 +271,26 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
                 if constexpr (STREAM) { a2 = elu_quad(mid(w2s, b2, a1)); a3 = elu_quad(mid(w3s, b3, a2)); }
                 else { a2 = elu_quad(mid(w2r, b2, a1)); a3 = elu_quad(mid(w3r, b3, a2)); }
                 if (valid) {     // rows for the parameter-gradient GEMMs: this wave's 16 units of trajectory j, 16 bytes per lane
-                    const size_t off = row_off(s);
-                    *reinterpret_cast<f4*>(a.act[0] + off) = a1;
-                    *reinterpret_cast<f4*>(a.act[1] + off) = a2;
-                    *reinterpret_cast<f4*>(a.act[2] + off) = a3;
+                    const size_t rb = row_blk(s) * H;
+                    *reinterpret_cast<f4*>(sbase(a.act[0] + rb) + offH) = a1;
+                    *reinterpret_cast<f4*>(sbase(a.act[1] + rb) + offH) = a2;
+                    *reinterpret_cast<f4*>(sbase(a.act[2] + rb) + offH) = a3;
                 }
                 if constexpr (!STREAM) { h1[s] = a1; h2[s] = a2; h3[s] = a3; }
+                if (s == S - 1) { la1 = a1; la2 = a2; la3 = a3; }
                 const f2 kk = out2(w4, a3, b4);
                 ks[s][0] = kk[0];
                 if constexpr (NX > 1) ks[s][1] = kk[1];
             }
         }
 
-        // ---- phase B: stages backwards
+        // ---- phase B: stages backwards.  The next step's inputs are requested here and consumed a whole backward half later.
+        if (k > a.k0) {
+            load_x2(a.xs, k - 1, x0n);
+            load_x2(a.gout, k, ginn);
+            load_ext(k - 1, event_of(k - 1), extn);
+            hn = load_dt(k - 1);
+        }
         float gks[S][NX], gx0[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
@@ -279,14 +300,18 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
         }
         f4 D1 = f4{0.f, 0.f, 0.f, 0.f}, D2 = D1, D3 = D1;
+        f4 na1 = la1, na2 = la2, na3 = la3;       // STREAM: rows of the stage handled next, requested one stage ahead
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
             if constexpr (STREAM) {     // this lane's own rows, written in phase A (lanes of a ragged tile read trajectory B-1's)
-                const size_t off = row_off(s);
-                a1 = *reinterpret_cast<const f4*>(a.act[0] + off);
-                a2 = *reinterpret_cast<const f4*>(a.act[1] + off);
-                a3 = *reinterpret_cast<const f4*>(a.act[2] + off);
+                a1 = na1; a2 = na2; a3 = na3;
+                if (s > 0) {
+                    const size_t rb = row_blk(s - 1) * H;
+                    na1 = *reinterpret_cast<const f4*>(sbase(a.act[0] + rb) + offH);
+                    na2 = *reinterpret_cast<const f4*>(sbase(a.act[1] + rb) + offH);
+                    na3 = *reinterpret_cast<const f4*>(sbase(a.act[2] + rb) + offH);
+                }
             } else {
                 a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
             }
@@ -299,17 +324,18 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
             D1 += d1; D2 += d2; D3 += d3;
             const f2 gx = out2(fT, d1, f4{0.f, 0.f, 0.f, 0.f});
             if (valid) {
-                const size_t off = row_off(s);
-                *reinterpret_cast<f4*>(a.delta[0] + off) = d1;
-                *reinterpret_cast<f4*>(a.delta[1] + off) = d2;
-                *reinterpret_cast<f4*>(a.delta[2] + off) = d3;
+                const size_t rb = row_blk(s) * H;
+                *reinterpret_cast<f4*>(sbase(a.delta[0] + rb) + offH) = d1;
+                *reinterpret_cast<f4*>(sbase(a.delta[1] + rb) + offH) = d2;
+                *reinterpret_cast<f4*>(sbase(a.delta[2] + rb) + offH) = d3;
                 if (w == 0) {
-                    const size_t row = (size_t)((k - a.k0) * S + s) * nrow + b;
+                    float* gkr = sbase(a.gk + row_blk(s) * xd);
+                    float* xsr = sbase(a.xst + row_blk(s) * xd);
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
                         if (4 * r + g < xd) {
-                            a.gk[row * xd + 4 * r + g] = gks[s][r];
-                            a.xst[row * xd + 4 * r + g] = X[s][r];
+                            gkr[offX + 4 * r] = gks[s][r];
+                            xsr[offX + 4 * r] = X[s][r];
                         }
                     }
                 }
@@ -323,10 +349,10 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
             }
         }
         if (valid) {     // per-step sums over the stages: what the bias / input gradients contract over (a quarter of the rows at RK4)
-            const size_t off = ((size_t)(k - a.k0) * nrow + b) * H + 16 * w + 4 * g;
-            *reinterpret_cast<f4*>(a.dsum[0] + off) = D1;
-            *reinterpret_cast<f4*>(a.dsum[1] + off) = D2;
-            *reinterpret_cast<f4*>(a.dsum[2] + off) = D3;
+            const size_t rb = (size_t)(k - a.k0) * nrow * H;
+            *reinterpret_cast<f4*>(sbase(a.dsum[0] + rb) + offH) = D1;
+            *reinterpret_cast<f4*>(sbase(a.dsum[1] + rb) + offH) = D2;
+            *reinterpret_cast<f4*>(sbase(a.dsum[2] + rb) + offH) = D3;
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];
