@@ -430,6 +430,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         // phase A: stage evaluations (K1's plan; the ELU outputs are kept)
         float X[S][NX], ks[S][NX];
         f4 h1[STREAM ? 1 : S], h2[STREAM ? 1 : S], h3[STREAM ? 1 : S];
+        f4 la1, la2, la3;    // ELU outputs of the last stage evaluated (the first one the backward half needs)
         auto row_blk = [&](const int s) -> size_t { return (size_t)((k - a.k0) * S + s) * nrow; };   // uniform
         {
             float w2s[STREAM ? 4 * NWV : 1], w3s[STREAM ? 4 * NWV : 1];
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
                     *reinterpret_cast<f4*>(sbase(a.act[2] + rb) + offH) = a3;
                 }
                 if constexpr (!STREAM) { h1[s] = a1; h2[s] = a2; h3[s] = a3; }
+                if (s == S - 1) { la1 = a1; la2 = a2; la3 = a3; }
                 const f2 kk = out2(w4, a3, sb4);
                 ks[s][0] = kk[0];
                 if constexpr (NX > 1) ks[s][1] = kk[1];
@@ -483,14 +485,18 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
         }
         f4 D1 = f4{0.f, 0.f, 0.f, 0.f}, D2 = D1, D3 = D1;
+        f4 na1 = la1, na2 = la2, na3 = la3;       // STREAM: rows of the stage handled next, requested one stage ahead
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
             if constexpr (STREAM) {
-                const size_t rb = row_blk(s) * H;
-                a1 = *reinterpret_cast<const f4*>(sbase(a.act[0] + rb) + offH);
-                a2 = *reinterpret_cast<const f4*>(sbase(a.act[1] + rb) + offH);
-                a3 = *reinterpret_cast<const f4*>(sbase(a.act[2] + rb) + offH);
+                a1 = na1; a2 = na2; a3 = na3;
+                if (s > 0) {
+                    const size_t rb = row_blk(s - 1) * H;
+                    na1 = *reinterpret_cast<const f4*>(sbase(a.act[0] + rb) + offH);
+                    na2 = *reinterpret_cast<const f4*>(sbase(a.act[1] + rb) + offH);
+                    na3 = *reinterpret_cast<const f4*>(sbase(a.act[2] + rb) + offH);
+                }
             } else {
                 a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
             }
