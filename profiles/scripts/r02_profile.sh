@@ -15,6 +15,8 @@ kt dae01_h128 $B --workload dae01 --hidden 128
 kt train_ode01 $B --train --steps 5
 kt train_dae01 $B --train --workload dae01 --steps 5
 kt train_models python $R/profiles/scripts/train_step_models.py ode02 dae02
+kt train_ode01_h128 $B --train --hidden 128 --steps 3 --warmup 1
+kt train_dae01_h128 $B --train --workload dae01 --hidden 128 --steps 3 --warmup 1
 pmc() { rocprofv3 --kernel-trace --pmc $2 -d $O/r02_$1_$2 -o p -- "${@:4}" > /dev/null 2>&1; python $R/profiles/summarize_pmc.py $O/r02_$1_$2/p_results.db $3 > $O/r02_$1_$2_pmc.txt; rm -rf $O/r02_$1_$2; }
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc ode01 $c integrate_mfma $B
@@ -35,6 +37,7 @@ python bench.py --steps 10 --workload ode02 2>/dev/null | tail -1 > $O/r02_bench
 python bench.py --steps 10 --workload ode02_latent16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode02_latent16_n1.json
 python bench.py --steps 5 --train --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode01_train_n1.json
 python bench.py --steps 5 --train --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_dae01_train_n1.json
+for w in ode01 dae01; do for h in 128 32; do python bench.py --steps 5 --warmup 2 --train --workload $w --hidden $h --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_${w}_h${h}_train_n1.json; done; done
 python bench.py --steps 5 --hidden 128 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode01_h128_n1.json
 python bench.py --steps 5 --hidden 128 --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_dae01_h128_n1.json
 ls $O | grep r02_

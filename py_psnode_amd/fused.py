@@ -216,6 +216,7 @@ def event_table(t: torch.Tensor, event_t: Optional[torch.Tensor], check_duplicat
         return None
     lib = _lib.load()
     dev = t.device
+    t_arg, event_arg = t, event_t          # the caller's objects: what the duplicate-check memo is keyed on (detach() makes new ones)
     t = _f32_dev(t, dev, "t")
     event_t = _f32_dev(event_t, dev, "event_t")
     tab = torch.empty(T - 1, dtype=torch.int32, device=dev)
@@ -225,16 +226,17 @@ def event_table(t: torch.Tensor, event_t: Optional[torch.Tensor], check_duplicat
     rc = lib.psnode_event_table_f32(T - 1, t.data_ptr(), t.stride(0), event_t.data_ptr(), event_t.stride(1), n_ev,
                                     tab.data_ptr(), dup.data_ptr(), st)
     _lib.check(rc, "psnode_event_table_f32")
-    if check_duplicates and not _dup_check_known(t, event_t):
+    if check_duplicates and not _dup_check_known(t_arg, event_arg):
         if int(dup.item()):
             raise RuntimeError("two events share one time stamp: the reference's jump_change_fn cannot view "
                                "z_jump[:, mask] as z0.shape (neural_base.py:61)")
-        _dup_check_remember(t, event_t)
+        _dup_check_remember(t_arg, event_arg)
     return tab
 
 
-# (clock, event list) pairs already found free of duplicate event times: the same tensor OBJECTS at the same in-place version
-# need no second 4-byte read-back (an evaluation loop over resident tensors, bench.py); a new batch is a new object and is checked.
+# (clock, event list) pairs already found free of duplicate event times: the same tensor OBJECTS (or views of the same base objects)
+# at the same in-place version need no second 4-byte read-back -- which is a device synchronisation per call, 0.9 ms of a 0.94 ms
+# ODE_02 forward (profiles/scripts/host_overhead.py); a new batch is a new object and is checked.
 _DUP_OK = {}      # id(event tensor's base) -> (weakref to it, key of the event view, weakref to the clock's base, key of the clock view)
 
 

@@ -453,6 +453,23 @@ def test_event_table_kernel_matches_reference_semantics():
         fused().event_table(t, dup, check_duplicates=True)
 
 
+def test_duplicate_event_check_is_memoised_per_tensor_version():
+    """The duplicate-event check reads 4 bytes back (a device sync); for the same clock / event tensors -- or fresh VIEWS of them, as
+    the solver route makes on every call -- at the same in-place version it is done once.  An in-place edit is seen."""
+    f = fused()
+    d = load("g2_ode.npz")
+    t_bm, ev = T(d["t"]).cuda(), T(d["event_t"]).cuda()       # B-major clock as the scripts hold it; the solver permutes per call
+    f._DUP_OK.clear()
+    assert not f._dup_check_known(t_bm.permute(1, 0, 2), ev)
+    tab = f.event_table(t_bm.permute(1, 0, 2), ev, check_duplicates=True)
+    assert f._dup_check_known(t_bm.permute(1, 0, 2), ev)      # a NEW view object of the same base: known
+    assert torch.equal(tab, f.event_table(t_bm.permute(1, 0, 2), ev, check_duplicates=True))
+    ev[:, 1] = ev[:, 0]                                       # in-place edit: version bump, checked again, and now it raises
+    assert not f._dup_check_known(t_bm.permute(1, 0, 2), ev)
+    with pytest.raises(RuntimeError):
+        f.event_table(t_bm.permute(1, 0, 2), ev, check_duplicates=True)
+
+
 def test_c_abi_error_codes_on_device():
     f = fused()
     ls, t, x, z, a0 = _synthetic_ode(4, 3)
