@@ -62,9 +62,10 @@ for tag in sys.argv[1:] or ["ode01", "ode02", "dae01", "dae02"]:
         n = 3
         for _ in range(n):
             step()
+        host_ms = (time.perf_counter() - t0) / n * 1e3          # enqueue time: a value near ms_per_train_step means host-bound
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        out[f"{tag}:{method}"] = {"ms_per_train_step": round(ms, 2), "grid_points": steps_T, "state_steps_per_s": round(B * (steps_T - 1) / ms * 1e3),
+        out[f"{tag}:{method}"] = {"ms_per_train_step": round(ms, 2), "host_enqueue_ms": round(host_ms, 2), "grid_points": steps_T, "state_steps_per_s": round(B * (steps_T - 1) / ms * 1e3),
                                   "prediction_grad_fn": route}
         print(tag, method, out[f"{tag}:{method}"], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)

@@ -34,6 +34,9 @@ def _view_bt(t: torch.Tensor, dev, name: str, keep: list) -> _lib.ViewF32:
     return _lib.ViewF32(t.data_ptr(), t.stride(1), t.stride(0))
 
 
+_COL_WEIGHTS = {}
+
+
 def masked_mse_terms(pred, target, mask=None, col_weight=None, inv_norm: Optional[torch.Tensor] = None, scale: float = 1.0,
                      t0_coef: float = 0.0, want_grad: bool = False):
     """Raw kernel call.  pred/target [B,T,D]; mask None | [B,T,1] | [B,T,D]; col_weight None | [D] tensor;
@@ -56,7 +59,13 @@ def masked_mse_terms(pred, target, mask=None, col_weight=None, inv_norm: Optiona
         a.mask_width = mask.shape[2]
         a.mask = _view_bt(mask, dev, "mask", keep)
     if col_weight is not None:
-        cw = torch.as_tensor(col_weight, dtype=torch.float32, device=dev).contiguous()
+        if isinstance(col_weight, torch.Tensor):
+            cw = col_weight.to(device=dev, dtype=torch.float32).contiguous()
+        else:       # a python sequence (the DAE scripts' [1, 10, 1, ...]): uploaded once per (values, device) -- a pageable H2D copy
+            key = (tuple(float(c) for c in col_weight), str(dev))   # per call is a device synchronisation in the middle of the step
+            cw = _COL_WEIGHTS.get(key)
+            if cw is None:
+                cw = _COL_WEIGHTS[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
         if cw.numel() != D:
             raise ValueError(f"col_weight has {cw.numel()} entries, expected {D}")
         keep.append(cw)
