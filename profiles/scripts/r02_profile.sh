@@ -33,8 +33,8 @@ bash profiles/scripts/batch_sweep.sh > $O/r02_batch_sweep.txt 2>&1
 python profiles/scripts/train_step_models.py > $O/r02_train_step_models.txt 2>&1; cp $O/train_step_models.json $O/r02_train_step_models.json
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/r02_bench_ode01_n1.json
 python bench.py --steps 10 --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_dae01_n1.json
-python bench.py --steps 10 --workload ode02 2>/dev/null | tail -1 > $O/r02_bench_ode02_n1.json
-python bench.py --steps 10 --workload ode02_latent16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode02_latent16_n1.json
+python bench.py --steps 50 --warmup 10 --workload ode02 2>/dev/null | tail -1 > $O/r02_bench_ode02_n1.json     # (sub-ms calls: the first ~10 carry a one-time 1.5 ms transient)
+python bench.py --steps 50 --warmup 10 --workload ode02_latent16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode02_latent16_n1.json
 python bench.py --steps 5 --train --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_ode01_train_n1.json
 python bench.py --steps 5 --train --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_dae01_train_n1.json
 for w in ode01 dae01; do for h in 128 32; do python bench.py --steps 5 --warmup 2 --train --workload $w --hidden $h --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_${w}_h${h}_train_n1.json; done; done
