@@ -220,8 +220,9 @@ int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* works
  * The parameter gradients are then PLAIN GEMMs over those rows (dW_l = delta_l^T . act_{l-1}, library GEMMs on the host side:
  * py_psnode_amd/fused.py:ode_backward_wide), as are dL/dz = D1 . (Ws+Wd)[:, z] and dL/dall_initial = sum_t D1 . (Wa-Wd), D1 = sum_s delta_1.
  * `carry` [B, x_dim] holds the adjoint of x[k1] WITHOUT dL/dxs[k1] on entry (zeros for the last chunk) and of x[k0] likewise on exit, so
- * the sweep can be cut into time chunks to bound the size of the stored rows.  Shape class: de = 3n -> H -> H -> H -> x_dim,
- * H in {32, 64, 128}, x_dim <= 8, z_dim <= 4. */
+ * the sweep can be cut into time chunks to bound the size of the stored rows.  Shape class: de = 3n -> h -> h -> h -> x_dim,
+ * h <= 128, x_dim <= 8, z_dim <= 4.  H in the row shapes above is h rounded up to the kernels' 32 / 64 / 128 (the integrators do the
+ * same, psnode_ode_integrate_f32): columns h..H-1 of the rows are exact zeros (zero-padded units: zero weights, ELU(0) = 0). */
 typedef struct {
     int32_t method;
     int32_t x_dim, z_dim;
@@ -297,7 +298,8 @@ int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* works
  * carry_x [B,x_dim] / carry_i [B,16] (slot layout): adjoint of x[k1] without dL/dxs[k1] / of is[k1] without dL/dis[k1] on entry (zeros for
  * the last chunk), of x[k0] / is[k0] likewise on exit -- except that the chunk with k0 == 0 also runs the head at grid point 0, so its
  * carry_x is dL/dx_init without dL/dxs[0] and its carry_i is zero.  Parameter and input gradients: py_psnode_amd/fused.py:dae_backward_wide.
- * Shape class: de = 3n -> H -> H -> H -> x_dim, ae = n+x+z+v -> H -> H -> H -> i_dim, x_dim <= 8, z+v+i <= 8. */
+ * Shape class: de = 3n -> h -> h -> h -> x_dim, ae = n+x+z+v -> h -> h -> h -> i_dim (the same h <= 128), x_dim <= 8, z+v+i <= 8;
+ * H = h rounded up to 32 / 64 / 128 as above. */
 typedef struct {
     int32_t method;
     int32_t x_dim, z_dim, v_dim, i_dim;

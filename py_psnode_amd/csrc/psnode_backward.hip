@@ -582,7 +582,7 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     d.xs = a->xs; d.gout = a->grad_xs; d.gx0 = a->grad_x0; d.gz = a->grad_z; d.gzj = a->grad_z_jump; d.n_events = a->n_events;
     d.ga0 = a->grad_all_initial; d.wpart = wpart; d.NP = bwd_np(xd, zd);
     PackBwd pb;
-    pb.f.fold = 0; pb.f.ae = 0; pb.f.nw = NW; pb.f.xd = xd; pb.f.ne = zd; pb.f.n = n; pb.f.nzv = zd; pb.f.NX = kNXc; pb.f.NB = kNXc; pb.f.NE = NZM; pb.f.NA = NA;
+    pb.f.fold = 0; pb.f.hreal = HID; pb.f.ae = 0; pb.f.nw = NW; pb.f.xd = xd; pb.f.ne = zd; pb.f.n = n; pb.f.nzv = zd; pb.f.NX = kNXc; pb.f.NB = kNXc; pb.f.NE = NZM; pb.f.NA = NA;
     pb.f.w1 = a->de.weight[0]; pb.f.b1 = a->de.bias[0]; pb.f.w2 = a->de.weight[1]; pb.f.b2 = a->de.bias[1];
     pb.f.w3 = a->de.weight[2]; pb.f.b3 = a->de.bias[2]; pb.f.w4 = a->de.weight[3]; pb.f.b4 = a->de.bias[3];
     pb.f.out_dim = xd; pb.f.out = nullptr;

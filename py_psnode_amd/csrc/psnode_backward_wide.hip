@@ -33,7 +33,7 @@ __device__ __forceinline__ f4 wdact(f4 h) {   // ELU'(pre) from h = ELU(pre)
 }
 
 struct WideDev {
-    int method, xd, zd;
+    int method, xd, zd, hreal;            // hreal: the MLP's hidden width (<= H = 16 * NWV; units beyond it are zero padding)
     long long T, B, k0, k1;
     const float *w1, *w4;                 // raw nn.Linear tensors for the small transposed operands
     ViewDev t, z;
@@ -49,19 +49,22 @@ struct WideDev {
 // transposed images of W2 / W3 in the order the kernel's LDS array wants: [(layer * NWV + c) * NWV + w][lane] (f4):
 //   reg r = W[16((w+c) % NWV) + 4g + r][16w + i]
 struct PackWideT {
-    int nw;
+    int nw, hreal;
     const float *w2, *w3;
     f4* out;
 };
 __global__ void pack_wide_t_kernel(const PackWideT p) {
-    const int H = 16 * p.nw, total = 2 * p.nw * p.nw * 64;
+    const int H = p.hreal, total = 2 * p.nw * p.nw * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, w = (idx >> 6) % p.nw, c = ((idx >> 6) / p.nw) % p.nw, layer = (idx >> 6) / (p.nw * p.nw);
         const int i = lane & 15, g = lane >> 4, ws = (w + c) & (p.nw - 1);
         const float* W = layer ? p.w3 : p.w2;
         f4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = W[(size_t)(16 * ws + 4 * g + r) * H + 16 * w + i];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ws + 4 * g + r, col = 16 * w + i;
+            v[r] = (row < H && col < H) ? W[(size_t)row * H + col] : 0.0f;
+        }
         p.out[idx] = v;
     }
 }
@@ -111,14 +114,14 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
     //   fT[r]   = (Ws+Wd)[16w+4g+r][o],  o = x-dim carried by output row i (as the W4 rows of the forward image)
     float w4T[NX], fT[4];
     {
-        const int i = j, u = 16 * w + i, K1 = 3 * n;
+        const int i = j, u = 16 * w + i, K1 = 3 * n, HR = a.hreal;
 #pragma unroll
-        for (int r = 0; r < NX; ++r) { const int d = 4 * r + g; w4T[r] = d < xd ? a.w4[(size_t)d * H + u] : 0.0f; }
+        for (int r = 0; r < NX; ++r) { const int d = 4 * r + g; w4T[r] = (d < xd && u < HR) ? a.w4[(size_t)d * HR + u] : 0.0f; }
         const int o = 4 * (i & 3) + (i >> 2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int uu = 16 * w + 4 * g + r;
-            fT[r] = o < xd ? a.w1[(size_t)uu * K1 + 2 * n + o] + a.w1[(size_t)uu * K1 + n + o] : 0.0f;
+            fT[r] = (o < xd && uu < HR) ? a.w1[(size_t)uu * K1 + 2 * n + o] + a.w1[(size_t)uu * K1 + n + o] : 0.0f;
         }
     }
 
@@ -367,7 +370,7 @@ int wide_hidden(const psnode_mlp_f32& m) {
     if (m.n_layers != 4) return 0;
     const int h = m.out_dim[0];
     if (m.out_dim[1] != h || m.out_dim[2] != h) return 0;
-    return (h == 32 || h == 64 || h == 128) ? h : 0;
+    return padded_hidden(h);      // the width class the kernel runs at (zero-padded units beyond h)
 }
 size_t wide_fwd_floats(int nw, int n) { return (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64; }
 size_t wide_t_floats(int nw) { return (size_t)2 * nw * nw * 64 * 4; }
@@ -448,16 +451,17 @@ int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* p, void
     PackMfma f;
     memset(&f, 0, sizeof(f));
     f.ae = 0; f.nw = nw; f.xd = xd; f.ne = zd; f.n = n; f.nzv = zd; f.NX = kNXc; f.NB = 0; f.NE = NZM; f.NA = NA; f.fold = 1;
+    f.hreal = p->de.out_dim[0];
     f.w1 = p->de.weight[0]; f.b1 = p->de.bias[0]; f.w2 = p->de.weight[1]; f.b2 = p->de.bias[1];
     f.w3 = p->de.weight[2]; f.b3 = p->de.bias[2]; f.w4 = p->de.weight[3]; f.b4 = p->de.bias[3];
     f.out_dim = xd; f.out = pde;
     hipLaunchKernelGGL(pack_wide_fwd_kernel, dim3(32), dim3(256), 0, s, f);
-    PackWideT t{nw, p->de.weight[1], p->de.weight[2], pt};
+    PackWideT t{nw, p->de.out_dim[0], p->de.weight[1], p->de.weight[2], pt};
     hipLaunchKernelGGL(pack_wide_t_kernel, dim3(64), dim3(256), 0, s, t);
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
     WideDev a;
     memset(&a, 0, sizeof(a));
-    a.method = p->method; a.xd = xd; a.zd = zd; a.T = p->T; a.B = p->B; a.k0 = p->k0; a.k1 = p->k1;
+    a.method = p->method; a.xd = xd; a.zd = zd; a.hreal = p->de.out_dim[0]; a.T = p->T; a.B = p->B; a.k0 = p->k0; a.k1 = p->k1;
     a.w1 = p->de.weight[0]; a.w4 = p->de.weight[3];
     a.t = ViewDev{p->t.ptr, p->t.stride_t, p->t.stride_b};
     a.z = ViewDev{p->z.ptr, p->z.stride_t, p->z.stride_b};

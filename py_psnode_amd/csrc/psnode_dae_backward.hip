@@ -802,7 +802,7 @@ int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipS
     d.NP_de = np_of(3 * n, xd); d.NP_ae = np_of(n + xd + nzv, id);
 
     PackDaeBwd pd;
-    pd.f.fold = 0; pd.f.ae = 0; pd.f.nw = NW; pd.f.xd = xd; pd.f.ne = ne; pd.f.n = n; pd.f.nzv = nzv;
+    pd.f.fold = 0; pd.f.hreal = HID; pd.f.ae = 0; pd.f.nw = NW; pd.f.xd = xd; pd.f.ne = ne; pd.f.n = n; pd.f.nzv = nzv;
     pd.f.NX = kNXc; pd.f.NB = kNXc; pd.f.NE = NZM; pd.f.NA = NA;
     pd.f.w1 = a->de.weight[0]; pd.f.b1 = a->de.bias[0]; pd.f.w2 = a->de.weight[1]; pd.f.b2 = a->de.bias[1];
     pd.f.w3 = a->de.weight[2]; pd.f.b3 = a->de.bias[2]; pd.f.w4 = a->de.weight[3]; pd.f.b4 = a->de.bias[3];

@@ -4,12 +4,13 @@
 namespace psnode {
 namespace {
 
-// hidden width of a 4-layer in -> H -> H -> H -> out MLP if H is one the MFMA kernels are built for, else 0
+// width class (32 / 64 / 128) the MFMA kernels run a 4-layer in -> H -> H -> H -> out MLP at: H itself or, zero-padded, the next
+// one up (psnode_pack.h: PackMfma::hreal); 0 if H > 128 or the shape is another one
 int mfma_hidden(const MlpDev& m, int in_dim, int out_dim) {
     if (m.n_layers != 4 || m.in_dim != in_dim || m.out_dim[3] != out_dim) return 0;
     const int h = m.out_dim[0];
     if (m.out_dim[1] != h || m.out_dim[2] != h) return 0;
-    return (h == 32 || h == 64 || h == 128) ? h : 0;
+    return padded_hidden(h);
 }
 
 }  // namespace
@@ -27,7 +28,7 @@ bool mfma_dae_supported(const IntegrateDev& a) {
     const int n = a.xd + a.zd + a.vd + a.id;
     if (a.xd < 1 || a.xd > 4 * kNXc || a.id < 1) return false;
     const int h = mfma_hidden(a.de, 3 * n, a.xd);
-    if (!h || mfma_hidden(a.ae, n + a.xd + a.zd + a.vd, a.id) != h) return false;   // DE and AE share --hidden
+    if (!h || mfma_hidden(a.ae, n + a.xd + a.zd + a.vd, a.id) != h || a.ae.out_dim[0] != a.de.out_dim[0]) return false;   // DE and AE share --hidden
     const int NZM = nzm_of(a, true), NZA = nza_of(a);
     switch (NZM * 10 + NZA) {
         case 11: case 21: case 31: case 41: case 32: case 42: return true;
@@ -38,7 +39,7 @@ bool mfma_dae_supported(const IntegrateDev& a) {
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
     if (de && de->n_layers == 2) return latent_pack_floats() > latent64_pack_floats() ? latent_pack_floats() : latent64_pack_floats();
     if (!de || de->n_layers != 4) return 0;
-    const int n = de->in_dim / 3, nw = (de->out_dim[0] + 15) / 16;
+    const int n = de->in_dim / 3, nw = (padded_hidden(de->out_dim[0]) ? padded_hidden(de->out_dim[0]) : de->out_dim[0] + 15) / 16;
     const size_t one = (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64;
     return ae ? 2 * one : one;
 }
@@ -46,7 +47,7 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
     if (latent_shape_ok(a, dae)) return launch_latent(a, dae, pack, stream);
     if (latent64_shape_ok(a, dae)) return launch_latent64(a, dae, pack, stream);
-    switch (a.de.out_dim[0]) {
+    switch (padded_hidden(a.de.out_dim[0])) {
         case 32: return launch_mfma_h32(a, dae, pack, stream);
         case 128: return launch_mfma_h128(a, dae, pack, stream);
         default: return launch_mfma_nw<NW>(a, dae, pack, stream);

@@ -549,7 +549,7 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     const int ne = a.zd + (dae ? a.vd + a.id : 0);
     PackMfma p;
     p.ae = 0; p.nw = NWV; p.xd = a.xd; p.ne = ne; p.n = a.xd + ne; p.nzv = a.zd + (dae ? a.vd : 0);
-    p.NX = kNXc; p.NB = 0; p.NE = NZM; p.NA = NA; p.fold = 1;
+    p.NX = kNXc; p.NB = 0; p.NE = NZM; p.NA = NA; p.fold = 1; p.hreal = a.de.out_dim[0];
     p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
     p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
     p.out_dim = a.xd;

@@ -44,50 +44,61 @@ struct PackMfma {
     int xd, ne, n, nzv;     // ne = z+v+i (DE ext), n = xd+ne, nzv = z+v
     int NX, NB, NE, NA;
     int fold;               // DE forward image only: W1A = Ws + Wd on the x dims, no W1B registers (NB = 0), a0 columns = Wa - Wd there
+    int hreal;              // the MLP's hidden width (row stride of its H->H tensors); 0 = 16 * nw.  Widths between the kernels'
+                            // 32 / 64 / 128 run zero-padded: units >= hreal have zero weights and biases, ELU(0) = 0, so they
+                            // contribute exact zeros to every sum
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
     int out_dim;            // x_dim (DE) or i_dim (AE)
     float* out;
 };
 
+// the hidden width the MFMA kernels run a width-h MLP at (0: none)
+__host__ __device__ inline int padded_hidden(int h) { return h < 1 ? 0 : (h <= 32 ? 32 : (h <= 64 ? 64 : (h <= 128 ? 128 : 0))); }
+
 __host__ __device__ inline int pack_fwd_count(const PackMfma& p) { return p.NX + p.NB + p.NE + 20 + 8 * p.nw + p.NA; }
 
 // value of forward-image register `reg` (0 .. pack_fwd_count) for wave w, lane `lane`
 __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int lane) {
-    const int H = 16 * p.nw;
+    const int H = p.hreal ? p.hreal : 16 * p.nw;      // real width: row stride and bound of the unit indices
     const int W1B = p.NX, W1E = p.NX + p.NB, B1 = W1E + p.NE, W2 = B1 + 4, B2 = W2 + 4 * p.nw, W3 = B2 + 4, B3 = W3 + 4 * p.nw,
               W4 = B3 + 4, B4 = W4 + 4, COUNT = B4 + 4;
     const int K1 = p.ae ? p.n + p.xd + p.nzv : 3 * p.n;
     const int i = lane & 15, g = lane >> 4, u = 16 * w + i;
+    const bool urow = u < H;                          // padding units: every register of their rows is zero
     float v = 0.0f;
     if (reg < W1B) {                      // x columns: DE `s` block / AE x block
         const int d = 4 * reg + g;
-        if (d < p.xd) {
+        if (d < p.xd && urow) {
             v = p.w1[u * K1 + (p.ae ? p.n : 2 * p.n) + d];
             if (p.fold) v += p.w1[u * K1 + p.n + d];      // W.cat(a0, s-a0, s) = (Ws+Wd).s + (Wa-Wd).a0 on the x dims
         }
     } else if (reg < W1E) {               // DE `s - a0` block, x dims
         const int d = 4 * (reg - W1B) + g;
-        if (d < p.xd) v = p.w1[u * K1 + p.n + d];
+        if (d < p.xd && urow) v = p.w1[u * K1 + p.n + d];
     } else if (reg < B1) {                // external-input columns
         const int q = 4 * (reg - W1E) + g;
-        if (p.ae) {
+        if (!urow) {
+        } else if (p.ae) {
             if (q < p.nzv) v = p.w1[u * K1 + p.n + p.xd + q];
         } else {
             if (q < p.ne) v = p.w1[u * K1 + p.n + p.xd + q];
             else if (q < 2 * p.ne) v = p.w1[u * K1 + 2 * p.n + p.xd + (q - p.ne)];
         }
     } else if (reg < W2) {
-        v = p.b1[16 * w + 4 * g + (reg - B1)];
+        const int uu = 16 * w + 4 * g + (reg - B1);
+        if (uu < H) v = p.b1[uu];
     } else if (reg < B2) {
-        const int kk = reg - W2, ws = (w + (kk >> 2)) & (p.nw - 1);
-        v = p.w2[u * H + 16 * ws + 4 * g + (kk & 3)];
+        const int kk = reg - W2, ws = (w + (kk >> 2)) & (p.nw - 1), col = 16 * ws + 4 * g + (kk & 3);
+        if (urow && col < H) v = p.w2[u * H + col];
     } else if (reg < W3) {
-        v = p.b2[16 * w + 4 * g + (reg - B2)];
+        const int uu = 16 * w + 4 * g + (reg - B2);
+        if (uu < H) v = p.b2[uu];
     } else if (reg < B3) {
-        const int kk = reg - W3, ws = (w + (kk >> 2)) & (p.nw - 1);
-        v = p.w3[u * H + 16 * ws + 4 * g + (kk & 3)];
+        const int kk = reg - W3, ws = (w + (kk >> 2)) & (p.nw - 1), col = 16 * ws + 4 * g + (kk & 3);
+        if (urow && col < H) v = p.w3[u * H + col];
     } else if (reg < W4) {
-        v = p.b3[16 * w + 4 * g + (reg - B3)];
+        const int uu = 16 * w + 4 * g + (reg - B3);
+        if (uu < H) v = p.b3[uu];
     } else if (reg < COUNT) {
         // output row rho = 4*gr + rr (A operand: rho = i; bias in D layout: gr = g, rr = reg - B4)
         const bool bias = reg >= B4;
@@ -99,10 +110,11 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
         } else {                          // row (gr, rr) <- x-dim 4*rr+gr
             o = 4 * rr + gr;
         }
-        if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : p.w4[o * H + 16 * w + 4 * g + (reg - W4)];
+        const int col = 16 * w + 4 * g + (reg - W4);
+        if (o >= 0 && o < p.out_dim) v = bias ? p.b4[o] : (col < H ? p.w4[o * H + col] : 0.0f);
     } else {
         const int q = 4 * (reg - COUNT) + g;
-        if (q < p.n) {
+        if (q < p.n && urow) {
             v = p.w1[u * K1 + q];
             if (p.fold && q < p.xd) v -= p.w1[u * K1 + p.n + q];
         }

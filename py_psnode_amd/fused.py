@@ -425,6 +425,16 @@ def ode_backward_wide_supported(method: str, de_layers: Layers, x_dim: int, z_di
     return bool(lib.psnode_ode_backward_wide_supported(ctypes.byref(a)))
 
 
+def _padded_hidden(h: int) -> int:
+    """Width class the MFMA kernels run a hidden width at (csrc/psnode_pack.h: padded_hidden): rows they store have this many columns,
+    the ones beyond `h` are exact zeros."""
+    return 32 if h <= 32 else (64 if h <= 64 else 128)
+
+
+def _pad_rows(m: torch.Tensor, rows: int) -> torch.Tensor:
+    return m if m.shape[0] == rows else torch.cat((m, m.new_zeros((rows - m.shape[0],) + tuple(m.shape[1:]))), 0)
+
+
 def _gemm_tn(a2: torch.Tensor, b2: torch.Tensor, groups: int) -> torch.Tensor:
     """a2^T @ b2 for tall-skinny [N, p], [N, q] (N in the millions): `groups` independent partial products + one sum, so the library
     GEMM has parallelism over the contraction (one [p,N]x[N,q] call runs on a handful of workgroups: 21 vs 124 TFLOP/s at p=q=128)."""
@@ -444,7 +454,8 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
     T, B, xd = xs.shape
     zd = z.shape[-1]
     n = xd + zd
-    H = de_layers[0][0].shape[0]
+    Hr = de_layers[0][0].shape[0]                       # the MLP's width; H = the width the kernel runs it at (zero-padded rows)
+    H = _padded_hidden(Hr)
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     keep: list = []
     a = _lib.OdeBwdWideArgsF32()
@@ -470,7 +481,7 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
     if T >= 2:
         if chunk_steps is None:      # ~3 GB of stored rows per chunk
             chunk_steps = max(1, min(T - 1, int(3e9 // (6 * 4 * S * B * H))))
-        Fz = (W1[:, 2 * n + xd:3 * n] + W1[:, n + xd:2 * n]) if zd > 0 else None          # (Ws + Wd)[:, z columns]
+        Fz = _pad_rows(W1[:, 2 * n + xd:3 * n] + W1[:, n + xd:2 * n], H) if zd > 0 else None   # (Ws + Wd)[:, z columns]
         with torch.cuda.device(dev):
             nbytes = lib.psnode_ode_backward_wide_workspace_bytes(ctypes.byref(a))
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
@@ -491,9 +502,9 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                 _lib.check(lib.psnode_ode_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_ode_backward_wide_f32")
                 h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
                 G = Tc * S
-                gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
-                gW[2] += _gemm_tn(d3, h2, G); gb[2] += dsum[2].sum((0, 1))
-                gW[1] += _gemm_tn(d2, h1, G); gb[1] += dsum[1].sum((0, 1))
+                gW[3] += _gemm_tn(gk.view(-1, xd), h3, G)[:, :Hr]; gb[3] += gk.view(-1, xd).sum(0)
+                gW[2] += _gemm_tn(d3, h2, G)[:Hr, :Hr]; gb[2] += dsum[2].sum((0, 1))[:Hr]
+                gW[1] += _gemm_tn(d2, h1, G)[:Hr, :Hr]; gb[1] += dsum[1].sum((0, 1))[:Hr]
                 # input of L1 per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z of the step (jump values at event steps))
                 if zd > 0:
                     zc = zt[k0:k1]                                                           # [Tc, B, zd] view
@@ -505,10 +516,10 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                 else:
                     s_in = Xs
                 U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
-                gW[0] += _gemm_tn(d1, U, G)
+                gW[0] += _gemm_tn(d1, U, G)[:Hr]
                 D1 = dsum[0]                                                                 # [Tc, B, H]: sum over the stages
                 D1s = D1.sum(0)
-                S1 += D1s; gb[0] += D1s.sum(0)
+                S1 += D1s; gb[0] += D1s.sum(0)[:Hr]
                 if zd > 0 and (gz is not None or gzj is not None):
                     gzc = D1.reshape(-1, H) @ Fz                                             # [Tc*B, zd]
                     gzc = gzc.view(Tc, B, zd)
@@ -520,7 +531,7 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
                         gz[k0:k1] = gzc
                 del rows, gk, Xs, U, D1, dsum
     gx0 = carry + g_c[0]
-    ga0 = S1 @ (W1[:, 0:n] - W1[:, n:2 * n])                                                # d all_initial = sum_t D1 . (Wa - Wd)
+    ga0 = S1 @ _pad_rows(W1[:, 0:n] - W1[:, n:2 * n], H)                                    # d all_initial = sum_t D1 . (Wa - Wd)
     return gx0, gz, gzj, ga0, [gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3]]
 
 
@@ -569,7 +580,8 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
     zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
     nzv, ne = zd + vd, zd + vd + idim
     n = xd + ne
-    H = de_layers[0][0].shape[0]
+    Hr = de_layers[0][0].shape[0]                       # the MLPs' width; H = the width the kernel runs them at (zero-padded rows)
+    H = _padded_hidden(Hr)
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     keep: list = []
     a = _lib.DaeBwdWideArgsF32()
@@ -610,8 +622,8 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
     Sa1 = torch.zeros((B, H), **f32)                            # sum over the heads of the AE's delta_1
     carry_x, carry_i = torch.zeros((B, xd), **f32), torch.zeros((B, 16), **f32)
     a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
-    Fe = W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv]       # (Ws + Wd)[:, z|v columns]
-    Ae = A1[:, n + xd:n + xd + nzv]
+    Fe = _pad_rows(W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv], H)       # (Ws + Wd)[:, z|v columns]
+    Ae = _pad_rows(A1[:, n + xd:n + xd + nzv], H)
     zv_all = torch.cat((z.detach(), v.detach()), -1)            # [T, B, nzv] (one copy of the two input views)
     jump_all = None
     if n_ev:
@@ -624,11 +636,11 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         h1, h2, h3, d1, d2, d3 = (r.reshape(-1, H) for r in (*act, *delta))
         R = act[0].shape[0]
         gi = (gi_slots[..., nzv:ne] + gi_slots[..., ne + nzv:2 * ne]).reshape(-1, idim)
-        gA[3].add_(_gemm_tn(gi, h3, R)); gab[3].add_(gi.sum(0))
-        gA[2].add_(_gemm_tn(d3, h2, R)); gab[2].add_(d3.sum(0))
-        gA[1].add_(_gemm_tn(d2, h1, R)); gab[1].add_(d2.sum(0))
+        gA[3].add_(_gemm_tn(gi, h3, R)[:, :Hr]); gab[3].add_(gi.sum(0))
+        gA[2].add_(_gemm_tn(d3, h2, R)[:Hr, :Hr]); gab[2].add_(d3.sum(0)[:Hr])
+        gA[1].add_(_gemm_tn(d2, h1, R)[:Hr, :Hr]); gab[1].add_(d2.sum(0)[:Hr])
         U = torch.cat((a0.view(1, B, n).expand(R, B, n), x_rows, zv_rows), -1).reshape(-1, n + xd + nzv)
-        gA[0].add_(_gemm_tn(d1, U, R)); gab[0].add_(d1.sum(0))
+        gA[0].add_(_gemm_tn(d1, U, R)[:Hr]); gab[0].add_(d1.sum(0)[:Hr])
         Sa1 += delta[0].sum(0)
         return (d1 @ Ae).view(R, B, nzv)
 
@@ -657,9 +669,9 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
             # ---- DE
             h1, h2, h3, d1, d2, d3 = (r.view(-1, H) for r in rows)
             G = Tc * S
-            gW[3] += _gemm_tn(gk.view(-1, xd), h3, G); gb[3] += gk.view(-1, xd).sum(0)
-            gW[2] += _gemm_tn(d3, h2, G); gb[2] += dsum[2].sum((0, 1))
-            gW[1] += _gemm_tn(d2, h1, G); gb[1] += dsum[1].sum((0, 1))
+            gW[3] += _gemm_tn(gk.view(-1, xd), h3, G)[:, :Hr]; gb[3] += gk.view(-1, xd).sum(0)
+            gW[2] += _gemm_tn(d3, h2, G)[:Hr, :Hr]; gb[2] += dsum[2].sum((0, 1))[:Hr]
+            gW[1] += _gemm_tn(d2, h1, G)[:Hr, :Hr]; gb[1] += dsum[1].sum((0, 1))[:Hr]
             # L1 input per (step, stage): cat(a0, s - a0, s), s = cat(X_s, z|v|i of the step -- jump values and recomputed i0 at events)
             ext = torch.cat((zv_all[k0:k1], is_c[k0:k1]), -1)                                  # [Tc, B, ne]
             if n_ev:
@@ -670,10 +682,10 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 ext = torch.where(hit, ext_ev, ext)
             s_in = torch.cat((Xs, ext.unsqueeze(1).expand(Tc, S, B, ne)), -1)
             U = torch.cat((a0.view(1, 1, B, n).expand(Tc, S, B, n), s_in - a0, s_in), -1).reshape(-1, 3 * n)
-            gW[0] += _gemm_tn(d1, U, G)
+            gW[0] += _gemm_tn(d1, U, G)[:Hr]
             D1 = dsum[0]                                                                         # [Tc, B, H]
             D1s = D1.sum(0)
-            S1 += D1s; gb[0] += D1s.sum(0)
+            S1 += D1s; gb[0] += D1s.sum(0)[:Hr]
             if nzv > 0:
                 gc = (D1.reshape(-1, H) @ Fe).view(Tc, B, nzv)
                 if n_ev:
@@ -696,7 +708,7 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 gjump += gza.permute(1, 0, 2)
     g = {"z_jump": None, "v_jump": None}
     g["x_init"] = carry_x + gx_c[0]
-    ga0 = S1 @ (W1[:, 0:n] - W1[:, n:2 * n]) + Sa1 @ A1[:, 0:n]
+    ga0 = S1 @ _pad_rows(W1[:, 0:n] - W1[:, n:2 * n], H) + Sa1 @ _pad_rows(A1[:, 0:n], H)
     g["all_initial"] = ga0
     g["z"] = gzv[..., :zd].contiguous() if zd > 0 else None
     g["v"] = gzv[..., zd:].contiguous() if vd > 0 else None
@@ -783,7 +795,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     T, B, xd = xs.shape
     zd = z.shape[-1]
     # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K4w + library GEMMs instead of the generic K5
-    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64
+    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
                             and ode_backward_wide_supported(method, de_layers, xd, zd)):
         return ode_backward_wide(method, de_layers, t, z, all_initial, xs, grad_xs, event_idx=event_idx, z_jump=z_jump,
                                  need_grad_z=need_grad_z)

@@ -435,6 +435,41 @@ def test_dae_wide_backward_matches_generic_every_shape_class(xd, zd, vd, idim, H
     _dae_wide_vs_generic(method, H, 21, 9, xd, zd, vd, idim, seed=140 + xd + zd, events=True)
 
 
+@pytest.mark.parametrize("H", [20, 48, 100])
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_wide_backwards_at_zero_padded_hidden_widths(method, H):
+    """hidden widths between the kernels' 32 / 64 / 128: forward and backward run zero-padded on the next one up; gradients (sliced
+    back to the real width on the host side) against the generic backward K5, ODE and DAE, with events and two time chunks."""
+    from py_psnode_amd import fused
+    _dae_wide_vs_generic(method, H, 21, 9, 8, 2, 2, 2, seed=340 + H, events=True)
+    _dae_wide_vs_generic(method, H, 19, 9, 5, 1, 1, 1, seed=343 + H, events=True, chunk_steps=5)
+    g = torch.Generator().manual_seed(250 + H)
+    torch.manual_seed(250 + H)
+    B, Tn, xd, zd = 21, 9, 8, 2
+    lin = [nn.Linear(a_, b_) for a_, b_ in zip([3 * (xd + zd), H, H, H], [H, H, H, xd])]
+    layers = [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1)
+    t[:, 1:] = t[:, 1:] * (0.5 + torch.rand(1, B - 1, 1, generator=g))
+    r = lambda *s_: (0.1 * torch.randn(*s_, generator=g)).cuda()
+    x_in, z = torch.zeros(Tn, B, xd, device="cuda"), r(Tn, B, zd)
+    x_in[0] = r(B, xd)
+    a0 = torch.cat((x_in[0], z[0]), -1)
+    ev = torch.stack([t[1, :, :], t[Tn - 2, :, :]], dim=1).contiguous().cuda()
+    zj = r(B, 2, zd)
+    tab = fused.event_table(t.cuda(), ev)
+    G = torch.randn(Tn, B, xd, generator=g).cuda()
+    xs = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj, kernel="mfma")
+    xs_g = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj, kernel="generic")
+    _close(xs, xs_g.double().cpu(), "xs (padded MFMA vs generic)")
+    a = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj)           # auto: the split backward
+    b = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="generic")
+    for nme, p_, q_ in zip(["grad x0", "grad z", "grad z_jump", "grad all_initial"], a[:4], b[:4]):
+        _close(p_, q_.double().cpu(), nme)
+    for k, (p_, q_) in enumerate(zip(a[4], b[4])):
+        assert p_.shape == q_.shape
+        _close(p_, q_.double().cpu(), f"grad param {k}")
+
+
 @pytest.mark.parametrize("H", [32, 128])
 @pytest.mark.parametrize("B,Tn,chunk", [(1, 2, None), (17, 2, None), (33, 3, 1), (16, 12, 4), (37, 12, 5)])
 def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):

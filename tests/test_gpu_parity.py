@@ -152,6 +152,15 @@ def test_mfma_kernel_hidden_widths(xd, zd, method, H):
     _check_mfma_ode(xd, zd, method, H)
 
 
+@pytest.mark.parametrize("H", [7, 20, 48, 100, 127])
+@pytest.mark.parametrize("method", METHODS)
+def test_mfma_kernel_other_hidden_widths_run_zero_padded(method, H):
+    """--hidden is a free knob of the scripts: widths between the kernels' 32 / 64 / 128 run on the next one up with zero-padded
+    units (zero weights and biases, ELU(0) = 0: exact zeros in every sum) instead of falling to the generic kernel."""
+    _check_mfma_ode(8, 2, method, H)
+    _check_mfma_dae(8, 2, 2, 2, method, H)
+
+
 def _check_mfma_ode(xd, zd, method, H):
     B, Tn = 37, 14
     ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=11, H=H)
@@ -369,8 +378,12 @@ def test_auto_picks_mfma_for_reference_shape():
     for k, (o1, o2) in enumerate(zip((64, 64, 64, 8), (64, 64, 64, 2))):
         d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
     assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA
-    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=48)
-    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel for H=48
+    for H in (48, 100):                        # in-between widths run zero-padded on the next instantiation up
+        for k in range(3):
+            a.de.out_dim[k] = H
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=160)
+    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel above hidden 128
         fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
 
 
