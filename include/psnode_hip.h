@@ -221,7 +221,7 @@ int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* works
  * py_psnode_amd/fused.py:ode_backward_wide), as are dL/dz = D1 . (Ws+Wd)[:, z] and dL/dall_initial = sum_t D1 . (Wa-Wd), D1 = sum_s delta_1.
  * `carry` [B, x_dim] holds the adjoint of x[k1] WITHOUT dL/dxs[k1] on entry (zeros for the last chunk) and of x[k0] likewise on exit, so
  * the sweep can be cut into time chunks to bound the size of the stored rows.  Shape class: de = 3n -> h -> h -> h -> x_dim,
- * h <= 128, x_dim <= 8, z_dim <= 4.  H in the row shapes above is h rounded up to the kernels' 32 / 64 / 128 (the integrators do the
+ * h <= 128, x_dim <= 8, z_dim <= 8.  H in the row shapes above is h rounded up to the kernels' 32 / 64 / 128 (the integrators do the
  * same, psnode_ode_integrate_f32): columns h..H-1 of the rows are exact zeros (zero-padded units: zero weights, ELU(0) = 0). */
 typedef struct {
     int32_t method;

@@ -391,6 +391,8 @@ hipError_t launch_wide(const WideDev& a, int NZM, const float* pde, const f4* pt
         case 0: PSNODE_WIDE(0)
         case 1: PSNODE_WIDE(1)
         case 2: PSNODE_WIDE(2)
+        case 3: PSNODE_WIDE(3)
+        case 4: PSNODE_WIDE(4)
         default: return hipErrorNotSupported;
     }
 #undef PSNODE_WIDE
@@ -420,7 +422,7 @@ extern "C" {
 
 int32_t psnode_ode_backward_wide_supported(const psnode_ode_bwd_wide_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
-    if (a->x_dim < 1 || a->x_dim > 4 * kNXc || a->z_dim < 0 || 2 * a->z_dim > 8) return 0;
+    if (a->x_dim < 1 || a->x_dim > 4 * kNXc || a->z_dim < 0 || 2 * a->z_dim > 4 * kMaxNZM) return 0;
     if (!wide_hidden(a->de)) return 0;
     return a->de.in_dim == 3 * (a->x_dim + a->z_dim) && a->de.out_dim[3] == a->x_dim;
 }

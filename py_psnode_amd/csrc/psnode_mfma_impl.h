@@ -521,6 +521,8 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
             case 0: PSNODE_LAUNCH(0, 0, false)
             case 1: PSNODE_LAUNCH(1, 0, false)
             case 2: PSNODE_LAUNCH(2, 0, false)
+            case 3: PSNODE_LAUNCH(3, 0, false)
+            case 4: PSNODE_LAUNCH(4, 0, false)
             default: return hipErrorNotSupported;
         }
     }

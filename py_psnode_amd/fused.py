@@ -794,8 +794,10 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     dev = xs.device
     T, B, xd = xs.shape
     zd = z.shape[-1]
-    # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K4w + library GEMMs instead of the generic K5
-    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
+    # the one-launch MFMA backward covers hidden 64 with z_dim <= 4; other widths <= 128 and z_dim <= 8: the adjoint sweep on K4w +
+    # library GEMMs instead of the generic K5
+    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and T >= 2
+                            and not (de_layers[0][0].shape[0] == 64 and ode_backward_supported(method, de_layers, xd, zd, "mfma"))
                             and ode_backward_wide_supported(method, de_layers, xd, zd)):
         return ode_backward_wide(method, de_layers, t, z, all_initial, xs, grad_xs, event_idx=event_idx, z_jump=z_jump,
                                  need_grad_z=need_grad_z)

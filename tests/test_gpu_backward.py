@@ -123,7 +123,7 @@ def _param_grads(seq):
 
 
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-@pytest.mark.parametrize("xd,zd,H", [(8, 2, 128), (8, 2, 32), (8, 2, 64), (5, 3, 128), (3, 0, 32), (8, 4, 128)])
+@pytest.mark.parametrize("xd,zd,H", [(8, 2, 128), (8, 2, 32), (8, 2, 64), (5, 3, 128), (3, 0, 32), (8, 4, 128), (8, 6, 64), (5, 8, 128), (8, 7, 48)])
 def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
     """K4w (psnode_ode_backward_wide_f32: MFMA adjoint sweep in time chunks + library GEMMs for the parameter gradients) at hidden
     128 / 32 / 64 vs the fp64 autograd walk: ragged tile, per-trajectory clocks, two events, three time chunks, every NZM class."""

@@ -137,9 +137,9 @@ def test_other_shapes_generic(xd, zd, H, nh):
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (5, 3), (8, 4), (1, 1), (8, 0)])
+@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (5, 3), (8, 4), (1, 1), (8, 0), (8, 6), (4, 8), (8, 7)])
 def test_mfma_kernel_shapes(xd, zd, method):
-    """Every (x_dim, z_dim) class of the MFMA kernel (NX=2; NZM=0,1,2), forced with kernel='mfma', with events,
+    """Every (x_dim, z_dim) class of the MFMA kernel (NX=2; NZM=0..4: z_dim <= 8), forced with kernel='mfma', with events,
     per-trajectory clocks and a ragged last tile."""
     _check_mfma_ode(xd, zd, method, 64)
 
