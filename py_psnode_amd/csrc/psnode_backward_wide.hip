@@ -447,6 +447,11 @@ int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* p, void
         return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = wide_hidden(p->de), nw = H / 16, xd = p->x_dim, zd = p->z_dim, n = xd + zd;
+    {   // per-lane offsets inside a row are 32-bit next to a scalar row base
+        const int64_t lim = (int64_t)1 << 30, Bm = p->B;
+        const int64_t sb[] = {H, p->t.stride_b, zd > 0 ? p->z.stride_b : 0, p->event_idx && zd > 0 ? p->zj_stride_b : 0};
+        for (int64_t q : sb) if (q < 0 || Bm * q + 64 >= lim) return PSNODE_ERR_DIMS;
+    }
     const int NZM = (2 * zd + 3) / 4, NA = (n + 3) / 4;
     float* pde = static_cast<float*>(workspace);
     f4* pt = reinterpret_cast<f4*>(pde + ((wide_fwd_floats(nw, n) + 63) / 64) * 64);

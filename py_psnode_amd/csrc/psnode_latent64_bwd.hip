@@ -559,6 +559,8 @@ int np9(int k1) { return H9 * k1 + H9 + H9 * H9 + H9; }
 bool two9(const psnode_mlp_f32& m, int in_dim) { return m.n_layers == 2 && m.in_dim == in_dim && m.out_dim[0] == H9 && m.out_dim[1] == H9; }
 bool mis9(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 bool view9(const psnode_view_f32& v) { return v.ptr && !mis9(v.ptr) && v.stride_t % 4 == 0 && v.stride_b % 4 == 0; }
+// per-lane offsets inside a row are 32-bit element offsets next to a scalar row base (psnode_common.h: sbase)
+bool fits9(long long B, long long stride_b) { return stride_b >= 0 && (unsigned long long)B * (unsigned long long)stride_b + 64 < (1ull << 32); }
 size_t pack9_floats(int nblk) { return (size_t)2 * NW9 * p9_regs(nblk, nblk) * 64; }
 size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 + 4 * NW9 * 64 + nlb * 4 * NW9 * 64) * sizeof(f4) + (size_t)NW9 * SCR9 * sizeof(float); }
 
@@ -617,6 +619,8 @@ bool latent64_ode_bwd_shape_ok(const psnode_ode_bwd_args_f32* a) { return a->x_d
 bool latent64_ode_bwd_ptrs_ok(const psnode_ode_bwd_args_f32* a) {
     if (mis9(a->all_initial) || mis9(a->xs) || mis9(a->grad_xs) || mis9(a->grad_x0) || mis9(a->grad_all_initial) || !view9(a->z)) return false;
     if (a->grad_z && mis9(a->grad_z)) return false;
+    if (!fits9(a->B, a->t.stride_b) || !fits9(a->B, a->z.stride_b) || !fits9(a->B, (long long)H9 * (a->n_events > 0 ? a->n_events : 1))) return false;
+    if (a->event_idx && !fits9(a->B, a->zj_stride_b)) return false;
     if (a->event_idx && (mis9(a->z_jump) || a->zj_stride_b % 4 || a->zj_stride_e % 4 || (a->grad_z_jump && mis9(a->grad_z_jump)))) return false;
     return true;
 }
@@ -643,6 +647,9 @@ bool latent64_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a) {
     if (mis9(a->all_initial) || mis9(a->xs) || mis9(a->is) || mis9(a->grad_xs) || mis9(a->grad_x_init) || mis9(a->grad_all_initial)) return false;
     if ((a->grad_is && mis9(a->grad_is)) || !view9(a->v) || (a->z_dim && !view9(a->z))) return false;
     if ((a->grad_z && mis9(a->grad_z)) || (a->grad_v && mis9(a->grad_v))) return false;
+    if (!fits9(a->B, a->t.stride_b) || !fits9(a->B, a->v.stride_b) || (a->z_dim && !fits9(a->B, a->z.stride_b))
+        || !fits9(a->B, (long long)H9 * (a->n_events > 0 ? a->n_events : 1))) return false;
+    if (a->event_idx && (!fits9(a->B, a->vj_stride_b) || (a->z_dim && !fits9(a->B, a->zj_stride_b)))) return false;
     if (a->event_idx) {
         if (a->z_dim && (mis9(a->z_jump) || a->zj_stride_b % 4 || a->zj_stride_e % 4 || (a->grad_z_jump && mis9(a->grad_z_jump)))) return false;
         if (mis9(a->v_jump) || a->vj_stride_b % 4 || a->vj_stride_e % 4 || (a->grad_v_jump && mis9(a->grad_v_jump))) return false;
