@@ -38,6 +38,9 @@ WORKLOADS = {
     "ode02_latent64": dict(kind="ode", B=4096, T=1001, xd=64, zd=64, H=64, nh=1),   # hidden_dim 64 (generic kernel)
     # BASELINE config 3: whole ODE_02 direct_encode forward (enc x, enc z, latent integrate, dec pred, dec recon), H=16
     "ode02": dict(kind="ode02_model", B=4096, T=1001, xd=8, zd=2, H=16, nh=1),
+    # BASELINE's literal "enc/dec 64 -> 16 latent": encoders / decoder of hidden 64 on the MFMA row kernels (K3b) around the 16-wide
+    # latent integrator (K3f); an extension kwarg of models.ODE_Model -- upstream has ONE hidden_dim for all three
+    "ode02_enc64": dict(kind="ode02_model", B=4096, T=1001, xd=8, zd=2, H=16, E=64, nh=1),
 }
 
 
@@ -61,7 +64,7 @@ def make_problem(w, B, T, seed_offset=0):
         from py_psnode_amd import models
         from py_psnode_amd import neural_dae as nd
         torch.manual_seed(0)
-        model = models.ODE_Model(xd, zd, w["H"], direct_encode=True, solver=nd.RK4())
+        model = models.ODE_Model(xd, zd, w["H"], direct_encode=True, solver=nd.RK4(), enc_hidden=w.get("E"))
         model.solver.fused = "require"
         p = dict(model=model, de=[(l.weight.detach(), l.bias.detach()) for l in model.de_func.x_dot if isinstance(l, torch.nn.Linear)])
     else:
@@ -134,8 +137,8 @@ def flops_per_state_step(w, p, method):
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     f = 2 * stages * mlp_macs(p["de"])
     if w["kind"] == "ode02_model":   # + enc x, enc z, 2x dec per grid point (2 880 flop at H=16)
-        H, xd, zd = w["H"], w["xd"], w["zd"]
-        f += 2 * ((xd * H + H * H) + (zd * H + H * H) + 2 * (H * H + H * xd))
+        H, xd, zd, E = w["H"], w["xd"], w["zd"], w.get("E", w["H"])
+        f += 2 * ((xd * E + E * H) + (zd * E + E * H) + 2 * (H * E + E * xd))
     if w["kind"] == "dae":
         f += 2 * mlp_macs(p["ae"])
     return f

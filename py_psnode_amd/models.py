@@ -152,15 +152,20 @@ class Init_Func(nn.Module):
 
 
 class ODE_Model(nn.Module):
-    def __init__(self, x_dim, z_dim, hidden_dim, direct_encode=False, solver=None):
+    def __init__(self, x_dim, z_dim, hidden_dim, direct_encode=False, solver=None, enc_hidden=None):
+        """`enc_hidden` is an EXTENSION to the reference (whose one `hidden_dim` drives encoder width, latent width and RHS width
+        alike, neural_00_ODE_02_direct_encode.py:52-53,64-70): encoders / decoder with their own hidden width around a
+        `hidden_dim`-wide latent space -- BASELINE's "enc/dec 64 -> 16 latent" reading of the direct_encode config.  None = upstream."""
         super().__init__()
         H = hidden_dim
+        E = H if enc_hidden is None else int(enc_hidden)
         self.hidden_dim = H
+        self.enc_hidden = E
         self.direct_encode = direct_encode
         if direct_encode:
-            self.x_encoder = _elu_mlp(x_dim, H, H)
-            self.x_decoder = _elu_mlp(H, H, x_dim)
-            self.z_encoder = _elu_mlp(z_dim, H, H)
+            self.x_encoder = _elu_mlp(x_dim, E, H)
+            self.x_decoder = _elu_mlp(H, E, x_dim)
+            self.z_encoder = _elu_mlp(z_dim, E, H)
             self.de_func = DE_Func(2 * H, (H,), H)                 # Linear(6H,H) ELU Linear(H,H)
         else:
             self.de_func = DE_Func(x_dim + z_dim, (H, H, H), x_dim)

@@ -214,3 +214,43 @@ def test_accelerate_puts_script_style_encoders_on_the_row_kernels(method):
         ref = torch.as_tensor(dg[f"{method}_gp__" + name.replace(".", "__")], dtype=torch.float64)
         err = float((p.grad.double().cpu() - ref).abs().max())
         assert err <= 2e-4 * max(float(ref.abs().max()), 1e-6), (name, err)
+
+
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_enc_hidden_extension_matches_the_oracle_and_trains_fused(method):
+    """models.ODE_Model(..., enc_hidden=64): BASELINE's "enc/dec 64 -> 16 latent" reading of the direct_encode config (an extension:
+    upstream has one hidden_dim).  Encoders / decoder of hidden 64 on the MFMA row kernels around the hidden-16 latent integrator:
+    forward against the oracle, gradients against the same model walked on the CPU."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    B, Tn, xd, zd = 21, 12, 8, 2
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    cls = {"euler": nd.Euler, "rk4": nd.RK4}[method]
+    m_cpu = models.ODE_Model(xd, zd, 16, direct_encode=True, solver=cls(), enc_hidden=64)
+    assert m_cpu.x_encoder[0].out_features == 64 and m_cpu.x_encoder[2].out_features == 16 and m_cpu.x_decoder[0].in_features == 16
+    m_gpu = models.ODE_Model(xd, zd, 16, direct_encode=True, solver=cls(), enc_hidden=64)
+    m_gpu.load_state_dict(m_cpu.state_dict())
+    m_gpu = m_gpu.cuda()
+    m_cpu.solver.fused = "off"
+    m_gpu.solver.fused = "require"
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    x, z = 0.3 * torch.randn(B, Tn, xd, generator=g), 0.3 * torch.randn(B, Tn, zd, generator=g)
+    ev, zj = t[:, [1, Tn - 2], :].contiguous(), 0.3 * torch.randn(B, 2, zd, generator=g)
+    seq = lambda s: [(s[0].weight.detach(), s[0].bias.detach()), (s[2].weight.detach(), s[2].bias.detach())]
+    de = [(l.weight.detach(), l.bias.detach()) for l in m_cpu.de_func.x_dot if isinstance(l, nn.Linear)]
+    ref_pred, ref_re, _ = _oracle(method, seq(m_cpu.x_encoder), seq(m_cpu.z_encoder), seq(m_cpu.x_decoder), de, t, x, z, ev, zj)
+    c = lambda a: a.cuda()
+    with torch.no_grad():
+        pred, re = m_gpu(t=c(t), x=c(x), z=c(z), event_t=c(ev), z_jump=c(zj))
+    assert traj_rel_err(pred.cpu().permute(1, 0, 2), ref_pred.permute(1, 0, 2)) <= TOL_GPU
+    assert traj_rel_err(re.cpu().permute(1, 0, 2), ref_re.permute(1, 0, 2)) <= TOL_GPU
+    G1, G2 = torch.randn(B, Tn, xd, generator=g), torch.randn(B, Tn, xd, generator=g)
+    outs = m_cpu(t=t, x=x, z=z, event_t=ev, z_jump=zj)
+    ((outs[0] * G1).sum() + (outs[1] * G2).sum()).backward()
+    outs = m_gpu(t=c(t), x=c(x), z=c(z), event_t=c(ev), z_jump=c(zj))
+    ((outs[0] * c(G1)).sum() + (outs[1] * c(G2)).sum()).backward()
+    for (name, pc), pg in zip(m_cpu.named_parameters(), m_gpu.parameters()):
+        scale = float(pc.grad.abs().max())
+        err = float((pg.grad.cpu() - pc.grad).abs().max())
+        assert err <= 5e-4 * max(scale, 1e-6), f"{name}: err {err:.3e} vs scale {scale:.3e}"
