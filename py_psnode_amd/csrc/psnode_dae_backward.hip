@@ -629,7 +629,21 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
         gcarry = gx0;
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Lane coordinates are re-derived from an opaque copy of the thread index: computed from the prologue's values, the
+    //      epilogue's addresses are live (spilled: 28 B/lane at NZM = 3) across the whole time loop.
+    {
+    int tid_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id without keeping v0 (threadIdx.x) alive
+    asm volatile("" : "+v"(tid_e));
+    const int l = tid_e & 63, g = l >> 4, j = l & 15, i = j;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    float* scr = scr_all + w * SCRD;
+    auto put_tile = [&](const f4 v) { *reinterpret_cast<f4*>(scr + 4 * l + 8 * g) = v; };
+    auto get_row = [&](const int row) -> f4 {
+        const float* s = scr + 4 * (16 * (row >> 2) + g) + 8 * (row >> 2) + (row & 3);
+        return f4{s[0], s[16], s[32], s[48]};
+    };
+    auto transpose = [&](const f4 v) -> f4 { put_tile(v); return get_row(i); };
     if (w == 0 && valid) {
 #pragma unroll
         for (int r = 0; r < NX; ++r)
@@ -726,6 +740,7 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
     };
     write_mlp(wp, 3 * n, 0, 0, xd, false, S1, S2, S3, accW1s, accW2, accW3, accW4, db4);
     write_mlp(wp + d.NP_de, n + xd + nzv, n, xd + nzv, idim, true, AS1, AS2, AS3, aaccW1, aaccW2, aaccW3, aaccW4, adb4);
+    }
 }
 
 int np_of(int k1, int out) { return HID * k1 + HID + 2 * (HID * HID + HID) + out * HID + out; }

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     // ---- epilogue.  Lane coordinates are re-derived from an opaque copy of the thread index: computed from the prologue's values, the
     //      epilogue's addresses are live (spilled) across the whole time loop.
     {
-    int tid_e = threadIdx.x;
+    int tid_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id without keeping v0 (threadIdx.x) alive
     asm volatile("" : "+v"(tid_e));
     const int l_e = tid_e & 63, g = l_e >> 4, j = l_e & 15, own = 16 * w + 4 * g;
     const bool valid = b0 + j < a.B;
