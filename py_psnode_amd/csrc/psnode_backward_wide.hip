@@ -201,24 +201,24 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
         return out;
     };
 
-    // addressing: sbase(uniform row base) + 32-bit per-lane offset (psnode_common.h)
-    const unsigned offH = (unsigned)(b * H) + 16 * w + 4 * g;      // rows of H floats: this lane's 4 units of its trajectory
-    const unsigned offX = (unsigned)(b * xd) + g;                  // rows of x_dim floats (+ 4r)
-    const unsigned offT = (unsigned)(b * a.t.sb), offZ = (unsigned)(b * a.z.sb), offZJ = (unsigned)(b * a.zjb);
+    // addressing: sbase(uniform row base) + 32-bit per-lane BYTE offset (psnode_common.h: ldg / stg)
+    const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);      // rows of H floats: this lane's 4 units of its trajectory
+    const unsigned offX = 4u * ((unsigned)(b * xd) + g);                  // rows of x_dim floats (+ 16 r)
+    const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offZJ = 4u * (unsigned)(b * a.zjb);
     auto load_ext = [&, offZ, offZJ](const long long k, const int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
         if constexpr (NZM > 0) {
-            const float* row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
+            const gptr<const float> row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
             const unsigned m_ = ev >= 0 ? ~0u : 0u, zo = (offZJ & m_) | (offZ & ~m_);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? row[zo + ecol[m]] : 0.0f;
+            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? ldg<float>(row, zo + 4u * ecol[m]) : 0.0f;
         }
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
-        const float* row = sbase(base + k * a.B * xd);
+        const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? row[offX + 4 * r] : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
     };
-    auto load_dt = [&](const long long k) -> float { return sbase(a.t.p + (k + 1) * a.t.st)[offT] - sbase(a.t.p + k * a.t.st)[offT]; };
+    auto load_dt = [&](const long long k) -> float { return ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT); };
 
     float gcar[NX];
 #pragma unroll
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
                 else { a2 = elu_quad(mid(w2r, b2, a1)); a3 = elu_quad(mid(w3r, b3, a2)); }
                 if (valid) {     // rows for the parameter-gradient GEMMs: this wave's 16 units of trajectory j, 16 bytes per lane
                     const size_t rb = row_blk(s) * H;
-                    *reinterpret_cast<f4*>(sbase(a.act[0] + rb) + offH) = a1;
-                    *reinterpret_cast<f4*>(sbase(a.act[1] + rb) + offH) = a2;
-                    *reinterpret_cast<f4*>(sbase(a.act[2] + rb) + offH) = a3;
+                    stg<f4>(sbase(a.act[0] + rb), offH, a1);
+                    stg<f4>(sbase(a.act[1] + rb), offH, a2);
+                    stg<f4>(sbase(a.act[2] + rb), offH, a3);
                 }
                 if constexpr (!STREAM) { h1[s] = a1; h2[s] = a2; h3[s] = a3; }
                 if (s == S - 1) { la1 = a1; la2 = a2; la3 = a3; }
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
                 a1 = na1; a2 = na2; a3 = na3;
                 if (s > 0) {
                     const size_t rb = row_blk(s - 1) * H;
-                    na1 = *reinterpret_cast<const f4*>(sbase(a.act[0] + rb) + offH);
-                    na2 = *reinterpret_cast<const f4*>(sbase(a.act[1] + rb) + offH);
-                    na3 = *reinterpret_cast<const f4*>(sbase(a.act[2] + rb) + offH);
+                    na1 = ldg<f4>(sbase(a.act[0] + rb), offH);
+                    na2 = ldg<f4>(sbase(a.act[1] + rb), offH);
+                    na3 = ldg<f4>(sbase(a.act[2] + rb), offH);
                 }
             } else {
                 a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
@@ -328,17 +328,17 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
             const f2 gx = out2(fT, d1, f4{0.f, 0.f, 0.f, 0.f});
             if (valid) {
                 const size_t rb = row_blk(s) * H;
-                *reinterpret_cast<f4*>(sbase(a.delta[0] + rb) + offH) = d1;
-                *reinterpret_cast<f4*>(sbase(a.delta[1] + rb) + offH) = d2;
-                *reinterpret_cast<f4*>(sbase(a.delta[2] + rb) + offH) = d3;
+                stg<f4>(sbase(a.delta[0] + rb), offH, d1);
+                stg<f4>(sbase(a.delta[1] + rb), offH, d2);
+                stg<f4>(sbase(a.delta[2] + rb), offH, d3);
                 if (w == 0) {
-                    float* gkr = sbase(a.gk + row_blk(s) * xd);
-                    float* xsr = sbase(a.xst + row_blk(s) * xd);
+                    const gptr<float> gkr = sbase(a.gk + row_blk(s) * xd);
+                    const gptr<float> xsr = sbase(a.xst + row_blk(s) * xd);
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
                         if (4 * r + g < xd) {
-                            gkr[offX + 4 * r] = gks[s][r];
-                            xsr[offX + 4 * r] = X[s][r];
+                            stg<float>(gkr, offX + 16u * r, gks[s][r]);
+                            stg<float>(xsr, offX + 16u * r, X[s][r]);
                         }
                     }
                 }
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
         }
         if (valid) {     // per-step sums over the stages: what the bias / input gradients contract over (a quarter of the rows at RK4)
             const size_t rb = (size_t)(k - a.k0) * nrow * H;
-            *reinterpret_cast<f4*>(sbase(a.dsum[0] + rb) + offH) = D1;
-            *reinterpret_cast<f4*>(sbase(a.dsum[1] + rb) + offH) = D2;
-            *reinterpret_cast<f4*>(sbase(a.dsum[2] + rb) + offH) = D3;
+            stg<f4>(sbase(a.dsum[0] + rb), offH, D1);
+            stg<f4>(sbase(a.dsum[1] + rb), offH, D2);
+            stg<f4>(sbase(a.dsum[2] + rb), offH, D3);
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];

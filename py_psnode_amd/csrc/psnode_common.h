@@ -226,17 +226,33 @@ bool latent64_ptrs_ok(const IntegrateDev& a, bool dae);
 size_t latent64_pack_floats();
 hipError_t launch_latent64(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 
-// Addressing idiom of the time-loop kernels: <uniform row base in SGPRs> + <32-bit per-lane offset>.  sbase() makes the row base
-// opaque at each use.  Left visible, `base + lane offset` is loop-invariant per array (or a strength-reduced induction pointer), and the
-// compiler keeps one precomputed 64-bit per-lane pointer for every array the loop touches -- dozens of VGPR pairs, which the
-// register-bound kernels then spill to scratch (K7w: 1652 B -> 0; K9: 200 B -> 0).
+// Addressing idiom of the time-loop kernels: <uniform row base in SGPRs> + <32-bit per-lane BYTE offset> = the hardware's
+// `global_* v, voffset, s[base:base+1]` form.  sbase() makes the row base opaque at each use: left visible, `base + lane offset` is
+// loop-invariant per array (or a strength-reduced induction pointer), and the compiler keeps one precomputed 64-bit per-lane pointer for
+// every array the loop touches -- dozens of VGPR pairs, which the register-bound kernels then spill to scratch (K7w: 1652 B -> 0; K9: 200 B
+// -> 0).  The rebuilt pointer is typed GLOBAL (address space 1): a generic pointer made from integers makes every access a flat_* one with
+// a 64-bit VGPR address.  ldg / stg read / write an element at a byte offset (one VGPR; an element index would be widened to 64 bits).
 template <typename T>
-__device__ __forceinline__ T* sbase(T* p) {
+using gptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ gptr<T> sbase(T* p) {
     unsigned lo = (unsigned)reinterpret_cast<uintptr_t>(p), hi = (unsigned)(reinterpret_cast<uintptr_t>(p) >> 32);
     lo = __builtin_amdgcn_readfirstlane(lo);
     hi = __builtin_amdgcn_readfirstlane(hi);
     asm volatile("" : "+s"(lo), "+s"(hi));
-    return reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo);
+    return (gptr<T>)(((uintptr_t)hi << 32) | lo);
+}
+// (the offset is made opaque too: instruction selection works per basic block, and a zero-extension hoisted out of the loop arrives as
+//  a 64-bit register pair, which selects `v_lshl_add_u64` + a 64-bit vaddr instead of saddr + 32-bit voffset)
+template <typename V, typename T>
+__device__ __forceinline__ V ldg(gptr<T> base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return *(gptr<const V>)((gptr<const char>)base + byte_off);
+}
+template <typename V, typename T>
+__device__ __forceinline__ void stg(gptr<T> base, unsigned byte_off, V v) {
+    asm volatile("" : "+v"(byte_off));
+    *(gptr<V>)((gptr<char>)base + byte_off) = v;
 }
 
 }  // namespace psnode

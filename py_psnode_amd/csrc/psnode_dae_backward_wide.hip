@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        w4[r] = pw[(RD::W4 + r) * 64]; aw4[r] = pwa[(RA::W4 + r) * 64];
+        w4[r] = pw[(RD::W4 + r) * 64]; aw4[r] = STREAM ? 0.0f : pwa[(RA::W4 + r) * 64];
         b1r[r] = pw[(RD::B1 + r) * 64]; ab1r[r] = pwa[(RA::B1 + r) * 64];
         if constexpr (!STREAM) {     // (STREAM: re-read next to the H->H weights)
             b2[r] = pw[(RD::B2 + r) * 64]; b3[r] = pw[(RD::B3 + r) * 64]; b4[r] = pw[(RD::B4 + r) * 64];
@@ -226,8 +226,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     // the same with the image read from the packed tensor in global memory (hidden 128's AE: the LDS holds the DE's transposes);
     // all chunks are requested before the exchange so that their latency overlaps it
     auto midTg = [&](const f4* __restrict__ img, const f4 d) -> f4 {
-        const f4* wl = img + w * 64 + l;
-        asm volatile("" : "+v"(wl));
+        const f4* wlo = img + w * 64 + l;
+        asm volatile("" : "+v"(wlo));
+        const gptr<const f4> wl = (gptr<const f4>)wlo;
         f4 wq[NWV];
 #pragma unroll
         for (int c = 0; c < NWV; ++c) wq[c] = wl[c * NWV * 64];
@@ -270,14 +271,15 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         return out;
     };
 
-    const unsigned offH = (unsigned)(b * H) + 16 * w + 4 * g;      // rows of H floats: this lane's 4 units of its trajectory
-    const unsigned offX = (unsigned)(b * xd) + g;                  // rows of x_dim floats (+ 4r)
-    const unsigned offI = (unsigned)(b * idim);                    // rows of i_dim floats (+ column)
-    const unsigned offS = (unsigned)(b * 16) + g;                  // slot rows (+ 4m)
-    const unsigned offT = (unsigned)(b * a.t.sb), offZ = (unsigned)(b * a.z.sb), offV = (unsigned)(b * a.v.sb);
-    const unsigned offZJ = (unsigned)(b * a.zjb), offVJ = (unsigned)(b * a.vjb);
+    // per-lane BYTE offsets (psnode_common.h: at)
+    const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);      // rows of H floats: this lane's 4 units of its trajectory
+    const unsigned offX = 4u * ((unsigned)(b * xd) + g);                  // rows of x_dim floats (+ 16 r)
+    const unsigned offI = 4u * (unsigned)(b * idim);                      // rows of i_dim floats (+ 4 column)
+    const unsigned offS = 4u * ((unsigned)(b * 16) + g);                  // slot rows (+ 16 m)
+    const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offV = 4u * (unsigned)(b * a.v.sb);
+    const unsigned offZJ = 4u * (unsigned)(b * a.zjb), offVJ = 4u * (unsigned)(b * a.vjb);
     // z | v rows of grid point k (ev >= 0: the jump values of event ev); both sources are read with a clamped column
-    struct RowZV { const float *z, *v; unsigned zo, vo; };
+    struct RowZV { gptr<const float> z, v; unsigned zo, vo; };
     auto zv_rows = [&, offZ, offV, offZJ, offVJ](const long long k, const int ev) -> RowZV {
         RowZV r;
         r.z = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
@@ -288,14 +290,14 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         return r;
     };
     auto zv_val = [&](const RowZV& r, const int kind, const int col) -> float {
-        const float zr = zd > 0 ? r.z[r.zo + (kind == 0 ? col : 0)] : 0.0f;
-        const float vr = vd > 0 ? r.v[r.vo + (kind == 1 ? col : 0)] : 0.0f;
+        const float zr = zd > 0 ? ldg<float>(r.z, r.zo + 4u * (kind == 0 ? col : 0)) : 0.0f;
+        const float vr = vd > 0 ? ldg<float>(r.v, r.vo + 4u * (kind == 1 ? col : 0)) : 0.0f;
         return kind == 0 ? zr : (kind == 1 ? vr : 0.0f);
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
-        const float* row = sbase(base + k * a.B * xd);
+        const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? row[offX + 4 * r] : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
     };
     // AE head, hidden activations of g(xa; z|v of grid point k or of event ev)
     auto ae_hidden = [&](const float (&xa)[NX], const long long k, const int ev, f4& a1, f4& a2, f4& a3) {
@@ -309,8 +311,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         if constexpr (STREAM) {
             // (the pointer is made opaque at every use: left visible, the loads are loop-invariant, get hoisted out of the time loop
             //  and the 64 registers they were meant to free are spilled to scratch instead)
-            const float* pws = pwa;
-            asm volatile("" : "+v"(pws));
+            const float* pwo = pwa;
+            asm volatile("" : "+v"(pwo));
+            const gptr<const float> pws = (gptr<const float>)pwo;     // (global, not generic: an opaque generic pointer loads flat_*)
             float ws2[4 * NWV], ws3[4 * NWV];
 #pragma unroll
             for (int q = 0; q < 4 * NWV; ++q) { ws2[q] = pws[(RA::W2 + q) * 64]; ws3[q] = pws[(RA::W3 + q) * 64]; }
@@ -342,16 +345,16 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         const f2 gx = out2(afT, d1, f4{0.f, 0.f, 0.f, 0.f});
         if (valid) {
             const size_t rb = row * a.B * H;
-            *reinterpret_cast<f4*>(sbase(hr.a1 + rb) + offH) = a1;
-            *reinterpret_cast<f4*>(sbase(hr.a2 + rb) + offH) = a2;
-            *reinterpret_cast<f4*>(sbase(hr.a3 + rb) + offH) = a3;
-            *reinterpret_cast<f4*>(sbase(hr.d1 + rb) + offH) = d1;
-            *reinterpret_cast<f4*>(sbase(hr.d2 + rb) + offH) = d2;
-            *reinterpret_cast<f4*>(sbase(hr.d3 + rb) + offH) = d3;
+            stg<f4>(sbase(hr.a1 + rb), offH, a1);
+            stg<f4>(sbase(hr.a2 + rb), offH, a2);
+            stg<f4>(sbase(hr.a3 + rb), offH, a3);
+            stg<f4>(sbase(hr.d1 + rb), offH, d1);
+            stg<f4>(sbase(hr.d2 + rb), offH, d2);
+            stg<f4>(sbase(hr.d3 + rb), offH, d3);
             if (w == 0) {
-                float* gr = sbase(hr.gi + row * a.B * 16);
+                const gptr<float> gr = sbase(hr.gi + row * a.B * 16);
 #pragma unroll
-                for (int m = 0; m < NZM; ++m) gr[offS + 4 * m] = gs[m];
+                for (int m = 0; m < NZM; ++m) stg<float>(gr, offS + 16u * m, gs[m]);
             }
         }
         return gx;
@@ -359,10 +362,10 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     // dL/dis[k] enters through the `s`-block slot of its i-dim (one slot per i-dim)
     auto add_gis = [&](const long long k, float (&gs)[NZM]) {
         if (a.gis) {
-            const float* row = sbase(a.gis + k * a.B * idim);
+            const gptr<const float> row = sbase(a.gis + k * a.B * idim);
 #pragma unroll
             for (int m = 0; m < NZM; ++m)
-                if (ekind[m] == 2 && 4 * m + g >= ne) gs[m] += row[offI + ecol[m]];
+                if (ekind[m] == 2 && 4 * m + g >= ne) gs[m] += ldg<float>(row, offI + 4u * ecol[m]);
         }
     };
 
@@ -394,39 +397,41 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         load_x2(a.gxs, k + 1, gin);
         {
             const RowZV zr = zv_rows(k, ev);
-            const float* irow = sbase(a.is + k * a.B * idim);
+            const gptr<const float> irow = sbase(a.is + k * a.B * idim);
 #pragma unroll
             for (int m = 0; m < NZM; ++m) {
                 ext[m] = zv_val(zr, ekind[m], ecol[m]);
-                if (ekind[m] == 2) ext[m] = irow[offI + ecol[m]];
+                if (ekind[m] == 2) ext[m] = ldg<float>(irow, offI + 4u * ecol[m]);
             }
         }
         if (ev >= 0) {   // event: i0 = g(x0; z_jump, v_jump) (my_solvers.py:108-110); its rows travel through the event buffers
             f4 e1, e2, e3;
             ae_hidden(x0, k, ev, e1, e2, e3);
             f4 sb4 = ab4;
-            if constexpr (STREAM) {
-                const float* pws = pwa;
-                asm volatile("" : "+v"(pws));
+            float sw4[4] = {aw4[0], aw4[1], aw4[2], aw4[3]};
+            if constexpr (STREAM) {     // event steps are rare: their output layer is read where it is used, not kept for the whole launch
+                const float* pwo = pwa;
+                asm volatile("" : "+v"(pwo));
+                const gptr<const float> pws = (gptr<const float>)pwo;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sb4[r] = pws[(RA::B4 + r) * 64];
+                for (int r = 0; r < 4; ++r) { sb4[r] = pws[(RA::B4 + r) * 64]; sw4[r] = pws[(RA::W4 + r) * 64]; }
             }
-            const f4 i0 = out4(aw4, e3, sb4);
+            const f4 i0 = out4(sw4, e3, sb4);
 #pragma unroll
             for (int m = 0; m < NZM; ++m) if (ekind[m] == 2) ext[m] = i0[m];
             if (valid) {
                 const size_t rb = (size_t)ev * a.B * H;
-                *reinterpret_cast<f4*>(sbase(a.eact[0] + rb) + offH) = e1;
-                *reinterpret_cast<f4*>(sbase(a.eact[1] + rb) + offH) = e2;
-                *reinterpret_cast<f4*>(sbase(a.eact[2] + rb) + offH) = e3;
+                stg<f4>(sbase(a.eact[0] + rb), offH, e1);
+                stg<f4>(sbase(a.eact[1] + rb), offH, e2);
+                stg<f4>(sbase(a.eact[2] + rb), offH, e3);
                 if (w == 0) {
-                    float* er = sbase(a.ei + (size_t)ev * a.B * 16);
+                    const gptr<float> er = sbase(a.ei + (size_t)ev * a.B * 16);
 #pragma unroll
-                    for (int m = 0; m < NZM; ++m) er[offS + 4 * m] = i0[m];
+                    for (int m = 0; m < NZM; ++m) stg<float>(er, offS + 16u * m, i0[m]);
                 }
             }
         }
-        const float h_ = sbase(a.t.p + (k + 1) * a.t.st)[offT] - sbase(a.t.p + k * a.t.st)[offT];
+        const float h_ = ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT);
         f4 cz = c0;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) cz = wm4(w1z[m], ext[m] - a0e[m], cz);
@@ -440,8 +445,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
             float w2s[STREAM ? 4 * NWV : 1], w3s[STREAM ? 4 * NWV : 1];
             f4 sb2 = b2, sb3 = b3, sb4 = b4;
             if constexpr (STREAM) {
-                const float* pws = pw;
-                asm volatile("" : "+v"(pws));
+                const float* pwo = pw;
+                asm volatile("" : "+v"(pwo));
+                const gptr<const float> pws = (gptr<const float>)pwo;
 #pragma unroll
                 for (int q = 0; q < 4 * NWV; ++q) { w2s[q] = pws[(RD::W2 + q) * 64]; w3s[q] = pws[(RD::W3 + q) * 64]; }
 #pragma unroll
@@ -468,9 +474,14 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
                 else { a2 = elu_quad(mid(w2r, b2, a1)); a3 = elu_quad(mid(w3r, b3, a2)); }
                 if (valid) {
                     const size_t rb = row_blk(s) * H;
-                    *reinterpret_cast<f4*>(sbase(a.act[0] + rb) + offH) = a1;
-                    *reinterpret_cast<f4*>(sbase(a.act[1] + rb) + offH) = a2;
-                    *reinterpret_cast<f4*>(sbase(a.act[2] + rb) + offH) = a3;
+                    stg<f4>(sbase(a.act[0] + rb), offH, a1);
+                    stg<f4>(sbase(a.act[1] + rb), offH, a2);
+                    stg<f4>(sbase(a.act[2] + rb), offH, a3);
+                    if (w == 0) {     // the stage's state input goes out here, so that X[] does not have to live through the backward half
+                        const gptr<float> xsr = sbase(a.xst + row_blk(s) * xd);
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) if (4 * r + g < xd) stg<float>(xsr, offX + 16u * r, X[s][r]);
+                    }
                 }
                 if constexpr (!STREAM) { h1[s] = a1; h2[s] = a2; h3[s] = a3; }
                 if (s == S - 1) { la1 = a1; la2 = a2; la3 = a3; }
@@ -497,9 +508,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
                 a1 = na1; a2 = na2; a3 = na3;
                 if (s > 0) {
                     const size_t rb = row_blk(s - 1) * H;
-                    na1 = *reinterpret_cast<const f4*>(sbase(a.act[0] + rb) + offH);
-                    na2 = *reinterpret_cast<const f4*>(sbase(a.act[1] + rb) + offH);
-                    na3 = *reinterpret_cast<const f4*>(sbase(a.act[2] + rb) + offH);
+                    na1 = ldg<f4>(sbase(a.act[0] + rb), offH);
+                    na2 = ldg<f4>(sbase(a.act[1] + rb), offH);
+                    na3 = ldg<f4>(sbase(a.act[2] + rb), offH);
                 }
             } else {
                 a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
@@ -514,19 +525,13 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
             const f2 gx = out2(fT, d1, f4{0.f, 0.f, 0.f, 0.f});
             if (valid) {
                 const size_t rb = row_blk(s) * H;
-                *reinterpret_cast<f4*>(sbase(a.delta[0] + rb) + offH) = d1;
-                *reinterpret_cast<f4*>(sbase(a.delta[1] + rb) + offH) = d2;
-                *reinterpret_cast<f4*>(sbase(a.delta[2] + rb) + offH) = d3;
+                stg<f4>(sbase(a.delta[0] + rb), offH, d1);
+                stg<f4>(sbase(a.delta[1] + rb), offH, d2);
+                stg<f4>(sbase(a.delta[2] + rb), offH, d3);
                 if (w == 0) {
-                    float* gkr = sbase(a.gk + row_blk(s) * xd);
-                    float* xsr = sbase(a.xst + row_blk(s) * xd);
+                    const gptr<float> gkr = sbase(a.gk + row_blk(s) * xd);
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) {
-                        if (4 * r + g < xd) {
-                            gkr[offX + 4 * r] = gks[s][r];
-                            xsr[offX + 4 * r] = X[s][r];
-                        }
-                    }
+                    for (int r = 0; r < NX; ++r) if (4 * r + g < xd) stg<float>(gkr, offX + 16u * r, gks[s][r]);
                 }
             }
 #pragma unroll
@@ -539,9 +544,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         }
         if (valid) {     // per-step sums over the stages: what the bias / input gradients contract over (a quarter of the rows at RK4)
             const size_t rb = (size_t)(k - a.k0) * nrow * H;
-            *reinterpret_cast<f4*>(sbase(a.dsum[0] + rb) + offH) = D1;
-            *reinterpret_cast<f4*>(sbase(a.dsum[1] + rb) + offH) = D2;
-            *reinterpret_cast<f4*>(sbase(a.dsum[2] + rb) + offH) = D3;
+            stg<f4>(sbase(a.dsum[0] + rb), offH, D1);
+            stg<f4>(sbase(a.dsum[1] + rb), offH, D2);
+            stg<f4>(sbase(a.dsum[2] + rb), offH, D3);
         }
         const f4 gE = out4(fE, D1, f4{0.f, 0.f, 0.f, 0.f});      // adjoint of the algebraic inputs of this step, slot layout
 #pragma unroll
@@ -552,9 +557,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
         //          (is[k], un-jumped) then only sees dL/dis[k]
         if (ev >= 0) {
             const size_t rb = (size_t)ev * a.B * H;                              // this lane's own rows, written above
-            const f4 e1 = *reinterpret_cast<const f4*>(sbase(a.eact[0] + rb) + offH);
-            const f4 e2 = *reinterpret_cast<const f4*>(sbase(a.eact[1] + rb) + offH);
-            const f4 e3 = *reinterpret_cast<const f4*>(sbase(a.eact[2] + rb) + offH);
+            const f4 e1 = ldg<f4>(sbase(a.eact[0] + rb), offH);
+            const f4 e2 = ldg<f4>(sbase(a.eact[1] + rb), offH);
+            const f4 e3 = ldg<f4>(sbase(a.eact[2] + rb), offH);
             const f2 gxa = ae_adjoint(e1, e2, e3, gsl, event_rows, (size_t)ev);
             gcar[0] += gxa[0];
             if constexpr (NX > 1) gcar[1] += gxa[1];
@@ -576,9 +581,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     }
     if (w == 0 && valid) {
 #pragma unroll
-        for (int r = 0; r < NX; ++r) if (4 * r + g < xd) a.carry_x[b * xd + 4 * r + g] = gcar[r];
+        for (int r = 0; r < NX; ++r) if (4 * r + g < xd) stg<float>(sbase(a.carry_x), offX + 16u * r, gcar[r]);
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) a.carry_i[b * 16 + 4 * m + g] = gsl[m];
+        for (int m = 0; m < NZM; ++m) stg<float>(sbase(a.carry_i), offS + 16u * m, gsl[m]);
     }
 }
 

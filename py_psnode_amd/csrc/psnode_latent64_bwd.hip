@@ -282,16 +282,16 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     float* gjdst[2] = {has_z ? d.gzj : d.gvj, d.gvj};
     const unsigned offJ = (unsigned)(b * d.n_events * H9) + own;
     auto load_zv = [&](const int s, const long long k, const int ev) -> f4 {
-        if (ev >= 0) return *reinterpret_cast<const f4*>(sbase(jpb[s] + ev * jse[s]) + jpo[s]);
-        return *reinterpret_cast<const f4*>(sbase(spb[s] + k * sst[s]) + spo[s]);
+        if (ev >= 0) return ldg<f4>(sbase(jpb[s] + ev * jse[s]), 4u * jpo[s]);
+        return ldg<f4>(sbase(spb[s] + k * sst[s]), 4u * spo[s]);
     };
     auto row_of = [&](const float* base, const long long k) -> f4 {
-        return *reinterpret_cast<const f4*>(sbase(base + k * a.B * H9) + offR);
+        return ldg<f4>(sbase(base + k * a.B * H9), 4u * offR);
     };
     auto store_zv = [&](const int s, const long long grid, const int ev, const f4 val) {
         if (!valid) return;
-        if (ev >= 0) { if (gjdst[s]) *reinterpret_cast<f4*>(sbase(gjdst[s] + (long long)ev * H9) + offJ) = val; }
-        else if (gdst[s]) *reinterpret_cast<f4*>(sbase(gdst[s] + grid * a.B * H9) + offR) = val;
+        if (ev >= 0) { if (gjdst[s]) stg<f4>(sbase(gjdst[s] + (long long)ev * H9), 4u * offJ, val); }
+        else if (gdst[s]) stg<f4>(sbase(gdst[s] + grid * a.B * H9), 4u * offR, val);
     };
 
     // ---- accumulators (whole launch)
@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         f4 accA = ab2r, accB = z9();
         // (opaque pointer: the addresses of these 16 loads are loop-invariant, and hoisted out of the time loop they are 13 VGPR pairs
         //  that live -- spilled -- across every step for the sake of the event steps)
-        const float* pq = pwa + A_W2 * 64;
-        asm volatile("" : "+v"(pq));
+        const float* pqo = pwa + A_W2 * 64;
+        asm volatile("" : "+v"(pqo));
+        const gptr<const float> pq = (gptr<const float>)pqo;      // (global, not generic: an opaque generic pointer loads flat_*)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             accA = m9(pq[(4 * c + 0) * 64], hg.v[c][0], accA); accB = m9(pq[(4 * c + 1) * 64], hg.v[c][1], accB);
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         // ================= (2) step k = jg-1
         const long long k = jg - 1;
         const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
-        const float h_ = sbase(a.t.p + jg * tst)[offT] - sbase(a.t.p + k * tst)[offT];
+        const float h_ = ldg<float>(sbase(a.t.p + jg * tst), 4u * offT) - ldg<float>(sbase(a.t.p + k * tst), 4u * offT);
         const f4 x0 = row_of(d.xs, k);
         f4 ext[NBE];
 #pragma unroll
@@ -560,7 +561,7 @@ bool two9(const psnode_mlp_f32& m, int in_dim) { return m.n_layers == 2 && m.in_
 bool mis9(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 bool view9(const psnode_view_f32& v) { return v.ptr && !mis9(v.ptr) && v.stride_t % 4 == 0 && v.stride_b % 4 == 0; }
 // per-lane offsets inside a row are 32-bit element offsets next to a scalar row base (psnode_common.h: sbase)
-bool fits9(long long B, long long stride_b) { return stride_b >= 0 && (unsigned long long)B * (unsigned long long)stride_b + 64 < (1ull << 32); }
+bool fits9(long long B, long long stride_b) { return stride_b >= 0 && (unsigned long long)B * (unsigned long long)stride_b + 64 < (1ull << 30); }   // byte offsets fit 32 bits
 size_t pack9_floats(int nblk) { return (size_t)2 * NW9 * p9_regs(nblk, nblk) * 64; }
 size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 + 4 * NW9 * 64 + nlb * 4 * NW9 * 64) * sizeof(f4) + (size_t)NW9 * SCR9 * sizeof(float); }
 
