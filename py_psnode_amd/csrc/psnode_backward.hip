@@ -85,7 +85,7 @@ __device__ __forceinline__ f4 bmfma(float a, float b, f4 c) { return __builtin_a
 __device__ __forceinline__ f4 elu4b(f4 v) { return elu_quad(v); }
 // ELU'(pre) from h = ELU(pre): 1 for pre > 0 (h > 0), exp(pre) = h + 1 otherwise
 __device__ __forceinline__ f4 dact(f4 h) {
-    return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
+    return elu_grad_quad(h);
 }
 constexpr int SCR = 64 * 4 + 4 * 8;   // padded transpose tile per wave (floats)
 

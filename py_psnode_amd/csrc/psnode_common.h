@@ -226,6 +226,14 @@ bool latent64_ptrs_ok(const IntegrateDev& a, bool dae);
 size_t latent64_pack_floats();
 hipError_t launch_latent64(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 
+// ELU'(pre) from h = ELU(pre): 1 for pre > 0 (h > 0), exp(pre) = h + 1 otherwise -- written min(h, 0) + 1 (identical values; one clamp
+// + one packed add per pair instead of add + compare + select per value: VALU instructions are wall time next to fp32 MFMAs)
+typedef float psnode_f4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float elu_grad(float h) { return fminf(h, 0.0f) + 1.0f; }
+__device__ __forceinline__ psnode_f4_ elu_grad_quad(psnode_f4_ h) {
+    return psnode_f4_{fminf(h[0], 0.0f), fminf(h[1], 0.0f), fminf(h[2], 0.0f), fminf(h[3], 0.0f)} + 1.0f;
+}
+
 // Addressing idiom of the time-loop kernels: <uniform row base in SGPRs> + <32-bit per-lane BYTE offset> = the hardware's
 // `global_* v, voffset, s[base:base+1]` form.  sbase() makes the row base opaque at each use: left visible, `base + lane offset` is
 // loop-invariant per array (or a strength-reduced induction pointer), and the compiler keeps one precomputed 64-bit per-lane pointer for

@@ -98,7 +98,7 @@ __global__ void pack_dae_bwd_kernel(const PackDaeBwd pb) {
 __device__ __forceinline__ f4 bm(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 elu4d(f4 v) { return elu_quad(v); }
 __device__ __forceinline__ f4 dactd(f4 h) {   // ELU'(pre) from h = ELU(pre)
-    return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
+    return elu_grad_quad(h);
 }
 constexpr int SCRD = 64 * 4 + 4 * 8;   // padded transpose tile per wave (floats)
 __device__ __forceinline__ f4 z4() { return f4{0.f, 0.f, 0.f, 0.f}; }

@@ -23,7 +23,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f4 wm4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 wdact(f4 h) {   // ELU'(pre) from h = ELU(pre)
-    return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
+    return elu_grad_quad(h);
 }
 
 struct WideDaeDev {

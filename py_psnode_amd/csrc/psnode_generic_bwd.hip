@@ -51,7 +51,7 @@ struct GBwd {
     int gacc_global;   // parameter-gradient accumulators in this workgroup's slice of wpart (global, L2) instead of LDS
 };
 
-__device__ __forceinline__ float delu(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }   // ELU'(pre) from h = ELU(pre)
+__device__ __forceinline__ float delu(float h) { return elu_grad(h); }   // ELU'(pre) from h = ELU(pre)
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v gm(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

@@ -29,7 +29,7 @@ constexpr int LSCR = 64 * 4 + 4 * 8;                           // padded transpo
 __device__ __forceinline__ f4 km(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 kelu4(f4 v) { return elu_quad(v); }
 __device__ __forceinline__ f4 kdact(f4 h) {
-    return f4{h[0] > 0.f ? 1.f : h[0] + 1.f, h[1] > 0.f ? 1.f : h[1] + 1.f, h[2] > 0.f ? 1.f : h[2] + 1.f, h[3] > 0.f ? 1.f : h[3] + 1.f};
+    return elu_grad_quad(h);
 }
 __device__ __forceinline__ f4 kz4() { return f4{0.f, 0.f, 0.f, 0.f}; }
 

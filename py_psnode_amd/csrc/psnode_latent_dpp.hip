@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
     EluS elu;
     elu.knee = elu_knee();
     elu.neg_t0 = -__builtin_amdgcn_exp2f(elu.knee * kLog2e);
-    auto dact = [](const float h) -> float { return h > 0.0f ? 1.0f : h + 1.0f; };   // ELU'(pre) from h = ELU(pre)
+    auto dact = [](const float h) -> float { return elu_grad(h); };   // ELU'(pre) from h = ELU(pre)
 
     // rows (forward) and columns (transposed products) of the folded blocks F = Ws + Wd and of W2
     float fx[16], fz[16], w2[16], fxT[16], fzT[16], w2T[16];

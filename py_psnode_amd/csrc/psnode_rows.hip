@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
             }
             const f4 tt = tA + tB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d1[ht][r] = valid ? tt[r] * (h[ht][r] > 0.f ? 1.f : h[ht][r] + 1.f) : 0.0f;
+            for (int r = 0; r < 4; ++r) d1[ht][r] = valid ? tt[r] * elu_grad(h[ht][r]) : 0.0f;
             sb1[ht] += d1[ht];
         }
         // d in
