@@ -298,3 +298,41 @@ def test_fused_recognition_probes_the_forward_not_just_the_attribute_names():
             return self.i_calculator(torch.cat((all_initial, xt, vt, zt), dim=-1))
     bad = BadAE(26, (64, 64, 64), 2)
     assert not fused._recipe_ok(bad, fused.ae_layers_of(bad, 14, 12, 2), "ae", (8, 2, 2, 14))
+
+
+def test_enc_hidden_extension_builds_the_64_to_16_reading_and_walks_on_cpu():
+    """models.ODE_Model(enc_hidden=64): encoders / decoder of hidden 64 around a hidden-16 latent RHS (BASELINE's "enc/dec 64 -> 16
+    latent"; an extension, None = upstream's single hidden_dim).  CPU walk == manual composition with the oracle's latent loop."""
+    import torch.nn.functional as F
+    from oracle import psnode_oracle as O
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(5)
+    m = models.ODE_Model(8, 2, 16, direct_encode=True, solver=nd.RK4(), enc_hidden=64)
+    up = models.ODE_Model(8, 2, 16, direct_encode=True, solver=nd.RK4())
+    assert [tuple(p.shape) for p in m.x_encoder.parameters()] == [(64, 8), (64,), (16, 64), (16,)]
+    assert [tuple(p.shape) for p in m.x_decoder.parameters()] == [(64, 16), (64,), (8, 64), (8,)]
+    assert [tuple(p.shape) for p in up.x_encoder.parameters()] == [(16, 8), (16,), (16, 16), (16,)]      # upstream layout untouched
+    assert [tuple(p.shape) for p in m.de_func.x_dot.parameters()] == [tuple(p.shape) for p in up.de_func.x_dot.parameters()]
+    B, Tn = 5, 9
+    g = torch.Generator().manual_seed(6)
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1)
+    x, z = 0.3 * torch.randn(B, Tn, 8, generator=g), 0.3 * torch.randn(B, Tn, 2, generator=g)
+    ev, zj = t[:, [2, 6], :].contiguous(), 0.3 * torch.randn(B, 2, 2, generator=g)
+    with torch.no_grad():
+        pred, re = m(t=t, x=x, z=z, event_t=ev, z_jump=zj)
+        seq = lambda s, a: F.linear(F.elu(F.linear(a, s[0].weight, s[0].bias)), s[2].weight, s[2].bias)
+        P = lambda a: a.permute(1, 0, 2)
+        Xh, Zh = seq(m.x_encoder, x), seq(m.z_encoder, z)
+        de = [(l.weight, l.bias) for l in m.de_func.x_dot if isinstance(l, torch.nn.Linear)]
+        sol = O.integrate_ode("rk4", de, P(t), P(Xh), P(Zh), torch.cat((Xh[:, 0], Zh[:, 0]), -1), ev, seq(m.z_encoder, zj))
+        assert torch.allclose(pred, P(seq(m.x_decoder, sol)), atol=1e-6)
+        assert torch.allclose(re, seq(m.x_decoder, Xh), atol=1e-6)
+
+
+def test_padded_hidden_classes():
+    from py_psnode_amd import fused
+    assert [fused._padded_hidden(h) for h in (1, 16, 32, 33, 64, 65, 100, 128)] == [32, 32, 32, 64, 64, 128, 128, 128]
+    m = torch.arange(6.0).view(3, 2)
+    p = fused._pad_rows(m, 5)
+    assert p.shape == (5, 2) and torch.equal(p[:3], m) and not p[3:].any() and fused._pad_rows(m, 3) is m
