@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- integrated state-steps/sec of the fused HIP integrator (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N>1 runs one rank per GPU over RCCL.  Either launcher works: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / WORLD_SIZE in the environment), or plain `python bench.py --gpus N`, which re-launches itself under
+torch.distributed.run (127.0.0.1 rendezvous, a free port) and passes the ranks' output through -- rank 0 prints the JSON line.
 
 One "step" = one pass of the hot path over one batch: a full integrate_ODE of B trajectories over T-1 grid
 steps (default workload = BASELINE.json configs[1]: ODE_01 RK4, B=4096, T=1001, x8 z2 H64, fp32), inputs
@@ -185,6 +189,101 @@ def cpu_baseline(w, p_cpu, method, budget_s=12.0):
                       f"host cpus={os.cpu_count()}"}
 
 
+def kernel_name_for(lib, _lib, fused, w, p, method, kernel, dev):
+    """Which kernel family `auto` resolves to for this workload (what `config.kernel` and the pmc_traffic.json key say)."""
+    B, T = w["B"], w["T"]
+    if w["kind"] == "ode02_model":
+        auto_kernel = 2
+    elif w["kind"] == "ode":
+        a = _lib.OdeArgsF32()
+        a.method, a.x_dim, a.z_dim, a.T, a.B = fused.METHOD_ID[method], w["xd"], w["zd"], T, B
+        a.de = fused._mlp(p["de"], dev, "de", [])
+        auto_kernel = lib.psnode_ode_kernel_for(a)
+    else:
+        a = _lib.DaeArgsF32()
+        a.method, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = fused.METHOD_ID[method], w["xd"], w["zd"], w["vd"], w["id"], T, B
+        a.de = fused._mlp(p["de"], dev, "de", [])
+        a.ae = fused._mlp(p["ae"], dev, "ae", [])
+        auto_kernel = lib.psnode_dae_kernel_for(a)
+    kname = kernel if kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
+    if kname == "mfma" and w["H"] == 16 and w["kind"] in ("ode", "ode02_model"):
+        kname = "valu_dpp"       # K3f: the hidden-16 latent ODE runs on VALU + DPP row broadcasts (psnode_latent_dpp.hip)
+    return kname
+
+
+def traffic_for(workload, method, kname, B, T, H):
+    """HBM bytes per launch from the PMC counters of a separate rocprofv3 run of the same command (profiles/pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) -- counters cannot be read from inside this process; null when that
+    configuration was not profiled."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if H is not None or not os.path.exists(tpath):
+        return None
+    try:
+        return json.load(open(tpath)).get(f"{workload}:{method}:{kname}:B{B}:T{T}")
+    except Exception:
+        return None
+
+
+# The other single-GPU configurations of BASELINE.json (configs[2], configs[3]) and the solver the four scripts ship with
+# (Euler: neural_00_ODE_01_no_encode.py:75, neural_01_DAE_01_no_encode.py:92) timed in the default run, after the headline.
+EXTRAS = [("dae01", "rk4"), ("ode02", "rk4"), ("ode01", "euler"), ("dae01", "euler")]
+
+
+def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10):
+    """One more workload on the driver's clock: `steps` passes at B=4096 x 1000 steps, every launch bracketed by HIP events on the
+    launch stream; the passes as a whole by synchronize + perf_counter.  Same accounting as the headline line."""
+    w = dict(WORKLOADS[workload])
+    B, T = w["B"], w["T"]
+    p_cpu = make_problem(w, B, T)
+    p = to_dev(p_cpu, dev)
+    if w["kind"] == "ode02_model":
+        from py_psnode_amd import neural_dae as nd
+        p["model"].solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+        p["model"].solver.fused, p["model"].solver.kernel = "require", "auto"
+    for _ in range(warmup):
+        outs = run_fused(fused, w, p, method, "auto")
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        outs = run_fused(fused, w, p, method, "auto")
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern = sorted(a.elapsed_time(b) for a, b in ev)
+    avg, med = sum(kern) / len(kern), kern[len(kern) // 2]
+    ss = B * (T - 1)
+    flops, bts = flops_per_state_step(w, p_cpu, method), bytes_per_state_step(w)
+    kname = kernel_name_for(lib, _lib, fused, w, p, method, "auto", dev)
+    ach = flops * ss / (avg * 1e-3) / 1e12
+    return {"workload": f"{workload} {method}: B={B} x {T - 1} steps, H{w['H']}", "kernel": kname, "steps": steps, "warmup": warmup,
+            "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
+            "outputs_finite": bool(torch.isfinite(outs[0]).all()),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                         "traffic": traffic_for(workload, method, kname, B, T, None), "kernel_ms": avg, "kernel_ms_median": med,
+                         "flop_per_state_step": flops, "bytes_per_state_step": bts,
+                         "hbm_achieved_GBs": bts * ss / (avg * 1e-3) / 1e9}}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run on this
+    node (one process per GPU, RCCL; rendezvous on 127.0.0.1 at a free port) and return its exit code.  The children see
+    WORLD_SIZE in their environment and run main() proper; their stdout / stderr pass through, rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n}: launching {n} rank(s) under torch.distributed.run (127.0.0.1:{port})", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +296,7 @@ def main():
     ap.add_argument("--grid", type=int, default=None, help="override grid points T")
     ap.add_argument("--hidden", type=int, default=None, help="override the MLPs' hidden width (the scripts' --hidden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="default run: skip the extra workloads (configs 3, 4, Euler) timed after the headline")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
     ap.add_argument("--train", action="store_true", help="time forward + backward (fused autograd route) instead of the forward alone")
     ap.add_argument("--loss", default="mse-fused", choices=["mse-fused", "mse-torch", "weighted-sum"],
@@ -208,15 +308,16 @@ def main():
     ap.add_argument("--chunks", type=int, default=4, help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist):
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-        args.gpus = world
+    args.gpus = world             # the launcher's world size is authoritative
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the fused integrator has no CPU path)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible) -- one process per GPU")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -224,8 +325,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from py_psnode_amd import _lib, fused
@@ -325,7 +424,9 @@ def main():
                 ev_pair[1].record()
             return outs
         if pipelined:
-            tab = fused.event_table(tmv(p["t"]), p["event_t"])
+            # trajectory 0 of the GLOBAL batch decides the event steps for everybody (neural_base.py:54,61): rank 0 builds the
+            # table, every rank receives it -- SURVEY 8(e); a per-rank table would let each shard decide for itself
+            tab = sharded.broadcast_event_table(tmv(p["t"]), p["event_t"])
             if w["kind"] == "ode":
                 xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                                                event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
@@ -365,10 +466,11 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kern_med_ms = kern_ms[len(kern_ms) // 2]
     if dist is not None:
-        tt = torch.tensor([elapsed, kern_avg_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, kern_avg_ms, kern_med_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kern_avg_ms = float(tt[0]), float(tt[1])
+        elapsed, kern_avg_ms, kern_med_ms = float(tt[0]), float(tt[1]), float(tt[2])
 
     gather_only_ms = None
     if do_gather and w["kind"] in ("ode", "dae"):
@@ -397,43 +499,25 @@ def main():
     ach_gbs = bts * state_steps_launch / (kern_avg_ms * 1e-3) / 1e9
 
     if rank == 0:
-        if w["kind"] == "ode02_model":
-            auto_kernel = 2
-        elif w["kind"] == "ode":
-            a = _lib.OdeArgsF32()
-            a.method, a.x_dim, a.z_dim, a.T, a.B = fused.METHOD_ID[args.method], w["xd"], w["zd"], T, B
-            a.de = fused._mlp(p["de"], dev, "de", [])
-            auto_kernel = lib.psnode_ode_kernel_for(a)
-        else:
-            a = _lib.DaeArgsF32()
-            a.method, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = fused.METHOD_ID[args.method], w["xd"], w["zd"], w["vd"], w["id"], T, B
-            a.de = fused._mlp(p["de"], dev, "de", [])
-            a.ae = fused._mlp(p["ae"], dev, "ae", [])
-            auto_kernel = lib.psnode_dae_kernel_for(a)
-        kname = args.kernel if args.kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
-        if kname == "mfma" and w["H"] == 16 and w["kind"] in ("ode", "ode02_model"):
-            kname = "valu_dpp"       # K3f: the hidden-16 latent ODE runs on VALU + DPP row broadcasts (psnode_latent_dpp.hip)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and not args.hidden and not args.train:
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}:{args.method}:{kname}:B{B}:T{T}")
-            except Exception:
-                traffic = None
+        kname = kernel_name_for(lib, _lib, fused, w, p, args.method, args.kernel, dev)
+        traffic = None if args.train else traffic_for(args.workload, args.method, kname, B, T, args.hidden)
         res = {
             "metric": "integrated state-steps/sec (batch x steps/s), RK4 neural-ODE, batch 4096" if (args.workload, args.method, B, w["H"]) == ("ode01", "rk4", 4096, 64)
                       else f"integrated state-steps/sec, {args.workload} {args.method}, batch {B}, hidden {w['H']}",
             "value": value, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median_kernel": kern_med_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {args.method}: B={B} trajectories/GPU x {T - 1} steps, x{w['xd']} z{w['zd']}"
                                    + (f" v{w['vd']} i{w['id']}" if w["kind"] == "dae" else "") + f" H{w['H']}, fp32, h=0.01, no events",
                        "kernel": kname, "trajectories_total": world * B,
+                       "world_size_seen": dist.get_world_size() if dist is not None else 1, "device_count": torch.cuda.device_count(),
+                       "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if dist is not None else None,
                        "collective": ((f"rccl all_gather of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration"
                                        if pipelined else "rccl all_gather of the output shards [T,B,D]") if do_gather else "none"),
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "kernel_ms": kern_avg_ms, "flop_per_state_step": flops,
+                         "traffic": traffic, "kernel_ms": kern_avg_ms, "kernel_ms_median": kern_med_ms,
+                         "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1], "flop_per_state_step": flops,
                          "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_state_step": bts},
         }
@@ -459,6 +543,10 @@ def main():
                 dtw = time.perf_counter() - t0
                 res["autograd_walk_gpu"] = {"value": B * (Ts - 1) / dtw, "unit": "state-steps/s", "sample": f"{Ts - 1} steps, unrolled PyTorch autograd on the same GPU",
                                             "fused_over_walk": value / (B * (Ts - 1) / dtw)}
+        headline = (args.workload, args.method, B, T, w["H"], args.kernel) == ("ode01", "rk4", 4096, 1001, 64, "auto")
+        if world == 1 and dist is None and headline and not args.train and not args.no_extras:
+            del outs
+            res["extra"] = [extra_line(lib, _lib, fused, wl, m, dev) for wl, m in EXTRAS]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method)
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

@@ -1,6 +1,8 @@
 """The N>1 code path of bench.py (RCCL process group, event-table broadcast, time-chunked integrate overlapped with the all-gather)
-on ONE GPU: `--force-dist` runs it with a world of size 1.  Covers both pipelined gathers (ODE, DAE) and the JSON contract fields
-the driver's multi-GPU run reads (integrate_only_ms, gather_only_ms, collective)."""
+on ONE GPU: `--force-dist` runs it with a world of size 1, THROUGH bench.py's own launcher (no WORLD_SIZE in the environment ->
+bench.py starts its rank under torch.distributed.run, which is what `python3 bench.py --gpus N` does for N > 1).  Covers both
+pipelined gathers (ODE, DAE) and the JSON contract fields the driver's multi-GPU run reads (integrate_only_ms, gather_only_ms,
+collective, world_size_seen)."""
 import json
 import os
 import subprocess
@@ -14,16 +16,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("workload", ["ode01", "dae01"])
 def test_bench_force_dist_runs_the_rccl_path(workload):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 300) + (1 if workload == "dae01" else 0)),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", workload, "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--grid", "301", "--batch", "512"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    assert "launching 1 rank(s) under torch.distributed.run" in res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE JSON line, from rank 0
+    d = json.loads(lines[-1])
     cfg = d["config"]
     assert d["n_gpus"] == 1 and cfg["outputs_finite"] is True
+    assert cfg["world_size_seen"] == 1 and cfg["device_count"] >= 1 and cfg["rccl_version"]
     assert "time chunks overlapped" in cfg["collective"]
     assert cfg["integrate_only_ms"] > 0 and cfg["gather_only_ms"] is not None and cfg["gather_only_ms"] > 0
     assert d["roofline"]["frac"] > 0
+
+
+def test_bench_under_an_external_launcher():
+    """The contract's other spelling: python -m torch.distributed.run ... bench.py --gpus N (no self-launch)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--grid", "201", "--batch", "256"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "launching" not in res.stderr
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["outputs_finite"] is True
+
+
+def test_default_bench_line_carries_the_extra_workloads():
+    """BASELINE configs 3 / 4 and the scripts' shipped Euler solver ride on the default run's JSON line (reduced grid here)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    names = [e["workload"].split(":")[0] for e in d["extra"]]
+    assert names == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"]
+    for e in d["extra"]:
+        assert e["outputs_finite"] and 0.05 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_median"] > 0
+    assert d["roofline"]["kernel_ms_median"] > 0
