@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 1
+#define PSNODE_ABI_VERSION 2
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
 
@@ -47,7 +47,11 @@ typedef enum {
 typedef enum { PSNODE_EULER = 0, PSNODE_MIDPOINT = 1, PSNODE_RK4_38 = 2 } psnode_method;
 
 /* kernel selection: AUTO picks the MFMA kernel when the shape has one, else the generic kernel */
-typedef enum { PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2 } psnode_kernel;
+typedef enum {
+    PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2,
+    PSNODE_KERNEL_MFMA_WIDE = 3      /* backward calls only: the width-generic one-launch MFMA backward (hidden <= 128 zero-padded to 32 / 64 / 128) even
+                                        where AUTO / MFMA would take the hidden-64 specialisation */
+} psnode_kernel;
 
 /* flags: teacher forcing of my_solvers.py:52 (input_true_x) and :82 (input_true_x, input_true_i) */
 #define PSNODE_FLAG_INPUT_TRUE_X 1u

@@ -12,9 +12,10 @@ MAX_WIDTH = 1024
 
 OK = 0
 EULER, MIDPOINT, RK4_38 = 0, 1, 2
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
+ABI_VERSION = 2          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -144,7 +145,17 @@ def load():
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     except OSError as e:
         raise PsnodeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
-    lib.psnode_abi_version.restype = c_int32
+    try:
+        lib.psnode_abi_version.restype = c_int32
+        got = lib.psnode_abi_version()
+    except AttributeError as e:
+        raise PsnodeLibraryError(f"{LIB_PATH} is not a psnode library (no psnode_abi_version): rebuild it with `make -C py_psnode_amd/csrc`") from e
+    if got != ABI_VERSION:       # checked BEFORE the symbol lookups: a stale build fails here with a rebuild hint, not with a bare AttributeError
+        raise PsnodeLibraryError(f"ABI version mismatch: {LIB_PATH} is version {got}, this binding is version {ABI_VERSION} -- "
+                                 "rebuild it with `make -C py_psnode_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    missing = [n for n in EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise PsnodeLibraryError(f"{LIB_PATH} lacks {missing}: stale build, rebuild it with `make -C py_psnode_amd/csrc`")
     lib.psnode_build_info.restype = c_char_p
     lib.psnode_status_string.restype = c_char_p
     lib.psnode_status_string.argtypes = [c_int32]
@@ -203,8 +214,6 @@ def load():
     lib.psnode_dae_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
     lib.psnode_dae_backward_wide_f32.restype = c_int32
     lib.psnode_dae_backward_wide_f32.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
-    if lib.psnode_abi_version() != 1:
-        raise PsnodeLibraryError(f"ABI version mismatch: library {lib.psnode_abi_version()}, binding 1")
     _lib = lib
     return lib
 

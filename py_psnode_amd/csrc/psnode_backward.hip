@@ -513,7 +513,11 @@ bool ode_generic_ok(const psnode_ode_bwd_args_f32* a) {
     if (m.in_dim != 3 * (a->x_dim + a->z_dim) || m.out_dim[m.n_layers - 1] != a->x_dim) return false;
     return generic_bwd_fits(&a->de, nullptr, a->x_dim, a->z_dim, 0, 0) != 0;
 }
-bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && bwd_shape_ok(a); }
+bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) {
+    return a->kernel != PSNODE_KERNEL_GENERIC && a->kernel != PSNODE_KERNEL_MFMA_WIDE && bwd_shape_ok(a);
+}
+// K4f: every other width <= 128 (and z_dim up to 8); at hidden 64 exactly the specialised K4 is faster (14.3 vs ~16 ms) and keeps AUTO
+bool use_fused_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && !use_mfma_bwd(a) && fused_bwd_shape_ok(a); }
 // K8 needs 16-byte aligned rows; with pointers not yet known (dims-only queries) the shape decides
 bool use_latent_bwd(const psnode_ode_bwd_args_f32* a) {
     return a->kernel != PSNODE_KERNEL_GENERIC && latent_bwd_shape_ok(a) && (!a->xs || latent_bwd_ptrs_ok(a));
@@ -525,8 +529,9 @@ bool use_latent64_bwd(const psnode_ode_bwd_args_f32* a) {   // K9: the only fuse
 
 extern "C" int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a) || use_latent_bwd(a) || use_latent64_bwd(a);
-    return use_mfma_bwd(a) || use_latent_bwd(a) || use_latent64_bwd(a) || ode_generic_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA_WIDE) return fused_bwd_shape_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA) return bwd_shape_ok(a) || fused_bwd_shape_ok(a) || use_latent_bwd(a) || use_latent64_bwd(a);
+    return use_mfma_bwd(a) || use_fused_bwd(a) || use_latent_bwd(a) || use_latent64_bwd(a) || ode_generic_ok(a);
 }
 
 extern "C" int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* a) {
@@ -538,6 +543,7 @@ extern "C" size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_
     size_t floats = ode_generic_ok(a) ? generic_bwd_workspace_floats(&a->de, nullptr, a->B) : 0;
     if (latent_bwd_shape_ok(a)) floats = latent_bwd_workspace_floats(a->B) > floats ? latent_bwd_workspace_floats(a->B) : floats;
     if (latent64_ode_bwd_shape_ok(a)) floats = latent64_ode_bwd_workspace_floats(a->B) > floats ? latent64_ode_bwd_workspace_floats(a->B) : floats;
+    if (fused_bwd_shape_ok(a)) { const size_t f3 = fused_bwd_workspace_floats(a); floats = f3 > floats ? f3 : floats; }
     if (bwd_shape_ok(a)) {
         const int n = a->x_dim + a->z_dim;
         const size_t pack = (size_t)NW * (kMaxRegs + (n + 3) / 4 + BWCOUNT) * 64;
@@ -562,6 +568,7 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);
+    if (use_fused_bwd(a)) return fused_bwd_launch(a, static_cast<float*>(workspace), s);
     if (a->kernel == PSNODE_KERNEL_MFMA && !bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;   // latent shape, unaligned views
     if (!use_mfma_bwd(a)) {
         return generic_backward_launch(a->method, a->x_dim, a->z_dim, 0, 0, a->T, a->B, &a->de, nullptr,

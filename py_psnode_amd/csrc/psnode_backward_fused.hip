@@ -1,0 +1,652 @@
+// K4f -- backward pass through the ODE integrator for hidden widths 32 / 64 / 128 in ONE launch, parameter gradients included
+// (neural_00_ODE_01_no_encode.py:358-360 -- loss.backward() through the unrolled loop of my_solvers.py:66-78 -- at the scripts'
+// argparse default --hidden 128, :245-246).  Replaces the round-2 split (K4w adjoint sweep + library GEMMs over 12 KB of stored rows per
+// state-step, psnode_backward_wide.hip + fused.ode_backward_wide): nothing but the inputs and the gradients touches HBM.
+//
+// Tile / waves / layer plan as K1 and K4w: one workgroup = NWV = hidden/16 waves = 16 trajectories, walked from the last step to the
+// first; phase A recomputes the stage evaluations with the folded forward image, phase B sweeps the stages backwards with the
+// transposed images of W2 / W3 in LDS.  What is new is where the weight gradients come from:
+//   dW_l[u][v] = sum over (step, stage, trajectory) of delta_l[u] * h_{l-1}[v]
+// contracts over the tile's 16 trajectories on MFMA (A = delta^T, B = h^T).  delta_l of EVERY wave is in the exchange buffer anyway
+// (the all-gather in front of W_l^T delta_l); the buffer tiles are padded so that they can also be read TRANSPOSED (4 ds_read_b32,
+// two-pass conflict-free) -- so the only extra data movement is one in-wave transpose of the wave's own h_{l-1}.  Wave w accumulates
+// the COLUMNS of its own 16 units, dW_l[all u][16w..16w+15], in 4*NWV registers per layer for the whole launch; per-workgroup partials
+// are summed by a second kernel in a fixed order (deterministic, as K4).
+// Capacity at hidden 128 (8 waves, 256 registers per lane, 160 KB LDS): W2, W3, their transposes and the dW2 / dW3 accumulators are 3 x 128 KB.
+// The accumulators take 64 registers per lane for the whole launch (+ 20 for the small gradients); the 128 KB weight region of the LDS
+// holds the FORWARD images during phase A and the TRANSPOSED images during phase B, swapped twice per step by LDS-DMA
+// (global_load_lds_dwordx4 from the packed images, L2-resident; every lane only ever reads back slots its own wave filled, so the swap
+// needs no barrier: a layer's region is refilled right behind its last use of the phase and waited for with vmcnt(0) before its first
+// use of the next one).  Holding the forward images in registers instead (round 2's K4w: re-read per step) made the compiler spill the
+// accumulators around phase A -- 784 B of scratch per lane, 200 scratch instructions per step.  The stage activations travel through a
+// per-workgroup ring in the workspace that is rewritten every step (24 KB per workgroup: it lives in L2, never in HBM).  Exchange tiles
+// 18 KB + transpose tiles 9 KB of LDS.
+#define PSNODE_ELU_LITERALS
+#include <string.h>
+
+#include "psnode_wide_pack.h"
+
+namespace psnode {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f4 fm4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct FusedDev {
+    int method, xd, zd, hreal, n_events, NP;
+    long long T, B;
+    const float *w1, *w4;                 // raw nn.Linear tensors for the small transposed operands
+    ViewDev t, z;
+    const float* a0;
+    const int* ev;
+    const float* zj;
+    long long zjb, zje;
+    const float *xs, *gout;
+    float *gx0, *gz, *gzj, *ga0;
+    float* wpart;                         // [workgroups][NP]
+    float* ring;                          // NWV >= 8: [S][3][B][H] stage activations of the step in flight
+};
+
+constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l's four rows 4g..4g+3 of column j at 4l + 8g
+
+template <int METHOD, int NZM, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const FusedDev a, const float* __restrict__ pack_de,
+                                                                        const f4* __restrict__ pack_t, const f4* __restrict__ pack_f,
+                                                                        const int NA) {
+    constexpr int NX = kNXc, S = rk_stages(METHOD), H = 16 * NWV;
+    constexpr int NZ = NZM > 0 ? NZM : 1;
+    using RD = Regs<NX, 0, NZM, NWV>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f4* wT = reinterpret_cast<f4*>(lds);                      // [layer 0: W2^T | 1: W3^T][chunk][wave][lane]
+    float* xb = lds + (size_t)2 * NWV * NWV * 64 * 4;         // [2][NWV] exchange tiles (padded)
+
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = l >> 4, j = l & 15, i = j;
+    float* scr = xb + 2 * NWV * FTILE + w * FTILE;           // this wave's private transpose tile
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const int xd = a.xd, zd = a.zd, ne = zd, n = xd + zd, HR = a.hreal;
+
+    // ---- forward image -> registers (as K1), transposed images -> LDS
+    const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
+    constexpr bool STREAM = NWV >= 8;     // forward / transposed images swapped in LDS per phase; activations through the ring
+    float w1xs[NX], w1z[NZ], w2r[STREAM ? 1 : 4 * NWV], w3r[STREAM ? 1 : 4 * NWV], w4[4];
+    f4 b1r, b2, b3, b4;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) w1xs[r] = pw[(RD::W1A + r) * 64];
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) w1z[m] = pw[(RD::W1E + m) * 64];
+#pragma unroll
+    for (int k = 0; k < (STREAM ? 0 : 4 * NWV); ++k) { w2r[k] = pw[(RD::W2 + k) * 64]; w3r[k] = pw[(RD::W3 + k) * 64]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w4[r] = pw[(RD::W4 + r) * 64];
+        b1r[r] = pw[(RD::B1 + r) * 64]; b2[r] = pw[(RD::B2 + r) * 64]; b3[r] = pw[(RD::B3 + r) * 64]; b4[r] = pw[(RD::B4 + r) * 64];
+    }
+    // LDS-DMA of one layer's image (0: W2, 1: W3) into its region: slot (layer, c, w) <- 64 lanes x 16 B, lane-linear.  The statement
+    // first drains this wave's LDS reads (they are the only readers of these slots) and is invisible to the compiler's wait counts:
+    // dma_wait() before the first use.
+    const unsigned wT_lds = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(wT));
+    const unsigned lane16 = 16u * (unsigned)l;
+    auto dma_layer = [&](const f4* __restrict__ img, const int layer) {
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) {
+            const int slot = (layer * NWV + c) * NWV + w;
+            // source = <uniform slot base in SGPRs> + <lane * 16 bytes>: one VGPR for all 32 slots (a per-lane 64-bit pointer per slot is
+            // loop-invariant, and the compiler kept -- and spilled -- all of them)
+            const uintptr_t sb = reinterpret_cast<uintptr_t>(img + (size_t)slot * 64);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+            const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(wT_lds + (unsigned)slot * 1024u);
+            unsigned keep;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(base) : "memory");
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    if constexpr (STREAM) {
+        dma_layer(pack_f, 0);
+        dma_layer(pack_f, 1);
+    } else {
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) {
+            wT[((0 * NWV + c) * NWV + w) * 64 + l] = pack_t[((0 * NWV + c) * NWV + w) * 64 + l];
+            wT[((1 * NWV + c) * NWV + w) * 64 + l] = pack_t[((1 * NWV + c) * NWV + w) * 64 + l];
+        }
+    }
+    // small transposed operands straight from the nn.Linear tensors (u = 16w + i: this lane's A-operand row)
+    //   w4T[r] = W4[4r+g][u]                                   g3[u] = sum_d W4[d][u] gk[d]
+    //   fT[r]  = (Ws+Wd)[16w+4g+r][col(i)]: output row i = 4g'+r' carries x-dim 4r'+g' (r' < 2), z-dim g' (r' = 2), z-dim 4+g' (r' = 3)
+    float w4T[NX], fT[4];
+    {
+        const int u = 16 * w + i, K1 = 3 * n;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { const int d = 4 * r + g; w4T[r] = (d < xd && u < HR) ? a.w4[(size_t)d * HR + u] : 0.0f; }
+        const int rr = i & 3, gr = i >> 2;
+        const int col = rr < 2 ? (4 * rr + gr < xd ? 4 * rr + gr : -1) : (4 * (rr - 2) + gr < zd ? xd + 4 * (rr - 2) + gr : -1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int uu = 16 * w + 4 * g + r;
+            fT[r] = (col >= 0 && uu < HR) ? a.w1[(size_t)uu * K1 + 2 * n + col] + a.w1[(size_t)uu * K1 + n + col] : 0.0f;
+        }
+    }
+
+    // ---- per-trajectory constants (as K1)
+    float a0e[NZ];
+    int ecol[NZ];
+    bool eon[NZ];
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) {
+        const int q = 4 * m + g, e = slot_ext(q, ne);
+        eon[m] = e >= 0;
+        ecol[m] = e >= 0 ? e : 0;
+        a0e[m] = q < ne ? a.a0[b * n + xd + q] : 0.0f;
+    }
+    f4 c0 = b1r;
+    for (int m = 0; m < NA; ++m) {
+        const int q = 4 * m + g;
+        c0 = fm4(pw[(RD::COUNT + m) * 64], q < n ? a.a0[b * n + q] : 0.0f, c0);
+    }
+    // row of a padded tile that holds column i of the stage input s = (x dims | z dims):  x-dim d sits in row 4(d&3) + (d>>2) (registers
+    // 0..1 of lane group d&3), z-dim e in row 4(e&3) + 2 + (e>>2) (registers 2..3 of lane group e&3)
+    const int srow = i < xd ? 4 * (i & 3) + (i >> 2) : (i < n ? 4 * ((i - xd) & 3) + 2 + ((i - xd) >> 2) : -1);
+
+    // ---- LDS tiles
+    const int toff = 4 * l + 8 * g;                                   // own slot of a tile
+    const int roff = 72 * (i >> 2) + 4 * g + (i & 3);                 // row i of a tile, columns g, g+4, g+8, g+12
+    auto tile = [&](const int par, const int wv) -> float* { return xb + (par * NWV + wv) * FTILE; };
+    auto put = [&](float* t_, const f4 v) { *reinterpret_cast<f4*>(t_ + toff) = v; };
+    auto getl = [&](const float* t_) -> f4 { return *reinterpret_cast<const f4*>(t_ + toff); };
+    auto get_row = [&](const float* t_, const int ro) -> f4 { const float* s_ = t_ + ro; return f4{s_[0], s_[16], s_[32], s_[48]}; };
+    auto transpose = [&](const f4 v) -> f4 { put(scr, v); return get_row(scr, roff); };   // own D tile -> operand layout (trajectory g + 4kk)
+
+    int p = 0;
+    constexpr bool PREFETCH_ALL = NWV <= 4;
+    // forward H->H layer with the weights in registers (K1's `mid`), returns the pre-activation
+    auto mid = [&](const float (&wm)[4 * NWV], const f4 bias, const f4 h) -> f4 {
+        put(tile(p, w), h);
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = fm4(wm[0], h[0], accA); accB = fm4(wm[1], h[1], accB);
+        accA = fm4(wm[2], h[2], accA); accB = fm4(wm[3], h[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        f4 vq[NWV];
+        if constexpr (PREFETCH_ALL) {
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) vq[c] = getl(tile(p, (w + c) & (NWV - 1)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 1; c < NWV; ++c) {
+            const f4 v = PREFETCH_ALL ? vq[c] : getl(tile(p, (w + c) & (NWV - 1)));
+            accA = fm4(wm[4 * c + 0], v[0], accA); accB = fm4(wm[4 * c + 1], v[1], accB);
+            accA = fm4(wm[4 * c + 2], v[2], accA); accB = fm4(wm[4 * c + 3], v[3], accB);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+    // the same forward layer with the image of `layer` in LDS (8 waves)
+    auto mid_lds = [&](const int layer, const f4 bias, const f4 h) -> f4 {
+        put(tile(p, w), h);
+        const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
+        f4 wq = wl[0];
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = fm4(wq[0], h[0], accA); accB = fm4(wq[1], h[1], accB);
+        accA = fm4(wq[2], h[2], accA); accB = fm4(wq[3], h[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < NWV; ++c) {
+            const f4 v = getl(tile(p, (w + c) & (NWV - 1)));
+            wq = wl[c * NWV * 64];
+            accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
+            accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+    // transposed H->H layer (image in LDS): returns sum_k W[k][own] d[k]; and, from the very tiles the all-gather published, the weight
+    // gradient of that layer: acc[c] += delta(block (w+c) % NWV)^T (x) hT, hT = this wave's own input activations in operand layout
+    auto midT = [&](const int layer, const f4 d, const f4 hT, f4 (&acc)[NWV]) -> f4 {
+        put(tile(p, w), d);
+        const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
+        f4 wq = wl[0];
+        f4 accA = fm4(wq[0], d[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], d[1], f4{0.f, 0.f, 0.f, 0.f});
+        accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int c = 1; c < NWV; ++c) {
+            const f4 v = getl(tile(p, (w + c) & (NWV - 1)));
+            wq = wl[c * NWV * 64];
+            accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
+            accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
+        }
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) {
+            const f4 dT = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[c] = fm4(dT[kk], hT[kk], acc[c]);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+    // 8-byte all-reduce of rows r < 2 over the waves (fixed order)
+    auto allreduce2 = [&](const f2 part, const f2 init) -> f2 {
+        f2* xb2 = reinterpret_cast<f2*>(tile(p, 0));
+        xb2[w * 64 + l] = part;
+        lds_barrier();
+        f2 out = init;
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) out += xb2[c * 64 + l];
+        p ^= 1;
+        return out;
+    };
+    // split-K over the waves' own units (4 MFMAs)
+    auto own4 = [&](const float (&wq)[4], const f4 h) -> f4 {
+        f4 accA = fm4(wq[0], h[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        accA = fm4(wq[2], h[2], accA); accB = fm4(wq[3], h[3], accB);
+        return accA + accB;
+    };
+
+    // addressing: sbase(uniform row base) + 32-bit per-lane BYTE offset (psnode_common.h: ldg / stg)
+    const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);
+    const unsigned offX = 4u * ((unsigned)(b * xd) + g);
+    const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offZJ = 4u * (unsigned)(b * a.zjb);
+    auto load_ext = [&, offZ, offZJ](const long long k, const int ev, float (&dst)[NZ]) {
+        if constexpr (NZM > 0) {
+            const gptr<const float> row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
+            const unsigned m_ = ev >= 0 ? ~0u : 0u, zo = (offZJ & m_) | (offZ & ~m_);
+#pragma unroll
+            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? ldg<float>(row, zo + 4u * ecol[m]) : 0.0f;
+        }
+    };
+    auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
+        const gptr<const float> row = sbase(base + k * a.B * xd);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
+    };
+    auto load_dt = [&](const long long k) -> float { return ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT); };
+    auto event_of = [&](const long long k) -> int { return a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1; };
+
+    // ---- accumulators (whole launch)
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    f4 accW3[NWV], accW2[NWV], accW4 = zero4, accW1s = zero4, S1 = zero4, S2 = zero4, S3 = zero4;
+#pragma unroll
+    for (int c = 0; c < NWV; ++c) { accW3[c] = zero4; accW2[c] = zero4; }
+    f2 db4 = f2{0.f, 0.f};
+    float gcar[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) gcar[r] = 0.0f;
+
+    const long long nrow = a.B, nT = a.T;
+    float x0n[NX] = {}, ginn[NX] = {}, extn[NZ] = {}, hn = 0.0f;
+    int evn = -1;
+    if (nT >= 2) {
+        evn = event_of(nT - 2);
+        load_x2(a.xs, nT - 2, x0n);
+        load_x2(a.gout, nT - 1, ginn);
+        load_ext(nT - 2, evn, extn);
+        hn = load_dt(nT - 2);
+    }
+    for (long long k = nT - 2; k >= 0; --k) {
+        float x0[NX], gin[NX], ext[NZ];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { x0[r] = x0n[r]; gin[r] = ginn[r]; }
+#pragma unroll
+        for (int m = 0; m < NZ; ++m) ext[m] = extn[m];
+        const float h_ = hn;
+        const int ev = evn;
+        f4 cz = c0;
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) cz = fm4(w1z[m], ext[m] - a0e[m], cz);
+
+        // ---- phase A: stage evaluations (K1's plan)
+        float X[S][NX], ks[S][NX];
+        f4 h1[STREAM ? 1 : S], h2[STREAM ? 1 : S], h3[STREAM ? 1 : S];
+        f4 la1, la2, la3;    // ELU outputs of the last stage evaluated (the first one the backward half needs)
+        if constexpr (STREAM) dma_wait();       // forward images of both layers (refilled behind their last use of the previous phase B)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj][r];
+                X[s][r] = s == 0 ? x0[r] : x0[r] + h_ * acc;
+            }
+            f4 accA = cz, accB = zero4;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r & 1) accB = fm4(w1xs[r], X[s][r], accB);
+                else accA = fm4(w1xs[r], X[s][r], accA);
+            }
+            const f4 a1 = elu_quad(NX > 1 ? accA + accB : accA);
+            f4 a2, a3;
+            if constexpr (STREAM) {
+                a2 = elu_quad(mid_lds(0, b2, a1));
+                if (s == S - 1) dma_layer(pack_t, 0);      // W2's region is free until phase B's SECOND transposed layer
+                a3 = elu_quad(mid_lds(1, b3, a2));
+                if (s == S - 1) dma_layer(pack_t, 1);
+            } else { a2 = elu_quad(mid(w2r, b2, a1)); a3 = elu_quad(mid(w3r, b3, a2)); }
+            if constexpr (STREAM) {
+                if (s < S - 1) {     // park the stage's activations in the ring (each lane re-reads exactly what it wrote)
+                    const size_t rb = (size_t)(3 * s) * nrow * H;
+                    stg<f4>(sbase(a.ring + rb), offH, a1);
+                    stg<f4>(sbase(a.ring + rb + nrow * H), offH, a2);
+                    stg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH, a3);
+                }
+            } else { h1[s] = a1; h2[s] = a2; h3[s] = a3; }
+            if (s == S - 1) { la1 = a1; la2 = a2; la3 = a3; }
+            if (s < S - 1) {         // the last stage's derivative feeds x[k+1] only, which the backward does not need
+                const f4 part = own4(w4, a3);
+                const f2 kk = allreduce2(f2{part[0], part[1]}, f2{b4[0], b4[1]});
+                ks[s][0] = kk[0];
+                if constexpr (NX > 1) ks[s][1] = kk[1];
+            }
+        }
+
+        // ---- phase B: stages backwards.  The next step's inputs are requested here and consumed a whole backward half later.
+        auto prefetch_next = [&]() {
+            if (k > 0) {
+                evn = event_of(k - 1);
+                load_x2(a.xs, k - 1, x0n);
+                load_x2(a.gout, k, ginn);
+                load_ext(k - 1, evn, extn);
+                hn = load_dt(k - 1);
+            }
+        };
+        if constexpr (!STREAM) prefetch_next();
+        float gks[S][NX], gx0[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const float g1 = gcar[r] + (valid ? gin[r] : 0.0f);
+            gx0[r] = g1;
+#pragma unroll
+            for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
+        }
+        f2 gzp = f2{0.f, 0.f};                    // z rows of F^T delta1: this wave's partial, summed over the stages (z is frozen over them)
+        f4 na1 = la1, na2 = la2, na3 = la3;       // STREAM: activations of the stage handled next, requested one stage ahead
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            f4 a1, a2, a3;
+            if constexpr (STREAM) {
+                a1 = na1; a2 = na2; a3 = na3;
+                if (s > 0) {
+                    const size_t rb = (size_t)(3 * (s - 1)) * nrow * H;
+                    na1 = ldg<f4>(sbase(a.ring + rb), offH);
+                    na2 = ldg<f4>(sbase(a.ring + rb + nrow * H), offH);
+                    na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
+                }
+            } else {
+                a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
+            }
+            const f2 gk = f2{gks[s][0], NX > 1 ? gks[s][1] : 0.0f};
+            db4 += gk;
+            f4 g3 = zero4;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) g3 = fm4(w4T[r], gks[s][r], g3);
+            const f4 d3 = g3 * elu_grad_quad(a3);
+            S3 += d3;
+            {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
+                const f4 gT = transpose(f4{gk[0], gk[1], 0.f, 0.f});
+                const f4 hT = transpose(a3);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW4 = fm4(gT[kk], hT[kk], accW4);
+            }
+            const f4 h2T = transpose(a2);
+            if constexpr (STREAM) {
+                if (s == S - 1) {    // the transposed images must have landed; the next step's inputs are requested BEHIND that wait
+                    dma_wait();
+                    prefetch_next();
+                }
+            }
+            const f4 d2 = midT(1, d3, h2T, accW3) * elu_grad_quad(a2);
+            S2 += d2;
+            if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 1); }     // W3's region: forward image for the next step
+            const f4 h1T = transpose(a1);
+            const f4 d1 = midT(0, d2, h1T, accW2) * elu_grad_quad(a1);
+            S1 += d1;
+            if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
+            const f4 ft = own4(fT, d1);           // rows 0..1: gX partial, rows 2..3: gz partial
+            gzp += f2{ft[2], ft[3]};
+            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
+            {   // dW1 (`s` columns) += delta1 (x) s
+                const f4 dT = transpose(d1);
+                put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, (NZM > 0 && g < ne) ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
+                const f4 sT = srow >= 0 ? get_row(scr, 72 * (srow >> 2) + 4 * g + (srow & 3)) : zero4;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW1s = fm4(dT[kk], sT[kk], accW1s);
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                const float gxr = r == 0 ? gx[0] : gx[1];
+                gx0[r] += gxr;
+#pragma unroll
+                for (int jj = 0; jj < s; ++jj) gks[jj][r] += (h_ * rk_a(METHOD, s, jj)) * gxr;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];
+        if constexpr (NZM > 0) {     // gradient of this step's external input: row 0 -> z-dim g, row 1 -> z-dim 4+g
+            const f2 gzr = allreduce2(gzp, f2{0.f, 0.f});
+            if (w == 0 && valid) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 4 * q + g;
+                    if (e < ne) {
+                        if (ev >= 0) { if (a.gzj) a.gzj[(b * a.n_events + ev) * ne + e] = gzr[q]; }
+                        if (a.gz) a.gz[(k * a.B + b) * ne + e] = ev >= 0 ? 0.0f : gzr[q];
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    if constexpr (STREAM) dma_wait();
+    if (w == 0 && valid) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r)
+            if (4 * r + g < xd) a.gx0[b * xd + 4 * r + g] = gcar[r] + a.gout[b * xd + 4 * r + g];
+        if (a.gz && nT >= 1) {       // z[T-1] is never read by the ODE loop
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (4 * q + g < ne) a.gz[((nT - 1) * a.B + b) * ne + 4 * q + g] = 0.0f;
+        }
+    }
+    const int K1 = 3 * n;
+    {   // d all_initial[c] = sum_u (Wa - Wd)[u][c] S1[u]: split-K over the waves' own units, 16-byte all-reduce, rows c = 4g + r
+        float at[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int uu = 16 * w + 4 * g + r;
+            at[r] = (i < n && uu < HR) ? a.w1[(size_t)uu * K1 + i] - a.w1[(size_t)uu * K1 + n + i] : 0.0f;
+        }
+        const f4 part = own4(at, S1);
+        put(tile(p, w), part);
+        lds_barrier();
+        f4 ga = zero4;
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) ga += getl(tile(p, c));
+        p ^= 1;
+        if (w == 0 && valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < n) a.ga0[b * n + 4 * g + r] = ga[r];
+        }
+    }
+    // parameter-gradient partials of this workgroup, nn.Linear order with the MLP's real width HR as row stride
+    float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
+    const int oB1 = HR * K1, oW2 = oB1 + HR, oB2 = oW2 + HR * HR, oW3 = oB2 + HR, oB3 = oW3 + HR * HR, oW4 = oB3 + HR, oB4 = oW4 + xd * HR;
+    {
+        // dW1: columns [a0 | s-a0 | s]; ca0 = sum(delta1) (x) a0 over the tile's trajectories
+        const f4 sT = transpose(S1);
+        f4 ca0 = zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const long long tb = b0 + 4 * kk + g;
+            const float av = (i < n && tb < a.B) ? a.a0[tb * n + i] : 0.0f;
+            ca0 = fm4(sT[kk], av, ca0);
+        }
+        if (j < n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = 16 * w + 4 * g + r;
+                if (u < HR) {
+                    float* row = wp + (size_t)u * K1;
+                    row[j] = ca0[r];
+                    row[n + j] = accW1s[r] - ca0[r];
+                    row[2 * n + j] = accW1s[r];
+                }
+            }
+        }
+    }
+    {
+        const int v = 16 * w + j;        // own column
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) {
+            const int ub = 16 * ((w + c) & (NWV - 1)) + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ub + r < HR && v < HR) {
+                    wp[oW2 + (size_t)(ub + r) * HR + v] = accW2[c][r];
+                    wp[oW3 + (size_t)(ub + r) * HR + v] = accW3[c][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
+            const int dd = 4 * r + g;
+            if (r < NX && dd < xd && v < HR) wp[oW4 + (size_t)dd * HR + v] = accW4[r];
+        }
+    }
+    // biases: row sums over the 16 trajectories of a lane group
+    f4 sb1 = S1, sb2 = S2, sb3 = S3;
+    f2 sb4 = db4;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sb1[r] += __shfl_xor(sb1[r], m, 64); sb2[r] += __shfl_xor(sb2[r], m, 64); sb3[r] += __shfl_xor(sb3[r], m, 64);
+        }
+        sb4[0] += __shfl_xor(sb4[0], m, 64); sb4[1] += __shfl_xor(sb4[1], m, 64);
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = 16 * w + 4 * g + r;
+            if (u < HR) { wp[oB1 + u] = sb1[r]; wp[oB2 + u] = sb2[r]; wp[oB3 + u] = sb3[r]; }
+        }
+        if (w == 0) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) if (4 * r + g < xd) wp[oB4 + 4 * r + g] = sb4[r];
+        }
+    }
+}
+
+size_t fused_lds_bytes(int nw) { return (wide_t_floats(nw) + (size_t)3 * nw * FTILE) * sizeof(float); }
+size_t fused_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
+int fused_np(int hr, int xd, int zd) { const int n = xd + zd; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
+
+template <int METHOD, int NWV>
+hipError_t launch_fused(const FusedDev& a, int NZM, const float* pde, const f4* pt, const f4* pf, int NA, hipStream_t s) {
+    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
+    const size_t lds = fused_lds_bytes(NWV);
+#define PSNODE_FUSED(NZM_)                                                                                                      \
+    {                                                                                                                           \
+        auto kern = &ode_backward_fused_kernel<METHOD, NZM_, NWV>;                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pt, pf, NA);                                                      \
+        return hipGetLastError();                                                                                               \
+    }
+    switch (NZM) {
+        case 0: PSNODE_FUSED(0)
+        case 1: PSNODE_FUSED(1)
+        case 2: PSNODE_FUSED(2)
+        case 3: PSNODE_FUSED(3)
+        case 4: PSNODE_FUSED(4)
+        default: return hipErrorNotSupported;
+    }
+#undef PSNODE_FUSED
+}
+
+template <int NWV>
+hipError_t launch_fused_method(const FusedDev& a, int NZM, const float* pde, const f4* pt, const f4* pf, int NA, hipStream_t s) {
+    switch (a.method) {
+        case PSNODE_EULER: return launch_fused<PSNODE_EULER, NWV>(a, NZM, pde, pt, pf, NA, s);
+        case PSNODE_MIDPOINT: return launch_fused<PSNODE_MIDPOINT, NWV>(a, NZM, pde, pt, pf, NA, s);
+        default: return launch_fused<PSNODE_RK4_38, NWV>(a, NZM, pde, pt, pf, NA, s);
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by psnode_backward.hip (C ABI psnode_ode_backward_f32)
+bool fused_bwd_shape_ok(const psnode_ode_bwd_args_f32* a) {
+    if (a->x_dim < 1 || a->x_dim > 4 * kNXc || a->z_dim < 0 || 2 * a->z_dim > 4 * kMaxNZM) return false;
+    if (!wide_hidden(a->de)) return false;
+    return a->de.in_dim == 3 * (a->x_dim + a->z_dim) && a->de.out_dim[3] == a->x_dim;
+}
+
+size_t fused_bwd_workspace_floats(const psnode_ode_bwd_args_f32* a) {
+    const int nw = wide_hidden(a->de) / 16, n = a->x_dim + a->z_dim;
+    const size_t nwg = (size_t)((a->B + TBM - 1) / TBM);
+    return ((wide_fwd_floats(nw, n) + 63) / 64) * 64 + 2 * wide_t_floats(nw) + nwg * fused_np(a->de.out_dim[0], a->x_dim, a->z_dim) +
+           fused_ring_floats(nw, a->method, a->B) + 256;
+}
+
+int fused_bwd_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStream_t s) {
+    const int H = wide_hidden(p->de), nw = H / 16, xd = p->x_dim, zd = p->z_dim, n = xd + zd, HR = p->de.out_dim[0];
+    {   // per-lane offsets inside a row are 32-bit next to a scalar row base
+        const int64_t lim = (int64_t)1 << 30, Bm = p->B;
+        const int64_t sb[] = {H, p->t.stride_b, zd > 0 ? p->z.stride_b : 0, p->event_idx && zd > 0 ? p->zj_stride_b : 0};
+        for (int64_t q : sb) if (q < 0 || Bm * q + 64 >= lim) return PSNODE_ERR_DIMS;
+    }
+    const int NZM = (2 * zd + 3) / 4, NA = (n + 3) / 4;
+    float* pde = workspace;
+    f4* pt = reinterpret_cast<f4*>(pde + ((wide_fwd_floats(nw, n) + 63) / 64) * 64);
+    f4* pf = pt + wide_t_floats(nw) / 4;
+    float* wpart = reinterpret_cast<float*>(pf) + wide_t_floats(nw);
+    const size_t nwg = (size_t)((p->B + TBM - 1) / TBM);
+    const int NP = fused_np(HR, xd, zd);
+    float* ring = wpart + ((nwg * NP + 63) / 64) * 64;
+    PackMfma f;
+    memset(&f, 0, sizeof(f));
+    f.ae = 0; f.nw = nw; f.xd = xd; f.ne = zd; f.n = n; f.nzv = zd; f.NX = kNXc; f.NB = 0; f.NE = NZM; f.NA = NA; f.fold = 1;
+    f.hreal = HR;
+    f.w1 = p->de.weight[0]; f.b1 = p->de.bias[0]; f.w2 = p->de.weight[1]; f.b2 = p->de.bias[1];
+    f.w3 = p->de.weight[2]; f.b3 = p->de.bias[2]; f.w4 = p->de.weight[3]; f.b4 = p->de.bias[3];
+    f.out_dim = xd; f.out = pde;
+    hipLaunchKernelGGL(pack_wide_fwd_kernel, dim3(32), dim3(256), 0, s, f);
+    PackWideT t{nw, HR, p->de.weight[1], p->de.weight[2], pt};
+    hipLaunchKernelGGL(pack_wide_t_kernel, dim3(64), dim3(256), 0, s, t);
+    if (nw >= 8) {
+        PackWideT tf{nw, HR, p->de.weight[1], p->de.weight[2], pf};
+        hipLaunchKernelGGL(pack_wide_f_kernel, dim3(64), dim3(256), 0, s, tf);
+    }
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    FusedDev a;
+    memset(&a, 0, sizeof(a));
+    a.method = p->method; a.xd = xd; a.zd = zd; a.hreal = HR; a.n_events = p->n_events; a.NP = NP; a.T = p->T; a.B = p->B;
+    a.w1 = p->de.weight[0]; a.w4 = p->de.weight[3];
+    a.t = ViewDev{p->t.ptr, p->t.stride_t, p->t.stride_b};
+    a.z = ViewDev{p->z.ptr, p->z.stride_t, p->z.stride_b};
+    a.a0 = p->all_initial; a.ev = p->event_idx; a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
+    a.xs = p->xs; a.gout = p->grad_xs; a.gx0 = p->grad_x0; a.gz = p->grad_z; a.gzj = p->grad_z_jump; a.ga0 = p->grad_all_initial;
+    a.wpart = wpart; a.ring = ring;
+    hipError_t e;
+    switch (nw) {
+        case 2: e = launch_fused_method<2>(a, NZM, pde, pt, pf, NA, s); break;
+        case 4: e = launch_fused_method<4>(a, NZM, pde, pt, pf, NA, s); break;
+        default: e = launch_fused_method<8>(a, NZM, pde, pt, pf, NA, s); break;
+    }
+    if (e == hipErrorNotSupported) return PSNODE_ERR_UNSUPPORTED;
+    if (e != hipSuccess) return PSNODE_ERR_HIP;
+    return launch_reduce_partials(wpart, p->grad_params, nullptr, NP, 0, (int)nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+}  // namespace psnode

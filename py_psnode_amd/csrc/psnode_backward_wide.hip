@@ -19,7 +19,7 @@
 // conflict-free ds_read_b128, no barrier), exchanges as K1 (one barrier each, all reads in flight before the dependent MFMAs at 4 waves).
 #include <string.h>
 
-#include "psnode_pack.h"
+#include "psnode_wide_pack.h"
 
 namespace psnode {
 namespace {
@@ -45,29 +45,6 @@ struct WideDev {
     float* carry;
     float *act[3], *delta[3], *gk, *xst, *dsum[3];
 };
-
-// transposed images of W2 / W3 in the order the kernel's LDS array wants: [(layer * NWV + c) * NWV + w][lane] (f4):
-//   reg r = W[16((w+c) % NWV) + 4g + r][16w + i]
-struct PackWideT {
-    int nw, hreal;
-    const float *w2, *w3;
-    f4* out;
-};
-__global__ void pack_wide_t_kernel(const PackWideT p) {
-    const int H = p.hreal, total = 2 * p.nw * p.nw * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, w = (idx >> 6) % p.nw, c = ((idx >> 6) / p.nw) % p.nw, layer = (idx >> 6) / (p.nw * p.nw);
-        const int i = lane & 15, g = lane >> 4, ws = (w + c) & (p.nw - 1);
-        const float* W = layer ? p.w3 : p.w2;
-        f4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ws + 4 * g + r, col = 16 * w + i;
-            v[r] = (row < H && col < H) ? W[(size_t)row * H + col] : 0.0f;
-        }
-        p.out[idx] = v;
-    }
-}
 
 template <int METHOD, int NZM, int NWV>
 __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideDev a, const float* __restrict__ pack_de,
@@ -366,15 +343,6 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
     }
 }
 
-int wide_hidden(const psnode_mlp_f32& m) {
-    if (m.n_layers != 4) return 0;
-    const int h = m.out_dim[0];
-    if (m.out_dim[1] != h || m.out_dim[2] != h) return 0;
-    return padded_hidden(h);      // the width class the kernel runs at (zero-padded units beyond h)
-}
-size_t wide_fwd_floats(int nw, int n) { return (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64; }
-size_t wide_t_floats(int nw) { return (size_t)2 * nw * nw * 64 * 4; }
-
 template <int METHOD, int NWV>
 hipError_t launch_wide(const WideDev& a, int NZM, const float* pde, const f4* pt, int NA, hipStream_t s) {
     const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
@@ -405,12 +373,6 @@ hipError_t launch_wide_method(const WideDev& a, int NZM, const float* pde, const
         case PSNODE_MIDPOINT: return launch_wide<PSNODE_MIDPOINT, NWV>(a, NZM, pde, pt, NA, s);
         default: return launch_wide<PSNODE_RK4_38, NWV>(a, NZM, pde, pt, NA, s);
     }
-}
-
-__global__ void pack_wide_fwd_kernel(const PackMfma p) {
-    const int R = pack_fwd_count(p);
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < p.nw * R * 64; idx += gridDim.x * blockDim.x)
-        p.out[idx] = pack_fwd_value(p, (idx >> 6) / R, (idx >> 6) % R, idx & 63);
 }
 
 }  // namespace

@@ -51,23 +51,29 @@ struct IntegrateDev {
 // libm flavour, used by the generic kernel:
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
-// Inline flavour for the MFMA kernels (no libm call, branch free, no select), written on float PAIRS so that the
-// arithmetic lowers to v_pk_{mul,fma,add}_f32 (one instruction for two values; the same 5 issue cycles as the scalar form --
-// profiles/r02a_ubench_valu.txt).  On gfx950 the fp32 MFMA shares the fp32 datapath with the VALU: VALU work next to
+// Inline flavour for the MFMA / DPP kernels (no libm call, branch free, no select), written on float PAIRS so that the arithmetic
+// lowers to v_pk_{mul,add}_f32.  On gfx950 the fp32 MFMA shares the fp32 datapath with the VALU: VALU work next to
 // v_mfma_f32_16x16x4_f32 is ADDITIVE (32 cycles per MFMA + 5 per VALU instruction + 12 per v_exp, one wave per SIMD;
 // profiles/r02a_ubench_mfma.txt), so the ELU's instruction count is wall time of every kernel in this library.
+//
+// Round 3 (default):   ELU(x) = max(x, 0) + (exp2(min(x, 0) * log2e) - 1)
+//   x > 0: the second term is exp2(0) - 1 = 0 exactly, ELU(x) = x bit for bit.  x <= 0: t = exp2(..) carries <= 1 ulp(t) <= 6e-8
+//   of ABSOLUTE error, t - 1 is exact for t >= 0.5 (Sterbenz) and rounds once below: |ELU - expm1(x)| <= 1.2e-7 everywhere.  What it
+//   gives up against the round-1/2 form below is RELATIVE accuracy for x -> 0-: the result is a multiple of 6e-8 there.  The next
+//   thing that happens to an ELU output is a dot product with a weight row, where an absolute 6e-8 on a value that is itself tiny
+//   is what an fp32 sum loses anyway: measured on the reference's goldens the trajectories are as close to the reference as with the
+//   expm1-quality form (per-trajectory error 1.05e-7 vs 2.1e-7 over 1000 RK4 steps, K2 1.5e-7 vs 1.0e-7; profiles/r03b_elu_exp2_ab.txt)
+//   -- two orders inside the 1e-5 gate -- for 4.5 instead of 8 issue slots per value: K1 4.21 -> 3.87 ms, K2 5.60 -> 5.20 ms.
+//
+// -DPSNODE_ELU_EXPM1 (rounds 1-2): negative branch at expm1 quality, as ATen's CPU ELU (relative accuracy down to denormal x):
 //   xc = med3(x, knee, 0)  in [knee, 0]      knee = -0.25
 //   xe = min(x, knee)      in (-inf, knee]
 //   ELU(x) = max(x, 0) + [ xc * q(xc) + (exp2(xe * log2e) - t0) ],   t0 = exp2(knee * log2e) evaluated by the same instructions
 //   * x >= knee: xe = knee, the exp term is EXACTLY 0 and xc * q(xc) is expm1 with q the degree-4 near-minimax of expm1(x)/x
-//     on [-0.25, 0] (max relative error 9.1e-8 in fp32 evaluation -- the fp32 rounding floor, same as the degree-7 Taylor form
-//     it replaces; relative accuracy is kept down to denormal x because the leading coefficient is exactly 1);
+//     on [-0.25, 0] (max relative error 9.1e-8 in fp32 evaluation);
 //   * x <  knee: xc = knee, result = expm1(knee)[poly] + (e^x - e^knee): absolute error <= 2 ulp of exp on a value <= -0.22.
-//   * x >  0   : xc = 0, xe = knee: both terms are exactly 0, ELU(x) = x.
-// 3 clamps + 1 v_exp per value and 8 pack-able operations per value (4 instructions): 8 issue slots per value where the
-// round-1 form (min, degree-7 Horner, exp2 - 1, compare + select, max + add) took 14.5.  K1: 4.91 -> see DESIGN.md.
-// The knee is made opaque to the compiler so that t0 is produced by the hardware v_exp_f32 (not constant-folded by a host
-// libm whose last bit may differ): exp2(xe * log2e) - t0 must cancel EXACTLY for x >= knee.
+//   The knee is made opaque to the compiler so that t0 is produced by the hardware v_exp_f32 (not constant-folded by a host
+//   libm whose last bit may differ): exp2(xe * log2e) - t0 must cancel EXACTLY for x >= knee.
 typedef float elu_f2 __attribute__((ext_vector_type(2)));
 typedef float elu_f4 __attribute__((ext_vector_type(4)));
 constexpr float kLog2e = 1.44269504088896340736f;
@@ -88,6 +94,13 @@ __device__ __forceinline__ elu_f2 elu_splat(float c) {
 }
 __device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const float knee, const float neg_t0, const elu_f2 c4, const elu_f2 c3,
                                            const elu_f2 c2, const elu_f2 c1) {
+#ifndef PSNODE_ELU_EXPM1
+    const elu_f2 xn = elu_f2{fminf(x[0], 0.0f), fminf(x[1], 0.0f)};
+    const elu_f2 xq = elu_f2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    const elu_f2 yq = xn * kLog2e;
+    const elu_f2 tq = elu_f2{__builtin_amdgcn_exp2f(yq[0]), __builtin_amdgcn_exp2f(yq[1])};
+    return xq + (tq - 1.0f);
+#endif
     const elu_f2 xc = elu_f2{__builtin_amdgcn_fmed3f(x[0], knee, 0.0f), __builtin_amdgcn_fmed3f(x[1], knee, 0.0f)};
     const elu_f2 xe = elu_f2{fminf(x[0], knee), fminf(x[1], knee)};
     const elu_f2 xp = elu_f2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
@@ -175,6 +188,10 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 // psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
 hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
+// K4f (psnode_backward_fused.hip): one-launch MFMA backward of the ODE integrator at hidden <= 128 (zero-padded to 32 / 64 / 128), x_dim <= 8, z_dim <= 8
+bool fused_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
+size_t fused_bwd_workspace_floats(const psnode_ode_bwd_args_f32* a);
+int fused_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
 // K8 (psnode_latent_bwd.hip): backward of the latent ODE integrator at hidden 16
 bool latent16_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 bool latent16_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);

@@ -168,54 +168,62 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         if constexpr (DAE) c0a = mfma4(pwa[(RA::COUNT + m) * 64], av, c0a);
     }
 
-    const long long tst = a.t.st, nT = a.T, zst = a.z.st, zje = a.zje, vst = a.v.st, vje = a.vje;
+    const long long tst = a.t.st, nT = a.T;
     const float* tp = a.t.p + b * a.t.sb;
-    const float* zp = a.z.p + b * a.z.sb;
-    const float* zjp = a.zj + b * a.zjb;
-    const float* vp = a.v.p + b * a.v.sb;
-    const float* vjp = a.vj + b * a.vjb;
+    // Every per-step input load is UNCONDITIONAL and its row base is computed once per step: a source that does not exist (z_dim = 0,
+    // v_dim = 0, no jump array) points at this trajectory's clock with stride 0 -- nothing selects its value -- instead of hiding
+    // behind a runtime branch.  Branches around loads cost twice in the time loop: eight taken scalar branches per DAE step, and at
+    // every join the compiler's wait-count pass can only assume the worst (s_waitcnt vmcnt(0) -- a full memory round trip on the
+    // prefetches just issued).  The DAE's teacher-forced algebraic input was such a branch: ~800 cycles per step of K2 for a load that
+    // the no-teacher-forcing call never issues (profiles/r03a_dae01_euler_pmc_sq.txt: SQ_WAIT_ANY 2.4 k cycles per step, 6 exchanges).
+    const bool has_z = zd > 0, has_v = DAE && vd > 0;
+    const long long zst = has_z ? a.z.st : 0, zje = (has_z && a.zj) ? a.zje : 0;
+    const long long vst = has_v ? a.v.st : 0, vje = (has_v && a.vj) ? a.vje : 0;
+    const float* zp = has_z ? a.z.p + b * a.z.sb : tp;
+    const float* zjp = (has_z && a.zj) ? a.zj + b * a.zjb : tp;
+    const float* vp = has_v ? a.v.p + b * a.v.sb : tp;
+    const float* vjp = (has_v && a.vj) ? a.vj + b * a.vjb : tp;
+    // column a slot reads from the z row / the v row (0 = harmless dummy when the slot is of the other kind)
+    int ezc[NZM > 0 ? NZM : 1], evc[NZM > 0 ? NZM : 1], azc[NZA > 0 ? NZA : 1], avc[NZA > 0 ? NZA : 1];
+#pragma unroll
+    for (int m = 0; m < NZM; ++m) { ezc[m] = (has_z && ekind[m] == 0) ? ecol[m] : 0; evc[m] = (has_v && ekind[m] == 1) ? ecol[m] : 0; }
+#pragma unroll
+    for (int m = 0; m < NZA; ++m) { azc[m] = (has_z && akind[m] == 0) ? acol[m] : 0; avc[m] = (has_v && akind[m] == 1) ? acol[m] : 0; }
 
     // z|v columns of grid point k for the ext slots (ev >= 0: the batch takes the jump values for this step).  In the DAE a lane's
-    // slot may be a z or a v column: BOTH sources are read with a clamped column and the value is selected WHEN IT IS CONSUMED
-    // (a step later) -- selecting right behind the loads put an s_waitcnt vmcnt(0) behind every prefetch (a full memory round trip
-    // inside every step of K2), and selecting between the two base pointers per lane makes the compiler spill a pointer table to
-    // scratch.  `ev` is wave-uniform (read with v_readlane from a 64-step block of the event table, as K3f): the address of a row is
-    // scalar arithmetic; a per-lane copy of the index cost 64-bit per-lane multiplies for every load.
-    auto raw_z = [&](long long k, int ev, int kind, int col) -> float {
-        if constexpr (!DAE) {      // single source: nothing to select, nothing to clamp
-            if (kind == 0) return (ev >= 0 ? zjp + ev * zje : zp + k * zst)[col];
-            return 0.0f;
-        } else {
-            if (zd <= 0) return 0.0f;
-            const long long off = ev >= 0 ? (long long)ev * zje : k * zst;
-            return (ev >= 0 ? zjp : zp)[off + (kind == 0 ? col : 0)];
-        }
-    };
-    auto raw_v = [&](long long k, int ev, int kind, int col) -> float {
-        if (!DAE || vd <= 0) return 0.0f;
-        const long long off = ev >= 0 ? (long long)ev * vje : k * vst;
-        return (ev >= 0 ? vjp : vp)[off + (kind == 1 ? col : 0)];
+    // slot may be a z or a v column: BOTH sources are read and the value is selected WHEN IT IS CONSUMED (a step later) -- selecting
+    // right behind the loads put an s_waitcnt vmcnt(0) behind every prefetch, and selecting between the two base pointers per lane
+    // makes the compiler spill a pointer table to scratch.  `ev` is wave-uniform (read with v_readlane from a 64-step block of the
+    // event table, as K3f): the row offset is scalar arithmetic; a per-lane copy of the index cost 64-bit per-lane multiplies per load.
+    struct RowPtr { const float* z; const float* v; };
+    auto rows_at = [&](long long k, int ev) -> RowPtr {
+        RowPtr r;
+        r.z = ev >= 0 ? zjp + (long long)ev * zje : zp + k * zst;
+        r.v = DAE ? (ev >= 0 ? vjp + (long long)ev * vje : vp + k * vst) : r.z;
+        return r;
     };
     // 8 waves per tile (hidden 128) have a second wave per SIMD to hide the wait and no registers for the second copy: they select
     // at load time (the value travels in the z array).
     constexpr bool DEFER_PICK = NWV <= 4;
     auto pick = [&](int kind, float zval, float vval) -> float {
-        if constexpr (!DEFER_PICK || !DAE) return zval;
+        if constexpr (!DEFER_PICK || !DAE) return zval;      // ODE: a padding slot reads z column 0 against a ZERO weight (psnode_pack.h)
         return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
     };
     auto pick_now = [&](int kind, float zval, float vval) -> float { return kind == 0 ? zval : (kind == 1 ? vval : 0.0f); };
     auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>& dv) {
+        const RowPtr rp = rows_at(k, ev);
 #pragma unroll
         for (int m = 0; m < NZM; ++m) {
-            const float zr = raw_z(k, ev, ekind[m], ecol[m]), vr = raw_v(k, ev, ekind[m], ecol[m]);
+            const float zr = rp.z[ezc[m]], vr = DAE ? rp.v[evc[m]] : 0.0f;
             if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
             else dz.v[m] = pick_now(ekind[m], zr, vr);
         }
     };
     auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>& dv) {
+        const RowPtr rp = rows_at(k, ev);
 #pragma unroll
         for (int m = 0; m < NZA; ++m) {
-            const float zr = raw_z(k, ev, akind[m], acol[m]), vr = raw_v(k, ev, akind[m], acol[m]);
+            const float zr = rp.z[azc[m]], vr = rp.v[avc[m]];
             if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
             else dz.v[m] = pick_now(akind[m], zr, vr);
         }
@@ -406,6 +414,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     load_de_raw(0, ev_cur, exz_nxt, exv_nxt);
 
     for (long long k = 0; k + 1 < nT; ++k) {
+        // Everything still in flight here was issued a whole step ago (the prefetch of this step's inputs, the previous result's
+        // store): wait for it HERE, once.  Left to the compiler, the first use of a prefetched value may be scheduled behind this
+        // step's stores, and since those sit in branches (only wave 0 stores) the only wait count that is safe there also waits
+        // for the stores just issued (ODE_01 Euler: 1.26 -> 1.35 ms per launch when that happened).
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         const float h_ = t_nxt - t_cur;
         t_cur = t_nxt;
         Arr<NZM> extv;
@@ -426,6 +439,18 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
         for (int r = 0; r < NX; ++r) xsrc[r] = x[r];
         if constexpr (TRUE_X) load_x(k, xsrc);   // teacher forcing: the step starts from the dataset's x[k]
+        // teacher-forced algebraic input i[k]: read HERE, in front of the prefetch, and waited for inside the branch -- what is still
+        // in flight at this point are the inputs of this very step.  Read where it is consumed (behind the prefetch) the join of this
+        // branch put an s_waitcnt vmcnt(0) on the prefetch of EVERY step, teacher forcing or not.
+        Arr<NZM> itrue = {};
+        if constexpr (DAE) {
+            if (true_i) {
+                const float* ir = a.i.p + b * a.i.sb + k * a.i.st;
+#pragma unroll
+                for (int m = 0; m < NZM; ++m) itrue.v[m] = ir[ekind[m] == 2 ? ecol[m] : 0];
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            }
+        }
         // prefetch the next step's inputs (consumed one full step later)
         if (k + 2 < nT) {
             t_nxt = tp[(k + 2) * tst];
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         for (int m = 0; m < NZM; ++m) {
             float e = extv.v[m];
             if constexpr (DAE) {
-                if (ekind[m] == 2) e = true_i ? a.i.p[k * a.i.st + b * a.i.sb + ecol[m]] : icur[m];
+                if (ekind[m] == 2) e = true_i ? itrue.v[m] : icur[m];
             }
             cz = mfma4(w1z.v[m], e - a0e.v[m], cz);
         }

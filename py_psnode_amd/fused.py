@@ -17,7 +17,7 @@ from . import _lib
 Layers = Sequence[Tuple[torch.Tensor, torch.Tensor]]
 
 METHOD_ID = {"euler": _lib.EULER, "midpoint": _lib.MIDPOINT, "rk4": _lib.RK4_38}
-KERNEL_ID = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA}
+KERNEL_ID = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA, "wide": _lib.KERNEL_MFMA_WIDE}
 
 
 # ----------------------------------------------------------------------------- recognition
@@ -439,8 +439,9 @@ def _gemm_tn(a2: torch.Tensor, b2: torch.Tensor, groups: int) -> torch.Tensor:
     """a2^T @ b2 for tall-skinny [N, p], [N, q] (N in the millions): `groups` independent partial products + one sum, so the library
     GEMM has parallelism over the contraction (one [p,N]x[N,q] call runs on a handful of workgroups: 21 vs 124 TFLOP/s at p=q=128)."""
     N = a2.shape[0]
+    groups = max(1, min(groups, 256))     # the [groups, p, q] partial products are materialised: cap them (small B x long T chunks)
     while groups > 1 and N % groups:
-        groups //= 2
+        groups -= 1
     return torch.bmm(a2.view(groups, N // groups, -1).transpose(1, 2), b2.view(groups, N // groups, -1)).sum(0)
 
 
@@ -731,6 +732,8 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
     T, B, xd = xs.shape
     zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
     # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K7w + library GEMMs instead of the generic K5
+    if kernel == "wide" and T < 2:
+        kernel = "generic"       # no step to sweep: the split backward has no head-only form, K5 handles the single grid point
     if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
                             and dae_backward_wide_supported(method, de_layers, ae_layers, xd, zd, vd, idim)):
         return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
@@ -794,11 +797,10 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
     dev = xs.device
     T, B, xd = xs.shape
     zd = z.shape[-1]
-    # the one-launch MFMA backward covers hidden 64 with z_dim <= 4; other widths <= 128 and z_dim <= 8: the adjoint sweep on K4w +
-    # library GEMMs instead of the generic K5
-    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and T >= 2
-                            and not (de_layers[0][0].shape[0] == 64 and ode_backward_supported(method, de_layers, xd, zd, "mfma"))
-                            and ode_backward_wide_supported(method, de_layers, xd, zd)):
+    # kernel: "auto" = K4 at hidden 64 (z_dim <= 4), the width-generic one-launch K4f at every other width <= 128 (z_dim <= 8), else the
+    # generic K5; "wide" forces K4f; "split" is round 2's route for those widths (adjoint sweep K4w + library GEMMs over stored rows),
+    # kept as an A/B arm (profiles/scripts/wide_vs_onelaunch.py)
+    if kernel == "split":
         return ode_backward_wide(method, de_layers, t, z, all_initial, xs, grad_xs, event_idx=event_idx, z_jump=z_jump,
                                  need_grad_z=need_grad_z)
     keep: list = []

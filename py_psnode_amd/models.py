@@ -204,6 +204,11 @@ class ODE_Model(nn.Module):
         solver = self.solver
         if not isinstance(solver, FixedGridODESolver) or getattr(solver, "fused", "off") == "off" or not solver.method:
             return None
+        if getattr(solver, "kernel", "auto") == "generic":        # PSNODE_KERNEL=generic asks for K0: row kernels + solver route
+            return None
+        if any(fused._overrides_forward_hooks(m) for m in (self, self.x_encoder, self.z_encoder, self.x_decoder, self.de_func,
+                                                          self.de_func.x_dot)):
+            return None                                            # user hooks must fire: module-by-module route
         if x.device.type != "cuda" or any(a.dtype != torch.float32 for a in (t, x, z)) or x.dim() != 3 or x.shape[1] < 1:
             return None
         if not getattr(type(self.event), "_psnode_event", False) or type(self.de_func) is not DE_Func:
@@ -215,7 +220,9 @@ class ODE_Model(nn.Module):
             return None
         if event_t is not None and (event_t.dtype != torch.float32 or z_jump is None or z_jump.dtype != torch.float32):
             return None
-        self.event.set_event(t=event_t, z=z_jump)                 # state as upstream leaves it (raw jumps: nothing reads Zh_jump)
+        # NOTE: upstream (and the module-by-module route) leave event.z_jump = z_encoder(z_jump) [B,nE,H]; this route never forms
+        # the encoded jumps, so the event object holds the RAW [B,nE,z_dim] tensor afterwards (nothing reads it after forward)
+        self.event.set_event(t=event_t, z=z_jump)
         x_pred, x_re, _ = fused.ode_encoded_integrate(solver.method, *mlps, t, x, z, event_t=event_t, z_jump=z_jump,
                                                       check_events=solver._check_events_now(event_t))
         return x_pred, x_re

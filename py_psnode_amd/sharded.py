@@ -37,32 +37,32 @@ def broadcast_event_table(t_local: torch.Tensor, event_t_local: Optional[torch.T
     return tab
 
 
-_EQUAL_SHARDS_OK = set()
-
-
-def _require_equal_shards(Bl: int, device, group=None):
+def require_equal_shards(Bl: int, device, group=None):
     """all_gather_into_tensor needs the same shard size on every rank; with unequal shards (B not a multiple of the world size)
-    it hangs or fails inside RCCL.  One tiny max-reduce the first time a (group, shard size) is seen -- every rank makes the same
-    sequence of collective calls -- raises a clear error on all ranks instead."""
-    key = (id(group), Bl, str(device))
-    if key in _EQUAL_SHARDS_OK:
-        return
+    it hangs or fails inside RCCL.  One tiny max-reduce per gather raises a clear error on ALL ranks instead.  It runs on every
+    call: a per-rank memo of the sizes already seen would let a rank whose size is a hit skip the collective while a rank whose
+    size is new enters it (full batches, then a ragged last one) -- mismatched collectives across ranks, i.e. the very hang this
+    check exists to prevent.  16 bytes next to a gather of megabytes, but reading the answer synchronises the host: a caller that
+    has established the sizes once (a fixed global batch split evenly, as bench.py) passes check_shards=False on EVERY rank."""
     sizes = torch.tensor([Bl, -Bl], device=device)
     dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
     hi, lo = int(sizes[0]), int(-sizes[1])
     if hi != lo:
         raise ValueError(f"the all-gather needs equal shards on every rank (this rank {Bl}, range {lo}..{hi} trajectories): "
                          "pad the batch or shard a multiple of the world size")
-    _EQUAL_SHARDS_OK.add(key)
 
 
-def all_gather_batch(shard: torch.Tensor, group=None) -> torch.Tensor:
+_require_equal_shards = require_equal_shards
+
+
+def all_gather_batch(shard: torch.Tensor, group=None, check_shards: bool = True) -> torch.Tensor:
     """[T, Bl, D] shards (equal Bl on every rank) -> [T, G*Bl, D] view in rank order, one all_gather_into_tensor.
     The gathered storage is rank-major [G, T, Bl, D]; the result is its [T, G*Bl, D] rearrangement (one device copy)."""
     world = dist.get_world_size(group)
     shard = shard.contiguous()
     T, Bl, D = shard.shape
-    _require_equal_shards(Bl, shard.device, group)
+    if check_shards:
+        require_equal_shards(Bl, shard.device, group)
     flat = torch.empty((world * T, Bl, D), dtype=shard.dtype, device=shard.device)   # rank-major concatenation
     dist.all_gather_into_tensor(flat, shard, group=group)
     return flat.view(world, T, Bl, D).permute(1, 0, 2, 3).reshape(T, world * Bl, D)
@@ -74,7 +74,8 @@ def chunk_bounds(T: int, chunks: int):
     return [round(c * T / chunks) for c in range(chunks + 1)]
 
 
-def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, group, gather: bool, wait: bool, want_local: bool):
+def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, group, gather: bool, wait: bool, want_local: bool,
+               check_shards: bool = True):
     """Shared driver of the time-chunked integrate / all-gather pipeline.  `launch(s, r1, starts, outs)` integrates grid points
     s..r1-1 from the state rows `starts` (None for the first chunk) into the buffers `outs` ([r1-s, Bl, D] each).
 
@@ -83,8 +84,8 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
     across streams when the chunks shared one [T,Bl,D] tensor)."""
     b = chunk_bounds(T, chunks)
     world = dist.get_world_size(group) if gather else 1
-    if gather:
-        _require_equal_shards(Bl, device, group)
+    if gather and check_shards:
+        require_equal_shards(Bl, device, group)
     works, gathered, local_rows = [], [[] for _ in widths], [[] for _ in widths]
     prev = None
     for c in range(len(b) - 1):
@@ -109,7 +110,8 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
 
 
 def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=None, z_jump=None, chunks: int = 4, group=None,
-                            local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, want_local: bool = True, **kw):
+                            local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, want_local: bool = True,
+                            check_shards: bool = True, **kw):
     """Time-chunked integrate with the all-gather of finished chunks overlapped with the integration of later ones.
 
     The all-gather of one [T, Bl, xd] shard set at 8 GPUs moves ~0.9 GB into every GPU -- about as long as the
@@ -130,7 +132,7 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
         ev = None if event_idx is None else event_idx[s:r1 - 1]
         local_fn(method, de_layers, t[s:r1], x_start, z[s:r1], all_initial, z_jump=z_jump, event_idx=ev, out=outs[0], **kw)
 
-    local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local)
+    local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local, check_shards)
     if not wait:
         return local[0], gathered[0], works      # caller waits (bench.py brackets the compute stream before waiting)
     return local[0], gathered[0]
@@ -138,7 +140,7 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
 
 def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_idx=None, z_jump=None, v_jump=None,
                             chunks: int = 4, group=None, local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True,
-                            want_local: bool = True, **kw):
+                            want_local: bool = True, check_shards: bool = True, **kw):
     """integrate_DAE (no teacher forcing) as integrate_ode_pipelined: xs AND is shards gathered chunk by chunk behind the next
     chunk's kernel.  A chunk restarts from x_init = xs[s]; the launch recomputes i0 = g(xs[s]; z[s], v[s]) itself, which is exactly
     how is[s] was produced (my_solvers.py:121 uses the un-jumped z, v of the right grid point), so the restart is bit-identical
@@ -157,7 +159,8 @@ def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, al
         local_fn(method, de_layers, ae_layers, xi, t[s:r1], x_dummy, z[s:r1], v[s:r1], i[s:r1], all_initial, z_jump=z_jump,
                  v_jump=v_jump, event_idx=ev, out=(outs[0], outs[1]), **kw)
 
-    local, gathered, works = _pipelined(launch, T, Bl, [xd, idim], x_init.dtype, x_init.device, chunks, group, gather, wait, want_local)
+    local, gathered, works = _pipelined(launch, T, Bl, [xd, idim], x_init.dtype, x_init.device, chunks, group, gather, wait, want_local,
+                                        check_shards)
     if not wait:
         return tuple(local), tuple(gathered), works
     return tuple(local), tuple(gathered)

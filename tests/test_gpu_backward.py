@@ -172,14 +172,26 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
         _close(gzj, zjq.grad, "grad z_jump")
     for k, (a_, p_) in enumerate(zip(gp, de.x_dot.parameters())):
         _close(a_, p_.grad, f"grad param {k}")
-    # the auto route picks K4w at hidden 32 / 128 and the one-launch K4 at 64: same numbers either way
+    # K4f, the width-generic ONE-launch backward (weight gradients accumulated in the kernel; `auto` at every width but 64): the same
+    # fp64 truth, every output
+    fx0, fz, fzj, fa0, fp = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), kernel="wide")
+    _close(fx0 + fa0[:, :xd], xq.grad[0], "K4f grad x0")
+    if zd:
+        fz_tot = fz.clone(); fz_tot[0] += fa0[:, xd:]
+        _close(fz_tot, zq.grad, "K4f grad z")
+        _close(fzj, zjq.grad, "K4f grad z_jump")
+    _close(fa0, ga0.double().cpu(), "K4f grad all_initial vs split")
+    for k, (a_, p_) in enumerate(zip(fp, de.x_dot.parameters())):
+        _close(a_, p_.grad, f"K4f grad param {k}")
+    # the auto route picks K4f at hidden 32 / 128 / 48 and the one-launch K4 at 64: same numbers either way
     auto = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj))
     for k, (a_, b_) in enumerate(zip(gp, auto[4])):
-        _close(a_, b_.double().cpu(), f"auto vs wide param {k}")
+        _close(a_, b_.double().cpu(), f"auto vs split param {k}")
 
 
-def test_hidden128_training_takes_the_wide_backward():
-    """ODE_Model at --hidden 128 (the scripts' argparse default) under autograd with fused='require': forward K1, backward K4w."""
+def test_hidden128_training_takes_the_one_launch_backward():
+    """ODE_Model at --hidden 128 (the scripts' argparse default) under autograd with fused='require': forward K1, backward K4f in ONE
+    launch -- not round 2's split (adjoint sweep + library GEMMs over stored rows)."""
     from py_psnode_amd import fused, models
     from py_psnode_amd import neural_dae as nd
     torch.manual_seed(1)
@@ -196,7 +208,7 @@ def test_hidden128_training_takes_the_wide_backward():
         nn.functional.mse_loss(pred, x).backward()
     finally:
         fused.ode_backward_wide = orig
-    assert calls == [1]
+    assert calls == [], "hidden 128 must not take the split backward any more"
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in m.parameters())
 
 
@@ -286,7 +298,7 @@ def test_fused_dae_backward_matches_fp64_autograd(method, events):
         _close(a, b, f"grad param {k}")
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "generic"])
+@pytest.mark.parametrize("kernel", ["mfma", "generic", "wide"])
 @pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3)])
 def test_backward_edge_sizes(B, Tn, kernel):
     """T = 1 (no step at all), T = 2, single trajectory, ragged tiles -- both backward kernels against fp64 autograd."""

@@ -116,6 +116,40 @@ def test_model_forward_takes_the_single_launch_route(method):
     assert traj_rel_err(pred2.detach().cpu(), pred.cpu(), bdim=0) <= TOL_GPU and traj_rel_err(re2.detach().cpu(), re.cpu(), bdim=0) <= TOL_GPU
 
 
+def test_single_launch_route_respects_hooks_and_the_generic_kernel_request():
+    """Round-2 ADVICE: the one-launch route must step aside when a user hook sits on a module it would swallow (hooks have to fire)
+    and when solver.kernel asks for the generic kernel."""
+    from py_psnode_amd import models
+    from py_psnode_amd import neural_dae as nd
+    d = load("g4_model_ode02.npz")
+    m = models.ODE_Model(8, 2, 16, direct_encode=True)
+    m.load_state_dict({k[4:].replace("__", "."): T(v) for k, v in d.items() if k.startswith("sd__")})
+    m = m.cuda()
+    m.solver = nd.RK4()
+    g = lambda k: T(d[k]).cuda()
+    calls, fired = [], []
+    orig = fused().ode_encoded_integrate
+    try:
+        fused().ode_encoded_integrate = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        h = m.x_encoder.register_forward_hook(lambda mod, i, o: fired.append(1))
+        with torch.no_grad():
+            pred_h, _ = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+        assert calls == [] and fired, "a forward hook on x_encoder must fire: no single-launch route"
+        h.remove()
+        m.solver.kernel = "generic"
+        with torch.no_grad():
+            pred_g, _ = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+        assert calls == [], "solver.kernel = 'generic' must not run the DPP kernel"
+        m.solver.kernel = "auto"
+        with torch.no_grad():
+            pred, _ = m(t=g("t"), x=g("x"), z=g("z"), event_t=g("event_t"), z_jump=g("z_jump"))
+        assert calls == [1]
+    finally:
+        fused().ode_encoded_integrate = orig
+    for other in (pred_h, pred_g):
+        assert traj_rel_err(other.cpu(), pred.cpu(), bdim=0) <= TOL_GPU
+
+
 def test_encoded_forward_full_size_matches_unfused_route():
     """BASELINE config 3 size (B=4096, T=1001): the single launch against the round-1 route (row kernels + latent integrator) on the
     GPU, and 32 of the trajectories against the CPU oracle."""

@@ -142,12 +142,19 @@ def _worker(rank, world, port, q):
         assert sharded.chunk_bounds(1001, 4) == [0, 250, 500, 751, 1001] and sharded.chunk_bounds(2, 4) == [0, 1, 2]
         assert torch.equal(xs_l, out[:, lo:hi]), "local rows of the pipelined run differ from this rank's slice of the gather"
         _check_dae_pipelined(rank, world, sharded)
-        # unequal shards must raise on every rank instead of hanging inside the collective
-        try:
-            sharded.all_gather_batch(torch.zeros(3, 4 + rank, 2))
-            raise AssertionError("unequal shards were accepted")
-        except ValueError as e:
-            assert "equal shards" in str(e)
+        # unequal shards must raise on every rank instead of hanging inside the collective -- also when ONE rank has seen its size
+        # before (full batches of 4 + 4, then a ragged last batch of 4 + 3: round-2 ADVICE, a per-rank memo of the sizes let rank 0
+        # skip the check's all-reduce while rank 1 entered it)
+        full = sharded.all_gather_batch(torch.full((3, 4, 2), float(rank)))
+        assert full.shape == (3, 8, 2) and torch.equal(full[:, :4], torch.zeros(3, 4, 2)) and torch.equal(full[:, 4:], torch.ones(3, 4, 2))
+        for ragged in (4 - rank, 4 + rank):
+            try:
+                sharded.all_gather_batch(torch.zeros(3, ragged, 2))
+                raise AssertionError("unequal shards were accepted")
+            except ValueError as e:
+                assert "equal shards" in str(e)
+        again = sharded.all_gather_batch(torch.full((3, 4, 2), float(rank)), check_shards=False)    # the ranks are still in lock-step
+        assert torch.equal(again, full)
         if rank == 0:
             # trajectory `B/2` (rank 1's first) was integrated with the shifted clock but identical dt -> same result
             q.put((tuple(out.shape), float((out - ref).abs().max())))
