@@ -305,6 +305,8 @@ def main():
     ap.add_argument("--train-baseline-steps", type=int, default=0,
                     help="with --train: also time the unrolled PyTorch-autograd walk on the GPU for this many grid steps")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
+    ap.add_argument("--gather-layout", default="chunks", choices=["chunks", "batch"],
+                    help="N>1, pipelined: per-chunk rank-major buffers (zero-copy) or every chunk gathered INTO one [T, N*B, D] tensor")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap)")
     args = ap.parse_args()
 
@@ -430,13 +432,13 @@ def main():
             if w["kind"] == "ode":
                 xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                                                event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
-                                                               kernel=args.kernel, check_shards=False)
+                                                               kernel=args.kernel, check_shards=False, layout=args.gather_layout)
                 outs = (xs,)
             else:
                 outs, _, works = sharded.integrate_dae_pipelined(args.method, p["de"], p["ae"], p["x_init"], tmv(p["t"]), tmv(p["z"]),
                                                                  tmv(p["v"]), tmv(p["i"]), p["a0"], event_idx=tab, z_jump=p["z_jump"],
                                                                  v_jump=p["v_jump"], chunks=args.chunks, wait=False, kernel=args.kernel,
-                                                                 check_shards=False)
+                                                                 check_shards=False, layout=args.gather_layout)
             if ev_pair:
                 ev_pair[1].record()
             for wk in works:

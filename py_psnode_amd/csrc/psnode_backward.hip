@@ -228,28 +228,37 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     float ga0z = 0.f;
     f2 gcarry = {0.f, 0.f};
 
-    // inputs of a step, prefetched one iteration ahead (the sweep runs k = T-2 .. 0)
+    // inputs of a step, prefetched one iteration ahead (the sweep runs k = T-2 .. 0).  Every load is UNCONDITIONAL (clamped row / column
+    // indices, masks applied where the value is consumed a step later): a load under a predicate or inside `if (k >= 1)` is a phi with a
+    // constant, the copy into the loop-carried register sits right behind the load, and the wait for it -- s_waitcnt vmcnt(0) on the whole
+    // prefetch just issued, a full HBM round trip -- sat in every step (round 3, found in the ISA: 14.3 -> see DESIGN.md).
     auto load_ext = [&](long long k, int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
         const float* src = ev >= 0 ? zjp + ev * zje : zp + k * zst;
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) dst[m] = 4 * m + g < 2 * ne ? src[eidx[m]] : 0.0f;
+        for (int m = 0; m < NZM; ++m) dst[m] = src[eidx[m]];     // padding slots read column 0 against a zero weight
     };
-    auto load_state = [&](long long k, float (&xk)[NX], float (&gk1)[NX]) {   // xs[k] and dL/dxs[k+1]
+    int xcol[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) xcol[r] = 4 * r + g < xd ? 4 * r + g : 0;
+    auto load_state = [&](long long k, float (&xk)[NX], float (&gk1)[NX]) {   // xs[k] and dL/dxs[k+1], raw (dims >= x_dim repeat dim 0)
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-            const bool on = 4 * r + g < xd;
-            xk[r] = on ? d.xs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
-            gk1[r] = (on && valid) ? d.gout[((k + 1) * a.B + b) * xd + 4 * r + g] : 0.0f;
+            xk[r] = d.xs[(k * a.B + b) * xd + xcol[r]];
+            gk1[r] = d.gout[((k + 1) * a.B + b) * xd + xcol[r]];
         }
     };
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const int* evp = a.ev + lane_zero;                    // per-lane load: the value stays in a VGPR until it is used
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;   // per-lane load: the value stays in a VGPR until it is used
     float t_hi = nT >= 2 ? tp[(nT - 1) * tst] : 0.0f, t_lo = nT >= 2 ? tp[(nT - 2) * tst] : 0.0f;
-    int ev_cur = (a.ev && nT >= 2) ? a.ev[nT - 2] : -1;
-    int ev_n1 = (a.ev && nT >= 3) ? evp[nT - 3] : -1;
+    int ev_cur = (has_ev && nT >= 2) ? a.ev[nT - 2] : -1;
+    int ev_raw = evp[nT >= 3 ? nT - 3 : 0];               // raw table entry of the step after; masked with has_ev when it becomes ev_cur
     float ext_n[NZM > 0 ? NZM : 1] = {}, x_n[NX] = {}, g_n[NX] = {};
     if (nT >= 2) { load_ext(nT - 2, ev_cur, ext_n); load_state(nT - 2, x_n, g_n); }
+    bool gon[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) gon[r] = valid && 4 * r + g < xd;
 
     for (long long k = nT - 2; k >= 0; --k) {
         // ---- inputs of step k (already in registers); issue the loads of step k-1
@@ -260,14 +269,15 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
 #pragma unroll
         for (int m = 0; m < (NZM > 0 ? NZM : 1); ++m) extv[m] = ext_n[m];
 #pragma unroll
-        for (int r = 0; r < NX; ++r) { x0[r] = x_n[r]; g1[r] += g_n[r]; }
-        if (k >= 1) {
+        for (int r = 0; r < NX; ++r) { x0[r] = x_n[r]; g1[r] += gon[r] ? g_n[r] : 0.0f; }
+        {
+            const long long kp = k >= 1 ? k - 1 : 0;
             t_hi = t_lo;
-            t_lo = tp[(k - 1) * tst];
-            load_ext(k - 1, ev_n1, ext_n);
-            load_state(k - 1, x_n, g_n);
-            ev_cur = ev_n1;
-            ev_n1 = (a.ev && k >= 2) ? evp[k - 2] : -1;
+            t_lo = tp[kp * tst];
+            ev_cur = has_ev ? ev_raw : -1;
+            load_ext(kp, ev_cur, ext_n);
+            load_state(kp, x_n, g_n);
+            ev_raw = evp[k >= 2 ? k - 2 : 0];
         }
         f4 cz = c0;
 #pragma unroll

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             wq = wl[c * NWV * 64];
             accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
+            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }   // 8 waves: bound the scheduler's read-ahead (registers)
         }
         p ^= 1;
         return accA + accB;
@@ -225,12 +226,14 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             wq = wl[c * NWV * 64];
             accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
+            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }
         }
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
             const f4 dT = get_row(tile(p, (w + c) & (NWV - 1)), roff);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc[c] = fm4(dT[kk], hT[kk], acc[c]);
+            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }
         }
         p ^= 1;
         return accA + accB;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             const gptr<const float> row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
             const unsigned m_ = ev >= 0 ? ~0u : 0u, zo = (offZJ & m_) | (offZ & ~m_);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? ldg<float>(row, zo + 4u * ecol[m]) : 0.0f;
+            for (int m = 0; m < NZM; ++m) dst[m] = ldg<float>(row, zo + 4u * ecol[m]);     // padding slots read column 0 against a zero weight
         }
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
@@ -270,8 +273,14 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #pragma unroll
         for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
     };
-    auto load_dt = [&](const long long k) -> float { return ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT); };
-    auto event_of = [&](const long long k) -> int { return a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1; };
+    // clock and event index of a step are RAW prefetched values (one grid point / one table entry per step, requested a step ahead);
+    // the difference and the readfirstlane happen a step later, at the consumer.  Subtracting / broadcasting right behind the load --
+    // inside the `if (k > 0)` of the prefetch -- made the compiler wait out the memory round trip on the spot, every step (K4w did that).
+    auto load_t = [&](const long long k) -> float { return ldg<float>(sbase(a.t.p + k * a.t.st), offT); };
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;   // per-lane load: the value stays in a VGPR until it is used
 
     // ---- accumulators (whole launch)
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
@@ -284,14 +293,17 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     for (int r = 0; r < NX; ++r) gcar[r] = 0.0f;
 
     const long long nrow = a.B, nT = a.T;
-    float x0n[NX] = {}, ginn[NX] = {}, extn[NZ] = {}, hn = 0.0f;
-    int evn = -1;
+    float x0n[NX] = {}, ginn[NX] = {}, extn[NZ] = {};
+    float t_hi = 0.0f, t_lo = 0.0f;          // t[k+1], t[k] of the step about to run
+    int evn = -1, evr = -1;                  // evn: event index of the step about to run; evr: raw table entry of the one after
     if (nT >= 2) {
-        evn = event_of(nT - 2);
+        evn = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[nT - 2]) : -1;
+        evr = evp[nT >= 3 ? nT - 3 : 0];
         load_x2(a.xs, nT - 2, x0n);
         load_x2(a.gout, nT - 1, ginn);
         load_ext(nT - 2, evn, extn);
-        hn = load_dt(nT - 2);
+        t_hi = load_t(nT - 1);
+        t_lo = load_t(nT - 2);
     }
     for (long long k = nT - 2; k >= 0; --k) {
         float x0[NX], gin[NX], ext[NZ];
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         for (int r = 0; r < NX; ++r) { x0[r] = x0n[r]; gin[r] = ginn[r]; }
 #pragma unroll
         for (int m = 0; m < NZ; ++m) ext[m] = extn[m];
-        const float h_ = hn;
+        const float h_ = t_hi - t_lo;
         const int ev = evn;
         f4 cz = c0;
 #pragma unroll
@@ -351,14 +363,17 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         }
 
         // ---- phase B: stages backwards.  The next step's inputs are requested here and consumed a whole backward half later.
+        // (unconditional, with the row indices clamped at the first step: a branch around the loads makes their results phi values, the
+        //  copies into the phi registers land inside the branch, and the wait for them with it -- the whole memory round trip, every step)
         auto prefetch_next = [&]() {
-            if (k > 0) {
-                evn = event_of(k - 1);
-                load_x2(a.xs, k - 1, x0n);
-                load_x2(a.gout, k, ginn);
-                load_ext(k - 1, evn, extn);
-                hn = load_dt(k - 1);
-            }
+            const long long kp = k > 0 ? k - 1 : 0;
+            evn = has_ev ? __builtin_amdgcn_readfirstlane(evr) : -1;          // requested a step ago
+            evr = evp[k >= 2 ? k - 2 : 0];
+            load_x2(a.xs, kp, x0n);
+            load_x2(a.gout, kp + 1, ginn);
+            load_ext(kp, evn, extn);
+            t_hi = t_lo;
+            t_lo = load_t(kp);
         };
         if constexpr (!STREAM) prefetch_next();
         float gks[S][NX], gx0[NX];

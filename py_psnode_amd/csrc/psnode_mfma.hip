@@ -18,7 +18,7 @@ int mfma_hidden(const MlpDev& m, int in_dim, int out_dim) {
 bool mfma_ode_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, false)) return a.a0 == nullptr || latent_ptrs_ok(a, false);   // a0 == NULL: dims-only query
     if (latent64_shape_ok(a, false)) return a.a0 == nullptr || latent64_ptrs_ok(a, false);
-    if (a.xd < 1 || a.xd > 4 * kNXc || !mfma_hidden(a.de, 3 * (a.xd + a.zd), a.xd)) return false;
+    if (a.xd < 1 || a.xd > 4 * kNXw || !mfma_hidden(a.de, 3 * (a.xd + a.zd), a.xd)) return false;
     return nzm_of(a, false) <= kMaxNZM;       // z_dim <= 8
 }
 

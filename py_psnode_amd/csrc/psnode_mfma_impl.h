@@ -525,13 +525,13 @@ inline int nzm_of(const IntegrateDev& a, bool dae) { return (2 * (a.zd + (dae ? 
 inline int nza_of(const IntegrateDev& a) { return (a.zd + a.vd + 3) / 4; }
 inline int na_of(const IntegrateDev& a, bool dae) { return (a.xd + a.zd + (dae ? a.vd + a.id : 0) + 3) / 4; }
 
-template <int NWV, int METHOD, bool TRUE_X>
+template <int NWV, int METHOD, bool TRUE_X, int NXR = kNXc>
 hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
     const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
     const int NZM = nzm_of(a, dae), NZA = dae ? nza_of(a) : 0;
 #define PSNODE_LAUNCH(NZM_, NZA_, DAE_)                                                                                    \
     {                                                                                                                      \
-        auto kern = &integrate_mfma_kernel<METHOD, kNXc, NZM_, NZA_, TRUE_X, DAE_, NWV>;                                  \
+        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, TRUE_X, DAE_, NWV>;                                   \
         const size_t lds = ae_weights_in_lds(DAE_, NWV) ? ae_lds_bytes(NWV) : 0;                                           \
         if (lds) {                                                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
@@ -551,6 +551,8 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
             default: return hipErrorNotSupported;
         }
     }
+    if constexpr (NXR != kNXc) return hipErrorNotSupported;     // the DAE kernels hold two register-resident MLPs: x_dim <= 8
+    else
     switch (NZM * 10 + NZA) {
         case 11: PSNODE_LAUNCH(1, 1, true)
         case 21: PSNODE_LAUNCH(2, 1, true)
@@ -565,6 +567,10 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
 
 template <int NWV, int METHOD>
 hipError_t launch_method(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
+    if (a.xd > 4 * kNXc) {     // x_dim 9..16: four x registers per lane (ODE only), 16-byte L4 all-reduce
+        if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_shape<NWV, METHOD, true, kNXw>(a, dae, pde, pae, NA, s);
+        return launch_shape<NWV, METHOD, false, kNXw>(a, dae, pde, pae, NA, s);
+    }
     if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_shape<NWV, METHOD, true>(a, dae, pde, pae, NA, s);
     return launch_shape<NWV, METHOD, false>(a, dae, pde, pae, NA, s);
 }
@@ -576,7 +582,7 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     const int ne = a.zd + (dae ? a.vd + a.id : 0);
     PackMfma p;
     p.ae = 0; p.nw = NWV; p.xd = a.xd; p.ne = ne; p.n = a.xd + ne; p.nzv = a.zd + (dae ? a.vd : 0);
-    p.NX = kNXc; p.NB = 0; p.NE = NZM; p.NA = NA; p.fold = 1; p.hreal = a.de.out_dim[0];
+    p.NX = a.xd > 4 * kNXc ? kNXw : kNXc; p.NB = 0; p.NE = NZM; p.NA = NA; p.fold = 1; p.hreal = a.de.out_dim[0];
     p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
     p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
     p.out_dim = a.xd;

@@ -9,7 +9,8 @@ namespace psnode {
 constexpr int HID = 64;        // hidden width of the backward kernel (the forward kernels take NWV = hidden / 16)
 constexpr int NW = HID / 16;   // waves per workgroup at hidden 64
 constexpr int TBM = 16;        // trajectories per workgroup
-constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8
+constexpr int kNXc = 2;        // x registers per lane: x_dim <= 4*kNXc = 8 (every kernel family)
+constexpr int kNXw = 4;        // ... and 4 for x_dim 9..16 (x_dim is data-defined upstream, neural_00_ODE_01_no_encode.py:293): the ODE forward K1
 constexpr int kMaxNZM = 4;     // per-step external MFMAs of the DE: 2*(z+v+i) <= 16
 
 // Forward image of one MLP.

@@ -35,6 +35,8 @@ def _rows(seq, inp):
     Linear-ELU-Linear with hidden 16 / 64): forward kernel alone without autograd, forward + fused backward kernel under it;
     otherwise the module itself (CPU, other widths)."""
     from . import fused
+    if fused._overrides_forward_hooks(seq) or any(fused._overrides_forward_hooks(m) for m in seq):
+        return seq(inp)          # user hooks on the module or its layers must fire: the module itself, layer by layer
     layers = fused.rows_layers_of(seq, inp, allow_grad=True)
     if layers is None:
         return seq(inp)

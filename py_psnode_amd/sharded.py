@@ -75,7 +75,7 @@ def chunk_bounds(T: int, chunks: int):
 
 
 def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, group, gather: bool, wait: bool, want_local: bool,
-               check_shards: bool = True):
+               check_shards: bool = True, layout: str = "chunks"):
     """Shared driver of the time-chunked integrate / all-gather pipeline.  `launch(s, r1, starts, outs)` integrates grid points
     s..r1-1 from the state rows `starts` (None for the first chunk) into the buffers `outs` ([r1-s, Bl, D] each).
 
@@ -87,6 +87,12 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
     if gather and check_shards:
         require_equal_shards(Bl, device, group)
     works, gathered, local_rows = [], [[] for _ in widths], [[] for _ in widths]
+    # layout "batch": the gather of every chunk lands in ONE [T, G*Bl, D] tensor per output -- rank r's rows at [:, r*Bl:(r+1)*Bl] -- so
+    # that no assemble() pass follows.  RCCL writes contiguous buffers only: c10d's list all_gather stages each chunk flat and scatters it
+    # into the strided views ON THE COLLECTIVE'S STREAM, i.e. the copy assemble() made afterwards on the compute stream now rides behind
+    # each chunk's gather, overlapped with the integration of the next chunk.  layout "chunks" (default) stays zero-copy: per-chunk
+    # rank-major buffers.
+    full = [torch.empty((T, world * Bl, d), dtype=dtype, device=device) for d in widths] if (gather and layout == "batch") else None
     prev = None
     for c in range(len(b) - 1):
         r0, r1 = b[c], b[c + 1]
@@ -98,7 +104,10 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
             rows = o[r0 - s:]                   # rows r0..r1-1 of output k (contiguous view of the chunk buffer)
             if want_local:
                 local_rows[k].append(rows)
-            if gather:
+            if gather and full is not None:
+                views = [full[k][r0:r1, r * Bl:(r + 1) * Bl] for r in range(world)]
+                works.append(dist.all_gather(views, rows.contiguous(), group=group, async_op=True))
+            elif gather:
                 buf = torch.empty((world * (r1 - r0), Bl, widths[k]), dtype=dtype, device=device)
                 works.append(dist.all_gather_into_tensor(buf, rows, group=group, async_op=True))
                 gathered[k].append((r0, r1, buf.view(world, r1 - r0, Bl, widths[k])))
@@ -106,12 +115,14 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
     if wait:
         for wk in works:
             wk.wait()
+    if full is not None:
+        gathered = full
     return local, gathered, works
 
 
 def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=None, z_jump=None, chunks: int = 4, group=None,
                             local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, want_local: bool = True,
-                            check_shards: bool = True, **kw):
+                            check_shards: bool = True, layout: str = "chunks", **kw):
     """Time-chunked integrate with the all-gather of finished chunks overlapped with the integration of later ones.
 
     The all-gather of one [T, Bl, xd] shard set at 8 GPUs moves ~0.9 GB into every GPU -- about as long as the
@@ -119,7 +130,8 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
     kernels read only x[0]), which is bit-identical to one long launch.  Each finished chunk is all-gathered with
     async_op=True: RCCL runs it on its own stream after the chunk's kernel, concurrently with the next chunk's kernel.
     Returns (xs_local[T,Bl,xd] or None, gathered) where `gathered` is a list of per-chunk rank-major buffers
-    [(r0, r1, buf[G, r1-r0, Bl, xd])] -- the reassembled batch in time-chunk-major order (no extra copy).  `want_local=False`
+    [(r0, r1, buf[G, r1-r0, Bl, xd])] -- the reassembled batch in time-chunk-major order (no extra copy) -- or, with
+    layout="batch", the plain [T, G*Bl, xd] tensor the chunks were gathered INTO (see _pipelined).  `want_local=False`
     skips the concatenation of the local chunks (this rank's rows are in `gathered` anyway).
     """
     if local_fn is None:
@@ -132,7 +144,8 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
         ev = None if event_idx is None else event_idx[s:r1 - 1]
         local_fn(method, de_layers, t[s:r1], x_start, z[s:r1], all_initial, z_jump=z_jump, event_idx=ev, out=outs[0], **kw)
 
-    local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local, check_shards)
+    local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local, check_shards,
+                                        layout)
     if not wait:
         return local[0], gathered[0], works      # caller waits (bench.py brackets the compute stream before waiting)
     return local[0], gathered[0]
@@ -140,7 +153,7 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
 
 def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_idx=None, z_jump=None, v_jump=None,
                             chunks: int = 4, group=None, local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True,
-                            want_local: bool = True, check_shards: bool = True, **kw):
+                            want_local: bool = True, check_shards: bool = True, layout: str = "chunks", **kw):
     """integrate_DAE (no teacher forcing) as integrate_ode_pipelined: xs AND is shards gathered chunk by chunk behind the next
     chunk's kernel.  A chunk restarts from x_init = xs[s]; the launch recomputes i0 = g(xs[s]; z[s], v[s]) itself, which is exactly
     how is[s] was produced (my_solvers.py:121 uses the un-jumped z, v of the right grid point), so the restart is bit-identical
@@ -160,7 +173,7 @@ def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, al
                  v_jump=v_jump, event_idx=ev, out=(outs[0], outs[1]), **kw)
 
     local, gathered, works = _pipelined(launch, T, Bl, [xd, idim], x_init.dtype, x_init.device, chunks, group, gather, wait, want_local,
-                                        check_shards)
+                                        check_shards, layout)
     if not wait:
         return tuple(local), tuple(gathered), works
     return tuple(local), tuple(gathered)

@@ -19,6 +19,8 @@ def test_bench_force_dist_runs_the_rccl_path(workload):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", workload, "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--grid", "301", "--batch", "512"]
+    if workload == "dae01":
+        cmd += ["--gather-layout", "batch"]          # RCCL with the list all_gather into strided views of the final tensors
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "launching 1 rank(s) under torch.distributed.run" in res.stderr

@@ -137,11 +137,20 @@ def test_other_shapes_generic(xd, zd, H, nh):
 
 
 @pytest.mark.parametrize("method", METHODS)
-@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (5, 3), (8, 4), (1, 1), (8, 0), (8, 6), (4, 8), (8, 7)])
+@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (5, 3), (8, 4), (1, 1), (8, 0), (8, 6), (4, 8), (8, 7), (12, 2), (16, 4), (9, 0), (13, 8)])
 def test_mfma_kernel_shapes(xd, zd, method):
-    """Every (x_dim, z_dim) class of the MFMA kernel (NX=2; NZM=0..4: z_dim <= 8), forced with kernel='mfma', with events,
-    per-trajectory clocks and a ragged last tile."""
+    """Every (x_dim, z_dim) class of the MFMA kernel (NX=2 for x_dim <= 8, NX=4 for x_dim 9..16 -- x_dim is data-defined upstream,
+    neural_00_ODE_01_no_encode.py:293; NZM=0..4: z_dim <= 8), forced with kernel='mfma', with events, per-trajectory clocks and a
+    ragged last tile."""
     _check_mfma_ode(xd, zd, method, 64)
+
+
+@pytest.mark.parametrize("H", [32, 100, 128])
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_mfma_kernel_wide_state_at_other_hidden_widths(method, H):
+    """x_dim 9..16 at 2 / 8 waves per tile and zero-padded widths."""
+    _check_mfma_ode(12, 2, method, H)
+    _check_mfma_ode(16, 4, method, H)
 
 
 @pytest.mark.parametrize("H", [32, 128])
@@ -382,6 +391,11 @@ def test_auto_picks_mfma_for_reference_shape():
         for k in range(3):
             a.de.out_dim[k] = H
         assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+    for xd_ in (9, 12, 16):                    # x_dim 9..16 (data-defined upstream): four x registers per lane, still MFMA
+        a.x_dim, a.de.in_dim, a.de.out_dim[3] = xd_, 3 * (xd_ + 2), xd_
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+    a.x_dim, a.de.in_dim, a.de.out_dim[3] = 17, 3 * 19, 17
+    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
     ls, t, x, z, a0 = _synthetic_ode(4, 3, H=160)
     with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel above hidden 128
         fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")

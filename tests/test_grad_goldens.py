@@ -15,16 +15,18 @@ from py_psnode_amd import models
 from py_psnode_amd import neural_dae as nd
 
 SOLVERS = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}
-TAGS = ["ode01", "dae01", "ode02", "ode02_h64", "dae02", "dae02_h64", "dae02_z0"]
+TAGS = ["ode01", "dae01", "ode02", "ode02_h64", "dae02", "dae02_h64", "dae02_z0",
+        # round 3 (make_goldens_r3.py): the scripts' argparse default --hidden 128 and --hidden 32 -- K4f (ODE) / K7w (DAE) on the GPU
+        "ode01_h128", "ode01_h32", "dae01_h128", "dae01_h32"]
 TOL_CPU = 2e-5      # same ATen ops in (almost) the same order as the reference
 TOL_GPU = 2e-4
 
 
 def _build(tag):
-    if tag == "ode01":
-        return models.ODE_Model(8, 2, 64)
-    if tag == "dae01":
-        return models.DAE_Model(8, 2, 2, 2, 64)
+    if tag.startswith("ode01"):
+        return models.ODE_Model(8, 2, int(tag.split("_h")[1]) if "_h" in tag else 64)
+    if tag.startswith("dae01"):
+        return models.DAE_Model(8, 2, 2, 2, int(tag.split("_h")[1]) if "_h" in tag else 64)
     if tag.startswith("ode02"):
         return models.ODE_Model(8, 2, 64 if tag.endswith("h64") else 16, direct_encode=True)
     return models.DAE_Model(8, 0 if tag.endswith("z0") else 2, 2, 2, 64 if tag.endswith("h64") else 16, direct_encode=True)
@@ -93,12 +95,14 @@ def test_fused_backward_matches_reference_gradients(tag, method):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["generic", "mfma"])
+@pytest.mark.parametrize("kernel,tag", [("generic", "ode01"), ("mfma", "ode01"), ("wide", "ode01"), ("wide", "ode01_h128"), ("wide", "ode01_h32"),
+                                        ("generic", "ode01_h128"), ("split", "ode01_h128")])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel):
-    """K5 (generic) and K4 (mfma) through the raw-tensor API against the reference's ODE_01 gradients."""
+def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel, tag):
+    """K5 (generic), K4 (mfma, hidden 64), K4f (wide: the one-launch backward at hidden 32 / 64 / 128) and round 2's split route through
+    the raw-tensor API against the reference's ODE_01 gradients at the matching --hidden."""
     from py_psnode_amd import fused
-    d = load("g7_grad_ode01.npz")
+    d = load(f"g7_grad_{tag}.npz")
     de = [(w.cuda(), b.cuda()) for w, b in layers(d, "sd__de_func__x_dot")]
     t, x, z = tm(d["t"]).cuda(), tm(d["x"]).cuda(), tm(d["z"]).cuda()
     ev, zj = T(d["event_t"]).cuda(), T(d["z_jump"]).cuda()

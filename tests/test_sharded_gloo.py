@@ -108,6 +108,11 @@ def _check_dae_pipelined(rank, world, sharded):
     rx, ri = T(d["rk4_tx0_ti0_ev1_x"]), T(d["rk4_tx0_ti0_ev1_i"])
     assert float((X - rx).abs().max()) <= 2e-6 and float((I - ri).abs().max()) <= 2e-6
     assert torch.equal(xl, X[:, lo:hi]) and torch.equal(il, I[:, lo:hi])
+    # layout="batch": both outputs gathered straight into their final [T, G*Bl, D] tensors
+    _, (fx, fi) = sharded.integrate_dae_pipelined("rk4", de, ae, xi[lo:hi], t[:, lo:hi], z[:, lo:hi], v[:, lo:hi], i[:, lo:hi], a0[lo:hi],
+                                                  event_idx=tab, z_jump=zj[lo:hi], v_jump=vj[lo:hi], chunks=4, local_fn=_oracle_dae_local,
+                                                  layout="batch", want_local=False)
+    assert torch.equal(fx, X) and torch.equal(fi, I)
 
 
 def _table(t, event_t):
@@ -139,6 +144,10 @@ def _worker(rank, world, port, q):
         xs_l, gathered = sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab,
                                                          z_jump=zj[lo:hi], chunks=3, local_fn=_oracle_local)
         assert torch.equal(sharded.assemble(gathered, tl.shape[0]), out), "pipelined gather differs from the one-shot gather"
+        # layout="batch": every chunk's gather lands directly in the final [T, G*Bl, xd] tensor -- no assemble() pass
+        _, full = sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab, z_jump=zj[lo:hi],
+                                                  chunks=3, local_fn=_oracle_local, layout="batch", want_local=False)
+        assert isinstance(full, torch.Tensor) and full.is_contiguous() and torch.equal(full, out), "in-place gather differs"
         assert sharded.chunk_bounds(1001, 4) == [0, 250, 500, 751, 1001] and sharded.chunk_bounds(2, 4) == [0, 1, 2]
         assert torch.equal(xs_l, out[:, lo:hi]), "local rows of the pipelined run differ from this rank's slice of the gather"
         _check_dae_pipelined(rank, world, sharded)
