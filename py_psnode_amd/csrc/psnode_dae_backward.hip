@@ -423,24 +423,33 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
     // z or v column of grid point k (ev >= 0: of event ev's jump values) for a slot of kind 0 (z) / 1 (v).  Both sources are
     // read with a clamped column and the VALUE is selected: selecting between the two base pointers per lane makes the
     // compiler build a pointer table in scratch.
-    auto zv_at = [&](const long long k, const int ev, const int kind, const int col) -> float {
-        float zval = 0.0f, vval = 0.0f;
-        if (zd > 0) zval = (ev >= 0 ? zjp + ev * zje : zp + k * zst)[kind == 0 ? col : 0];
-        if (vd > 0) vval = (ev >= 0 ? vjp + ev * vje : vp + k * vst)[kind == 1 ? col : 0];
-        return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
+    // (round 3: ONE load per slot from a per-lane row pointer selected behind the step-dependent offsets -- two loads and a select of the
+    //  values put an s_waitcnt vmcnt(0) right behind the loads, three memory round trips per step in the ISA; selecting between the
+    //  loop-invariant base pointers instead is what made the compiler build a pointer table in scratch)
+    struct Rows3 { const float *z, *v, *i; };
+    auto rows_of = [&](const long long k, const int ev) -> Rows3 {
+        Rows3 r;
+        r.z = ev >= 0 ? zjp + ev * zje : zp + k * zst;
+        r.v = ev >= 0 ? vjp + ev * vje : vp + k * vst;
+        r.i = d.is_ + (k * a.B + b) * idim;
+        return r;
     };
-    // DE ext of step k: z|v (jumped at an event step), algebraic slots from the saved is[k] unless an event recomputes them
+    auto slot_at = [&](const Rows3& r, const int kind, const int col) -> float {
+        float val = 0.0f;
+        if (kind != 3) val = (kind == 0 ? r.z : (kind == 1 ? r.v : r.i))[col];
+        return val;
+    };
+    // DE ext of step k: z|v (jumped at an event step), algebraic slots from the saved is[k] (at an event step the recomputed i overwrites them)
     auto load_ext = [&](const long long k, const int ev, ArrD<NZM>& dst) {
+        const Rows3 r = rows_of(k, ev);
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) {
-            if (ekind[m] == 2) dst.v[m] = ev >= 0 ? 0.0f : d.is_[(k * a.B + b) * idim + ecol[m]];
-            else dst.v[m] = zv_at(k, ev, ekind[m], ecol[m]);
-        }
+        for (int m = 0; m < NZM; ++m) dst.v[m] = slot_at(r, ekind[m], ecol[m]);
     };
     // AE ext of grid point k: raw z|v; AE slot (m, g) <-> q = 4m+g < nzv -- the DE's first-block slot of the same (m, g)
     auto load_zva = [&](const long long k, ArrD<NZA>& dst) {
+        const Rows3 r = rows_of(k, -1);
 #pragma unroll
-        for (int m = 0; m < NZA; ++m) dst.v[m] = 4 * m + g < nzv ? zv_at(k, -1, ekind[m], ecol[m]) : 0.0f;
+        for (int m = 0; m < NZA; ++m) dst.v[m] = slot_at(r, 4 * m + g < nzv ? ekind[m] : 3, ecol[m]);
     };
     auto load_x = [&](const long long k, float (&xk)[NX]) {
 #pragma unroll
@@ -451,14 +460,17 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
         for (int r = 0; r < NX; ++r) gk[r] = (4 * r + g < xd && valid) ? d.gxs[(k * a.B + b) * xd + 4 * r + g] : 0.0f;
     };
     // upstream dL/dis[k] in tile-E layout (row 0 <-> ext dim g, row 2 <-> ext dim 4+g; only the algebraic dims)
+    // (raw, unconditional, clamped columns; masked with gim0 / gim1 where it is consumed an iteration later -- an `else o = 0` branch next
+    //  to a pending load of the same register makes the compiler wait for the load on the spot)
+    const bool gim0 = d.gis && valid && qlo >= nzv && qlo < ne, gim1 = d.gis && valid && qhi >= nzv && qhi < ne;
+    const float* gis_safe = d.gis ? d.gis : d.gxs;
+    const int gic0 = gim0 ? qlo - nzv : 0, gic1 = gim1 ? qhi - nzv : 0;
+    const long long gi_row = d.gis ? idim : 0;
     auto load_gi = [&](const long long k) -> f2 {
-        f2 o = {0.f, 0.f};
-        if (d.gis && valid) {
-            if (qlo >= nzv && qlo < ne) o[0] = d.gis[(k * a.B + b) * idim + qlo - nzv];
-            if (qhi >= nzv && qhi < ne) o[1] = d.gis[(k * a.B + b) * idim + qhi - nzv];
-        }
-        return o;
+        const float* row = gis_safe + (k * a.B + b) * gi_row;
+        return f2{row[gic0], row[gic1]};
     };
+    auto mask_gi = [&](const f2 raw) -> f2 { return f2{gim0 ? raw[0] : 0.0f, gim1 ? raw[1] : 0.0f}; };
 
     // ---- state of the sweep
     f2 gcarry = {0.f, 0.f};      // adjoint of x at the current grid point, before its own upstream gradient is added
@@ -475,25 +487,37 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
         load_zva(nT - 1, zvj);
         giu = load_gi(nT - 1);
     }
+    // The event index and the clock of a step are RAW values requested one iteration ahead, and this iteration's loads are issued
+    // unconditionally with the step index clamped at 0 (the last iteration breaks before it looks at them): under `if (jg >= 1)` every
+    // result was a phi with a default, the copies into the phi registers -- and the wait for the loads -- sat inside the branch, and the
+    // event index fed the addresses of the very next loads: several exposed memory round trips per step.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
+    int ev_raw = evp[nT >= 2 ? nT - 2 : 0];
+    float t_hi = tp[(nT >= 1 ? nT - 1 : 0) * tst], t_lo = tp[(nT >= 2 ? nT - 2 : 0) * tst];
     for (long long jg = nT - 1; jg >= 0; --jg) {
         // ---- issue every load of this iteration's step and of the next grid point now: they are consumed after the AE head
-        const long long k = jg - 1;
-        int ev = -1;
-        float h_ = 0.0f, x0[NX], gxn[NX];
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): everything in flight was issued an iteration ago -- wait here, before new loads queue up behind it
+        const long long k = jg >= 1 ? jg - 1 : 0;
+        const int ev = has_ev ? ev_raw : -1;
+        const float h_ = t_hi - t_lo;
+        float x0[NX], gxn[NX];
         ArrD<NZM> extv;
         ArrD<NZA> zvn;
         f2 gin = {0.f, 0.f};
-        if (jg >= 1) {
-            ev = a.ev ? a.ev[k] : -1;
-            h_ = tp[jg * tst] - tp[k * tst];
-            load_x(k, x0);
-            load_ext(k, ev, extv);
-            load_gx(k, gxn);
-            load_zva(k, zvn);
-            gin = load_gi(k);
-        }
+        ev_raw = evp[k >= 1 ? k - 1 : 0];
+        t_hi = t_lo;
+        t_lo = tp[(k >= 1 ? k - 1 : 0) * tst];
+        load_x(k, x0);
+        load_ext(k, ev, extv);
+        load_gx(k, gxn);
+        load_zva(k, zvn);
+        gin = load_gi(k);
         // ================= (1) AE head at grid point jg
-        const f4 gi = f4{gicarry[0] + giu[0], 0.f, gicarry[1] + giu[1], 0.f};
+        const f2 gium = mask_gi(giu);
+        const f4 gi = f4{gicarry[0] + gium[0], 0.f, gicarry[1] + gium[1], 0.f};
         const f4 tX = ae_vjp(xj, zvj, gi);
         store_zv(jg, -1, dezv[0] + tX[2], dezv[1] + tX[3]);
         f2 g1 = gcarry + f2{gxj[0], gxj[1]} + f2{tX[0], tX[1]};     // adjoint of x_jg, complete

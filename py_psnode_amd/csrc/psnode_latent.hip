@@ -182,9 +182,12 @@ __global__ __launch_bounds__(64) void latent_kernel(const IntegrateDev a, const 
     float t_cur = tp[0], t_nxt = tp[tst];
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const int* evp = a.ev + lane_zero;
-    int ev_cur = a.ev ? a.ev[0] : -1;
-    int ev_n1 = (a.ev && nT > 2) ? evp[1] : -1;
+    // (unconditional prefetch with clamped indices and a raw event-table entry, as K3c: a load inside `if (k + 2 < nT)` is a phi with a
+    //  default, the copy into the loop-carried register and the wait for the whole prefetch sat right behind it)
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
+    int ev_cur = has_ev ? a.ev[0] : -1;
+    int ev_raw = evp[nT > 2 ? 1 : 0];
     F4s<NZV> ext_nxt = {};
     load_blocks(0, ev_cur, ext_nxt);
 
@@ -194,12 +197,14 @@ __global__ __launch_bounds__(64) void latent_kernel(const IntegrateDev a, const 
         const F4s<NZV> extv = ext_nxt;
         const F4s<NZV> zva = zva_nxt;
         const int ev_now = ev_cur;
-        if (k + 2 < nT) {
-            t_nxt = tp[(k + 2) * tst];
-            load_blocks(k + 1, ev_n1, ext_nxt);
-            if constexpr (DAE) load_blocks(k + 2, -1, zva_nxt);
-            ev_cur = ev_n1;
-            ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+        {
+            const bool more = k + 2 < nT;
+            const long long kn = more ? k + 1 : k;                    // the last step re-reads its own inputs (unused)
+            t_nxt = tp[(kn + 1) * tst];
+            ev_cur = (has_ev && more) ? ev_raw : -1;
+            load_blocks(kn, ev_cur, ext_nxt);
+            if constexpr (DAE) load_blocks(kn + 1, -1, zva_nxt);
+            ev_raw = evp[k + 3 < nT ? k + 2 : 0];
         }
         if constexpr (DAE) {
             if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {   // i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)

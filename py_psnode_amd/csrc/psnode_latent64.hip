@@ -220,9 +220,13 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
     float t_cur = tp[0], t_nxt = tp[tst];
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const int* evp = a.ev + lane_zero;
-    int ev_cur = a.ev ? a.ev[0] : -1;
-    int ev_n1 = (a.ev && nT > 2) ? evp[1] : -1;
+    // The prefetch of step k+1 is UNCONDITIONAL (indices clamped at the last step, the event index a raw table entry masked where it
+    // is used): inside `if (more)` the loaded event index was a phi with -1, its copy into the loop-carried register -- and with it an
+    // s_waitcnt vmcnt(0) on the nine loads just issued, a full HBM round trip -- sat in every step (round 3, found in the ISA).
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
+    int ev_cur = has_ev ? a.ev[0] : -1;
+    int ev_raw = evp[nT > 2 ? 1 : 0];
     Ext ext_nxt = {};
     load_ext(0, ev_cur, ext_nxt);
 
@@ -232,11 +236,12 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         const Ext extv = ext_nxt;
         const int ev_now = ev_cur;
         const bool more = k + 2 < nT;
-        if (more) {
-            t_nxt = tp[(k + 2) * tst];
-            load_ext(k + 1, ev_n1, ext_nxt);
-            ev_cur = ev_n1;
-            ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
+        {
+            const long long kn = more ? k + 1 : k;                    // the last step re-reads its own inputs (unused)
+            t_nxt = tp[(kn + 1) * tst];
+            ev_cur = (has_ev && more) ? ev_raw : -1;
+            load_ext(kn, ev_cur, ext_nxt);
+            ev_raw = evp[k + 3 < nT ? k + 2 : 0];
         }
         if constexpr (DAE) {
             if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {   // i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)

@@ -183,18 +183,20 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     const float* zjp = (has_z && a.zj) ? a.zj + b * a.zjb : tp;
     const float* vp = has_v ? a.v.p + b * a.v.sb : tp;
     const float* vjp = (has_v && a.vj) ? a.vj + b * a.vjb : tp;
-    // column a slot reads from the z row / the v row (0 = harmless dummy when the slot is of the other kind)
-    int ezc[NZM > 0 ? NZM : 1], evc[NZM > 0 ? NZM : 1], azc[NZA > 0 ? NZA : 1], avc[NZA > 0 ? NZA : 1];
+    // column a slot reads in the row of ITS source (z row or v row; algebraic / padding slots read column 0 of the z row: the value is
+    // replaced by i, or meets a zero weight)
+    int esc[NZM > 0 ? NZM : 1], asc[NZA > 0 ? NZA : 1];
 #pragma unroll
-    for (int m = 0; m < NZM; ++m) { ezc[m] = (has_z && ekind[m] == 0) ? ecol[m] : 0; evc[m] = (has_v && ekind[m] == 1) ? ecol[m] : 0; }
+    for (int m = 0; m < NZM; ++m) esc[m] = ((has_z && ekind[m] == 0) || (has_v && ekind[m] == 1)) ? ecol[m] : 0;
 #pragma unroll
-    for (int m = 0; m < NZA; ++m) { azc[m] = (has_z && akind[m] == 0) ? acol[m] : 0; avc[m] = (has_v && akind[m] == 1) ? acol[m] : 0; }
+    for (int m = 0; m < NZA; ++m) asc[m] = ((has_z && akind[m] == 0) || (has_v && akind[m] == 1)) ? acol[m] : 0;
 
     // z|v columns of grid point k for the ext slots (ev >= 0: the batch takes the jump values for this step).  In the DAE a lane's
-    // slot may be a z or a v column: BOTH sources are read and the value is selected WHEN IT IS CONSUMED (a step later) -- selecting
-    // right behind the loads put an s_waitcnt vmcnt(0) behind every prefetch, and selecting between the two base pointers per lane
-    // makes the compiler spill a pointer table to scratch.  `ev` is wave-uniform (read with v_readlane from a 64-step block of the
-    // event table, as K3f): the row offset is scalar arithmetic; a per-lane copy of the index cost 64-bit per-lane multiplies per load.
+    // slot may be a z or a v column: the lane picks the ROW POINTER of its source (two v_cndmask on the step's row pointers) and issues
+    // ONE load -- reading both sources and selecting the value put an s_waitcnt vmcnt(0) behind the prefetch (rounds 1-2 deferred that
+    // select by a step at the price of a second register per slot), and selecting between the loop-invariant BASE pointers makes the
+    // compiler spill a pointer table to scratch.  `ev` is wave-uniform (read with v_readlane from a 64-step block of the event table,
+    // as K3f): the row offset is scalar arithmetic; a per-lane copy of the index cost 64-bit per-lane multiplies per load.
     struct RowPtr { const float* z; const float* v; };
     auto rows_at = [&](long long k, int ev) -> RowPtr {
         RowPtr r;
@@ -202,31 +204,16 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         r.v = DAE ? (ev >= 0 ? vjp + (long long)ev * vje : vp + k * vst) : r.z;
         return r;
     };
-    // 8 waves per tile (hidden 128) have a second wave per SIMD to hide the wait and no registers for the second copy: they select
-    // at load time (the value travels in the z array).
-    constexpr bool DEFER_PICK = NWV <= 4;
-    auto pick = [&](int kind, float zval, float vval) -> float {
-        if constexpr (!DEFER_PICK || !DAE) return zval;      // ODE: a padding slot reads z column 0 against a ZERO weight (psnode_pack.h)
-        return kind == 0 ? zval : (kind == 1 ? vval : 0.0f);
-    };
-    auto pick_now = [&](int kind, float zval, float vval) -> float { return kind == 0 ? zval : (kind == 1 ? vval : 0.0f); };
-    auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>& dv) {
+    auto pick = [&](int, float val, float) -> float { return val; };     // the load already came from the slot's own source
+    auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>&) {
         const RowPtr rp = rows_at(k, ev);
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) {
-            const float zr = rp.z[ezc[m]], vr = DAE ? rp.v[evc[m]] : 0.0f;
-            if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
-            else dz.v[m] = pick_now(ekind[m], zr, vr);
-        }
+        for (int m = 0; m < NZM; ++m) dz.v[m] = ((DAE && ekind[m] == 1) ? rp.v : rp.z)[esc[m]];
     };
-    auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>& dv) {
+    auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>&) {
         const RowPtr rp = rows_at(k, ev);
 #pragma unroll
-        for (int m = 0; m < NZA; ++m) {
-            const float zr = rp.z[azc[m]], vr = rp.v[avc[m]];
-            if constexpr (DEFER_PICK) { dz.v[m] = zr; dv.v[m] = vr; }
-            else dz.v[m] = pick_now(akind[m], zr, vr);
-        }
+        for (int m = 0; m < NZA; ++m) dz.v[m] = (akind[m] == 1 ? rp.v : rp.z)[asc[m]];
     };
     auto pick_ae = [&](const Arr<NZA>& dz, const Arr<NZA>& dv) -> Arr<NZA> {
         Arr<NZA> o = {};
