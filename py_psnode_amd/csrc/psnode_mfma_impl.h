@@ -238,21 +238,32 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     auto mid = [&](const float (&wm)[4 * NWV], const f4 bias, const f4 h) -> f4 {
         xbuf[p][w][l] = h;
         f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
-        // the wave's own K quarter goes in front of the barrier (covers the LDS write); behind it ALL reads are issued before the
-        // first dependent MFMA (sched_barrier pins that order: left alone, the compiler serialises read -> wait -> 4 MFMAs three
-        // times, +0.25 ms per launch on K1).  Moving own-quarter MFMAs behind the reads instead measured 2.5 % slower.
-        accA = mfma4(wm[0], h[0], accA);
-        accB = mfma4(wm[1], h[1], accB);
-        accA = mfma4(wm[2], h[2], accA);
-        accB = mfma4(wm[3], h[3], accB);
+        // PSNODE_MID_PRE of the wave's own K-quarter MFMAs are PINNED in front of the barrier (they cover the LDS write), the rest go
+        // behind the reads (they cover the read latency).  Where an MFMA ends up relative to s_barrier is otherwise decided before the
+        // machine scheduler runs (the intrinsic is pure, the barrier only orders memory): sched_barrier does not hold it.  Round 3 found
+        // 1 in front / 3 behind in the ISA of a source that says 4 in front; the empty asm statements make the split explicit.
+#ifndef PSNODE_MID_PRE
+#define PSNODE_MID_PRE 2
+#endif
+        constexpr int PRE = PSNODE_MID_PRE;
+        if constexpr (PRE >= 1) accA = mfma4(wm[0], h[0], accA);
+        if constexpr (PRE >= 2) accB = mfma4(wm[1], h[1], accB);
+        if constexpr (PRE >= 3) accA = mfma4(wm[2], h[2], accA);
+        if constexpr (PRE >= 4) accB = mfma4(wm[3], h[3], accB);
+        if constexpr (PRE >= 1) asm volatile("" : "+v"(accA), "+v"(accB));
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
         f4 vq[NWV];
         if constexpr (PREFETCH_ALL) {
 #pragma unroll
             for (int c = 1; c < NWV; ++c) vq[c] = xbuf[p][(w + c) & (NWV - 1)][l];
+            if constexpr (PRE < 4) asm volatile("" : "+v"(accA), "+v"(accB));      // the remaining own-quarter MFMAs stay behind the read issue
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PRE < 1) accA = mfma4(wm[0], h[0], accA);
+        if constexpr (PRE < 2) accB = mfma4(wm[1], h[1], accB);
+        if constexpr (PRE < 3) accA = mfma4(wm[2], h[2], accA);
+        if constexpr (PRE < 4) accB = mfma4(wm[3], h[3], accB);
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
             const f4 v = PREFETCH_ALL ? vq[c] : xbuf[p][(w + c) & (NWV - 1)][l];
