@@ -56,8 +56,8 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x)
 // v_mfma_f32_16x16x4_f32 is ADDITIVE (32 cycles per MFMA + 5 per VALU instruction + 12 per v_exp, one wave per SIMD;
 // profiles/r02a_ubench_mfma.txt), so the ELU's instruction count is wall time of every kernel in this library.
 //
-// Round 3 (default):   ELU(x) = max(x, 0) + (exp2(min(x, 0) * log2e) - 1)
-//   x > 0: the second term is exp2(0) - 1 = 0 exactly, ELU(x) = x bit for bit.  x <= 0: t = exp2(..) carries <= 1 ulp(t) <= 6e-8
+// Round 3 (default):   ELU(x) = max(x, exp2(min(x, 0) * log2e) - 1)        [= max(x, 0) + (exp2(min(x, 0) log2e) - 1), one add less]
+//   x > 0: the exponential side is exp2(0) - 1 = 0 exactly, ELU(x) = x bit for bit.  x <= 0: t = exp2(..) carries <= 1 ulp(t) <= 6e-8
 //   of ABSOLUTE error, t - 1 is exact for t >= 0.5 (Sterbenz) and rounds once below: |ELU - expm1(x)| <= 1.2e-7 everywhere.  What it
 //   gives up against the round-1/2 form below is RELATIVE accuracy for x -> 0-: the result is a multiple of 6e-8 there.  The next
 //   thing that happens to an ELU output is a dot product with a weight row, where an absolute 6e-8 on a value that is itself tiny
@@ -95,11 +95,13 @@ __device__ __forceinline__ elu_f2 elu_splat(float c) {
 __device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const float knee, const float neg_t0, const elu_f2 c4, const elu_f2 c3,
                                            const elu_f2 c2, const elu_f2 c1) {
 #ifndef PSNODE_ELU_EXPM1
+    // = max(x, exp2(min(x,0) log2e) - 1): e^x - 1 >= x everywhere, so the max picks x for x > 0 (where the other side is exactly 0)
+    // and the exponential side for x <= 0 -- one packed add less than max(x,0) + (..)
     const elu_f2 xn = elu_f2{fminf(x[0], 0.0f), fminf(x[1], 0.0f)};
-    const elu_f2 xq = elu_f2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
     const elu_f2 yq = xn * kLog2e;
     const elu_f2 tq = elu_f2{__builtin_amdgcn_exp2f(yq[0]), __builtin_amdgcn_exp2f(yq[1])};
-    return xq + (tq - 1.0f);
+    const elu_f2 uq = tq - 1.0f;
+    return elu_f2{fmaxf(x[0], uq[0]), fmaxf(x[1], uq[1])};
 #endif
     const elu_f2 xc = elu_f2{__builtin_amdgcn_fmed3f(x[0], knee, 0.0f), __builtin_amdgcn_fmed3f(x[1], knee, 0.0f)};
     const elu_f2 xe = elu_f2{fminf(x[0], knee), fminf(x[1], knee)};

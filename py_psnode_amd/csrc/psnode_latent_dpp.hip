@@ -88,7 +88,7 @@ struct EluS {
     float knee, neg_t0;
     __device__ __forceinline__ float operator()(const float x) const {
 #ifndef PSNODE_ELU_EXPM1
-        return fmaxf(x, 0.0f) + (__builtin_amdgcn_exp2f(fminf(x, 0.0f) * kLog2e) - 1.0f);
+        return fmaxf(x, __builtin_amdgcn_exp2f(fminf(x, 0.0f) * kLog2e) - 1.0f);
 #endif
         const float xc = __builtin_amdgcn_fmed3f(x, knee, 0.0f), xe = fminf(x, knee), xp = fmaxf(x, 0.0f);
         const float u = __builtin_amdgcn_exp2f(xe * kLog2e) + neg_t0;

@@ -79,7 +79,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
                                                                   const float* __restrict__ pack_ae, const int NA) {
     using RD = Regs<NX, 0, NZM, NWV>;     // folded DE image: no `s - a0` registers for the x dims (psnode_pack.h)
     using RA = Regs<NX, 0, NZA, NWV>;
-    __shared__ f4 xbuf[2][NWV][64];
+    // Exchange buffers: three, used in a FIXED rotation by the three exchanges of an MLP evaluation (L2's gather -> 0, L3's gather -> 1,
+    // L4's all-reduce -> 2), so every LDS address of the time loop is a loop-invariant immediate.  A buffer is rewritten two barriers
+    // after its last read.  With two buffers and a running parity bit the Euler step (3 exchanges: odd) flipped the parity from step to
+    // step and paid ~10 address instructions per step for it (RK4 and Midpoint happen to have an even count).
+    __shared__ f4 xbuf[3][NWV][64];
     // 8 waves of 64 lanes leave 256 VGPRs per lane: the DAE's second weight set does not fit next to the DE's, so the
     // AE's H->H weights live in (dynamic) LDS, each lane reading back exactly the A-operand values it wrote.
     constexpr bool AE_LDS = ae_weights_in_lds(DAE, NWV);
@@ -205,16 +209,16 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         return r;
     };
     auto pick = [&](int, float val, float) -> float { return val; };     // the load already came from the slot's own source
-    auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>&) {
-        const RowPtr rp = rows_at(k, ev);
+    auto load_de_rows = [&](const RowPtr rp, Arr<NZM>& dz) {
 #pragma unroll
         for (int m = 0; m < NZM; ++m) dz.v[m] = ((DAE && ekind[m] == 1) ? rp.v : rp.z)[esc[m]];
     };
-    auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>&) {
-        const RowPtr rp = rows_at(k, ev);
+    auto load_ae_rows = [&](const RowPtr rp, Arr<NZA>& dz) {
 #pragma unroll
         for (int m = 0; m < NZA; ++m) dz.v[m] = (akind[m] == 1 ? rp.v : rp.z)[asc[m]];
     };
+    auto load_de_raw = [&](long long k, int ev, Arr<NZM>& dz, Arr<NZM>&) { load_de_rows(rows_at(k, ev), dz); };
+    auto load_ae_raw = [&](long long k, int ev, Arr<NZA>& dz, Arr<NZA>&) { load_ae_rows(rows_at(k, ev), dz); };
     auto pick_ae = [&](const Arr<NZA>& dz, const Arr<NZA>& dv) -> Arr<NZA> {
         Arr<NZA> o = {};
 #pragma unroll
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         return v;
     };
 
-    int p = 0;   // exchange buffer parity
+    int p = 0;   // exchange buffer of the next H->H layer (0, 1, 0, 1, ...: two per evaluation); the output all-reduce uses buffer 2
     // 4 waves per tile = one per SIMD: nothing else hides the exchange latency, so all reads are put in flight at once (12 VGPRs).
     // 8 waves (hidden 128) have a second wave per SIMD to hide it and no registers to spare.
     constexpr bool PREFETCH_ALL = NWV <= 4;
@@ -240,10 +244,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
         // PSNODE_MID_PRE of the wave's own K-quarter MFMAs are PINNED in front of the barrier (they cover the LDS write), the rest go
         // behind the reads (they cover the read latency).  Where an MFMA ends up relative to s_barrier is otherwise decided before the
-        // machine scheduler runs (the intrinsic is pure, the barrier only orders memory): sched_barrier does not hold it.  Round 3 found
+        // machine scheduler runs (the intrinsic is pure, the barrier only orders memory): sched_barrier does not hold it.  Same-box A/B of the split
+        // (profiles/r03i_mid_pre_ab.txt, r03j_mid_pre_ab.txt; K1 RK4 ms): 0 in front 4.04, 1: 3.88, 2: 3.83, 3: 3.77, 4: 3.90 -- 3 / 1 it is.  Round 3 found
         // 1 in front / 3 behind in the ISA of a source that says 4 in front; the empty asm statements make the split explicit.
 #ifndef PSNODE_MID_PRE
-#define PSNODE_MID_PRE 2
+#define PSNODE_MID_PRE 3
 #endif
         constexpr int PRE = PSNODE_MID_PRE;
         if constexpr (PRE >= 1) accA = mfma4(wm[0], h[0], accA);
@@ -319,18 +324,17 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         f4 out = t.b4;
         if constexpr (ROWS2) {
             typedef float f2 __attribute__((ext_vector_type(2)));
-            f2* xb2 = reinterpret_cast<f2*>(&xbuf[p][0][0]);
+            f2* xb2 = reinterpret_cast<f2*>(&xbuf[2][0][0]);
             xb2[w * 64 + l] = f2{part[0], part[1]};
             lds_barrier();
 #pragma unroll
             for (int c = 0; c < NWV; ++c) { const f2 q = xb2[c * 64 + l]; out[0] += q[0]; out[1] += q[1]; }
         } else {
-            xbuf[p][w][l] = part;
+            xbuf[2][w][l] = part;
             lds_barrier();
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) out += xbuf[p][c][l];
+            for (int c = 0; c < NWV; ++c) out += xbuf[2][c][l];
         }
-        p ^= 1;
         return out;
     };
     // DE right-hand side at xs with this step's constant part cz
@@ -360,23 +364,23 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
         for (int r = 0; r < NX; ++r) dst[r] = 4 * r + g < xd ? a.x.p[k * a.x.st + b * a.x.sb + 4 * r + g] : 0.0f;
     };
-    auto store_x = [&](long long k) {
+    auto store_x_at = [&](float* o) {        // o = this trajectory's output row
         if (w == 0 && valid) {
-            float* o = a.xo + (k * a.B + b) * xd;
 #pragma unroll
             for (int r = 0; r < NX; ++r) if (4 * r + g < xd) o[4 * r + g] = x[r];
         }
     };
+    auto store_x = [&](long long k) { store_x_at(a.xo + (k * a.B + b) * xd); };
     // i_out: each i-dim is stored from its `s`-block slot (q >= ne) so that exactly one lane group writes it
-    auto store_i = [&](long long k, const f4 iv) {
+    auto store_i_at = [&](float* o, const f4 iv) {
         if constexpr (DAE) {
             if (w == 1 && valid) {
-                float* o = a.io + (k * a.B + b) * idim;
 #pragma unroll
                 for (int m = 0; m < NZM; ++m) if (ekind[m] == 2 && 4 * m + g >= ne) o[ecol[m]] = iv[m];
             }
         }
     };
+    auto store_i = [&](long long k, const f4 iv) { if constexpr (DAE) store_i_at(a.io + (k * a.B + b) * idim, iv); };
 
     store_x(0);
     f4 icur = f4{0.f, 0.f, 0.f, 0.f};
@@ -410,6 +414,15 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     int ev_n1 = (!UNIFORM_EV && a.ev && nT > 2) ? evp[1] : -1;
     Arr<NZM> exz_nxt = {}, exv_nxt = {};
     load_de_raw(0, ev_cur, exz_nxt, exv_nxt);
+    // Running row pointers of the time loop (one 64-bit add per array and step instead of a 64-bit multiply per load): the clock entry the
+    // next prefetch reads (t[k+2]), the z / v rows of grid point k+1, the output rows of the deferred store.  They stop advancing at the
+    // last row, so the prefetch of the final step re-reads valid rows (its results are never used).
+    const float* trun = tp + (nT > 2 ? 2 : nT - 1) * tst;
+    const float* zrun = zp + zst;
+    const float* vrun = vp + vst;
+    float* xo_run = a.xo + (a.B + b) * xd;                            // row 1
+    float* io_run = DAE ? a.io + (a.B + b) * idim : nullptr;
+    const long long xo_step = a.B * xd, io_step = a.B * idim;
 
     for (long long k = 0; k + 1 < nT; ++k) {
         // Everything still in flight here was issued a whole step ago (the prefetch of this step's inputs, the previous result's
@@ -429,8 +442,9 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         // front of the loop-top s_waitcnt vmcnt(0) (the only count that is safe on the waves that do not store), and the storing
         // wave -- hence, through the barriers, the whole tile -- waited out the store's round trip every step.
         if (k > 0) {
-            store_x(k);
-            if constexpr (DAE) store_i(k, icur);
+            store_x_at(xo_run);
+            xo_run += xo_step;
+            if constexpr (DAE) { store_i_at(io_run, icur); io_run += io_step; }
         }
 
         float xsrc[NX];
@@ -449,9 +463,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             }
         }
-        // prefetch the next step's inputs (consumed one full step later)
-        if (k + 2 < nT) {
-            t_nxt = tp[(k + 2) * tst];
+        // prefetch the next step's inputs (consumed one full step later): unconditional -- inside `if (k + 2 < nT)` the results are phis
+        // whose copies (and the wait for the loads) land in the branch
+        {
+            const bool more = k + 2 < nT;
+            t_nxt = *trun;
             if constexpr (UNIFORM_EV) {
                 if (((k + 1) & 63) == 0) evb = load_evb((k + 1) >> 6);
                 ev_cur = __builtin_amdgcn_readlane(evb, (int)((k + 1) & 63));
@@ -459,8 +475,18 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
                 ev_cur = ev_n1;
                 ev_n1 = (a.ev && k + 3 < nT) ? evp[k + 2] : -1;
             }
-            load_de_raw(k + 1, ev_cur, exz_nxt, exv_nxt);
-            if constexpr (DAE) load_ae_raw(k + 2, -1, zaz_nxt, zav_nxt);
+            RowPtr rp;
+            rp.z = zrun; rp.v = vrun;
+            if (__builtin_amdgcn_readfirstlane(ev_cur) >= 0) rp = rows_at(k + 1, ev_cur);    // an event step takes the jump rows
+            load_de_rows(rp, exz_nxt);
+            if constexpr (DAE) {
+                RowPtr ra;
+                ra.z = zrun + (more ? zst : 0); ra.v = vrun + (more ? vst : 0);            // raw z|v of grid point k+2
+                load_ae_rows(ra, zaz_nxt);
+            }
+            trun += (k + 3 < nT) ? tst : 0;
+            zrun += more ? zst : 0;
+            vrun += more ? vst : 0;
         }
         if constexpr (DAE) {
             // event: i0 = g(x0; z_jump, v_jump) with the RUNNING state (my_solvers.py:108-110)
@@ -515,8 +541,8 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             icur = ae_eval(xa, zva);
         }
     }
-    store_x(nT - 1);
-    if constexpr (DAE) store_i(nT - 1, icur);
+    store_x_at(xo_run);
+    if constexpr (DAE) store_i_at(io_run, icur);
 }
 
 inline int nzm_of(const IntegrateDev& a, bool dae) { return (2 * (a.zd + (dae ? a.vd + a.id : 0)) + 3) / 4; }
