@@ -1,0 +1,10 @@
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+lib() { if [ "$1" = tree ]; then echo $R/py_psnode_amd/libpsnode_hip.so; else echo $R/build/var_$1/lib.so; fi; }
+( for r in 1 2 3; do for v in tree k4pre2 k4pre3; do
+  PSNODE_LIB_PATH=$(lib $v) python bench.py --steps 5 --warmup 2 --train --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('round $r $v h64 rk4 train ms', round(d['ms_per_step'],3))"
+done; done
+for r in 1 2; do for v in tree bound0 bound2; do for m in rk4 midpoint euler; do
+  PSNODE_LIB_PATH=$(lib $v) python bench.py --steps 4 --warmup 2 --train --hidden 128 --method $m --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('round $r $v h128 $m train ms', round(d['ms_per_step'],3))"
+done; done; done ) > $O/r03m_bwd_ab.txt 2>&1
+cat $O/r03m_bwd_ab.txt

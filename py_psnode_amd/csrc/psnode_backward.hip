@@ -170,13 +170,29 @@ __global__ __launch_bounds__(256) void ode_backward_kernel(const BwdDev d, const
     auto mid = [&](const float (&wm)[16], const f4 bias, const f4 h) -> f4 {
         xbuf[(p * NW + w) * 64 + l] = h;
         f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
-        accA = bmfma(wm[0], h[0], accA); accB = bmfma(wm[1], h[1], accB);
-        accA = bmfma(wm[2], h[2], accA); accB = bmfma(wm[3], h[3], accB);
+        // own-quarter MFMAs: PSNODE_BWD_MID_PRE of them pinned in front of the barrier, the rest behind the read issue (K1's finding:
+        // psnode_mfma_impl.h `mid`; -1 = leave the placement to the compiler, as rounds 1-2 did).  Same-box A/B of the training step
+        // (profiles/r03m_bwd_ab.txt): unpinned 17.42 ms, 2 in front 17.17, 3 in front 17.25.
+#ifndef PSNODE_BWD_MID_PRE
+#define PSNODE_BWD_MID_PRE 2
+#endif
+        constexpr int PRE = PSNODE_BWD_MID_PRE < 0 ? 4 : PSNODE_BWD_MID_PRE;
+        constexpr bool PIN = PSNODE_BWD_MID_PRE >= 0;
+        if constexpr (PRE >= 1) accA = bmfma(wm[0], h[0], accA);
+        if constexpr (PRE >= 2) accB = bmfma(wm[1], h[1], accB);
+        if constexpr (PRE >= 3) accA = bmfma(wm[2], h[2], accA);
+        if constexpr (PRE >= 4) accB = bmfma(wm[3], h[3], accB);
+        if constexpr (PIN && PRE >= 1) asm volatile("" : "+v"(accA), "+v"(accB));
         lds_barrier();
         f4 vq[4];      // all three reads in flight before the first dependent MFMA (K1: -5 % launch time)
 #pragma unroll
         for (int c = 1; c < 4; ++c) vq[c] = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+        if constexpr (PIN && PRE < 4) asm volatile("" : "+v"(accA), "+v"(accB));
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PRE < 1) accA = bmfma(wm[0], h[0], accA);
+        if constexpr (PRE < 2) accB = bmfma(wm[1], h[1], accB);
+        if constexpr (PRE < 3) accA = bmfma(wm[2], h[2], accA);
+        if constexpr (PRE < 4) accB = bmfma(wm[3], h[3], accB);
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
             const f4 v = vq[c];

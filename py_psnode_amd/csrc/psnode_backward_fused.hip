@@ -49,6 +49,13 @@ struct FusedDev {
     float* ring;                          // NWV >= 8: [S][3][B][H] stage activations of the step in flight
 };
 
+#ifndef PSNODE_K4F_BOUND
+#define PSNODE_K4F_BOUND 3      // 0: never bound the scheduler's read-ahead in the layer loops, 1: always at 8 waves, 2: only at RK4, 3: RK4 + Midpoint
+                                // (profiles/r03m_bwd_ab.txt, hidden-128 training step rk4 / midpoint / euler: 0 -> 65.1 / 28.0 / 11.95 ms, 1 -> 52.8 / 22.9 / 12.19)
+#endif
+#ifndef PSNODE_K4F_EVERY
+#define PSNODE_K4F_EVERY 2      // a sched_barrier behind every EVERY-th chunk
+#endif
 constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l's four rows 4g..4g+3 of column j at 4l + 8g
 
 template <int METHOD, int NZM, int NWV>
@@ -74,6 +81,8 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     // ---- forward image -> registers (as K1), transposed images -> LDS
     const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
     constexpr bool STREAM = NWV >= 8;     // forward / transposed images swapped in LDS per phase; activations through the ring
+    constexpr bool BOUND = STREAM && (PSNODE_K4F_BOUND == 1 || (PSNODE_K4F_BOUND == 2 && S >= 4) || (PSNODE_K4F_BOUND == 3 && S >= 2));
+    constexpr int EVERY = PSNODE_K4F_EVERY;
     float w1xs[NX], w1z[NZ], w2r[STREAM ? 1 : 4 * NWV], w3r[STREAM ? 1 : 4 * NWV], w4[4];
     f4 b1r, b2, b3, b4;
 #pragma unroll
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             wq = wl[c * NWV * 64];
             accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
-            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }   // 8 waves: bound the scheduler's read-ahead (registers)
+            if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }   // 8 waves: bound the scheduler's read-ahead (registers)
         }
         p ^= 1;
         return accA + accB;
@@ -226,14 +235,14 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             wq = wl[c * NWV * 64];
             accA = fm4(wq[0], v[0], accA); accB = fm4(wq[1], v[1], accB);
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
-            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
         }
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
             const f4 dT = get_row(tile(p, (w + c) & (NWV - 1)), roff);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc[c] = fm4(dT[kk], hT[kk], acc[c]);
-            if constexpr (STREAM) { if (c & 1) __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
         }
         p ^= 1;
         return accA + accB;

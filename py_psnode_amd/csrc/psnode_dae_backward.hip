@@ -231,13 +231,28 @@ __global__ __launch_bounds__(256) void dae_backward_kernel(const DaeBwdDev d, co
     auto mid = [&](const float (&wm)[16], const f4 bias, const f4 h) -> f4 {
         xbuf[(p * NW + w) * 64 + l] = h;
         f4 accA = bias, accB = z4();
-        accA = bm(wm[0], h[0], accA); accB = bm(wm[1], h[1], accB);
-        accA = bm(wm[2], h[2], accA); accB = bm(wm[3], h[3], accB);
+        // own-quarter MFMAs: PSNODE_K7_MID_PRE pinned in front of the barrier, the rest behind the read issue (K1's finding, psnode_mfma_impl.h
+        // `mid`; -1 = placement left to the compiler)
+#ifndef PSNODE_K7_MID_PRE
+#define PSNODE_K7_MID_PRE -1
+#endif
+        constexpr int PRE = PSNODE_K7_MID_PRE < 0 ? 4 : PSNODE_K7_MID_PRE;
+        constexpr bool PIN = PSNODE_K7_MID_PRE >= 0;
+        if constexpr (PRE >= 1) accA = bm(wm[0], h[0], accA);
+        if constexpr (PRE >= 2) accB = bm(wm[1], h[1], accB);
+        if constexpr (PRE >= 3) accA = bm(wm[2], h[2], accA);
+        if constexpr (PRE >= 4) accB = bm(wm[3], h[3], accB);
+        if constexpr (PIN && PRE >= 1) asm volatile("" : "+v"(accA), "+v"(accB));
         lds_barrier();
         f4 vq[4];      // all three reads in flight before the first dependent MFMA
 #pragma unroll
         for (int c = 1; c < 4; ++c) vq[c] = xbuf[(p * NW + ((w + c) & 3)) * 64 + l];
+        if constexpr (PIN && PRE < 4) asm volatile("" : "+v"(accA), "+v"(accB));
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PRE < 1) accA = bm(wm[0], h[0], accA);
+        if constexpr (PRE < 2) accB = bm(wm[1], h[1], accB);
+        if constexpr (PRE < 3) accA = bm(wm[2], h[2], accA);
+        if constexpr (PRE < 4) accB = bm(wm[3], h[3], accB);
 #pragma unroll
         for (int c = 1; c < 4; ++c) {
             const f4 v = vq[c];
