@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 2
+#define PSNODE_ABI_VERSION 3
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
 
@@ -100,6 +100,15 @@ typedef struct {
     const float* z_jump;       /* [B,nE,z_dim] : z_jump[b*zj_stride_b + e*zj_stride_e + d] */
     int64_t zj_stride_b, zj_stride_e;
     float* x_out;              /* [T,B,x_dim] contiguous (my_solvers.py:62) */
+    /* Training forward (ABI 3, optional, both NULL = off): what autograd would save for loss.backward() -- the hidden activations of the
+     * three ELU layers per (step, stage, trajectory) and the stage inputs -- written by the integrator itself so that the backward
+     * (psnode_ode_backward_f32 with saved_act / saved_xstage) does not recompute the stage evaluations (a third of its MFMA work):
+     *   save_act    [T-1, S, 3, B, Hp]   Hp = hidden rounded up to 32 / 64 / 128 (psnode_ode_save_hidden), S = stages of the method
+     *   save_xstage [T-1, S, B, x_dim]
+     * 6 KB per state-step at hidden 128: sized for the 288 GB of an MI355X, meant for the widths where the recompute is what bounds the
+     * training step.  Only the MFMA integrator K1 writes them (psnode_ode_save_hidden() > 0, no teacher forcing): else UNSUPPORTED. */
+    float* save_act;
+    float* save_xstage;
 } psnode_ode_args_f32;
 
 /* Arguments of FixedGridODESolver.integrate_DAE (my_solvers.py:82-131) with recognised DE_Func/AE_Func
@@ -203,6 +212,8 @@ typedef struct {
     float* grad_z_jump;              /* [B,n_events,z_dim] contiguous, zero-initialised by the caller, or NULL */
     float* grad_all_initial;         /* [B, x+z] */
     float* grad_params;              /* flat, psnode_ode_backward_param_count() floats */
+    const float* saved_act;          /* ABI 3, optional: what the forward call wrote to save_act / save_xstage (same method, T, B, MLP).  With them the */
+    const float* saved_xstage;       /* one-launch backward K4f skips the recompute of the stage evaluations; both NULL = recompute */
 } psnode_ode_bwd_args_f32;
 
 int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* args);
@@ -403,6 +414,9 @@ typedef struct {
 
 int32_t psnode_ode_encoded_supported(const psnode_ode_encoded_args_f32* args);   /* 1 / 0, dims only */
 int32_t psnode_ode_encoded_integrate_f32(const psnode_ode_encoded_args_f32* args, void* stream);
+
+/* Row width Hp of save_act for these dims (32 / 64 / 128) if an AUTO / MFMA call can save its activations, else 0 (dims only). */
+int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);
 
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);

@@ -15,7 +15,8 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 2          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image)
+ABI_VERSION = 3          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+                         #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -23,7 +24,7 @@ LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.
 EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
-    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
+    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_ode_save_hidden", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
@@ -59,7 +60,8 @@ class OdeArgsF32(ctypes.Structure):
     _fields_ = [("method", c_int32), ("kernel", c_int32), ("flags", c_uint32), ("x_dim", c_int32), ("z_dim", c_int32),
                 ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("t", ViewF32), ("x", ViewF32), ("z", ViewF32),
                 ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
-                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_out", c_void_p)]
+                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_out", c_void_p),
+                ("save_act", c_void_p), ("save_xstage", c_void_p)]
 
 
 class DaeArgsF32(ctypes.Structure):
@@ -78,7 +80,7 @@ class OdeBwdArgsF32(ctypes.Structure):
                 ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("n_events", c_int32), ("xs", c_void_p), ("grad_xs", c_void_p),
                 ("grad_x0", c_void_p), ("grad_z", c_void_p), ("grad_z_jump", c_void_p), ("grad_all_initial", c_void_p),
-                ("grad_params", c_void_p)]
+                ("grad_params", c_void_p), ("saved_act", c_void_p), ("saved_xstage", c_void_p)]
 
 
 class DaeBwdArgsF32(ctypes.Structure):
@@ -157,6 +159,8 @@ def load():
     if missing:
         raise PsnodeLibraryError(f"{LIB_PATH} lacks {missing}: stale build, rebuild it with `make -C py_psnode_amd/csrc`")
     lib.psnode_build_info.restype = c_char_p
+    lib.psnode_ode_save_hidden.restype = c_int32
+    lib.psnode_ode_save_hidden.argtypes = [ctypes.POINTER(OdeArgsF32)]
     lib.psnode_status_string.restype = c_char_p
     lib.psnode_status_string.argtypes = [c_int32]
     lib.psnode_workspace_bytes.restype = c_size_t

@@ -3,32 +3,65 @@
 This is what lets the reference's training loops (`loss.backward()` through the integrator,
 neural_00_ODE_01_no_encode.py:358-360) run on the fused HIP path instead of an unrolled T-step autograd graph.
 """
+import os
+
 import torch
 
 from . import fused
+
+# Save the stage activations in the training forward instead of recomputing them in the backward?  "auto": at hidden widths 33..128
+# (measured per 4096 x 1000 RK4 batch: hidden 128 52.9 -> 43.6 ms per training step, 64 17.2 -> 14.8, 32 10.5 -> 10.0:
+# profiles/r03p_saved_ab.txt) and only when the rows (6 KB per state-step at 128: 25 GB for that batch; 3.1 KB / 13 GB at 64) fit into
+# half of the free HBM; "1" / "0" force it on / off.
+SAVE_ACTIVATIONS = os.environ.get("PSNODE_SAVE_ACTIVATIONS", "auto")
+
+
+def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
+    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma"):
+        return False
+    Hp = fused.ode_save_hidden(method, layers, x_dim, z_dim, kernel)
+    if Hp <= 0 or not fused.ode_backward_supported(method, layers, x_dim, z_dim, "wide"):
+        return False
+    if SAVE_ACTIVATIONS == "1":
+        return True
+    if Hp < 64:
+        return False
+    S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    need = (T - 1) * S * B * (3 * Hp + x_dim) * 4
+    free, _ = torch.cuda.mem_get_info(layers[0][0].device)
+    return need <= free // 2
 
 
 class _FusedOde(torch.autograd.Function):
     @staticmethod
     def forward(ctx, method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params):
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
-        xs = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel)
+        save = _want_saved(method, kernel, layers, x0.shape[-1], z.shape[-1], t.shape[0], t.shape[1])
+        res = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
+                                  save=save)
+        xs, saved = res if save else (res, None)
         ctx.method = method
         ctx.has_jump = z_jump is not None
+        ctx.has_saved = saved is not None
         ctx.event_idx = event_idx
-        ctx.save_for_backward(t, z, all_initial, xs, *( (z_jump,) if z_jump is not None else () ), *params)
+        ctx.save_for_backward(t, z, all_initial, xs, *((z_jump,) if z_jump is not None else ()), *(saved if saved is not None else ()),
+                              *params)
         return xs
 
     @staticmethod
     def backward(ctx, grad_xs):
         saved = ctx.saved_tensors
         t, z, a0, xs = saved[:4]
-        z_jump = saved[4] if ctx.has_jump else None
-        params = saved[5 if ctx.has_jump else 4:]
+        pos = 4
+        z_jump = saved[pos] if ctx.has_jump else None
+        pos += 1 if ctx.has_jump else 0
+        acts = (saved[pos], saved[pos + 1]) if ctx.has_saved else None
+        pos += 2 if ctx.has_saved else 0
+        params = saved[pos:]
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
         need_z = ctx.needs_input_grad[5]
         gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, xs, grad_xs, event_idx=ctx.event_idx, z_jump=z_jump,
-                                                     need_grad_z=need_z)
+                                                     need_grad_z=need_z, saved=acts)
         if gz is None and need_z:
             gz = torch.zeros_like(z)
         return (None, None, None, None, gx0, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)

@@ -539,8 +539,8 @@ bool ode_generic_ok(const psnode_ode_bwd_args_f32* a) {
     if (m.in_dim != 3 * (a->x_dim + a->z_dim) || m.out_dim[m.n_layers - 1] != a->x_dim) return false;
     return generic_bwd_fits(&a->de, nullptr, a->x_dim, a->z_dim, 0, 0) != 0;
 }
-bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) {
-    return a->kernel != PSNODE_KERNEL_GENERIC && a->kernel != PSNODE_KERNEL_MFMA_WIDE && bwd_shape_ok(a);
+bool use_mfma_bwd(const psnode_ode_bwd_args_f32* a) {     // (saved activations are K4f's: K4 always recomputes)
+    return a->kernel != PSNODE_KERNEL_GENERIC && a->kernel != PSNODE_KERNEL_MFMA_WIDE && !a->saved_act && bwd_shape_ok(a);
 }
 // K4f: every other width <= 128 (and z_dim up to 8); at hidden 64 exactly the specialised K4 is faster (14.3 vs ~16 ms) and keeps AUTO
 bool use_fused_bwd(const psnode_ode_bwd_args_f32* a) { return a->kernel != PSNODE_KERNEL_GENERIC && !use_mfma_bwd(a) && fused_bwd_shape_ok(a); }
@@ -591,6 +591,8 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     if (a->event_idx && a->z_dim > 0 && !a->z_jump) return PSNODE_ERR_NULL;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
+    if ((a->saved_act != nullptr) != (a->saved_xstage != nullptr)) return PSNODE_ERR_NULL;
+    if (a->saved_act && !use_fused_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4f reads them
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);

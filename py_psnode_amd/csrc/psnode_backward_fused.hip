@@ -47,18 +47,24 @@ struct FusedDev {
     float *gx0, *gz, *gzj, *ga0;
     float* wpart;                         // [workgroups][NP]
     float* ring;                          // NWV >= 8: [S][3][B][H] stage activations of the step in flight
+    const float *sact, *sxst;             // saved by the forward call ([T-1,S,3,B,H] / [T-1,S,B,xd]) or null: recompute
 };
 
 #ifndef PSNODE_K4F_BOUND
 #define PSNODE_K4F_BOUND 3      // 0: never bound the scheduler's read-ahead in the layer loops, 1: always at 8 waves, 2: only at RK4, 3: RK4 + Midpoint
                                 // (profiles/r03m_bwd_ab.txt, hidden-128 training step rk4 / midpoint / euler: 0 -> 65.1 / 28.0 / 11.95 ms, 1 -> 52.8 / 22.9 / 12.19)
 #endif
+#ifndef PSNODE_K4F_BOUND_SAVED
+#define PSNODE_K4F_BOUND_SAVED 3      // the same knob for the instances that read saved activations (REC = false)
+#endif
 #ifndef PSNODE_K4F_EVERY
 #define PSNODE_K4F_EVERY 2      // a sched_barrier behind every EVERY-th chunk
 #endif
 constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l's four rows 4g..4g+3 of column j at 4l + 8g
 
-template <int METHOD, int NZM, int NWV>
+// REC = false: the forward call saved the stage activations and stage inputs (psnode_ode_args_f32::save_act / save_xstage): no phase A,
+// the transposed images stay in LDS for the whole launch, the rows of (step, stage) are requested one stage ahead along the sweep.
+template <int METHOD, int NZM, int NWV, bool REC = true>
 __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const FusedDev a, const float* __restrict__ pack_de,
                                                                         const f4* __restrict__ pack_t, const f4* __restrict__ pack_f,
                                                                         const int NA) {
@@ -80,8 +86,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 
     // ---- forward image -> registers (as K1), transposed images -> LDS
     const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
-    constexpr bool STREAM = NWV >= 8;     // forward / transposed images swapped in LDS per phase; activations through the ring
-    constexpr bool BOUND = STREAM && (PSNODE_K4F_BOUND == 1 || (PSNODE_K4F_BOUND == 2 && S >= 4) || (PSNODE_K4F_BOUND == 3 && S >= 2));
+    constexpr bool STREAM = NWV >= 8 && REC;     // forward / transposed images swapped in LDS per phase; activations through the ring
+    constexpr int BMODE = REC ? PSNODE_K4F_BOUND : PSNODE_K4F_BOUND_SAVED;
+    constexpr bool BOUND = NWV >= 8 && (BMODE == 1 || (BMODE == 2 && S >= 4) || (BMODE == 3 && S >= 2));
     constexpr int EVERY = PSNODE_K4F_EVERY;
     float w1xs[NX], w1z[NZ], w2r[STREAM ? 1 : 4 * NWV], w3r[STREAM ? 1 : 4 * NWV], w4[4];
     f4 b1r, b2, b3, b4;
@@ -120,6 +127,10 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     if constexpr (STREAM) {
         dma_layer(pack_f, 0);
         dma_layer(pack_f, 1);
+    } else if constexpr (NWV >= 8) {      // saved activations: the transposed images, once
+        dma_layer(pack_t, 0);
+        dma_layer(pack_t, 1);
+        dma_wait();
     } else {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
@@ -314,6 +325,18 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         t_hi = load_t(nT - 1);
         t_lo = load_t(nT - 2);
     }
+    // REC = false: rows of (step, stage), linear index idx = k S + s, walked downwards; requested one stage ahead
+    const long long act_layer = a.B * H;
+    auto load_saved = [&](const long long idx, f4& q1, f4& q2, f4& q3, float (&xq)[NX]) {
+        const float* rb = a.sact + (size_t)idx * 3 * act_layer;
+        q1 = ldg<f4>(sbase(rb), offH);
+        q2 = ldg<f4>(sbase(rb + act_layer), offH);
+        q3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
+        load_x2(a.sxst, idx, xq);
+    };
+    f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
+    float svx[NX] = {};
+    if constexpr (!REC) { if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx); }
     for (long long k = nT - 2; k >= 0; --k) {
         float x0[NX], gin[NX], ext[NZ];
 #pragma unroll
@@ -328,11 +351,11 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 
         // ---- phase A: stage evaluations (K1's plan)
         float X[S][NX], ks[S][NX];
-        f4 h1[STREAM ? 1 : S], h2[STREAM ? 1 : S], h3[STREAM ? 1 : S];
-        f4 la1, la2, la3;    // ELU outputs of the last stage evaluated (the first one the backward half needs)
+        f4 h1[(STREAM || !REC) ? 1 : S], h2[(STREAM || !REC) ? 1 : S], h3[(STREAM || !REC) ? 1 : S];
+        f4 la1 = zero4, la2 = zero4, la3 = zero4;    // ELU outputs of the last stage evaluated (the first one the backward half needs)
         if constexpr (STREAM) dma_wait();       // forward images of both layers (refilled behind their last use of the previous phase B)
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < (REC ? S : 0); ++s) {
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 float acc = 0.0f;
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             t_lo = load_t(kp);
         };
         if constexpr (!STREAM) prefetch_next();
+        (void)cz; (void)x0;
         float gks[S][NX], gx0[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
@@ -398,7 +422,13 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
-            if constexpr (STREAM) {
+            if constexpr (!REC) {
+                a1 = sv1; a2 = sv2; a3 = sv3;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                const long long idx = k * S + s;
+                load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+            } else if constexpr (STREAM) {
                 a1 = na1; a2 = na2; a3 = na3;
                 if (s > 0) {
                     const size_t rb = (size_t)(3 * (s - 1)) * nrow * H;
@@ -581,7 +611,7 @@ hipError_t launch_fused(const FusedDev& a, int NZM, const float* pde, const f4* 
     const size_t lds = fused_lds_bytes(NWV);
 #define PSNODE_FUSED(NZM_)                                                                                                      \
     {                                                                                                                           \
-        auto kern = &ode_backward_fused_kernel<METHOD, NZM_, NWV>;                                                              \
+        auto kern = a.sact ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false> : &ode_backward_fused_kernel<METHOD, NZM_, NWV, true>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pt, pf, NA);                                                      \
@@ -662,6 +692,7 @@ int fused_bwd_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStre
     a.a0 = p->all_initial; a.ev = p->event_idx; a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
     a.xs = p->xs; a.gout = p->grad_xs; a.gx0 = p->grad_x0; a.gz = p->grad_z; a.gzj = p->grad_z_jump; a.ga0 = p->grad_all_initial;
     a.wpart = wpart; a.ring = ring;
+    a.sact = p->saved_act; a.sxst = p->saved_xstage;
     hipError_t e;
     switch (nw) {
         case 2: e = launch_fused_method<2>(a, NZM, pde, pt, pf, NA, s); break;

@@ -131,6 +131,9 @@ int fill_ode(const psnode_ode_args_f32* a, IntegrateDev& d) {
     d.zjb = a->zj_stride_b;
     d.zje = a->zj_stride_e;
     d.xo = a->x_out;
+    if ((a->save_act != nullptr) != (a->save_xstage != nullptr)) return PSNODE_ERR_NULL;
+    d.sact = a->save_act;
+    d.sxst = a->save_xstage;
     return PSNODE_OK;
 }
 
@@ -224,10 +227,23 @@ int32_t psnode_event_table_f32(int64_t n_steps, const float* clock, int64_t stri
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
+int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* a) {
+    if (!a) return 0;
+    IntegrateDev d;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.T = a->T; d.B = a->B;
+    bind_dims(a->de, d.de);
+    return a->kernel == PSNODE_KERNEL_GENERIC ? 0 : mfma_ode_save_hidden(d);
+}
+
 int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspace, size_t workspace_bytes, void* stream) {
     IntegrateDev d;
     const int rc = fill_ode(args, d);
     if (rc) return rc;
+    if (d.sact) {      // only K1 proper writes the training side outputs
+        bind_dims(args->de, d.de);
+        if (args->kernel == PSNODE_KERNEL_GENERIC || !mfma_ode_save_hidden(d)) return PSNODE_ERR_UNSUPPORTED;
+    }
     return dispatch(d, false, args->kernel, &args->de, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

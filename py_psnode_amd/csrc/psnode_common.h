@@ -42,6 +42,8 @@ struct IntegrateDev {
     long long vjb, vje;
     float* xo;
     float* io;
+    float* sact;           // ODE training forward: saved activations [T-1,S,3,B,Hp] / stage inputs [T-1,S,B,xd], or null
+    float* sxst;
     int maxw;              // widest activation vector incl. the MLP inputs (generic kernel buffer A)
     int maxo;              // widest layer OUTPUT (generic kernel buffer B: it only ever holds layer outputs)
 };
@@ -185,6 +187,7 @@ hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t
 
 // psnode_mfma.hip
 bool mfma_ode_supported(const IntegrateDev& a);
+int mfma_ode_save_hidden(const IntegrateDev& a);     // row width of saved activations if K1 proper takes the shape (no latent / teacher forcing), else 0
 bool mfma_dae_supported(const IntegrateDev& a);
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);

@@ -22,6 +22,12 @@ bool mfma_ode_supported(const IntegrateDev& a) {
     return nzm_of(a, false) <= kMaxNZM;       // z_dim <= 8
 }
 
+int mfma_ode_save_hidden(const IntegrateDev& a) {
+    if (latent_shape_ok(a, false) || latent64_shape_ok(a, false)) return 0;
+    if ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) || a.xd < 1 || a.xd > 4 * kNXc || nzm_of(a, false) > kMaxNZM) return 0;
+    return mfma_hidden(a.de, 3 * (a.xd + a.zd), a.xd);
+}
+
 bool mfma_dae_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, true)) return a.a0 == nullptr || latent_ptrs_ok(a, true);
     if (latent64_shape_ok(a, true)) return a.a0 == nullptr || latent64_ptrs_ok(a, true);

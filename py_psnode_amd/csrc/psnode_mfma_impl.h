@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_tail(const float* pw, Tail<NWV>& t) {
 
 template <int N> struct Arr { float v[N > 0 ? N : 1]; };
 
-template <int METHOD, int NX, int NZM, int NZA, bool TRUE_X, bool DAE, int NWV>
+template <int METHOD, int NX, int NZM, int NZA, bool TRUE_X, bool DAE, int NWV, bool SAVE = false>
 __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const IntegrateDev a, const float* __restrict__ pack_de,
                                                                   const float* __restrict__ pack_ae, const int NA) {
     using RD = Regs<NX, 0, NZM, NWV>;     // folded DE image: no `s - a0` registers for the x dims (psnode_pack.h)
@@ -306,15 +306,18 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     };
     // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows.
     // ROWS2: only rows r < 2 of the output carry data (the DE with x_dim <= 8): all-reduce 8 bytes per lane instead of 16.
-    auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto from_lds) -> f4 {
+    auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto from_lds, auto&& keep) -> f4 {
         constexpr bool ROWS2 = decltype(rows2)::value;
         f4 h = elu4(pre1);
+        keep(0, h);
         if constexpr (decltype(from_lds)::value) {
             h = mid_lds(0, t.b2, h);
             h = mid_lds(1, t.b3, h);
         } else {
             h = mid(t.w2, t.b2, h);
+            keep(1, h);
             h = mid(t.w3, t.b3, h);
+            keep(2, h);
         }
         f4 accA = mfma4(t.w4[0], h[0], f4{0.f, 0.f, 0.f, 0.f});
         f4 accB = mfma4(t.w4[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
@@ -337,6 +340,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         }
         return out;
     };
+    // SAVE: running row pointers of the saved activations [T-1,S,3,B,H] (this lane's four units) and stage inputs [T-1,S,B,xd]
+    const size_t sa_layer = SAVE ? (size_t)a.B * (16 * NWV) : 0;
+    const long long sx_step = SAVE ? a.B * xd : 0;
+    float* sa_run = SAVE ? a.sact + (size_t)b * (16 * NWV) + 16 * w + 4 * g : nullptr;
+    float* sx_run = SAVE ? a.sxst + b * xd : nullptr;
     // DE right-hand side at xs with this step's constant part cz
     auto rhs = [&](const float (&xs)[NX], const f4 cz) -> f4 {
         // folded L1: (Ws + Wd) . xs, the -Wd . a0x term lives in c0 (two accumulator chains for NX = 2)
@@ -346,7 +354,20 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             if (r & 1) accB = mfma4(w1xs[r], xs[r], accB);
             else accA = mfma4(w1xs[r], xs[r], accA);
         }
-        return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{});
+        if constexpr (SAVE) {
+            // training forward: what autograd would save.  This wave's 16 units of the three ELU layers (16 bytes per lane and layer)
+            // and, from wave 0, the stage input -- rows (step, stage) of a.sact / a.sxst; the row pointers advance by one stage per call
+            if (w == 0 && valid) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) if (4 * r + g < xd) sx_run[4 * r + g] = xs[r];
+            }
+            sx_run += sx_step;
+            const f4 out = tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{},
+                                [&](const int q, const f4 hq) { if (valid) *reinterpret_cast<f4*>(sa_run + (size_t)q * sa_layer) = hq; });
+            sa_run += 3 * sa_layer;
+            return out;
+        }
+        return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{}, [](int, f4) {});
     };
     // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
     auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv) -> f4 {
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             for (int r = 0; r < NX; ++r) acc = mfma4(aw1x[r], xa[r], acc);
 #pragma unroll
             for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
-            return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{});
+            return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{}, [](int, f4) {});
         }
         return acc;
     };
@@ -565,6 +586,25 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, NA);                                                    \
         return hipGetLastError();                                                                                          \
     }
+    if constexpr (!TRUE_X && NXR == kNXc) {
+        if (!dae && a.sact) {
+#define PSNODE_LAUNCH_SAVE(NZM_)                                                                                           \
+    {                                                                                                                      \
+        hipLaunchKernelGGL((integrate_mfma_kernel<METHOD, NXR, NZM_, 0, false, false, NWV, true>), grid, block, 0, s, a, pde, pae, NA); \
+        return hipGetLastError();                                                                                          \
+    }
+            switch (NZM) {
+                case 0: PSNODE_LAUNCH_SAVE(0)
+                case 1: PSNODE_LAUNCH_SAVE(1)
+                case 2: PSNODE_LAUNCH_SAVE(2)
+                case 3: PSNODE_LAUNCH_SAVE(3)
+                case 4: PSNODE_LAUNCH_SAVE(4)
+                default: return hipErrorNotSupported;
+            }
+#undef PSNODE_LAUNCH_SAVE
+        }
+    }
+    if (a.sact) return hipErrorNotSupported;
     if (!dae) {
         switch (NZM) {
             case 0: PSNODE_LAUNCH(0, 0, false)

@@ -271,8 +271,11 @@ def _aligned_ptr(ws: torch.Tensor):
 
 def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=None, z_jump=None,
                   input_true_x: bool = False, kernel: str = "auto", event_idx: Optional[torch.Tensor] = None,
-                  check_events: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  check_events: bool = False, out: Optional[torch.Tensor] = None, save: bool = False):
     """Fused integrate_ODE (replaces my_solvers.py:52-80 + my_fixed_grid.py + DE_Func.forward).
+
+    save=True (training forward, K1 shapes only -- `ode_save_hidden`): the kernel also writes what autograd would save, the hidden
+    activations [T-1,S,3,B,Hp] and the stage inputs [T-1,S,B,xd]; returns (xs, (act, xstage)) for `ode_backward(..., saved=)`.
 
     t[T,B,1], x[T,B,xd], z[T,B,zd] may be arbitrary strided views with a unit-stride last dim
     (the scripts pass permute(1,0,2) views); returns a fresh contiguous xs[T,B,xd].
@@ -319,12 +322,33 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
         elif out.shape != (T, B, xd) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != dev:
             raise ValueError("out must be a contiguous fp32 [T,B,xd] tensor on the inputs' device")
         a.x_out = out.data_ptr()
+        saved = None
+        if save:
+            Hp = lib.psnode_ode_save_hidden(ctypes.byref(a))
+            if Hp <= 0:
+                raise _lib.UnsupportedShapeError("ode_integrate(save=True): the MFMA integrator K1 does not take this shape")
+            S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+            saved = (torch.empty((max(T - 1, 0), S, 3, B, Hp), dtype=torch.float32, device=dev),
+                     torch.empty((max(T - 1, 0), S, B, xd), dtype=torch.float32, device=dev))
+            if T >= 2:
+                a.save_act, a.save_xstage = saved[0].data_ptr(), saved[1].data_ptr()
         ws = _workspace(lib, a.de, None, dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_ode_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_ode_integrate_f32")
     # the stream-ordered caching allocator keeps `keep`/`ws` storage valid until the kernel has run
-    return out
+    return (out, saved) if save else out
+
+
+def ode_save_hidden(method: str, de_layers: Layers, x_dim: int, z_dim: int, kernel: str = "auto") -> int:
+    """Row width of the saved activations if the forward for these dims can save them (K1 proper), else 0."""
+    if de_layers[0][0].device.type != "cuda" or len(de_layers) > _lib.MAX_LAYERS:
+        return 0
+    lib = _lib.load()
+    a = _lib.OdeArgsF32()
+    a.method, a.kernel, a.x_dim, a.z_dim, a.T, a.B = METHOD_ID[method], KERNEL_ID[kernel], x_dim, z_dim, 2, 1
+    a.de = _mlp(de_layers, de_layers[0][0].device, "de", [])
+    return int(lib.psnode_ode_save_hidden(ctypes.byref(a)))
 
 
 def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, x, z, v, i, all_initial,
@@ -790,8 +814,9 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
 
 
 def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True,
-                 kernel: str = "auto"):
-    """Backward pass of `ode_integrate` (input_true_x=False) in one launch.
+                 kernel: str = "auto", saved=None):
+    """Backward pass of `ode_integrate` (input_true_x=False) in one launch.  `saved` = what `ode_integrate(save=True)` returned next to
+    xs: K4f then skips the recompute of the stage evaluations.
     Returns (grad_x0 [B,xd], grad_z [T,B,zd] | None, grad_z_jump | None, grad_all_initial [B,n], [grad W1, b1, ..., W4, b4])."""
     lib = _lib.load()
     dev = xs.device
@@ -830,6 +855,9 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
         gpar = torch.empty(npar, dtype=torch.float32, device=dev)
         a.grad_x0, a.grad_all_initial, a.grad_params = gx0.data_ptr(), ga0.data_ptr(), gpar.data_ptr()
         a.grad_z = gz.data_ptr() if gz is not None else None
+        if saved is not None and T >= 2:
+            keep += [saved[0], saved[1]]
+            a.saved_act, a.saved_xstage = saved[0].data_ptr(), saved[1].data_ptr()
         nbytes = lib.psnode_ode_backward_workspace_bytes(ctypes.byref(a))
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)

@@ -183,6 +183,20 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
     _close(fa0, ga0.double().cpu(), "K4f grad all_initial vs split")
     for k, (a_, p_) in enumerate(zip(fp, de.x_dot.parameters())):
         _close(a_, p_.grad, f"K4f grad param {k}")
+    # the same backward fed with the activations the FORWARD saved (ode_integrate(save=True): no recompute in K4f): the forward result must
+    # not depend on saving, the gradients must meet the same truth
+    xs_s, saved = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj), save=True)
+    assert torch.equal(xs_s, xs), "saving the activations changed the forward result"
+    S_ = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    assert saved[0].shape == (Tn - 1, S_, 3, B, 32 if H <= 32 else (64 if H <= 64 else 128)) and saved[1].shape == (Tn - 1, S_, B, xd)
+    sx0, sz, szj, sa0, sp = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), saved=saved)
+    _close(sx0 + sa0[:, :xd], xq.grad[0], "K4f(saved) grad x0")
+    if zd:
+        sz_tot = sz.clone(); sz_tot[0] += sa0[:, xd:]
+        _close(sz_tot, zq.grad, "K4f(saved) grad z")
+        _close(szj, zjq.grad, "K4f(saved) grad z_jump")
+    for k, (a_, p_) in enumerate(zip(sp, de.x_dot.parameters())):
+        _close(a_, p_.grad, f"K4f(saved) grad param {k}")
     # the auto route picks K4f at hidden 32 / 128 / 48 and the one-launch K4 at 64: same numbers either way
     auto = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj))
     for k, (a_, b_) in enumerate(zip(gp, auto[4])):
@@ -209,6 +223,12 @@ def test_hidden128_training_takes_the_one_launch_backward():
     finally:
         fused.ode_backward_wide = orig
     assert calls == [], "hidden 128 must not take the split backward any more"
+    # ... and by default (PSNODE_SAVE_ACTIVATIONS=auto) the training forward at this width saves its activations for the backward
+    from py_psnode_amd import autograd as pag
+    layers_ = fused.de_layers_of(m.de_func, 10, 8)
+    assert pag._want_saved("rk4", "auto", layers_, 8, 2, Tn, B) is True
+    assert pag._want_saved("rk4", "auto", [(w[:32, :] if k == 0 else (w[:32, :32] if k < 3 else w[:, :32]), b_[:32] if k < 3 else b_)
+                                           for k, (w, b_) in enumerate(layers_)], 8, 2, Tn, B) is False
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in m.parameters())
 
 

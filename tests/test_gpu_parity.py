@@ -415,6 +415,26 @@ def test_full_size_subset_vs_oracle():
     assert rel_err(sub, ref) <= TOL_GPU
 
 
+def test_config5_node_batch_on_one_gpu():
+    """BASELINE config 5's GLOBAL batch (32 768 trajectories = 8 tiles per CU: the regime where two waves share a SIMD) on one GPU,
+    1000 RK4 steps: 40 trajectories spread over the batch against the oracle run on just those, and -- trajectories being independent --
+    rank r's 4096-trajectory shard integrated on its own must reproduce its slice of the full run BIT FOR BIT (what the 8-GPU run
+    relies on; the gloo test checks the gather, this checks that a shard does not depend on who shares the launch)."""
+    B, Tn = 32768, 1001
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, seed=5)
+    lay = dl(ls)
+    tc, xc, zc, ac = t.cuda(), x.cuda(), z.cuda(), a0.cuda()
+    out = fused().ode_integrate("rk4", lay, tc, xc, zc, ac)
+    assert torch.isfinite(out).all()
+    idx = torch.tensor(sorted(set(range(0, B, 911)) | {B - 1, 4095, 4096, 16383}))
+    ref = O.integrate_ode("rk4", ls, t[:, idx], x[:, idx], z[:, idx], a0[idx])
+    assert rel_err(out[:, idx.cuda()].cpu(), ref) <= TOL_GPU
+    for r in (0, 3, 7):
+        lo, hi = 4096 * r, 4096 * (r + 1)
+        shard = fused().ode_integrate("rk4", lay, tc[:, lo:hi], xc[:, lo:hi], zc[:, lo:hi], ac[lo:hi])
+        assert torch.equal(shard, out[:, lo:hi]), f"shard {r} differs from its slice of the node-size launch"
+
+
 def test_accuracy_equivalent_to_reference_vs_fp64():
     """Against an fp64 evaluation of the same algorithm, the HIP result must be as accurate as the reference's own
     fp32 result (goldens), up to 3x, under BOTH metrics -- on the 1000-step run where roundoff accumulates most."""

@@ -96,7 +96,8 @@ def test_fused_backward_matches_reference_gradients(tag, method):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel,tag", [("generic", "ode01"), ("mfma", "ode01"), ("wide", "ode01"), ("wide", "ode01_h128"), ("wide", "ode01_h32"),
-                                        ("generic", "ode01_h128"), ("split", "ode01_h128")])
+                                        ("generic", "ode01_h128"), ("split", "ode01_h128"),
+                                        ("saved", "ode01"), ("saved", "ode01_h128"), ("saved", "ode01_h32")])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
 def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel, tag):
     """K5 (generic), K4 (mfma, hidden 64), K4f (wide: the one-launch backward at hidden 32 / 64 / 128) and round 2's split route through
@@ -111,7 +112,12 @@ def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel, tag
     _close(xs.permute(1, 0, 2), d[f"{method}_out0"], "xs", TOL_GPU)
     G = tm(d["G0"]).contiguous().cuda()
     tab = fused.event_table(t, ev)
-    gx0, gz, gzj, ga0, gp = fused.ode_backward(method, de, t, z, a0, xs, G, event_idx=tab, z_jump=zj, kernel=kernel)
+    saved = None
+    if kernel == "saved":       # K4f fed with the activations the forward saved (no recompute)
+        xs2, saved = fused.ode_integrate(method, de, t, x, z, a0, event_t=ev, z_jump=zj, save=True)
+        assert torch.equal(xs2, xs)
+    gx0, gz, gzj, ga0, gp = fused.ode_backward(method, de, t, z, a0, xs, G, event_idx=tab, z_jump=zj,
+                                               kernel="auto" if kernel == "saved" else kernel, saved=saved)
     gx_ref = T(d[f"{method}_g_x"])                       # [B,T,xd]: only x[:,0] carries gradient (directly + via all_initial)
     _close(gx0 + ga0[:, :8], gx_ref[:, 0], "grad x0", TOL_GPU)
     gz_tot = gz.clone()
