@@ -57,6 +57,12 @@ struct FusedDev {
 #ifndef PSNODE_K4F_BOUND_SAVED
 #define PSNODE_K4F_BOUND_SAVED 3      // the same knob for the instances that read saved activations (REC = false)
 #endif
+#ifndef PSNODE_K4F_ABLATE
+#define PSNODE_K4F_ABLATE 0     // timing experiments only (results WRONG): 1 = no weight-gradient MFMAs in the H->H layers, 2 = no in-wave transposes
+#endif
+#ifndef PSNODE_K4F_EVERY_SAVED
+#define PSNODE_K4F_EVERY_SAVED 2
+#endif
 #ifndef PSNODE_K4F_EVERY
 #define PSNODE_K4F_EVERY 2      // a sched_barrier behind every EVERY-th chunk
 #endif
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     constexpr bool STREAM = NWV >= 8 && REC;     // forward / transposed images swapped in LDS per phase; activations through the ring
     constexpr int BMODE = REC ? PSNODE_K4F_BOUND : PSNODE_K4F_BOUND_SAVED;
     constexpr bool BOUND = NWV >= 8 && (BMODE == 1 || (BMODE == 2 && S >= 4) || (BMODE == 3 && S >= 2));
-    constexpr int EVERY = PSNODE_K4F_EVERY;
+    constexpr int EVERY = REC ? PSNODE_K4F_EVERY : PSNODE_K4F_EVERY_SAVED;
     float w1xs[NX], w1z[NZ], w2r[STREAM ? 1 : 4 * NWV], w3r[STREAM ? 1 : 4 * NWV], w4[4];
     f4 b1r, b2, b3, b4;
 #pragma unroll
@@ -182,7 +188,10 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     auto put = [&](float* t_, const f4 v) { *reinterpret_cast<f4*>(t_ + toff) = v; };
     auto getl = [&](const float* t_) -> f4 { return *reinterpret_cast<const f4*>(t_ + toff); };
     auto get_row = [&](const float* t_, const int ro) -> f4 { const float* s_ = t_ + ro; return f4{s_[0], s_[16], s_[32], s_[48]}; };
-    auto transpose = [&](const f4 v) -> f4 { put(scr, v); return get_row(scr, roff); };   // own D tile -> operand layout (trajectory g + 4kk)
+    auto transpose = [&](const f4 v) -> f4 {
+        if constexpr (PSNODE_K4F_ABLATE & 2) return v;
+        put(scr, v); return get_row(scr, roff);
+    };   // own D tile -> operand layout (trajectory g + 4kk)
 
     int p = 0;
     constexpr bool PREFETCH_ALL = NWV <= 4;
@@ -248,6 +257,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
             if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
         }
+        if constexpr (!(PSNODE_K4F_ABLATE & 1))
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
             const f4 dT = get_row(tile(p, (w + c) & (NWV - 1)), roff);
@@ -407,7 +417,11 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             t_hi = t_lo;
             t_lo = load_t(kp);
         };
-        if constexpr (!STREAM) prefetch_next();
+#ifndef PSNODE_K4F_NEXT_LATE
+#define PSNODE_K4F_NEXT_LATE 0
+#endif
+        constexpr bool NEXT_LATE = !REC && NWV >= 8 && PSNODE_K4F_NEXT_LATE;
+        if constexpr (!STREAM && !NEXT_LATE) prefetch_next();
         (void)cz; (void)x0;
         float gks[S][NX], gx0[NX];
 #pragma unroll
@@ -423,18 +437,35 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
             if constexpr (!REC) {
-                a1 = sv1; a2 = sv2; a3 = sv3;
-#pragma unroll
-                for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+#ifndef PSNODE_K4F_SAVED_AHEAD
+#define PSNODE_K4F_SAVED_AHEAD 2      // 0: rows of a stage requested at its top; 1: a whole stage ahead; 2: late in the previous stage (in front of its last
+                                      // exchange).  vmcnt counts in order: every spilled-invariant reload behind an outstanding HBM request waits for it, so
+                                      // requesting EARLY is what exposed the latency at RK4 (43.8 / 39.2 / 37.9 ms per hidden-128 training step for 1 / 0 / 2;
+                                      // Euler, no spills: 9.3 / 10.5 / 9.4: profiles/r03t_ahead.txt)
+#endif
                 const long long idx = k * S + s;
-                load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+                if constexpr (PSNODE_K4F_SAVED_AHEAD) {
+                    a1 = sv1; a2 = sv2; a3 = sv3;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                    if constexpr (PSNODE_K4F_SAVED_AHEAD == 1) load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+                } else {
+                    load_saved(idx, a1, a2, a3, svx);
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                }
             } else if constexpr (STREAM) {
+#ifndef PSNODE_K4F_RING_LATE
+#define PSNODE_K4F_RING_LATE 1
+#endif
                 a1 = na1; a2 = na2; a3 = na3;
-                if (s > 0) {
-                    const size_t rb = (size_t)(3 * (s - 1)) * nrow * H;
-                    na1 = ldg<f4>(sbase(a.ring + rb), offH);
-                    na2 = ldg<f4>(sbase(a.ring + rb + nrow * H), offH);
-                    na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
+                if constexpr (!PSNODE_K4F_RING_LATE) {
+                    if (s > 0) {
+                        const size_t rb = (size_t)(3 * (s - 1)) * nrow * H;
+                        na1 = ldg<f4>(sbase(a.ring + rb), offH);
+                        na2 = ldg<f4>(sbase(a.ring + rb + nrow * H), offH);
+                        na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
+                    }
                 }
             } else {
                 a1 = h1[s]; a2 = h2[s]; a3 = h3[s];
@@ -468,6 +499,19 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
             const f4 ft = own4(fT, d1);           // rows 0..1: gX partial, rows 2..3: gz partial
             gzp += f2{ft[2], ft[3]};
+            if constexpr (NEXT_LATE) { if (s == PSNODE_K4F_NEXT_LATE - 1) prefetch_next(); }
+            if constexpr (STREAM && PSNODE_K4F_RING_LATE) {
+                if (s > 0) {
+                    const size_t rb = (size_t)(3 * (s - 1)) * nrow * H;
+                    na1 = ldg<f4>(sbase(a.ring + rb), offH);
+                    na2 = ldg<f4>(sbase(a.ring + rb + nrow * H), offH);
+                    na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
+                }
+            }
+            if constexpr (!REC && PSNODE_K4F_SAVED_AHEAD == 2) {      // request the next stage's rows late in this one (see SAVED_AHEAD)
+                const long long idx = k * S + s;
+                load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+            }
             const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
             {   // dW1 (`s` columns) += delta1 (x) s
                 const f4 dT = transpose(d1);
