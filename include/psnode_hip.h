@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 3
+#define PSNODE_ABI_VERSION 4
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
 
@@ -137,6 +137,20 @@ typedef struct {
     int64_t vj_stride_b, vj_stride_e;
     float* x_out;              /* [T,B,x_dim] contiguous */
     float* i_out;              /* [T,B,i_dim] contiguous */
+    /* Optional training side outputs, all of them or none (as psnode_ode_args_f32::save_act): what loss.backward() would have autograd
+     * keep, so that the backward call (psnode_dae_bwd_wide_args_f32::saved_*) does not recompute the forward:
+     *   save_act    [T-1, S, 3, B, Hp]   the DE's ELU outputs per (step, stage); Hp = psnode_dae_save_hidden()
+     *   save_xstage [T-1, S, B, x_dim]   the DE's stage inputs
+     *   save_ae_act [3, T, B, Hp]        the AE head's ELU outputs per grid point (my_solvers.py:95, :121)
+     *   save_ev_act [nE, 3, B, Hp]       the same for the event-time heads i0 = g(x_k; jumps) (my_solvers.py:108-110); rows of events no
+     *   save_ev_i   [nE, B, 16]          step takes are not written.  save_ev_i: i0 in the slot layout of psnode_dae_bwd_wide_args_f32.
+     * The two event buffers are required only with event_idx.  Only the MFMA integrator K2 writes them, without teacher forcing
+     * (psnode_dae_save_hidden() > 0): else UNSUPPORTED. */
+    float* save_act;
+    float* save_xstage;
+    float* save_ae_act;
+    float* save_ev_act;
+    float* save_ev_i;
 } psnode_dae_args_f32;
 
 /* ABI / build identification. */
@@ -314,7 +328,16 @@ int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* works
  * the last chunk), of x[k0] / is[k0] likewise on exit -- except that the chunk with k0 == 0 also runs the head at grid point 0, so its
  * carry_x is dL/dx_init without dL/dxs[0] and its carry_i is zero.  Parameter and input gradients: py_psnode_amd/fused.py:dae_backward_wide.
  * Shape class: de = 3n -> h -> h -> h -> x_dim, ae = n+x+z+v -> h -> h -> h -> i_dim (the same h <= 128), x_dim <= 8, z+v+i <= 8;
- * H = h rounded up to 32 / 64 / 128 as above. */
+ * H = h rounded up to 32 / 64 / 128 as above.
+ *
+ * grad_params_de != NULL selects the FUSED-DE form (K7f, csrc/psnode_dae_backward_fused.hip): one launch over the whole grid
+ * (k0 = 0, k1 = T-1 required; carry_x is output only), the DE's parameter gradients accumulated in the kernel (flat, nn.Linear order
+ * W1,b1,..,W4,b4), and the DE's share of the input gradients written in their final layout:
+ *     grad_zv             [T, B, z+v]          dL/d(z | v) through the DE (zero at event steps and at grid point T-1); every entry written
+ *     grad_jump           [B, n_events, z+v]   the same for the jump values of the events taken; zero-initialised by the caller
+ *     grad_all_initial_de [B, x+z+v+i]         the DE's share of dL/dall_initial
+ * act / delta / gk / xstage / dsum / carry_i are not touched (may be NULL); the AE head rows (ae_*, ev_*) are written as above, with
+ * row r = grid point r, and are what the caller still contracts (AE parameter gradients, the AE's share of the input gradients). */
 typedef struct {
     int32_t method;
     int32_t x_dim, z_dim, v_dim, i_dim;
@@ -345,6 +368,18 @@ typedef struct {
     float* ev_delta[3];
     float* ev_gi;
     float* ev_i;
+    float* grad_params_de;           /* NULL = the split form above */
+    float* grad_zv;
+    float* grad_jump;
+    float* grad_all_initial_de;
+    /* Fused-DE form only, optional, all of them or none: what the forward call wrote to psnode_dae_args_f32::save_* (same method, T, B,
+     * MLPs; the two event buffers with event_idx).  The kernel then evaluates nothing forwards; ae_act / ev_act / ev_i are NOT written
+     * (contract over saved_ae_act / saved_ev_act instead). */
+    const float* saved_act;
+    const float* saved_xstage;
+    const float* saved_ae_act;
+    const float* saved_ev_act;
+    const float* saved_ev_i;
 } psnode_dae_bwd_wide_args_f32;
 
 int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* args);   /* dims only */
@@ -417,6 +452,7 @@ int32_t psnode_ode_encoded_integrate_f32(const psnode_ode_encoded_args_f32* args
 
 /* Row width Hp of save_act for these dims (32 / 64 / 128) if an AUTO / MFMA call can save its activations, else 0 (dims only). */
 int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);
+int32_t psnode_dae_save_hidden(const psnode_dae_args_f32* args);
 
 /* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);

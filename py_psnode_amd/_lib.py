@@ -15,8 +15,10 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 3          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
-                         #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden)
+ABI_VERSION = 4          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+                         #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
+                         #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
+                         #     psnode_dae_save_hidden)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -24,7 +26,7 @@ LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.
 EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
-    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_ode_save_hidden", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
+    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_ode_save_hidden", "psnode_dae_save_hidden", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
@@ -72,7 +74,9 @@ class DaeArgsF32(ctypes.Structure):
                 ("x_init", c_void_p), ("all_initial", c_void_p), ("event_idx", c_void_p),
                 ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
                 ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64),
-                ("x_out", c_void_p), ("i_out", c_void_p)]
+                ("x_out", c_void_p), ("i_out", c_void_p),
+                ("save_act", c_void_p), ("save_xstage", c_void_p), ("save_ae_act", c_void_p), ("save_ev_act", c_void_p),
+                ("save_ev_i", c_void_p)]
 
 
 class OdeBwdArgsF32(ctypes.Structure):
@@ -119,7 +123,10 @@ class DaeBwdWideArgsF32(ctypes.Structure):
                 ("carry_x", c_void_p), ("carry_i", c_void_p),
                 ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p), ("dsum", c_void_p * 3),
                 ("ae_act", c_void_p * 3), ("ae_delta", c_void_p * 3), ("ae_gi", c_void_p),
-                ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p)]
+                ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p),
+                ("grad_params_de", c_void_p), ("grad_zv", c_void_p), ("grad_jump", c_void_p), ("grad_all_initial_de", c_void_p),
+                ("saved_act", c_void_p), ("saved_xstage", c_void_p), ("saved_ae_act", c_void_p), ("saved_ev_act", c_void_p),
+                ("saved_ev_i", c_void_p)]
 
 
 class LossArgsF32(ctypes.Structure):
@@ -161,6 +168,8 @@ def load():
     lib.psnode_build_info.restype = c_char_p
     lib.psnode_ode_save_hidden.restype = c_int32
     lib.psnode_ode_save_hidden.argtypes = [ctypes.POINTER(OdeArgsF32)]
+    lib.psnode_dae_save_hidden.restype = c_int32
+    lib.psnode_dae_save_hidden.argtypes = [ctypes.POINTER(DaeArgsF32)]
     lib.psnode_status_string.restype = c_char_p
     lib.psnode_status_string.argtypes = [c_int32]
     lib.psnode_workspace_bytes.restype = c_size_t

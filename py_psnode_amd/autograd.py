@@ -32,6 +32,24 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
     return need <= free // 2
 
 
+def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
+    """The same policy for the DAE: saved rows are read by the fused-DE backward K7f, i.e. at hidden widths other than 64 (K7, the
+    one-launch kernel there, recomputes)."""
+    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) != 4 or de[0][0].shape[0] == 64:
+        return False
+    Hp = fused.dae_save_hidden(method, de, ae, x_dim, z_dim, v_dim, i_dim, kernel)
+    if Hp <= 0 or not fused.dae_backward_wide_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim):
+        return False
+    if SAVE_ACTIVATIONS == "1":
+        return True
+    if Hp < 64:
+        return False
+    S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    need = ((T - 1) * S * (3 * Hp + x_dim) + 3 * T * Hp) * B * 4
+    free, _ = torch.cuda.mem_get_info(de[0][0].device)
+    return need <= free // 2
+
+
 class _FusedOde(torch.autograd.Function):
     @staticmethod
     def forward(ctx, method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params):
@@ -84,12 +102,16 @@ class _FusedDae(torch.autograd.Function):
         ae = [(params[k], params[k + 1]) for k in range(2 * n_de, len(params), 2)]
         T, B = t.shape[0], t.shape[1]
         x_dummy = x_init.new_zeros((1, B, 0))
-        xs, is_ = fused.dae_integrate(method, de, ae, x_init, t, x_dummy, z, v, i_shape_like, all_initial, z_jump=z_jump, v_jump=v_jump,
-                                      event_idx=event_idx, kernel=kernel)
+        save = _want_saved_dae(method, kernel, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i_shape_like.shape[-1], T, B)
+        res = fused.dae_integrate(method, de, ae, x_init, t, x_dummy, z, v, i_shape_like, all_initial, z_jump=z_jump, v_jump=v_jump,
+                                  event_idx=event_idx, kernel=kernel, save=save)
+        xs, is_ = res[0], res[1]
+        acts = [q for q in res[2] if q is not None] if save else []
         ctx.method, ctx.n_de, ctx.event_idx = method, n_de, event_idx
         ctx.has_zj, ctx.has_vj = z_jump is not None, v_jump is not None
+        ctx.n_saved = len(acts)
         ctx.save_for_backward(t, z, v, all_initial, xs, is_, *((z_jump,) if z_jump is not None else ()),
-                              *((v_jump,) if v_jump is not None else ()), *params)
+                              *((v_jump,) if v_jump is not None else ()), *acts, *params)
         return xs, is_
 
     @staticmethod
@@ -101,10 +123,15 @@ class _FusedDae(torch.autograd.Function):
         k += int(ctx.has_zj)
         v_jump = sv[k] if ctx.has_vj else None
         k += int(ctx.has_vj)
+        acts = None
+        if ctx.n_saved:
+            acts = tuple(sv[k:k + ctx.n_saved]) + (None,) * (5 - ctx.n_saved)
+            k += ctx.n_saved
         params = sv[k:]
         de = [(params[q], params[q + 1]) for q in range(0, 2 * ctx.n_de, 2)]
         ae = [(params[q], params[q + 1]) for q in range(2 * ctx.n_de, len(params), 2)]
-        g = fused.dae_backward(ctx.method, de, ae, t, z, v, a0, xs, is_, grad_xs, grad_is, event_idx=ctx.event_idx, z_jump=z_jump, v_jump=v_jump)
+        g = fused.dae_backward(ctx.method, de, ae, t, z, v, a0, xs, is_, grad_xs, grad_is, event_idx=ctx.event_idx, z_jump=z_jump, v_jump=v_jump,
+                               saved=acts)
         gz = g["z"] if g["z"] is not None else (torch.zeros_like(z) if ctx.needs_input_grad[6] else None)
         gv = g["v"] if g["v"] is not None else (torch.zeros_like(v) if ctx.needs_input_grad[7] else None)
         return (None, None, None, None, None, g["x_init"], gz, gv, None, g["all_initial"],

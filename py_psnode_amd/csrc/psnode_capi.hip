@@ -176,6 +176,14 @@ int fill_dae(const psnode_dae_args_f32* a, IntegrateDev& d) {
     d.vje = a->vj_stride_e;
     d.xo = a->x_out;
     d.io = a->i_out;
+    const bool sv = a->save_act != nullptr;
+    if ((a->save_xstage != nullptr) != sv || (a->save_ae_act != nullptr) != sv) return PSNODE_ERR_NULL;
+    if (sv && a->event_idx && (!a->save_ev_act || !a->save_ev_i)) return PSNODE_ERR_NULL;
+    d.sact = a->save_act;
+    d.sxst = a->save_xstage;
+    d.saeact = a->save_ae_act;
+    d.sevact = a->save_ev_act;
+    d.sevi = a->save_ev_i;
     return PSNODE_OK;
 }
 
@@ -247,10 +255,26 @@ int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspac
     return dispatch(d, false, args->kernel, &args->de, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int32_t psnode_dae_save_hidden(const psnode_dae_args_f32* a) {
+    if (!a) return 0;
+    IntegrateDev d;
+    memset(&d, 0, sizeof(d));
+    d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.vd = a->v_dim; d.id = a->i_dim; d.T = a->T; d.B = a->B;
+    bind_dims(a->de, d.de);
+    bind_dims(a->ae, d.ae);
+    return a->kernel == PSNODE_KERNEL_GENERIC ? 0 : mfma_dae_save_hidden(d);
+}
+
 int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspace, size_t workspace_bytes, void* stream) {
     IntegrateDev d;
     const int rc = fill_dae(args, d);
     if (rc) return rc;
+    if (d.sact) {      // only K2 proper writes the training side outputs
+        IntegrateDev q = d;
+        bind_dims(args->de, q.de);
+        bind_dims(args->ae, q.ae);
+        if (args->kernel == PSNODE_KERNEL_GENERIC || !mfma_dae_save_hidden(q)) return PSNODE_ERR_UNSUPPORTED;
+    }
     return dispatch(d, true, args->kernel, &args->de, &args->ae, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

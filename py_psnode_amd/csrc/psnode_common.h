@@ -44,6 +44,9 @@ struct IntegrateDev {
     float* io;
     float* sact;           // ODE training forward: saved activations [T-1,S,3,B,Hp] / stage inputs [T-1,S,B,xd], or null
     float* sxst;
+    float* saeact;         // DAE training forward: AE head activations per grid point [3,T,B,Hp], per event [nE,3,B,Hp] and the event's i0 [nE,B,16]
+    float* sevact;
+    float* sevi;
     int maxw;              // widest activation vector incl. the MLP inputs (generic kernel buffer A)
     int maxo;              // widest layer OUTPUT (generic kernel buffer B: it only ever holds layer outputs)
 };
@@ -189,6 +192,7 @@ hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t
 bool mfma_ode_supported(const IntegrateDev& a);
 int mfma_ode_save_hidden(const IntegrateDev& a);     // row width of saved activations if K1 proper takes the shape (no latent / teacher forcing), else 0
 bool mfma_dae_supported(const IntegrateDev& a);
+int mfma_dae_save_hidden(const IntegrateDev& a);     // likewise for K2 proper
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 // psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
@@ -197,6 +201,9 @@ hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b,
 bool fused_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
 size_t fused_bwd_workspace_floats(const psnode_ode_bwd_args_f32* a);
 int fused_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
+// K7f (psnode_dae_backward_fused.hip): the DAE backward at hidden <= 128 with the DE's parameter gradients formed in the kernel
+size_t dae_fused_bwd_workspace_floats(const psnode_dae_bwd_wide_args_f32* a);
+int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* a, float* workspace, hipStream_t s);
 // K8 (psnode_latent_bwd.hip): backward of the latent ODE integrator at hidden 16
 bool latent16_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 bool latent16_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);

@@ -653,6 +653,7 @@ int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* a
 
 size_t psnode_dae_backward_wide_workspace_bytes(const psnode_dae_bwd_wide_args_f32* a) {
     if (!psnode_dae_backward_wide_supported(a)) return 0;
+    if (a->grad_params_de) return dae_fused_bwd_workspace_floats(a) * sizeof(float);
     const int nw = wide_hidden(a->de) / 16, n = a->x_dim + a->z_dim + a->v_dim + a->i_dim;
     return (2 * wide_fwd_floats(nw, n) + 2 * wide_t_floats(nw) + 128) * sizeof(float);
 }
@@ -663,9 +664,21 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
     if (!psnode_dae_backward_wide_supported(p)) return PSNODE_ERR_UNSUPPORTED;
     if (p->T < 2 || p->B < 1 || p->k0 < 0 || p->k1 <= p->k0 || p->k1 > p->T - 1) return PSNODE_ERR_DIMS;
     for (int l = 0; l < 4; ++l) if (!p->de.weight[l] || !p->de.bias[l] || !p->ae.weight[l] || !p->ae.bias[l]) return PSNODE_ERR_NULL;
-    if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || !p->carry_i || !p->gk || !p->xstage || !p->ae_gi)
+    const bool fused = p->grad_params_de != nullptr;
+    if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || !p->ae_gi) return PSNODE_ERR_NULL;
+    if (fused) {
+        if (p->k0 != 0 || p->k1 != p->T - 1) return PSNODE_ERR_DIMS;
+        const bool sv = p->saved_act != nullptr;
+        if ((p->saved_xstage != nullptr) != sv || (p->saved_ae_act != nullptr) != sv) return PSNODE_ERR_NULL;
+        if (sv && p->event_idx && (!p->saved_ev_act || !p->saved_ev_i)) return PSNODE_ERR_NULL;
+        if (!p->grad_all_initial_de || (p->z_dim + p->v_dim > 0 && (!p->grad_zv || (p->event_idx && !p->grad_jump)))) return PSNODE_ERR_NULL;
+    } else if (!p->carry_i || !p->gk || !p->xstage) {
         return PSNODE_ERR_NULL;
-    for (int l = 0; l < 3; ++l) if (!p->act[l] || !p->delta[l] || !p->dsum[l] || !p->ae_act[l] || !p->ae_delta[l]) return PSNODE_ERR_NULL;
+    }
+    for (int l = 0; l < 3; ++l) {
+        if (!p->ae_act[l] || !p->ae_delta[l]) return PSNODE_ERR_NULL;
+        if (!fused && (!p->act[l] || !p->delta[l] || !p->dsum[l])) return PSNODE_ERR_NULL;
+    }
     if ((p->z_dim > 0 && !p->z.ptr) || (p->v_dim > 0 && !p->v.ptr)) return PSNODE_ERR_NULL;
     if (p->event_idx) {
         if (p->n_events < 1 || (p->z_dim > 0 && !p->z_jump) || (p->v_dim > 0 && !p->v_jump) || !p->ev_gi || !p->ev_i) return PSNODE_ERR_NULL;
@@ -681,6 +694,7 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
                               p->event_idx && zd > 0 ? p->zj_stride_b : 0, p->event_idx && vd > 0 ? p->vj_stride_b : 0};
         for (int64_t q : sb) if (q < 0 || Bm * q + 64 >= lim) return PSNODE_ERR_DIMS;
     }
+    if (fused) return dae_fused_bwd_launch(p, static_cast<float*>(workspace), s);
     const int nzv = zd + vd, ne = nzv + id, n = xd + ne;
     const int NZM = (2 * ne + 3) / 4, NZA = (nzv + 3) / 4, NA = (n + 3) / 4;
     float* pde = static_cast<float*>(workspace);

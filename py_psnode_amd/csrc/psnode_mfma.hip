@@ -42,6 +42,12 @@ bool mfma_dae_supported(const IntegrateDev& a) {
     }
 }
 
+int mfma_dae_save_hidden(const IntegrateDev& a) {
+    if (latent_shape_ok(a, true) || latent64_shape_ok(a, true)) return 0;
+    if ((a.flags & (PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I)) || !mfma_dae_supported(a)) return 0;
+    return mfma_hidden(a.de, 3 * (a.xd + a.zd + a.vd + a.id), a.xd);
+}
+
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
     if (de && de->n_layers == 2) return latent_pack_floats() > latent64_pack_floats() ? latent_pack_floats() : latent64_pack_floats();
     if (!de || de->n_layers != 4) return 0;

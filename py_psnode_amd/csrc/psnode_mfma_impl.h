@@ -312,7 +312,9 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         keep(0, h);
         if constexpr (decltype(from_lds)::value) {
             h = mid_lds(0, t.b2, h);
+            keep(1, h);
             h = mid_lds(1, t.b3, h);
+            keep(2, h);
         } else {
             h = mid(t.w2, t.b2, h);
             keep(1, h);
@@ -370,17 +372,25 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{}, [](int, f4) {});
     };
     // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
-    auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv) -> f4 {
+    // SAVE: `rows` = this lane's four units in layer 0 of the head's saved activations, `lstride` floats to the next layer (null: not saved)
+    auto ae_eval = [&](const float (&xa)[NX], const Arr<NZA>& zv, float* rows, const size_t lstride) -> f4 {
         f4 acc = c0a;
         if constexpr (DAE) {
 #pragma unroll
             for (int r = 0; r < NX; ++r) acc = mfma4(aw1x[r], xa[r], acc);
 #pragma unroll
             for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
+            if constexpr (SAVE)
+                return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{},
+                            [&](const int q, const f4 hq) { if (valid) *reinterpret_cast<f4*>(rows + (size_t)q * lstride) = hq; });
             return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{}, [](int, f4) {});
         }
         return acc;
     };
+    // SAVE (DAE): AE head activations per grid point [3,T,B,H], per event [nE,3,B,H]; the event's i0 in slot layout [nE,B,16]
+    const size_t sae_layer = (SAVE && DAE) ? (size_t)a.T * a.B * (16 * NWV) : 0;
+    float* sae_lane = (SAVE && DAE) ? a.saeact + (size_t)b * (16 * NWV) + 16 * w + 4 * g : nullptr;
+    auto sae_rows = [&](const long long kk) -> float* { return (SAVE && DAE) ? sae_lane + (size_t)kk * a.B * (16 * NWV) : nullptr; };
     auto load_x = [&](long long k, float (&dst)[NX]) {
 #pragma unroll
         for (int r = 0; r < NX; ++r) dst[r] = 4 * r + g < xd ? a.x.p[k * a.x.st + b * a.x.sb + 4 * r + g] : 0.0f;
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
         for (int r = 0; r < NX; ++r) xa[r] = x[r];
         if constexpr (TRUE_X) load_x(0, xa);
-        icur = ae_eval(xa, pick_ae(rz, rv));
+        icur = ae_eval(xa, pick_ae(rz, rv), sae_rows(0), sae_layer);
         store_i(0, icur);
         if (nT > 1) load_ae_raw(1, -1, zaz_nxt, zav_nxt);
     }
@@ -514,7 +524,16 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {
                 Arr<NZA> rz, rv;
                 load_ae_raw(k, ev_now, rz, rv);
-                icur = ae_eval(x, pick_ae(rz, rv));
+                float* erows = nullptr;
+                if constexpr (SAVE) erows = a.sevact + ((size_t)ev_now * 3 * a.B + b) * (16 * NWV) + 16 * w + 4 * g;
+                icur = ae_eval(x, pick_ae(rz, rv), erows, (size_t)a.B * (16 * NWV));
+                if constexpr (SAVE) {
+                    if (w == 0 && valid) {
+                        float* er = a.sevi + ((size_t)ev_now * a.B + b) * 16 + g;
+#pragma unroll
+                        for (int m = 0; m < NZM; ++m) er[4 * m] = icur[m];
+                    }
+                }
             }
         }
         // per-step constant of L1: c0 + W1[:, ext columns] . (ext - a0 | ext)
@@ -559,7 +578,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
             for (int r = 0; r < NX; ++r) xa[r] = x[r];
             if constexpr (TRUE_X) load_x(k + 1, xa);
-            icur = ae_eval(xa, zva);
+            icur = ae_eval(xa, zva, sae_rows(k + 1), sae_layer);
         }
     }
     store_x_at(xo_run);
@@ -599,6 +618,33 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
                 case 2: PSNODE_LAUNCH_SAVE(2)
                 case 3: PSNODE_LAUNCH_SAVE(3)
                 case 4: PSNODE_LAUNCH_SAVE(4)
+                default: return hipErrorNotSupported;
+            }
+#undef PSNODE_LAUNCH_SAVE
+        }
+    }
+    if constexpr (!TRUE_X && NXR == kNXc) {
+        if (dae && a.sact) {
+            if (a.flags & PSNODE_FLAG_INPUT_TRUE_I) return hipErrorNotSupported;
+#define PSNODE_LAUNCH_SAVE(NZM_, NZA_)                                                                                     \
+    {                                                                                                                      \
+        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, false, true, NWV, true>;                              \
+        const size_t lds = ae_weights_in_lds(true, NWV) ? ae_lds_bytes(NWV) : 0;                                           \
+        if (lds) {                                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+            if (e != hipSuccess) return e;                                                                                 \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, NA);                                                    \
+        return hipGetLastError();                                                                                          \
+    }
+            switch (NZM * 10 + NZA) {
+                case 11: PSNODE_LAUNCH_SAVE(1, 1)
+                case 21: PSNODE_LAUNCH_SAVE(2, 1)
+                case 31: PSNODE_LAUNCH_SAVE(3, 1)
+                case 41: PSNODE_LAUNCH_SAVE(4, 1)
+                case 32: PSNODE_LAUNCH_SAVE(3, 2)
+                case 42: PSNODE_LAUNCH_SAVE(4, 2)
                 default: return hipErrorNotSupported;
             }
 #undef PSNODE_LAUNCH_SAVE

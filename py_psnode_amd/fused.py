@@ -353,9 +353,13 @@ def ode_save_hidden(method: str, de_layers: Layers, x_dim: int, z_dim: int, kern
 
 def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, x, z, v, i, all_initial,
                   event_t=None, z_jump=None, v_jump=None, input_true_x: bool = False, input_true_i: bool = False,
-                  kernel: str = "auto", event_idx: Optional[torch.Tensor] = None, check_events: bool = False, out=None):
+                  kernel: str = "auto", event_idx: Optional[torch.Tensor] = None, check_events: bool = False, out=None,
+                  save: bool = False):
     """Fused integrate_DAE (replaces my_solvers.py:82-131 + step functions + DE_Func/AE_Func forwards).
-    `out` = (xs, is) contiguous [T,B,xd] / [T,B,id] tensors to write into (time-chunked launches)."""
+    `out` = (xs, is) contiguous [T,B,xd] / [T,B,id] tensors to write into (time-chunked launches).
+    save=True (training forward, K2 shapes without teacher forcing -- `dae_save_hidden`): the kernel also writes what autograd would
+    save (psnode_dae_args_f32::save_*); returns (xs, is, saved) with saved = (act [T-1,S,3,B,Hp], xstage [T-1,S,B,xd],
+    ae_act [3,T,B,Hp], ev_act [nE,3,B,Hp] | None, ev_i [nE,B,16] | None) for `dae_backward(..., saved=)`."""
     lib = _lib.load()
     dev = x_init.device
     if dev.type != "cuda":
@@ -412,11 +416,42 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
             if xs.shape != (T, B, xd) or is_.shape != (T, B, idim) or not (xs.is_contiguous() and is_.is_contiguous()):
                 raise ValueError("out must be contiguous fp32 ([T,B,xd], [T,B,id])")
         a.x_out, a.i_out = xs.data_ptr(), is_.data_ptr()
+        saved = None
+        if save:
+            Hp = lib.psnode_dae_save_hidden(ctypes.byref(a))
+            if Hp <= 0:
+                raise _lib.UnsupportedShapeError("dae_integrate(save=True): the MFMA integrator K2 does not take this shape")
+            S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+            f32 = dict(dtype=torch.float32, device=dev)
+            n_ev = (z_jump if z_jump is not None else v_jump).shape[1] if event_idx is not None else 0
+            saved = (torch.empty((max(T - 1, 0), S, 3, B, Hp), **f32), torch.empty((max(T - 1, 0), S, B, xd), **f32),
+                     torch.empty((3, T, B, Hp), **f32),
+                     torch.zeros((n_ev, 3, B, Hp), **f32) if n_ev else None, torch.zeros((n_ev, B, 16), **f32) if n_ev else None)
+            a.save_act, a.save_xstage, a.save_ae_act = saved[0].data_ptr(), saved[1].data_ptr(), saved[2].data_ptr()
+            if T < 2:       # no step: nothing but the head at grid point 0 is written; the struct wants all three or none
+                dummy = torch.empty(16, **f32)
+                keep.append(dummy)
+                a.save_act = a.save_xstage = dummy.data_ptr()
+            if n_ev:
+                a.save_ev_act, a.save_ev_i = saved[3].data_ptr(), saved[4].data_ptr()
         ws = _workspace(lib, a.de, a.ae, dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_dae_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_dae_integrate_f32")
-    return xs, is_
+    return (xs, is_, saved) if save else (xs, is_)
+
+
+def dae_save_hidden(method: str, de_layers: Layers, ae_layers: Layers, x_dim: int, z_dim: int, v_dim: int, i_dim: int,
+                    kernel: str = "auto") -> int:
+    """Row width of the saved activations if the forward for these dims can save them (K2 proper), else 0."""
+    if de_layers[0][0].device.type != "cuda" or max(len(de_layers), len(ae_layers)) > _lib.MAX_LAYERS:
+        return 0
+    lib = _lib.load()
+    a = _lib.DaeArgsF32()
+    a.method, a.kernel, a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = METHOD_ID[method], KERNEL_ID[kernel], x_dim, z_dim, v_dim, i_dim, 2, 1
+    dev = de_layers[0][0].device
+    a.de, a.ae = _mlp(de_layers, dev, "de", []), _mlp(ae_layers, dev, "ae", [])
+    return int(lib.psnode_dae_save_hidden(ctypes.byref(a)))
 
 
 def _bwd_args(method, de_layers, x_dim, z_dim, T, B, dev, keep, kernel="auto"):
@@ -594,11 +629,13 @@ def dae_backward_wide_supported(method: str, de_layers: Layers, ae_layers: Layer
 
 
 def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
-                      z_jump=None, v_jump=None, chunk_steps: Optional[int] = None):
-    """Backward of `dae_integrate` for hidden widths without a one-launch backward kernel (32, 128; also valid at 64): the sequential
-    adjoint sweep -- DE stages, AE head per grid point, event-time recompute -- on the MFMA kernel K7w in time chunks
-    (psnode_dae_backward_wide_f32); parameter gradients and the input gradients that are plain contractions over its stored rows as
-    library GEMMs.  Same return value as `dae_backward`."""
+                      z_jump=None, v_jump=None, chunk_steps: Optional[int] = None, fuse_de: bool = True, saved=None):
+    """Backward of `dae_integrate` for hidden widths <= 128 other than the one-launch kernel's (K7, hidden 64): the sequential adjoint
+    sweep -- DE stages, AE head per grid point, event-time recompute -- on an MFMA kernel (psnode_dae_backward_wide_f32).
+    fuse_de (default): ONE launch over the whole grid (K7f) that also forms the DE's parameter gradients and the DE's share of the
+    input gradients; only the AE head's rows (one set per grid point) are contracted here.  fuse_de=False: round 2's split (K7w in time
+    chunks, every contraction a library GEMM over stored rows).  saved = what `dae_integrate(save=True)` returned for the same call
+    (fuse_de only): the kernel evaluates nothing forwards.  Same return value as `dae_backward`."""
     lib = _lib.load()
     dev = xs.device
     T, B, xd = xs.shape
@@ -647,6 +684,12 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
     Sa1 = torch.zeros((B, H), **f32)                            # sum over the heads of the AE's delta_1
     carry_x, carry_i = torch.zeros((B, xd), **f32), torch.zeros((B, 16), **f32)
     a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
+    if fuse_de:
+        gp_de = torch.empty(sum(w.numel() + w.shape[0] for w in (W1, W2, W3, W4)), **f32)
+        ga0_de = torch.empty((B, n), **f32)
+        a.grad_params_de, a.grad_all_initial_de = gp_de.data_ptr(), ga0_de.data_ptr()
+        a.grad_zv = gzv.data_ptr()
+        a.grad_jump = gjump.data_ptr() if gjump is not None else None
     Fe = _pad_rows(W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv], H)       # (Ws + Wd)[:, z|v columns]
     Ae = _pad_rows(A1[:, n + xd:n + xd + nzv], H)
     zv_all = torch.cat((z.detach(), v.detach()), -1)            # [T, B, nzv] (one copy of the two input views)
@@ -669,6 +712,58 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         Sa1 += delta[0].sum(0)
         return (d1 @ Ae).view(R, B, nzv)
 
+    if saved is not None and not fuse_de:
+        raise ValueError("saved activations are read by the fused-DE form only")
+    if fuse_de:
+        if saved is not None:
+            s_act, s_xst, s_ae, s_ev, s_evi = saved
+            if s_ae.shape != (3, T, B, H) or s_act.shape != (T - 1, S, 3, B, H) or (n_ev and (s_ev is None or s_ev.shape != (n_ev, 3, B, H))):
+                raise ValueError("saved activations do not belong to this call (shape)")
+            keep += [s_act, s_xst, s_ae, s_ev, s_evi]
+            a.saved_act, a.saved_xstage, a.saved_ae_act = s_act.data_ptr(), s_xst.data_ptr(), s_ae.data_ptr()
+            if n_ev:
+                a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
+                for q in range(3):
+                    ev_rows[q] = s_ev[:, q]
+            arows = [s_ae[0], s_ae[1], s_ae[2]] + [torch.empty((T, B, H), **f32) for _ in range(3)]
+        else:
+            arows = [torch.empty((T, B, H), **f32) for _ in range(6)]
+        agi = torch.empty((T, B, 16), **f32)
+        a.k0, a.k1 = 0, T - 1
+        for q in range(3):
+            a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
+        a.ae_gi = agi.data_ptr()
+        with torch.cuda.device(dev):
+            nbytes = lib.psnode_dae_backward_wide_workspace_bytes(ctypes.byref(a))
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            wp, wn = _aligned_ptr(ws)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
+            rc = max(1, min(T, int(1.5e9 // (7 * 4 * B * H))))      # AE heads in row chunks (bounds the temporaries of the contractions)
+            for r0 in range(0, T, rc):
+                r1 = min(T, r0 + rc)
+                gza = head_grads([r[r0:r1] for r in arows[:3]], [r[r0:r1] for r in arows[3:]], agi[r0:r1], xs_c[r0:r1], zv_all[r0:r1])
+                if nzv > 0:
+                    gzv[r0:r1] += gza
+            del arows, agi
+            if n_ev:
+                evl = event_idx.long()
+                step_of = torch.zeros(n_ev, dtype=torch.long, device=dev).scatter_reduce_(
+                    0, evl.clamp_min(0), torch.arange(T - 1, device=dev) * (evl >= 0), "amax")
+                gza = head_grads(ev_rows[:3], ev_rows[3:], ev_gi, xs_c[step_of], jump_all.permute(1, 0, 2))
+                if nzv > 0:
+                    gjump += gza.permute(1, 0, 2)
+        g = {"z_jump": None, "v_jump": None}
+        g["x_init"] = carry_x + gx_c[0]
+        g["all_initial"] = ga0_de + Sa1 @ _pad_rows(A1[:, 0:n], H)
+        g["z"] = gzv[..., :zd].contiguous() if zd > 0 else None
+        g["v"] = gzv[..., zd:].contiguous() if vd > 0 else None
+        if n_ev:
+            g["z_jump"] = gjump[..., :zd].contiguous() if zd > 0 else None
+            g["v_jump"] = gjump[..., zd:].contiguous() if vd > 0 else None
+        g["de"] = _split_grads(gp_de, de_layers)
+        g["ae"] = [gA[0], gab[0], gA[1], gab[1], gA[2], gab[2], gA[3], gab[3]]
+        return g
     if chunk_steps is None:      # ~3 GB of stored rows per chunk
         chunk_steps = max(1, min(T - 1, int(3e9 // ((6 * S + 6) * 4 * B * H))))
     with torch.cuda.device(dev):
@@ -746,22 +841,26 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
 
 
 def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
-                 z_jump=None, v_jump=None, kernel: str = "auto"):
+                 z_jump=None, v_jump=None, kernel: str = "auto", saved=None):
     """Backward pass of `dae_integrate` (no teacher forcing): the one-launch MFMA backward (K7) for the DAE_01 shape class at hidden 64,
-    the adjoint sweep + GEMMs (`dae_backward_wide`) at hidden 32 / 128, else the generic backward kernel (K5);
-    `kernel` = "auto" | "mfma" | "generic" | "wide".
+    the fused-DE sweep K7f (`dae_backward_wide`) at the other hidden widths <= 128, else the generic backward kernel (K5);
+    `kernel` = "auto" | "mfma" | "generic" | "wide" (K7f at any width <= 128) | "split" (round 2's K7w + library GEMMs).
+    saved = what `dae_integrate(save=True)` returned (read by K7f only; the other kernels recompute).
     Returns dict(x_init, z, v, z_jump, v_jump, all_initial, de=[...], ae=[...]) of gradients."""
     lib = _lib.load()
     dev = xs.device
     T, B, xd = xs.shape
     zd, vd, idim = z.shape[-1], v.shape[-1], is_.shape[-1]
     # hidden 32 / 128 (no one-launch MFMA backward): the adjoint sweep on K7w + library GEMMs instead of the generic K5
-    if kernel == "wide" and T < 2:
+    if kernel in ("wide", "split") and T < 2:
         kernel = "generic"       # no step to sweep: the split backward has no head-only form, K5 handles the single grid point
+    if kernel == "split":
+        return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
+                                 z_jump=z_jump, v_jump=v_jump, fuse_de=False)
     if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
                             and dae_backward_wide_supported(method, de_layers, ae_layers, xd, zd, vd, idim)):
         return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
-                                 z_jump=z_jump, v_jump=v_jump)
+                                 z_jump=z_jump, v_jump=v_jump, saved=saved)
     keep: list = []
     a = _lib.DaeBwdArgsF32()
     a.method = METHOD_ID[method]

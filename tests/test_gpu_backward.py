@@ -447,23 +447,36 @@ def _dae_wide_vs_generic(method, H, B, Tn, xd, zd, vd, idim, seed, events, with_
         a = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj,
                                kernel="wide" if H == 64 else "auto")
     else:
-        a = fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, chunk_steps=chunk_steps)
-    for key in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial"):
-        if b[key] is None:
-            assert a[key] is None, key
-            continue
-        _close(a[key], b[key].double().cpu(), f"{key} (K7w vs K5)")
-    for grp in ("de", "ae"):
-        for k, (p, q) in enumerate(zip(a[grp], b[grp])):
-            _close(p, q.double().cpu(), f"grad {grp} {k} (K7w vs K5)")
+        a = fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, chunk_steps=chunk_steps,
+                                    fuse_de=False)      # round 2's split (K7w in time chunks + library GEMMs)
+    runs = [("K7f" if chunk_steps is None else "K7w", a)]
+    if chunk_steps is None:
+        # the same backward fed with what the FORWARD saved (dae_integrate(save=True): K7f evaluates nothing forwards); the forward's
+        # results must not depend on saving
+        xs_s, is_s, saved = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj, save=True)
+        assert torch.equal(xs_s, xs) and torch.equal(is_s, is_)
+        Hp = 32 if H <= 32 else (64 if H <= 64 else 128)
+        assert saved[2].shape == (3, Tn, B, Hp)
+        runs.append(("K7f(saved)", fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj,
+                                                      kernel="wide", saved=saved)))
+    for name, a in runs:
+        for key in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial"):
+            if b[key] is None:
+                assert a[key] is None, key
+                continue
+            _close(a[key], b[key].double().cpu(), f"{key} ({name} vs K5)")
+        for grp in ("de", "ae"):
+            for k, (p, q) in enumerate(zip(a[grp], b[grp])):
+                _close(p, q.double().cpu(), f"grad {grp} {k} ({name} vs K5)")
 
 
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
 @pytest.mark.parametrize("H", [32, 64, 128])
 @pytest.mark.parametrize("xd,zd,vd,idim", [(8, 2, 2, 2), (8, 0, 2, 2), (5, 1, 1, 1), (8, 2, 2, 4), (3, 1, 0, 1), (8, 4, 3, 1), (2, 2, 4, 2)])
 def test_dae_wide_backward_matches_generic_every_shape_class(xd, zd, vd, idim, H, method):
-    """K7w (adjoint sweep + library GEMMs; `auto` at hidden 32 / 128, forced at 64) against K5 (generic backward, itself checked
-    against fp64 autograd above) on every (NZM, NZA) register class, with two event steps, per-trajectory clocks and a ragged tile."""
+    """K7f (one-launch sweep with the DE's parameter gradients in the kernel, AE head rows contracted on the host side; `auto` at hidden
+    32 / 128, forced at 64) against K5 (generic backward, itself checked against fp64 autograd above) on every (NZM, NZA) register
+    class, with two event steps, per-trajectory clocks and a ragged tile."""
     _dae_wide_vs_generic(method, H, 21, 9, xd, zd, vd, idim, seed=140 + xd + zd, events=True)
 
 
@@ -509,6 +522,9 @@ def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):
     grad_is = None"""
     _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True, chunk_steps=chunk)
     _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False, chunk_steps=chunk)
+    if chunk is not None:      # the same cases on the one-launch form (K7f)
+        _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True)
+        _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False)
 
 
 @pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3), (16, 5)])
