@@ -386,6 +386,35 @@ int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* a
 size_t psnode_dae_backward_wide_workspace_bytes(const psnode_dae_bwd_wide_args_f32* args);
 int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
+/* K7h: every contraction over the AE head's rows that the fused-DE form of psnode_dae_backward_wide_f32 leaves to the caller, in one
+ * launch (no library GEMM): for rows r < R (grid points, or events) and trajectories b, with h_l = act[l] row r (the head's ELU outputs:
+ * saved by the forward call or written by the backward call) and delta_l its layer adjoints,
+ *     out = [ dAW2 (h x h) | dAW3 (h x h) | P3 (16 x h): gi[slot] (x) h3 | P0 (h x 16): delta1 (x) u | db1 db2 db3 (3 x h) | sum gi (16) ]
+ *     sa1[b] = sum_r delta1[r, b]                      (for dL/dall_initial and dAW1's all_initial columns)
+ *     grad_zv[r, b, c] = sum_unit AW1[unit][zv_col0 + c] delta1[r, b][unit],  c < n_zv   (row stride 8)
+ * with h = hidden (the MLP's real width; rows are Hp = 32 / 64 / 128 floats wide, zero padded), gi / u rows of 16 floats (gi: slot layout
+ * of psnode_dae_bwd_wide_args_f32; u: the head's first-layer input columns behind all_initial, x | z | v, zero padded).  Deterministic
+ * (per-workgroup partials summed in a fixed order). */
+typedef struct {
+    int64_t R, B;
+    int32_t hidden;
+    int32_t n_zv;
+    const float* act[3];             /* row r of layer l: act[l] + r * act_row_stride, [B, Hp] */
+    int64_t act_row_stride;
+    const float* delta[3];           /* [R, B, Hp] */
+    const float* gi;                 /* [R, B, 16] */
+    const float* u;                  /* [R, B, 16] */
+    const float* aw1;                /* the AE's first nn.Linear weight [hidden, aw1_cols] (read for grad_zv only) */
+    int32_t aw1_cols, zv_col0;
+    float* grad_zv;                  /* [R, B, 8] or NULL */
+    float* sa1;                      /* [B, Hp] */
+    float* out;                      /* [psnode_dae_head_grads_out_floats(hidden)] */
+} psnode_dae_head_grads_args_f32;
+
+int32_t psnode_dae_head_grads_out_floats(int32_t hidden);
+size_t psnode_dae_head_grads_workspace_bytes(const psnode_dae_head_grads_args_f32* args);
+int32_t psnode_dae_head_grads_f32(const psnode_dae_head_grads_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Masked, column-weighted squared-error loss of one (prediction, target) pair and its gradient, in one pass:
  *
  *   out[d]   = scale * inv_norm * col_weight[d] * sum_{t,b} mask[t,b,(d)] * (pred[t,b,d] - target[t,b,d])^2     d < D

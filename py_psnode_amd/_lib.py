@@ -26,7 +26,8 @@ LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.
 EXPORTS = (
     "psnode_abi_version", "psnode_build_info", "psnode_status_string", "psnode_workspace_bytes",
     "psnode_event_table_f32", "psnode_ode_integrate_f32", "psnode_dae_integrate_f32",
-    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_ode_save_hidden", "psnode_dae_save_hidden", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
+    "psnode_ode_kernel_for", "psnode_dae_kernel_for", "psnode_ode_save_hidden", "psnode_dae_save_hidden", "psnode_dae_head_grads_out_floats",
+    "psnode_dae_head_grads_workspace_bytes", "psnode_dae_head_grads_f32", "psnode_mlp_rows_supported", "psnode_mlp_rows_f32",
     "psnode_ode_backward_supported", "psnode_ode_backward_param_count", "psnode_ode_backward_workspace_bytes",
     "psnode_ode_backward_f32", "psnode_dae_backward_supported", "psnode_dae_backward_workspace_bytes", "psnode_dae_backward_f32",
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
@@ -129,6 +130,12 @@ class DaeBwdWideArgsF32(ctypes.Structure):
                 ("saved_ev_i", c_void_p)]
 
 
+class DaeHeadGradsArgsF32(ctypes.Structure):
+    _fields_ = [("R", c_int64), ("B", c_int64), ("hidden", c_int32), ("n_zv", c_int32), ("act", c_void_p * 3), ("act_row_stride", c_int64),
+                ("delta", c_void_p * 3), ("gi", c_void_p), ("u", c_void_p), ("aw1", c_void_p), ("aw1_cols", c_int32), ("zv_col0", c_int32),
+                ("grad_zv", c_void_p), ("sa1", c_void_p), ("out", c_void_p)]
+
+
 class LossArgsF32(ctypes.Structure):
     _fields_ = [("T", c_int64), ("B", c_int64), ("D", c_int32), ("mask_width", c_int32),
                 ("pred", ViewF32), ("target", ViewF32), ("mask", ViewF32),
@@ -168,6 +175,12 @@ def load():
     lib.psnode_build_info.restype = c_char_p
     lib.psnode_ode_save_hidden.restype = c_int32
     lib.psnode_ode_save_hidden.argtypes = [ctypes.POINTER(OdeArgsF32)]
+    lib.psnode_dae_head_grads_out_floats.restype = c_int32
+    lib.psnode_dae_head_grads_out_floats.argtypes = [c_int32]
+    lib.psnode_dae_head_grads_workspace_bytes.restype = c_size_t
+    lib.psnode_dae_head_grads_workspace_bytes.argtypes = [ctypes.POINTER(DaeHeadGradsArgsF32)]
+    lib.psnode_dae_head_grads_f32.restype = c_int32
+    lib.psnode_dae_head_grads_f32.argtypes = [ctypes.POINTER(DaeHeadGradsArgsF32), c_void_p, c_size_t, c_void_p]
     lib.psnode_dae_save_hidden.restype = c_int32
     lib.psnode_dae_save_hidden.argtypes = [ctypes.POINTER(DaeArgsF32)]
     lib.psnode_status_string.restype = c_char_p

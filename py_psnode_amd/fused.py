@@ -712,6 +712,48 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         Sa1 += delta[0].sum(0)
         return (d1 @ Ae).view(R, B, nzv)
 
+    def head_grads_hip(act, act_row_stride, delta, gi_slots, x_rows, zv_rows):
+        """the same contractions on K7h (psnode_dae_head_grads_f32): act = 3 device pointers' tensors whose row r lies r*act_row_stride
+        floats behind the first; delta / gi_slots / x_rows / zv_rows [R, B, .] contiguous"""
+        nonlocal Sa1
+        R = delta[0].shape[0]
+        u = torch.zeros((R, B, 16), **f32)
+        u[..., :xd] = x_rows
+        if nzv > 0:
+            u[..., xd:xd + nzv] = zv_rows
+        h = _lib.DaeHeadGradsArgsF32()
+        h.R, h.B, h.hidden, h.n_zv = R, B, Hr, nzv
+        for q in range(3):
+            h.act[q], h.delta[q] = act[q].data_ptr(), delta[q].data_ptr()
+        h.act_row_stride = act_row_stride
+        h.gi, h.u = gi_slots.data_ptr(), u.data_ptr()
+        A1c = A1.contiguous()
+        h.aw1, h.aw1_cols, h.zv_col0 = A1c.data_ptr(), A1c.shape[1], n + xd
+        gza = torch.empty((R, B, 8), **f32) if nzv > 0 else None
+        sa1 = torch.empty((B, H), **f32)
+        out = torch.empty(lib.psnode_dae_head_grads_out_floats(Hr), **f32)
+        h.grad_zv = gza.data_ptr() if gza is not None else None
+        h.sa1, h.out = sa1.data_ptr(), out.data_ptr()
+        nb = lib.psnode_dae_head_grads_workspace_bytes(ctypes.byref(h))
+        hws = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+        hp_, hn_ = _aligned_ptr(hws)
+        _lib.check(lib.psnode_dae_head_grads_f32(ctypes.byref(h), hp_, hn_, torch.cuda.current_stream(dev).cuda_stream),
+                   "psnode_dae_head_grads_f32")
+        o = 0
+        gA[1].add_(out[o:o + Hr * Hr].view(Hr, Hr)); o += Hr * Hr
+        gA[2].add_(out[o:o + Hr * Hr].view(Hr, Hr)); o += Hr * Hr
+        P3 = out[o:o + 16 * Hr].view(16, Hr); o += 16 * Hr
+        gA[3].add_(P3[nzv:ne] + P3[ne + nzv:2 * ne])
+        P0 = out[o:o + Hr * 16].view(Hr, 16); o += Hr * 16
+        gA[0][:, n:n + xd + nzv].add_(P0[:, :xd + nzv])
+        gA[0][:, :n].add_(sa1[:, :Hr].t() @ a0)
+        for q in range(3):
+            gab[q].add_(out[o:o + Hr]); o += Hr
+        sg = out[o:o + 16]
+        gab[3].add_(sg[nzv:ne] + sg[ne + nzv:2 * ne])
+        Sa1 += sa1
+        return gza[..., :nzv] if gza is not None else None
+
     if saved is not None and not fuse_de:
         raise ValueError("saved activations are read by the fused-DE form only")
     if fuse_de:
@@ -739,18 +781,17 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
             wp, wn = _aligned_ptr(ws)
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
-            rc = max(1, min(T, int(1.5e9 // (7 * 4 * B * H))))      # AE heads in row chunks (bounds the temporaries of the contractions)
-            for r0 in range(0, T, rc):
-                r1 = min(T, r0 + rc)
-                gza = head_grads([r[r0:r1] for r in arows[:3]], [r[r0:r1] for r in arows[3:]], agi[r0:r1], xs_c[r0:r1], zv_all[r0:r1])
-                if nzv > 0:
-                    gzv[r0:r1] += gza
+            # the AE head's rows -> its parameter gradients and its share of the input gradients (K7h)
+            gza = head_grads_hip(arows[:3], B * H, arows[3:], agi, xs_c, zv_all)
+            if nzv > 0:
+                gzv += gza
             del arows, agi
             if n_ev:
                 evl = event_idx.long()
                 step_of = torch.zeros(n_ev, dtype=torch.long, device=dev).scatter_reduce_(
                     0, evl.clamp_min(0), torch.arange(T - 1, device=dev) * (evl >= 0), "amax")
-                gza = head_grads(ev_rows[:3], ev_rows[3:], ev_gi, xs_c[step_of], jump_all.permute(1, 0, 2))
+                ev_stride = ev_rows[0].stride(0)         # B*H (own buffers) or 3*B*H (layer q of the forward call's [nE,3,B,H])
+                gza = head_grads_hip(ev_rows[:3], ev_stride, ev_rows[3:], ev_gi, xs_c[step_of], jump_all.permute(1, 0, 2))
                 if nzv > 0:
                     gjump += gza.permute(1, 0, 2)
         g = {"z_jump": None, "v_jump": None}
