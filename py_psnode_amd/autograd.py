@@ -35,7 +35,11 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
 def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
     """The same policy for the DAE: saved rows are read by the fused-DE backward K7f, i.e. at hidden widths other than 64 (K7, the
     one-launch kernel there, recomputes)."""
-    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) != 4 or de[0][0].shape[0] == 64:
+    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) != 4:
+        return False
+    # hidden 64 has the one-launch kernel K7 (recompute): the saved form beats it at RK4 only (training step at 4096 x 1000:
+    # 21.4 vs 23.0 ms; Midpoint 14.8 vs 14.9, Euler 11.3 vs 10.7: profiles/r03z_h64.txt)
+    if de[0][0].shape[0] == 64 and not (method == "rk4" or SAVE_ACTIVATIONS == "1"):
         return False
     Hp = fused.dae_save_hidden(method, de, ae, x_dim, z_dim, v_dim, i_dim, kernel)
     if Hp <= 0 or not fused.dae_backward_wide_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim):

@@ -898,7 +898,7 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
     if kernel == "split":
         return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
                                  z_jump=z_jump, v_jump=v_jump, fuse_de=False)
-    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and de_layers[0][0].shape[0] != 64 and T >= 2
+    if kernel == "wide" or (kernel == "auto" and len(de_layers) == 4 and (de_layers[0][0].shape[0] != 64 or saved is not None) and T >= 2
                             and dae_backward_wide_supported(method, de_layers, ae_layers, xd, zd, vd, idim)):
         return dae_backward_wide(method, de_layers, ae_layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=event_idx,
                                  z_jump=z_jump, v_jump=v_jump, saved=saved)
