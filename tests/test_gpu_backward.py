@@ -232,6 +232,100 @@ def test_hidden128_training_takes_the_one_launch_backward():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in m.parameters())
 
 
+def test_dae_hidden128_training_takes_the_fused_backward_without_library_gemms():
+    """DAE_Model at --hidden 128 (the scripts' argparse default, neural_01_DAE_01_no_encode.py) under autograd with fused='require':
+    forward K2 saving its activations, backward K7f (DE gradients in the kernel) + K7h (AE head contractions): neither round 2's
+    split nor a torch matmul / bmm over stored rows; two runs are bit-identical."""
+    from py_psnode_amd import fused, models
+    from py_psnode_amd import autograd as pag
+    from py_psnode_amd import neural_dae as nd
+    torch.manual_seed(2)
+    m = models.DAE_Model(8, 2, 2, 2, 128, solver=nd.RK4()).cuda()
+    m.solver.fused = "require"
+    B, Tn = 40, 24
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1).cuda()
+    r = lambda *s_: (0.1 * torch.randn(*s_)).cuda()
+    x, z, v, i = r(B, Tn, 8), r(B, Tn, 2), r(B, Tn, 2), r(B, Tn, 2)
+    ev = torch.stack([t[:, 5], t[:, 17]], dim=1).contiguous()           # two event steps
+    zj, vj = r(B, 2, 2), r(B, 2, 2)
+    de, ae = fused.de_layers_of(m.de_func, 14, 8), fused.ae_layers_of(m.ae_func, 14, 12, 2)
+    assert pag._want_saved_dae("rk4", "auto", de, ae, 8, 2, 2, 2, Tn, B) is True
+    seen = {"split": 0, "head": 0, "mm": 0}
+    orig_wide, orig_gemm = fused.dae_backward_wide, fused._gemm_tn
+
+    def wide(*a, **k):
+        seen["split"] += int(k.get("fuse_de", True) is False)
+        assert k.get("saved") is not None, "the training forward must have saved its activations"
+        return orig_wide(*a, **k)
+
+    grads = []
+    try:
+        fused.dae_backward_wide = wide
+        fused._gemm_tn = lambda *a, **k: (seen.__setitem__("mm", seen["mm"] + 1), orig_gemm(*a, **k))[1]
+        for _ in range(2):
+            m.zero_grad()
+            xp, ip = m(t=t, x=x, z=z, v=v, i=i, event_t=ev, z_jump=zj, v_jump=vj)
+            (nn.functional.mse_loss(xp, x) + nn.functional.mse_loss(ip, i)).backward()
+            grads.append([p.grad.clone() for p in m.parameters()])
+    finally:
+        fused.dae_backward_wide, fused._gemm_tn = orig_wide, orig_gemm
+    assert seen["split"] == 0 and seen["mm"] == 0
+    assert all(torch.isfinite(g_).all() and float(g_.abs().max()) > 0 for g_ in grads[0])
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(*grads)), "training step not bit-reproducible"
+
+
+@pytest.mark.parametrize("hidden,R,B,nzv,ev_layout", [(128, 7, 37, 4, False), (20, 3, 16, 0, False), (64, 4, 21, 7, True), (32, 1, 5, 2, False)])
+def test_head_grads_kernel_against_torch(hidden, R, B, nzv, ev_layout):
+    """K7h (psnode_dae_head_grads_f32) on random rows against fp64 einsums: every block of `out`, sa1, grad_zv; zero-padded hidden
+    widths, ragged tile, the [nE,3,B,Hp] row layout of the forward call's event buffers."""
+    import ctypes
+    from py_psnode_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(hidden + R)
+    Hp = 32 if hidden <= 32 else (64 if hidden <= 64 else 128)
+    def rows(*s_):
+        q = torch.randn(*s_, generator=g)
+        q[..., hidden:] = 0.0           # units beyond the real width are zero padding in every row the kernels write
+        return q
+    if ev_layout:
+        hbuf = rows(R, 3, B, Hp).cuda()
+        act, stride = [hbuf[:, q] for q in range(3)], 3 * B * Hp
+    else:
+        hbuf = rows(3, R, B, Hp).cuda()
+        act, stride = [hbuf[q] for q in range(3)], B * Hp
+    delta = [rows(R, B, Hp).cuda() for _ in range(3)]
+    gi, u = torch.randn(R, B, 16, generator=g).cuda(), torch.randn(R, B, 16, generator=g).cuda()
+    k1a, zv0 = 30, 20
+    aw1 = torch.randn(hidden, k1a, generator=g).cuda()
+    a = _lib.DaeHeadGradsArgsF32()
+    a.R, a.B, a.hidden, a.n_zv = R, B, hidden, nzv
+    for q in range(3):
+        a.act[q], a.delta[q] = act[q].data_ptr(), delta[q].data_ptr()
+    a.act_row_stride = stride
+    a.gi, a.u, a.aw1, a.aw1_cols, a.zv_col0 = gi.data_ptr(), u.data_ptr(), aw1.data_ptr(), k1a, zv0
+    gza = torch.full((R, B, 8), float("nan"), device="cuda")
+    sa1 = torch.empty(B, Hp, device="cuda")
+    out = torch.empty(lib.psnode_dae_head_grads_out_floats(hidden), device="cuda")
+    a.grad_zv, a.sa1, a.out = (gza.data_ptr() if nzv else None), sa1.data_ptr(), out.data_ptr()
+    nb = lib.psnode_dae_head_grads_workspace_bytes(ctypes.byref(a))
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.psnode_dae_head_grads_f32(ctypes.byref(a), wp, nb, torch.cuda.current_stream().cuda_stream), "head_grads")
+    d64 = [q.double().cpu()[..., :hidden] for q in delta]
+    h64 = [q.double().cpu()[..., :hidden] for q in act]
+    gi64, u64 = gi.double().cpu(), u.double().cpu()
+    o = 0
+    for name, ref in [("dAW2", torch.einsum("rbu,rbv->uv", d64[1], h64[0])), ("dAW3", torch.einsum("rbu,rbv->uv", d64[2], h64[1])),
+                      ("P3", torch.einsum("rbs,rbv->sv", gi64, h64[2])), ("P0", torch.einsum("rbu,rbc->uc", d64[0], u64)),
+                      ("db", torch.stack([q.sum((0, 1)) for q in d64])), ("sum gi", gi64.sum((0, 1)))]:
+        got = out[o:o + ref.numel()].view(ref.shape); o += ref.numel()
+        _close(got, ref, name)
+    assert o == out.numel()
+    _close(sa1[:, :hidden], d64[0].sum(0), "sa1")
+    if nzv:
+        _close(gza[..., :nzv], torch.einsum("rbu,uc->rbc", d64[0], aw1.double().cpu()[:, zv0:zv0 + nzv]), "grad_zv")
+
+
 @pytest.mark.parametrize("method", ["euler", "rk4"])
 @pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2), (8, 2, 128, 3), (8, 2, 32, 3)])
 def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
