@@ -19,6 +19,7 @@ kt train_dae01 $B --train --workload dae01 --steps 5
 kt train_ode01_h128 $B --train --hidden 128 --steps 3 --warmup 1
 kt train_ode01_h32 $B --train --hidden 32 --steps 3 --warmup 1
 kt train_dae01_h128 $B --train --workload dae01 --hidden 128 --steps 3 --warmup 1
+kt train_dae01_h32 $B --train --workload dae01 --hidden 32 --steps 3 --warmup 1
 kt train_models python $R/profiles/scripts/train_step_models.py ode02 dae02
 pmc() { rocprofv3 --kernel-trace --pmc $2 -d $O/r03_$1_$2 -o p -- "${@:4}" > /dev/null 2>&1; python $R/profiles/summarize_pmc.py $O/r03_$1_$2/p_results.db $3 > $O/r03_$1_$2_pmc.txt; rm -rf $O/r03_$1_$2; }
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -37,6 +38,7 @@ bash profiles/scripts/pmc_sq.sh r03_dae01_euler integrate_mfma --workload dae01 
 bash profiles/scripts/pmc_sq.sh r03_k4 ode_backward_kernel --train --steps 2 --warmup 1 > /dev/null
 bash profiles/scripts/pmc_sq.sh r03_k7 dae_backward_kernel --train --workload dae01 --steps 2 --warmup 1 > /dev/null
 bash profiles/scripts/pmc_sq.sh r03_k4f_h128 ode_backward_fused --train --hidden 128 --steps 2 --warmup 1 > /dev/null
+bash profiles/scripts/pmc_sq.sh r03_k7f_h128 dae_backward_fused --train --workload dae01 --hidden 128 --steps 2 --warmup 1 > /dev/null
 rm -f $O/pmc_r03_*.log
 python profiles/scripts/accuracy_report.py > $O/r03_accuracy_report.txt 2>&1
 bash profiles/scripts/batch_sweep.sh > $O/r03_batch_sweep.txt 2>&1
@@ -46,6 +48,8 @@ python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-cpu-baseline 2>
 python bench.py --steps 5 --train --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_ode01_train_n1.json
 python bench.py --steps 5 --train --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_dae01_train_n1.json
 for w in ode01 dae01; do for h in 128 32; do python bench.py --steps 5 --warmup 2 --train --workload $w --hidden $h --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_${w}_h${h}_train_n1.json; done; done
+for w in ode01 dae01; do for m in midpoint euler; do python bench.py --steps 5 --warmup 2 --train --workload $w --hidden 128 --method $m --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_${w}_h128_${m}_train_n1.json; done; done
+for w in ode01 dae01; do PSNODE_SAVE_ACTIVATIONS=0 python bench.py --steps 5 --warmup 2 --train --workload $w --hidden 128 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_${w}_h128_train_recompute_n1.json; done
 python bench.py --steps 5 --hidden 128 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/r03_bench_ode01_h128_n1.json
 python bench.py --steps 5 --hidden 128 --workload dae01 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_dae01_h128_n1.json
 ls $O | grep r03_
