@@ -139,12 +139,13 @@ typedef struct {
     float* i_out;              /* [T,B,i_dim] contiguous */
     /* Optional training side outputs, all of them or none (as psnode_ode_args_f32::save_act): what loss.backward() would have autograd
      * keep, so that the backward call (psnode_dae_bwd_wide_args_f32::saved_*) does not recompute the forward:
-     *   save_act    [T-1, S, 3, B, Hp]   the DE's ELU outputs per (step, stage); Hp = psnode_dae_save_hidden()
+     *   save_act    [T-1, S, L, B, Hp]   the DE's ELU outputs per (step, stage); Hp = psnode_dae_save_hidden(), L = hidden layers of the MLPs
      *   save_xstage [T-1, S, B, x_dim]   the DE's stage inputs
-     *   save_ae_act [3, T, B, Hp]        the AE head's ELU outputs per grid point (my_solvers.py:95, :121)
-     *   save_ev_act [nE, 3, B, Hp]       the same for the event-time heads i0 = g(x_k; jumps) (my_solvers.py:108-110); rows of events no
-     *   save_ev_i   [nE, B, 16]          step takes are not written.  save_ev_i: i0 in the slot layout of psnode_dae_bwd_wide_args_f32.
-     * The two event buffers are required only with event_idx.  Only the MFMA integrator K2 writes them, without teacher forcing
+     *   save_ae_act [L, T, B, Hp]        the AE head's ELU outputs per grid point (my_solvers.py:95, :121)
+     *   save_ev_act [nE, L, B, Hp]       the same for the event-time heads i0 = g(x_k; jumps) (my_solvers.py:108-110); rows of events no
+     *   save_ev_i   [nE, B, W]           step takes are not written.  save_ev_i: i0 -- K2 shapes (L = 3): W = 16, the slot layout of
+     *                                    psnode_dae_bwd_wide_args_f32; latent shapes at hidden 64 (L = 1, K3c): W = i_dim = 64.
+     * The two event buffers are required only with event_idx.  Only the MFMA integrators K2 and K3c write them, without teacher forcing
      * (psnode_dae_save_hidden() > 0): else UNSUPPORTED. */
     float* save_act;
     float* save_xstage;
@@ -306,6 +307,14 @@ typedef struct {
     float* grad_all_initial;         /* [B, x+z+v+i] */
     float* grad_params_de;
     float* grad_params_ae;
+    /* ABI 4, optional, all or none (the two event buffers only with event_idx): what the forward call wrote to
+     * psnode_dae_args_f32::save_* (same method, T, B, MLPs).  Read by K9 (the latent shapes at hidden 64), which then evaluates nothing
+     * forwards; UNSUPPORTED for the shapes whose kernel behind this entry point recomputes (K7, K8, K5). */
+    const float* saved_act;
+    const float* saved_xstage;
+    const float* saved_ae_act;
+    const float* saved_ev_act;
+    const float* saved_ev_i;
 } psnode_dae_bwd_args_f32;
 
 int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* args);

@@ -96,7 +96,9 @@ class DaeBwdArgsF32(ctypes.Structure):
                 ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64), ("n_events", c_int32),
                 ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
                 ("grad_x_init", c_void_p), ("grad_z", c_void_p), ("grad_v", c_void_p), ("grad_z_jump", c_void_p),
-                ("grad_v_jump", c_void_p), ("grad_all_initial", c_void_p), ("grad_params_de", c_void_p), ("grad_params_ae", c_void_p)]
+                ("grad_v_jump", c_void_p), ("grad_all_initial", c_void_p), ("grad_params_de", c_void_p), ("grad_params_ae", c_void_p),
+                ("saved_act", c_void_p), ("saved_xstage", c_void_p), ("saved_ae_act", c_void_p), ("saved_ev_act", c_void_p),
+                ("saved_ev_i", c_void_p)]
 
 
 class OdeEncodedArgsF32(ctypes.Structure):

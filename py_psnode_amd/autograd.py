@@ -20,14 +20,15 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
     if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma"):
         return False
     Hp = fused.ode_save_hidden(method, layers, x_dim, z_dim, kernel)
-    if Hp <= 0 or not fused.ode_backward_supported(method, layers, x_dim, z_dim, "wide"):
+    latent = len(layers) == 2            # the direct_encode latent shape at hidden 64: K3c saves, K9 reads
+    if Hp <= 0 or not (latent or fused.ode_backward_supported(method, layers, x_dim, z_dim, "wide")):
         return False
     if SAVE_ACTIVATIONS == "1":
         return True
     if Hp < 64:
         return False
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
-    need = (T - 1) * S * B * (3 * Hp + x_dim) * 4
+    need = (T - 1) * S * B * ((len(layers) - 1) * Hp + x_dim) * 4
     free, _ = torch.cuda.mem_get_info(layers[0][0].device)
     return need <= free // 2
 
@@ -35,8 +36,16 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
 def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
     """The same policy for the DAE: saved rows are read by the fused-DE backward K7f, i.e. at hidden widths other than 64 (K7, the
     one-launch kernel there, recomputes)."""
-    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) != 4:
+    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) not in (2, 4):
         return False
+    if len(de) == 2:                     # the direct_encode latent shape at hidden 64 (K3c saves, K9 reads); hidden 16 (K3a / K8) recomputes
+        if fused.dae_save_hidden(method, de, ae, x_dim, z_dim, v_dim, i_dim, kernel) != 64:
+            return False
+        if SAVE_ACTIVATIONS == "1":
+            return True
+        S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+        free, _ = torch.cuda.mem_get_info(de[0][0].device)
+        return ((T - 1) * S * 2 + T) * 64 * B * 4 <= free // 2
     # hidden 64 has the one-launch kernel K7 (recompute): the saved form beats it at RK4 only (training step at 4096 x 1000:
     # 21.4 vs 23.0 ms; Midpoint 14.8 vs 14.9, Euler 11.3 vs 10.7: profiles/r03z_h64.txt)
     if de[0][0].shape[0] == 64 and not (method == "rk4" or SAVE_ACTIVATIONS == "1"):

@@ -592,7 +592,7 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
     if ((a->saved_act != nullptr) != (a->saved_xstage != nullptr)) return PSNODE_ERR_NULL;
-    if (a->saved_act && !use_fused_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4f reads them
+    if (a->saved_act && !use_fused_bwd(a) && !use_latent64_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4f and K9 read them
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);
@@ -693,6 +693,12 @@ extern "C" int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* a, voi
     if (a->event_idx && ((a->z_dim > 0 && !a->z_jump) || (a->v_dim > 0 && !a->v_jump))) return PSNODE_ERR_NULL;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_dae_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
+    {
+        const bool sv = a->saved_act != nullptr;
+        if ((a->saved_xstage != nullptr) != sv || (a->saved_ae_act != nullptr) != sv) return PSNODE_ERR_NULL;
+        if (sv && a->event_idx && (!a->saved_ev_act || !a->saved_ev_i)) return PSNODE_ERR_NULL;
+        if (sv && (use_mfma_dae_bwd(a) || !use_latent64_dae_bwd(a))) return PSNODE_ERR_UNSUPPORTED;      // only K9 reads them here
+    }
     if (use_mfma_dae_bwd(a)) return dae_mfma_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     if (use_latent64_dae_bwd(a)) return latent64_dae_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     if (use_latent16_dae_bwd(a)) return latent16_dae_bwd_launch(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));

@@ -59,7 +59,10 @@ __global__ void pack64_kernel(const Pack64 p) {
 
 struct V4 { f4 v[4]; };   // a 64-wide vector in chunk layout: v[c] = dims 16((w+c)&3) + 4g + (0..3) of trajectory j
 
-template <int METHOD, int NBE, bool DAE>
+// SAVE (training forward): what autograd would keep for loss.backward() -- the hidden ELU outputs and stage inputs of the DE per
+// (step, stage) (a.sact [T-1,S,B,64], a.sxst [T-1,S,B,64]), of the AE head per grid point (a.saeact [T,B,64]) and, for events taken,
+// of the event-time head and its value i0 (a.sevact / a.sevi [nE,B,64]): K9's REC = false instance reads them instead of recomputing.
+template <int METHOD, int NBE, bool DAE, bool SAVE = false>
 __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, const float* __restrict__ pack_de,
                                                         const float* __restrict__ pack_ae) {
     constexpr int NBLK = 1 + NBE, NZV = DAE ? NBE - 1 : NBE, n = H64 * NBLK;
@@ -189,22 +192,42 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         p ^= 1;
         return accA + accB;
     };
-    auto rhs_from_gathered = [&](const V4& xg, const f4 cz) -> f4 {      // stage whose input is already gathered
+    // SAVE: running row pointers of (step, stage) -- this lane's own four dims
+    const long long srow = SAVE ? a.B * H64 : 0;
+    float* sa_run = SAVE ? a.sact + b * H64 + 16 * w + 4 * g : nullptr;
+    float* sx_run = SAVE ? a.sxst + b * H64 + 16 * w + 4 * g : nullptr;
+    auto keep_stage = [&](const f4 xs_own, const f4 h1) {
+        if constexpr (SAVE) {
+            if (valid) { *reinterpret_cast<f4*>(sx_run) = xs_own; *reinterpret_cast<f4*>(sa_run) = h1; }
+            sx_run += srow; sa_run += srow;
+        }
+    };
+    auto rhs_from_gathered = [&](const V4& xg, const f4 cz) -> f4 {      // stage whose input is already gathered (xg.v[0] = own dims)
         f4 accA = cz, accB = {0.f, 0.f, 0.f, 0.f};
         mm(wf[0], xg, accA, accB);
-        return layer(w2, b2r, elu4l(accA + accB));
+        const f4 h1 = elu4l(accA + accB);
+        keep_stage(xg.v[0], h1);
+        return layer(w2, b2r, h1);
     };
-    auto rhs = [&](const f4 xs_own, const f4 cz) -> f4 { return layer(w2, b2r, elu4l(layer(wf[0], cz, xs_own))); };
-    auto ae_eval = [&](const V4& xg, const Ext& zv) -> f4 {
+    auto rhs = [&](const f4 xs_own, const f4 cz) -> f4 {
+        const f4 h1 = elu4l(layer(wf[0], cz, xs_own));
+        keep_stage(xs_own, h1);
+        return layer(w2, b2r, h1);
+    };
+    // `hrow` (SAVE): where this lane's four units of the head's hidden layer go, or null
+    auto ae_eval = [&](const V4& xg, const Ext& zv, float* hrow) -> f4 {
         f4 accA = c0a, accB = {0.f, 0.f, 0.f, 0.f};
         if constexpr (DAE) {
             mm(af[0], xg, accA, accB);
 #pragma unroll
             for (int s = 0; s < NZV; ++s) mm(af[1 + s], zv.b[s], accA, accB);
-            return layer(aw2, ab2r, elu4l(accA + accB));
+            const f4 h1 = elu4l(accA + accB);
+            if constexpr (SAVE) { if (valid) *reinterpret_cast<f4*>(hrow) = h1; }
+            return layer(aw2, ab2r, h1);
         }
         return accA;
     };
+    auto head_row = [&](float* base, const long long r) -> float* { return SAVE ? base + (r * a.B + b) * H64 + 16 * w + 4 * g : nullptr; };
 
     store_own(a.xo, 0, x);
     V4 xg = gather(x);                      // gathered x_k: stage 1 of the step and the AE head both consume it
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
     if constexpr (DAE) {
         Ext zv0;
         load_ext(0, -1, zv0);
-        icur = ae_eval(xg, zv0);
+        icur = ae_eval(xg, zv0, head_row(a.saeact, 0));
         store_own(a.io, 0, icur);
     }
     if (nT < 2) return;
@@ -247,7 +270,8 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
             if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {   // i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)
                 Ext zvj;
                 load_ext(k, ev_now, zvj);
-                icur = ae_eval(xg, zvj);
+                icur = ae_eval(xg, zvj, head_row(a.sevact, ev_now));
+                if constexpr (SAVE) { if (valid) *reinterpret_cast<f4*>(head_row(a.sevi, ev_now)) = icur; }
             }
         }
         // per-step constant: c0 + sum over external blocks F_blk . block
@@ -276,11 +300,11 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
         xg = gather(x);
         if constexpr (DAE) {   // i1 = g(x1; z[k+1], v[k+1]) with the RAW inputs: the prefetch of step k+1 unless that step jumps
             if (more && __builtin_amdgcn_readfirstlane(ev_cur) < 0) {
-                icur = ae_eval(xg, ext_nxt);
+                icur = ae_eval(xg, ext_nxt, head_row(a.saeact, k + 1));
             } else {
                 Ext zva;
                 load_ext(k + 1, -1, zva);
-                icur = ae_eval(xg, zva);
+                icur = ae_eval(xg, zva, head_row(a.saeact, k + 1));
             }
             store_own(a.io, k + 1, icur);
         }
@@ -293,6 +317,12 @@ bool al4(const ViewDev& v) { return v.p && (reinterpret_cast<uintptr_t>(v.p) & 1
 template <int METHOD>
 hipError_t launch64_method(const IntegrateDev& a, bool dae, const float* pde, const float* pae, hipStream_t s) {
     const dim3 grid((unsigned)((a.B + 15) / 16)), block(256);
+    if (a.sact) {       // training forward
+        if (!dae) hipLaunchKernelGGL((latent64_kernel<METHOD, 1, false, true>), grid, block, 0, s, a, pde, pae);
+        else if (a.zd) hipLaunchKernelGGL((latent64_kernel<METHOD, 3, true, true>), grid, block, 0, s, a, pde, pae);
+        else hipLaunchKernelGGL((latent64_kernel<METHOD, 2, true, true>), grid, block, 0, s, a, pde, pae);
+        return hipGetLastError();
+    }
     if (!dae) hipLaunchKernelGGL((latent64_kernel<METHOD, 1, false>), grid, block, 0, s, a, pde, pae);
     else if (a.zd) hipLaunchKernelGGL((latent64_kernel<METHOD, 3, true>), grid, block, 0, s, a, pde, pae);
     else hipLaunchKernelGGL((latent64_kernel<METHOD, 2, true>), grid, block, 0, s, a, pde, pae);

@@ -92,7 +92,11 @@ struct Bwd9Dev {
 struct V9 { f4 v[4]; };      // a 64-wide vector in chunk layout: v[c] = dims 16((w+c)&3) + 4g + (0..3) of trajectory j
 struct A9 { f4 c[4]; };      // gradient of one 64x64 block, own 16 rows: c[chunk] rows 16w+4g+r, columns 16((w+chunk)&3) + j
 
-template <int METHOD, int NBE, bool DAE>
+// REC = false: the training forward (K3c SAVE instances) saved the hidden ELU outputs and stage inputs of every DE stage, the AE head's
+// hidden layer per grid point and per event taken, and the event-time i0 (IntegrateDev::sact / sxst / saeact / sevact / sevi): nothing is
+// evaluated forwards in here -- no per-step constant, no phase A, no head recompute --, the forward blocks are not even loaded, and the
+// rows of step k are requested in front of the head of grid point k+1, whose work hides their latency.
+template <int METHOD, int NBE, bool DAE, bool REC = true>
 __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d, const float* __restrict__ pack_de,
                                                                  const float* __restrict__ pack_ae) {
     constexpr int S = rk_stages(METHOD);
@@ -124,13 +128,15 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     // ---- weights
     const float* pw = pack_de + (size_t)w * D_R * 64 + l;
     const float* pwa = pack_ae + (size_t)w * A_R * 64 + l;
-    float wf[NBLK][16], w2[16], w2t[16], wftx[16], wfti[DAE ? 16 : 1], wftz[DAE ? 1 : 16];
+    float wf[REC ? NBLK : 1][16], w2[16], w2t[16], wftx[16], wfti[DAE ? 16 : 1], wftz[DAE ? 1 : 16];
     f4 b1r, b2r;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        if constexpr (REC) {
 #pragma unroll
-        for (int blk = 0; blk < NBLK; ++blk) wf[blk][k] = pw[(16 * blk + k) * 64];
-        w2[k] = pw[(D_W2 + k) * 64];
+            for (int blk = 0; blk < NBLK; ++blk) wf[blk][k] = pw[(16 * blk + k) * 64];
+            w2[k] = pw[(D_W2 + k) * 64];
+        } else { wf[0][k] = 0.0f; w2[k] = 0.0f; }
         w2t[k] = pw[(D_W2T + k) * 64];
         wftx[k] = pw[(D_FT + k) * 64];
         if constexpr (DAE) wfti[k] = pw[(D_FT + 16 * (NBLK - 1) + k) * 64];
@@ -138,16 +144,18 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { b1r[r] = pw[(D_B1 + r) * 64]; b2r[r] = pw[(D_B2 + r) * 64]; }
-    float af[DAE ? NAE : 1][16];
+    float af[(DAE && REC) ? NAE : 1][16];
     f4 ab1r = z9(), ab2r = z9();
     f4* wlp = wl + w * 64 + l;                              // block q, chunk c at wlp[(q*4 + c) * 256]
     if constexpr (DAE) {
+        if constexpr (REC) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+            for (int k = 0; k < 16; ++k)
 #pragma unroll
-            for (int bb = 0; bb < NAE; ++bb) af[bb][k] = pwa[(16 * bb + k) * 64];
+                for (int bb = 0; bb < NAE; ++bb) af[bb][k] = pwa[(16 * bb + k) * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ab1r[r] = pwa[(A_B1 + r) * 64]; ab2r[r] = pwa[(A_B2 + r) * 64]; }
+            for (int r = 0; r < 4; ++r) { ab1r[r] = pwa[(A_B1 + r) * 64]; ab2r[r] = pwa[(A_B2 + r) * 64]; }
+        }
         auto stage_blk = [&](const int q, const float* src) {   // 16 packed registers -> LDS block q
 #pragma unroll
             for (int c = 0; c < 4; ++c) wlp[(q * 4 + c) * 256] = f4{src[(4 * c) * 64], src[(4 * c + 1) * 64], src[(4 * c + 2) * 64], src[(4 * c + 3) * 64]};
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 
     // ---- per-trajectory constants: c0 = b1 + sum_blk A0_blk . a0_blk   (DE and AE)
     f4 c0A = b1r, c0B = z9(), caA = ab1r, caB = z9();
-    for (int blk = 0; blk < NBLK; ++blk) {
+    for (int blk = 0; blk < (REC ? NBLK : 0); ++blk) {
         const V9 a0v = load_chunks(a.a0 + b * n + H9 * blk);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -313,13 +321,15 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         publish(0, xo);
 #pragma unroll
         for (int s = 0; s < NZV; ++s) publish(1 + s, zv.b[s]);
-        f4 accA = c0a, accB = z9();
-        if constexpr (DAE) {
-            { const V9 xg = gather(xo); mm(af[0], xg, accA, accB); }
+        if constexpr (REC) {
+            f4 accA = c0a, accB = z9();
+            if constexpr (DAE) {
+                { const V9 xg = gather(xo); mm(af[0], xg, accA, accB); }
 #pragma unroll
-            for (int s = 0; s < NZV; ++s) { const V9 zg = gather(zv.b[s]); mm(af[1 + s], zg, accA, accB); }
-        }
-        ah1 = elu9(accA + accB);
+                for (int s = 0; s < NZV; ++s) { const V9 zg = gather(zv.b[s]); mm(af[1 + s], zg, accA, accB); }
+            }
+            ah1 = elu9(accA + accB);
+        }                                       // REC = false: the caller has put the saved hidden layer into ah1
     };
     // output of the AE head from ah1 (event steps only): W2 streamed from the packed image
     auto ae_output = [&]() -> f4 {
@@ -366,6 +376,13 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 
     for (long long jg = nT - 1; jg >= 0; --jg) {
         f4 g1 = gcarry + (valid ? row_of(d.gxs, jg) : z9());
+        // REC = false: the saved rows of step jg-1 (clamped at the last iteration: no branch around the loads), consumed behind the head
+        f4 xst[S], h1[S];
+        if constexpr (!REC) {
+            const long long ks_ = (jg > 0 ? jg - 1 : 0) * S;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { xst[s] = row_of(a.sxst, ks_ + s); h1[s] = row_of(a.sact, ks_ + s); }
+        }
         if constexpr (DAE) {
             // ================= (1) AE head at grid point jg (raw z|v)
             const f4 xj = row_of(d.xs, jg);
@@ -373,6 +390,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 #pragma unroll
             for (int s = 0; s < NZV; ++s) zvj.b[s] = load_zv(s, jg, -1);
             const f4 gi = gicarry + ((d.gis && valid) ? row_of(d.gis, jg) : z9());
+            if constexpr (!REC) ah1 = row_of(a.saeact, jg);
             g1 += ae_vjp(xj, zvj, gi, gzv);
 #pragma unroll
             for (int s = 0; s < NZV; ++s) store_zv(s, jg, -1, dezv.b[s] + gzv.b[s]);
@@ -390,31 +408,37 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 #pragma unroll
         for (int s = 0; s < NZV; ++s) ext[s] = load_zv(s, k, ev);
         if constexpr (DAE) {
-            if (ev >= 0) {       // i_in = g(x_k; z_jump, v_jump)  (my_solvers.py:108-110)
-                ZV zq;
+            if constexpr (REC) {
+                if (ev >= 0) {       // i_in = g(x_k; z_jump, v_jump)  (my_solvers.py:108-110)
+                    ZV zq;
 #pragma unroll
-                for (int s = 0; s < NZV; ++s) zq.b[s] = ext[s];
-                ae_hidden(x0, zq);
-                ext[NBE - 1] = ae_output();
-            } else {
-                ext[NBE - 1] = row_of(d.is_, k);
+                    for (int s = 0; s < NZV; ++s) zq.b[s] = ext[s];
+                    ae_hidden(x0, zq);
+                    ext[NBE - 1] = ae_output();
+                } else {
+                    ext[NBE - 1] = row_of(d.is_, k);
+                }
+            } else {                 // (one load: the row base is selected, not the loaded values)
+                ext[NBE - 1] = row_of(ev >= 0 ? a.sevi : d.is_, ev >= 0 ? (long long)ev : k);
             }
         }
-        f4 czA = c0, czB = z9();
+        if constexpr (REC) {
+            f4 czA = c0, czB = z9();
 #pragma unroll
-        for (int e = 0; e < NBE; ++e) { const V9 eg = gather(ext[e]); mm(wf[1 + e], eg, czA, czB); }
-        const f4 cz = czA + czB;
+            for (int e = 0; e < NBE; ++e) { const V9 eg = gather(ext[e]); mm(wf[1 + e], eg, czA, czB); }
+            const f4 cz = czA + czB;
 
-        // ---- phase A: stage evaluations
-        f4 xst[S], h1[S], ks[S];
+            // ---- phase A: stage evaluations
+            f4 ks[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            f4 acc = z9();
+            for (int s = 0; s < S; ++s) {
+                f4 acc = z9();
 #pragma unroll
-            for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj];
-            xst[s] = s == 0 ? x0 : x0 + h_ * acc;
-            h1[s] = elu9(layer(wf[0], cz, xst[s]));
-            ks[s] = layer(w2, b2r, h1[s]);
+                for (int jj = 0; jj < s; ++jj) acc += rk_a(METHOD, s, jj) * ks[jj];
+                xst[s] = s == 0 ? x0 : x0 + h_ * acc;
+                h1[s] = elu9(layer(wf[0], cz, xst[s]));
+                ks[s] = layer(w2, b2r, h1[s]);
+            }
         }
         // ---- phase B: stages backwards
         f4 gks[S], gx0 = g1, D1 = z9();
@@ -454,6 +478,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
                 ZV zq, gq;
 #pragma unroll
                 for (int s = 0; s < NZV; ++s) zq.b[s] = ext[s];
+                if constexpr (!REC) ah1 = row_of(a.sevact, (long long)ev);
                 gx0 += ae_vjp(x0, zq, gext[NBE - 1], gq);
 #pragma unroll
                 for (int s = 0; s < NZV; ++s) { store_zv(s, k, ev, gext[s] + gq.b[s]); dezv.b[s] = z9(); }
@@ -567,7 +592,7 @@ size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 +
 
 template <int METHOD, int NBE, bool DAE>
 hipError_t launch9(const Bwd9Dev& d, const float* pde, const float* pae, hipStream_t s) {
-    auto kern = &latent64_backward_kernel<METHOD, NBE, DAE>;
+    auto kern = d.a.sact ? &latent64_backward_kernel<METHOD, NBE, DAE, false> : &latent64_backward_kernel<METHOD, NBE, DAE, true>;
     const size_t lds = lds9_bytes(DAE ? 2 * NBE : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -635,6 +660,7 @@ int latent64_ode_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, 
     d.a.a0 = a->all_initial; d.a.ev = a->event_idx; d.a.zj = a->z_jump; d.a.zjb = a->zj_stride_b; d.a.zje = a->zj_stride_e;
     d.xs = a->xs; d.gxs = a->grad_xs; d.gx0 = a->grad_x0; d.gz = a->grad_z; d.gzj = a->grad_z_jump; d.ga0 = a->grad_all_initial;
     d.n_events = a->n_events;
+    d.a.sact = const_cast<float*>(a->saved_act); d.a.sxst = const_cast<float*>(a->saved_xstage);
     return run9(d, false, 2, a->de, nullptr, workspace, a->grad_params, nullptr, s);
 }
 
@@ -674,6 +700,8 @@ int latent64_dae_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, 
     d.xs = a->xs; d.is_ = a->is; d.gxs = a->grad_xs; d.gis = a->grad_is;
     d.gx0 = a->grad_x_init; d.gz = a->grad_z; d.gv = a->grad_v; d.gzj = a->grad_z_jump; d.gvj = a->grad_v_jump; d.ga0 = a->grad_all_initial;
     d.n_events = a->n_events;
+    d.a.sact = const_cast<float*>(a->saved_act); d.a.sxst = const_cast<float*>(a->saved_xstage);
+    d.a.saeact = const_cast<float*>(a->saved_ae_act); d.a.sevact = const_cast<float*>(a->saved_ev_act); d.a.sevi = const_cast<float*>(a->saved_ev_i);
     return run9(d, true, a->z_dim ? 4 : 3, a->de, &a->ae, workspace, a->grad_params_de, a->grad_params_ae, s);
 }
 

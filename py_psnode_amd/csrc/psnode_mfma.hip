@@ -23,7 +23,8 @@ bool mfma_ode_supported(const IntegrateDev& a) {
 }
 
 int mfma_ode_save_hidden(const IntegrateDev& a) {
-    if (latent_shape_ok(a, false) || latent64_shape_ok(a, false)) return 0;
+    if (latent64_shape_ok(a, false)) return 64;       // K3c: one hidden layer per MLP
+    if (latent_shape_ok(a, false)) return 0;
     if ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) || a.xd < 1 || a.xd > 4 * kNXc || nzm_of(a, false) > kMaxNZM) return 0;
     return mfma_hidden(a.de, 3 * (a.xd + a.zd), a.xd);
 }
@@ -43,7 +44,8 @@ bool mfma_dae_supported(const IntegrateDev& a) {
 }
 
 int mfma_dae_save_hidden(const IntegrateDev& a) {
-    if (latent_shape_ok(a, true) || latent64_shape_ok(a, true)) return 0;
+    if (latent64_shape_ok(a, true)) return 64;
+    if (latent_shape_ok(a, true)) return 0;
     if ((a.flags & (PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I)) || !mfma_dae_supported(a)) return 0;
     return mfma_hidden(a.de, 3 * (a.xd + a.zd + a.vd + a.id), a.xd);
 }

@@ -328,7 +328,8 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
             if Hp <= 0:
                 raise _lib.UnsupportedShapeError("ode_integrate(save=True): the MFMA integrator K1 does not take this shape")
             S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
-            saved = (torch.empty((max(T - 1, 0), S, 3, B, Hp), dtype=torch.float32, device=dev),
+            L = len(de_layers) - 1       # hidden layers: 3 for the no_encode MLPs (K1), 1 for the latent ones at hidden 64 (K3c)
+            saved = (torch.empty((max(T - 1, 0), S, L, B, Hp), dtype=torch.float32, device=dev),
                      torch.empty((max(T - 1, 0), S, B, xd), dtype=torch.float32, device=dev))
             if T >= 2:
                 a.save_act, a.save_xstage = saved[0].data_ptr(), saved[1].data_ptr()
@@ -424,9 +425,11 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
             S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
             f32 = dict(dtype=torch.float32, device=dev)
             n_ev = (z_jump if z_jump is not None else v_jump).shape[1] if event_idx is not None else 0
-            saved = (torch.empty((max(T - 1, 0), S, 3, B, Hp), **f32), torch.empty((max(T - 1, 0), S, B, xd), **f32),
-                     torch.empty((3, T, B, Hp), **f32),
-                     torch.zeros((n_ev, 3, B, Hp), **f32) if n_ev else None, torch.zeros((n_ev, B, 16), **f32) if n_ev else None)
+            L = len(de_layers) - 1       # hidden layers: 3 (K2), 1 for the latent shapes at hidden 64 (K3c; i0 rows are then i_dim wide)
+            saved = (torch.empty((max(T - 1, 0), S, L, B, Hp), **f32), torch.empty((max(T - 1, 0), S, B, xd), **f32),
+                     torch.empty((L, T, B, Hp), **f32),
+                     torch.zeros((n_ev, L, B, Hp), **f32) if n_ev else None,
+                     torch.zeros((n_ev, B, 16 if L == 3 else idim), **f32) if n_ev else None)
             a.save_act, a.save_xstage, a.save_ae_act = saved[0].data_ptr(), saved[1].data_ptr(), saved[2].data_ptr()
             if T < 2:       # no step: nothing but the head at grid point 0 is written; the struct wants all three or none
                 dummy = torch.empty(16, **f32)
@@ -886,7 +889,8 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
     """Backward pass of `dae_integrate` (no teacher forcing): the one-launch MFMA backward (K7) for the DAE_01 shape class at hidden 64,
     the fused-DE sweep K7f (`dae_backward_wide`) at the other hidden widths <= 128, else the generic backward kernel (K5);
     `kernel` = "auto" | "mfma" | "generic" | "wide" (K7f at any width <= 128) | "split" (round 2's K7w + library GEMMs).
-    saved = what `dae_integrate(save=True)` returned (read by K7f only; the other kernels recompute).
+    saved = what `dae_integrate(save=True)` returned (read by K7f and, for the latent shapes at hidden 64, K9; K7 / K8 / K5 recompute
+    and refuse them).
     Returns dict(x_init, z, v, z_jump, v_jump, all_initial, de=[...], ae=[...]) of gradients."""
     lib = _lib.load()
     dev = xs.device
@@ -944,6 +948,12 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
         a.grad_z = g["z"].data_ptr() if g["z"] is not None else None
         a.grad_v = g["v"].data_ptr() if g["v"] is not None else None
         a.grad_params_de, a.grad_params_ae = gde.data_ptr(), gae.data_ptr()
+        if saved is not None and T >= 2:        # (K9 reads them; the C side refuses them for the kernels that recompute)
+            s_act, s_xst, s_ae, s_ev, s_evi = saved
+            keep += [s_act, s_xst, s_ae, s_ev, s_evi]
+            a.saved_act, a.saved_xstage, a.saved_ae_act = s_act.data_ptr(), s_xst.data_ptr(), s_ae.data_ptr()
+            if event_idx is not None:
+                a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
         nbytes = lib.psnode_dae_backward_workspace_bytes(ctypes.byref(a))
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)

@@ -95,6 +95,35 @@ def test_fused_backward_matches_reference_gradients(tag, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["ode01", "dae01", "ode02_h64", "dae02_h64", "ode01_h128", "dae01_h128"])
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_fused_backward_recompute_route_matches_reference_gradients(tag, method, monkeypatch):
+    """The same with PSNODE_SAVE_ACTIVATIONS = 0: the backward kernels recompute the forward (K4 / K7 / K9 / K4f / K7f `REC = true`) instead
+    of reading what the training forward saved (the default route of these models, covered by the test above)."""
+    from py_psnode_amd import autograd as pag
+    monkeypatch.setattr(pag, "SAVE_ACTIVATIONS", "0")
+    d, m, res, leaves = _run_model(tag, method, "cuda", "require")
+    _check(tag, method, d, m, res, leaves, TOL_GPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["ode02_h64", "dae02_h64", "dae02_z0"])
+def test_latent_models_save_their_activations_by_default(tag):
+    """hidden-64 direct_encode models: the training forward (K3c) saves, K9 reads; the hidden-16 ones recompute."""
+    from py_psnode_amd import autograd as pag
+    from py_psnode_amd import fused
+    seen = []
+    orig_o, orig_d = fused.ode_backward, fused.dae_backward
+    try:
+        fused.ode_backward = lambda *a, **k: (seen.append(k.get("saved") is not None), orig_o(*a, **k))[1]
+        fused.dae_backward = lambda *a, **k: (seen.append(k.get("saved") is not None), orig_d(*a, **k))[1]
+        _run_model(tag, "rk4", "cuda", "require")
+    finally:
+        fused.ode_backward, fused.dae_backward = orig_o, orig_d
+    assert seen == [tag.endswith("_h64")], seen
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kernel,tag", [("generic", "ode01"), ("mfma", "ode01"), ("wide", "ode01"), ("wide", "ode01_h128"), ("wide", "ode01_h32"),
                                         ("generic", "ode01_h128"), ("split", "ode01_h128"),
                                         ("saved", "ode01"), ("saved", "ode01_h128"), ("saved", "ode01_h32")])
