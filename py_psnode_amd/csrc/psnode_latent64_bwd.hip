@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
                                                                  const float* __restrict__ pack_ae) {
     constexpr int S = rk_stages(METHOD);
     constexpr int NBLK = 1 + NBE, NZV = DAE ? NBE - 1 : NBE, n = H9 * NBLK, NAE = DAE ? NBE : 0;
-    constexpr int NLB = DAE ? 2 * NBE : 0;                  // 64x64 blocks kept in LDS: AE FT[NAE], AE W2T, DE FT of the z|v blocks
+    constexpr bool TREG = DAE && !REC;                      // REC = false: the forward blocks are gone, every transposed block fits the registers
+    constexpr int NLB = (DAE && REC) ? 2 * NBE : 0;         // 64x64 blocks kept in LDS: AE FT[NAE], AE W2T, DE FT of the z|v blocks
     constexpr int LQ_AFT = 0, LQ_AW2T = NAE, LQ_DFT = NAE + 1;
     // register indices of the packed images
     constexpr int D_B1 = 16 * NBLK, D_W2 = D_B1 + 4, D_B2 = D_W2 + 16, D_A0 = D_B2 + 4, D_FT = D_A0 + 16 * NBLK, D_W2T = D_FT + 16 * NBLK,
@@ -160,11 +161,25 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
 #pragma unroll
             for (int c = 0; c < 4; ++c) wlp[(q * 4 + c) * 256] = f4{src[(4 * c) * 64], src[(4 * c + 1) * 64], src[(4 * c + 2) * 64], src[(4 * c + 3) * 64]};
         };
+        if constexpr (REC) {
 #pragma unroll
-        for (int bb = 0; bb < NAE; ++bb) stage_blk(LQ_AFT + bb, pwa + (A_FT + 16 * bb) * 64);
-        stage_blk(LQ_AW2T, pwa + A_W2T * 64);
+            for (int bb = 0; bb < NAE; ++bb) stage_blk(LQ_AFT + bb, pwa + (A_FT + 16 * bb) * 64);
+            stage_blk(LQ_AW2T, pwa + A_W2T * 64);
 #pragma unroll
-        for (int s = 0; s < NZV; ++s) stage_blk(LQ_DFT + s, pw + (D_FT + 16 * (1 + s)) * 64);
+            for (int s = 0; s < NZV; ++s) stage_blk(LQ_DFT + s, pw + (D_FT + 16 * (1 + s)) * 64);
+        }
+    }
+    // TREG: the same six blocks in registers (LQ order: AE FT[NAE], AE W2T, DE FT of the z|v blocks)
+    float tq[TREG ? 2 * NBE : 1][16];
+    if constexpr (TREG) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int bb = 0; bb < NAE; ++bb) tq[LQ_AFT + bb][k] = pwa[(A_FT + 16 * bb + k) * 64];
+            tq[LQ_AW2T][k] = pwa[(A_W2T + k) * 64];
+#pragma unroll
+            for (int s = 0; s < NZV; ++s) tq[LQ_DFT + s][k] = pw[(D_FT + 16 * (1 + s) + k) * 64];
+        }
     }
 
     int coff[4];
@@ -227,7 +242,10 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     auto blkT_lds = [&](const int qb, const f4 dl) -> f4 {
         f4 part[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) part[c] = mulT(wlp[(qb * 4 + c) * 256], dl);
+        for (int c = 0; c < 4; ++c) {
+            if constexpr (TREG) part[c] = mulT(f4{tq[qb][4 * c], tq[qb][4 * c + 1], tq[qb][4 * c + 2], tq[qb][4 * c + 3]}, dl);
+            else part[c] = mulT(wlp[(qb * 4 + c) * 256], dl);
+        }
         return reduce_scatter(part);
     };
     auto partT_mem = [&](const float* src, const f4 dl, f4 (&part)[4], const bool accumulate) {
@@ -593,7 +611,7 @@ size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 +
 template <int METHOD, int NBE, bool DAE>
 hipError_t launch9(const Bwd9Dev& d, const float* pde, const float* pae, hipStream_t s) {
     auto kern = d.a.sact ? &latent64_backward_kernel<METHOD, NBE, DAE, false> : &latent64_backward_kernel<METHOD, NBE, DAE, true>;
-    const size_t lds = lds9_bytes(DAE ? 2 * NBE : 0);
+    const size_t lds = lds9_bytes((DAE && !d.a.sact) ? 2 * NBE : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((d.a.B + 15) / 16)), dim3(256), lds, s, d, pde, pae);
