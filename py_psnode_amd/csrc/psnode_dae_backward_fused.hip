@@ -64,7 +64,10 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     constexpr bool STREAM = NWV >= 8 && REC; // DE forward / transposed images swapped in LDS per phase; activations through the ring
     constexpr bool AEG = NWV >= 8;           // AE images read from L2
     constexpr bool AET_LDS = aet_in_lds(NWV);
-    constexpr bool BOUND = NWV >= 8 && S >= 2;
+#ifndef PSNODE_K7F_BOUND
+#define PSNODE_K7F_BOUND 3      // as PSNODE_K4F_BOUND: 0 never, 1 always at 8 waves, 2 RK4 only, 3 RK4 + Midpoint
+#endif
+    constexpr bool BOUND = NWV >= 8 && (PSNODE_K7F_BOUND == 1 || (PSNODE_K7F_BOUND == 2 && S >= 4) || (PSNODE_K7F_BOUND == 3 && S >= 2));
     constexpr int EVERY = PSNODE_K7F_EVERY;
     constexpr int TSZ = 2 * NWV * NWV * 64;  // f4 per pair of H->H images
     extern __shared__ __attribute__((aligned(16))) float lds[];
