@@ -30,6 +30,11 @@ def _tm(a):
     return a.permute(1, 0, 2)
 
 
+def _time_major_route(x) -> bool:
+    """fp32 HIP tensors: the direct_encode models lay their latent tensors out time-major (the fused kernels' layout)."""
+    return x.device.type == "cuda" and x.dtype == torch.float32 and x.dim() == 3
+
+
 def _rows(seq, inp):
     """Encoder / decoder over every (b,t) row on the fused HIP row kernels when the call is fusable (fp32 HIP tensor,
     Linear-ELU-Linear with hidden 16 / 64): forward kernel alone without autograd, forward + fused backward kernel under it;
@@ -184,6 +189,18 @@ class ODE_Model(nn.Module):
         fused_out = self._forward_encoded(t, x, z, event_t, z_jump)
         if fused_out is not None:
             return fused_out
+        if _time_major_route(x):
+            # HIP route: the encoders run over the TIME-MAJOR views of the raw inputs (a few floats per row to gather) and write the
+            # latent tensors in the layout the integrator and its backward use, so no [T,B,H] tensor is ever permuted, copied or summed
+            # on the way there or back; the first row is encoded once more for all_initial (B rows) instead of being selected out of the
+            # big tensor, whose gradient would otherwise be a zero-filled [T,B,H] tensor added to the integrator's.  Row-wise functions:
+            # the values are the ones of the B-major evaluation.
+            Xh, Zh = _rows(self.x_encoder, _tm(x)), _rows(self.z_encoder, _tm(z))
+            a0 = torch.cat((_rows(self.x_encoder, x[:, 0]), _rows(self.z_encoder, z[:, 0])), dim=-1)
+            self.event.set_event(t=event_t, z=_rows(self.z_encoder, z_jump))
+            Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh, z=Zh, all_initial=a0,
+                                               event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
+            return _tm(_rows(self.x_decoder, Xh_sol)), _tm(_rows(self.x_decoder, Xh))
         Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view
         Xh = _tm(Xh_bt)
         Zh = _tm(_rows(self.z_encoder, z))
@@ -277,6 +294,17 @@ class DAE_Model(nn.Module):
             return _tm(xs), _tm(is_)
         enc_z = (lambda a: a) if self.z_encoder is None else (lambda a: _rows(self.z_encoder, a))
         Xh0 = _rows(self.x_encoder, x0)
+        if _time_major_route(x):      # HIP route: time-major latent tensors, first row re-encoded for all_initial (see ODE_Model.forward)
+            Xh, Ih = _rows(self.x_encoder, _tm(x)), _rows(self.i_encoder, _tm(i))
+            Zh, Vh = enc_z(_tm(z)), _rows(self.v_encoder, _tm(v))
+            a0 = torch.cat((Xh0, enc_z(z[:, 0]), _rows(self.v_encoder, v[:, 0]), _rows(self.i_encoder, i[:, 0])), dim=-1)
+            self.event.set_event(t=event_t, z=enc_z(z_jump), v=_rows(self.v_encoder, v_jump))
+            Xh_sol, Ih_sol = self.solver.integrate_DAE(x_init=Xh0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=Xh,
+                                                       z=Zh, v=Vh, i=Ih, all_initial=a0, event_fn=self.event.event_fn,
+                                                       jump_change_fn=self.event.jump_change_fn)
+            x_pred = _rows(self.x_decoder, Xh_sol)
+            x_pred[0] = x0                                         # neural_01_DAE_02_direct_encode.py:150
+            return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _tm(_rows(self.x_decoder, Xh)), _tm(_rows(self.i_decoder, Ih))
         Xh_bt, Ih_bt = _rows(self.x_encoder, x), _rows(self.i_encoder, i)
         Xh, Zh, Vh, Ih = _tm(Xh_bt), _tm(enc_z(z)), _tm(_rows(self.v_encoder, v)), _tm(Ih_bt)
         a0 = torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), dim=-1)
