@@ -291,6 +291,28 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
+#ifndef PSNODE_K7F_TREAD_AHEAD
+#define PSNODE_K7F_TREAD_AHEAD 1     // <= 4 waves: every LDS read of the layer in flight before the first MFMA that needs one (K4f: PSNODE_K4F_TREAD_AHEAD)
+#endif
+        if constexpr (PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD) {
+            f4 vq[NWV], wqq[NWV], dTq[NWV];
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = wl[c * NWV * 64]; }
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) {
+                accA = fm4(wqq[c][0], vq[c][0], accA); accB = fm4(wqq[c][1], vq[c][1], accB);
+                accA = fm4(wqq[c][2], vq[c][2], accA); accB = fm4(wqq[c][3], vq[c][3], accB);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < NWV; ++c) acc[c] = fm4(dTq[c][kk], hT[kk], acc[c]);      // NWV independent chains
+            p ^= 1;
+            return accA + accB;
+        }
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
             const f4 v = getl(tile(p, (w + c) & (NWV - 1)));
