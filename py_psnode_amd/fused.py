@@ -759,6 +759,12 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
 
     if saved is not None and not fuse_de:
         raise ValueError("saved activations are read by the fused-DE form only")
+    if fuse_de and saved is None:
+        # one launch over the whole grid stores the AE head's rows of EVERY grid point (6 x [T,B,H] + [T,B,16] + the u rows of K7h): a very
+        # long grid on a full card goes through the time-chunked split form instead (bounded at ~3 GB of rows per chunk)
+        free, _ = torch.cuda.mem_get_info(dev)
+        if (6 * H + 40) * 4 * T * B > free // 2:
+            fuse_de = False
     if fuse_de:
         if saved is not None:
             s_act, s_xst, s_ae, s_ev, s_evi = saved
