@@ -120,6 +120,30 @@ __global__ __launch_bounds__(64 * NWV) void head_grads_kernel(const HeadDev a) {
         const f4 h1T = transpose(q.h1);
         const f4 h2T = transpose(q.h2);
         lds_barrier();
+#ifndef PSNODE_K7H_AHEAD
+#define PSNODE_K7H_AHEAD 8      // transposed tiles read this many chunks ahead of the MFMAs that consume them (0: read where used; 0 / 2 / 4 / 8 at hidden 128: 4.67 / 4.66 / 4.58 / 4.25 ms, profiles/r03y_k7h_ahead_ab.txt)
+#endif
+        if constexpr (PSNODE_K7H_AHEAD > 0) {
+            constexpr int G = PSNODE_K7H_AHEAD < NWV ? PSNODE_K7H_AHEAD : NWV;
+#pragma unroll
+            for (int c0 = 0; c0 < NWV; c0 += G) {
+                f4 d2T[G], d3T[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int ws = (w + c0 + q) & (NWV - 1);
+                    d2T[q] = get_row(tile(p, 0, ws));
+                    d3T[q] = get_row(tile(p, 1, ws));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {      // 2 G independent accumulator chains
+                        acc2[c0 + q] = hm4(d2T[q][kk], h1T[kk], acc2[c0 + q]);
+                        acc3[c0 + q] = hm4(d3T[q][kk], h2T[kk], acc3[c0 + q]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
             const int ws = (w + c) & (NWV - 1);
@@ -127,6 +151,7 @@ __global__ __launch_bounds__(64 * NWV) void head_grads_kernel(const HeadDev a) {
             const f4 d3T = get_row(tile(p, 1, ws));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) { acc2[c] = hm4(d2T[kk], h1T[kk], acc2[c]); acc3[c] = hm4(d3T[kk], h2T[kk], acc3[c]); }
+        }
         }
         if (want_gza) {
             if (w == 0) {
