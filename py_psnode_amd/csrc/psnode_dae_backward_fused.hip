@@ -321,12 +321,26 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             accA = fm4(wq[2], v[2], accA); accB = fm4(wq[3], v[3], accB);
             if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
         }
+#ifndef PSNODE_K7F_DW_PAIR
+#define PSNODE_K7F_DW_PAIR 1     // 8 waves: the weight-gradient MFMAs of two chunks interleaved (K4f: PSNODE_K4F_DW_PAIR)
+#endif
+        if constexpr (PSNODE_K7F_DW_PAIR && NWV >= 8) {
+#pragma unroll
+            for (int c = 0; c < NWV; c += 2) {
+                const f4 dT0 = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+                const f4 dT1 = get_row(tile(p, (w + c + 1) & (NWV - 1)), roff);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { acc[c] = fm4(dT0[kk], hT[kk], acc[c]); acc[c + 1] = fm4(dT1[kk], hT[kk], acc[c + 1]); }
+                if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
             const f4 dT = get_row(tile(p, (w + c) & (NWV - 1)), roff);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc[c] = fm4(dT[kk], hT[kk], acc[c]);
             if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
+        }
         }
         p ^= 1;
         return accA + accB;
