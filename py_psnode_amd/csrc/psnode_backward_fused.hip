@@ -283,16 +283,20 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             if constexpr (BOUND) { if (c % EVERY == EVERY - 1) __builtin_amdgcn_sched_barrier(0); }
         }
 #ifndef PSNODE_K4F_DW_PAIR
-#define PSNODE_K4F_DW_PAIR 1     // 8 waves: the weight-gradient MFMAs of two chunks interleaved (two accumulator chains, both transposed tiles read first)
+#define PSNODE_K4F_DW_PAIR 4     // 8 waves: the weight-gradient MFMAs of two chunks interleaved (two accumulator chains, both transposed tiles read first)
 #endif
         if constexpr (!(PSNODE_K4F_ABLATE & 1)) {
         if constexpr (PSNODE_K4F_DW_PAIR && NWV >= 8 && !REC) {      // (recompute instance at RK4: 48.2 -> 50.3 ms with it, profiles/r03y_dw_pair_ab.txt)
+            constexpr int DG = PSNODE_K4F_DW_PAIR == 1 ? 2 : PSNODE_K4F_DW_PAIR;      // chunks per group
 #pragma unroll
-            for (int c = 0; c < NWV; c += 2) {
-                const f4 dT0 = get_row(tile(p, (w + c) & (NWV - 1)), roff);
-                const f4 dT1 = get_row(tile(p, (w + c + 1) & (NWV - 1)), roff);
+            for (int c = 0; c < NWV; c += DG) {
+                f4 dTg[DG];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { acc[c] = fm4(dT0[kk], hT[kk], acc[c]); acc[c + 1] = fm4(dT1[kk], hT[kk], acc[c + 1]); }
+                for (int q = 0; q < DG; ++q) dTg[q] = get_row(tile(p, (w + c + q) & (NWV - 1)), roff);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < DG; ++q) acc[c + q] = fm4(dTg[q][kk], hT[kk], acc[c + q]);
                 if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
