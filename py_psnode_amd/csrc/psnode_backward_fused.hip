@@ -274,6 +274,25 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             p ^= 1;
             return accA + accB;
         }
+#ifndef PSNODE_K4F_DP_GROUP
+#define PSNODE_K4F_DP_GROUP 7      // 8 waves, transposed layers: tiles and weight chunks of this many chunks read ahead of their MFMAs (0: as the forward layers).
+                                     // hidden-128 training step RK4, 0 / 3 / 4 / 7: ODE (K4f) 35.9 / 34.6 / 36.0 / 34.5 ms, DAE (K7f) 52.1 / 51.9 / 51.9 / 52.0 (profiles/r03y_dp_group_ab.txt)
+#endif
+        if constexpr (PSNODE_K4F_DP_GROUP > 0 && NWV >= 8) {
+            constexpr int PG = PSNODE_K4F_DP_GROUP > 0 ? PSNODE_K4F_DP_GROUP : 1;
+#pragma unroll
+            for (int c0 = 1; c0 < NWV; c0 += PG) {
+                f4 vg[PG], wg[PG];
+#pragma unroll
+                for (int q = 0; q < PG; ++q) if (c0 + q < NWV) { vg[q] = getl(tile(p, (w + c0 + q) & (NWV - 1))); wg[q] = wl[(c0 + q) * NWV * 64]; }
+#pragma unroll
+                for (int q = 0; q < PG; ++q) if (c0 + q < NWV) {
+                    accA = fm4(wg[q][0], vg[q][0], accA); accB = fm4(wg[q][1], vg[q][1], accB);
+                    accA = fm4(wg[q][2], vg[q][2], accA); accB = fm4(wg[q][3], vg[q][3], accB);
+                }
+                if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
             const f4 v = getl(tile(p, (w + c) & (NWV - 1)));
