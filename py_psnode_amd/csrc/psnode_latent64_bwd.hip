@@ -264,7 +264,20 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     };
     auto publish = [&](const int slot, const f4 ownv) { pub[(slot * NW9 + w) * 64 + l] = transpose(ownv); };
     // dBlk[own units][:] += d (x) v  with dT = transpose(d_own) and v's tiles published in `slot`
+#ifndef PSNODE_K9_OUTER_AHEAD
+#define PSNODE_K9_OUTER_AHEAD 1      // the four published tiles read first, then four independent accumulator chains (as K4f / K7f / K7h)
+#endif
     auto outer = [&](A9& acc, const f4 dT, const int slot) {
+        if constexpr (PSNODE_K9_OUTER_AHEAD) {
+            f4 vT[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vT[c] = pub[(slot * NW9 + ((w + c) & 3)) * 64 + l];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc.c[c] = m9(dT[kk], vT[c][kk], acc.c[c]);
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const f4 vT = pub[(slot * NW9 + ((w + c) & 3)) * 64 + l];
