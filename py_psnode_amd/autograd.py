@@ -9,10 +9,10 @@ import torch
 
 from . import fused
 
-# Save the stage activations in the training forward instead of recomputing them in the backward?  "auto": at hidden widths 33..128
-# (measured per 4096 x 1000 RK4 batch: hidden 128 52.9 -> 43.6 ms per training step, 64 17.2 -> 14.8, 32 10.5 -> 10.0:
-# profiles/r03p_saved_ab.txt) and only when the rows (6 KB per state-step at 128: 25 GB for that batch; 3.1 KB / 13 GB at 64) fit into
-# half of the free HBM; "1" / "0" force it on / off.
+# Save the stage activations in the training forward instead of recomputing them in the backward?  "auto": at every hidden width the
+# MFMA integrators take (measured per 4096 x 1000 RK4 batch, end of round 3: hidden 128 48.2 -> 34.5 ms per ODE_01 training step, 64
+# 17.5 -> 14.3, 32 10.4 -> 9.6; DAE_01 77.0 -> 52.2, 23.0 -> 21.4, 16.9 -> 14.7) whenever the rows (6 KB per state-step at 128: 25 GB for
+# that batch; 3.1 KB / 13 GB at 64) fit into half of the free HBM; "1" / "0" force it on / off.
 SAVE_ACTIVATIONS = os.environ.get("PSNODE_SAVE_ACTIVATIONS", "auto")
 
 
@@ -25,8 +25,6 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
         return False
     if SAVE_ACTIVATIONS == "1":
         return True
-    if Hp < 64:
-        return False
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     need = (T - 1) * S * B * ((len(layers) - 1) * Hp + x_dim) * 4
     free, _ = torch.cuda.mem_get_info(layers[0][0].device)
@@ -55,8 +53,6 @@ def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
         return False
     if SAVE_ACTIVATIONS == "1":
         return True
-    if Hp < 64:
-        return False
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     need = ((T - 1) * S * (3 * Hp + x_dim) + 3 * T * Hp) * B * 4
     free, _ = torch.cuda.mem_get_info(de[0][0].device)

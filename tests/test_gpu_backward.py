@@ -228,7 +228,8 @@ def test_hidden128_training_takes_the_one_launch_backward():
     layers_ = fused.de_layers_of(m.de_func, 10, 8)
     assert pag._want_saved("rk4", "auto", layers_, 8, 2, Tn, B) is True
     assert pag._want_saved("rk4", "auto", [(w[:32, :] if k == 0 else (w[:32, :32] if k < 3 else w[:, :32]), b_[:32] if k < 3 else b_)
-                                           for k, (w, b_) in enumerate(layers_)], 8, 2, Tn, B) is False
+                                           for k, (w, b_) in enumerate(layers_)], 8, 2, Tn, B) is True      # ... and so does hidden 32
+    assert pag._want_saved("rk4", "generic", layers_, 8, 2, Tn, B) is False
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in m.parameters())
 
 
