@@ -402,9 +402,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     const long long act_layer = a.B * H;
     auto load_saved = [&](const long long idx, f4& q1, f4& q2, f4& q3, float (&xq)[NX]) {
         const float* rb = a.sact + (size_t)idx * 3 * act_layer;
-        q1 = ldg<f4>(sbase(rb), offH);
-        q2 = ldg<f4>(sbase(rb + act_layer), offH);
-        q3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
+        q1 = ldg_nt<f4, (NWV >= 8)>(sbase(rb), offH);
+        q2 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + act_layer), offH);
+        q3 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + 2 * act_layer), offH);
         load_x2(a.sxst, idx, xq);
     };
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;

@@ -286,6 +286,24 @@ __device__ __forceinline__ V ldg(gptr<T> base, unsigned byte_off) {
     asm volatile("" : "+v"(byte_off));
     return *(gptr<const V>)((gptr<const char>)base + byte_off);
 }
+// read-once / write-once rows (the activations a training forward saves for its backward): nontemporal at 8 waves (NT = true), so that
+// they stream past L2 instead of evicting the packed weight images those kernels re-read every step (PSNODE_SAVED_NT=0: plain accesses).
+// Same-box A/B (profiles/r03y_saved_nt_ab.txt), training step with / without: hidden 128 ODE 34.55 / 34.69 ms, DAE 51.7 / 52.2; at hidden 64
+// (weights in registers, nothing to evict) 14.45 / 14.27 and 21.8 / 21.6 -- hence only at 8 waves.
+#ifndef PSNODE_SAVED_NT
+#define PSNODE_SAVED_NT 1
+#endif
+template <typename V, bool NT, typename T>
+__device__ __forceinline__ V ldg_nt(gptr<T> base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    if constexpr (NT && PSNODE_SAVED_NT) return __builtin_nontemporal_load((gptr<const V>)((gptr<const char>)base + byte_off));
+    else return *(gptr<const V>)((gptr<const char>)base + byte_off);
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void store_nt(V* p, const V v) {
+    if constexpr (NT && PSNODE_SAVED_NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 template <typename V, typename T>
 __device__ __forceinline__ void stg(gptr<T> base, unsigned byte_off, V v) {
     asm volatile("" : "+v"(byte_off));

@@ -489,9 +489,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     auto load_head = [&](const long long kk, f4& a1, f4& a2, f4& a3) {
         const size_t lay = (size_t)a.T * a.B * H;
         const float* rb = a.saeact + (size_t)kk * a.B * H;
-        a1 = ldg<f4>(sbase(rb), offH);
-        a2 = ldg<f4>(sbase(rb + lay), offH);
-        a3 = ldg<f4>(sbase(rb + 2 * lay), offH);
+        a1 = ldg_nt<f4, (NWV >= 8)>(sbase(rb), offH);
+        a2 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + lay), offH);
+        a3 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + 2 * lay), offH);
     };
     const HeadRows grid_rows{a.aact[0], a.aact[1], a.aact[2], a.adelta[0], a.adelta[1], a.adelta[2], a.agi};
     const HeadRows event_rows{a.eact[0], a.eact[1], a.eact[2], a.edelta[0], a.edelta[1], a.edelta[2], a.egi};
@@ -512,9 +512,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     const long long act_layer = a.B * H;
     auto load_saved = [&](const long long idx, f4& q1, f4& q2, f4& q3, float (&xq)[NX]) {
         const float* rb = a.sact + (size_t)idx * 3 * act_layer;
-        q1 = ldg<f4>(sbase(rb), offH);
-        q2 = ldg<f4>(sbase(rb + act_layer), offH);
-        q3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
+        q1 = ldg_nt<f4, (NWV >= 8)>(sbase(rb), offH);
+        q2 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + act_layer), offH);
+        q3 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + 2 * act_layer), offH);
         load_x2(a.sxst, idx, xq);
     };
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             }
             sx_run += sx_step;
             const f4 out = tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{},
-                                [&](const int q, const f4 hq) { if (valid) *reinterpret_cast<f4*>(sa_run + (size_t)q * sa_layer) = hq; });
+                                [&](const int q, const f4 hq) { if (valid) store_nt<(NWV >= 8)>(reinterpret_cast<f4*>(sa_run + (size_t)q * sa_layer), hq); });
             sa_run += 3 * sa_layer;
             return out;
         }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
             if constexpr (SAVE)
                 return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{},
-                            [&](const int q, const f4 hq) { if (valid) *reinterpret_cast<f4*>(rows + (size_t)q * lstride) = hq; });
+                            [&](const int q, const f4 hq) { if (valid) store_nt<(NWV >= 8)>(reinterpret_cast<f4*>(rows + (size_t)q * lstride), hq); });
             return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{}, [](int, f4) {});
         }
         return acc;
