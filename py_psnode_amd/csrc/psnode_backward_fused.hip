@@ -241,12 +241,31 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     };
     // transposed H->H layer (image in LDS): returns sum_k W[k][own] d[k]; and, from the very tiles the all-gather published, the weight
     // gradient of that layer: acc[c] += delta(block (w+c) % NWV)^T (x) hT, hT = this wave's own input activations in operand layout
-    auto midT = [&](const int layer, const f4 d, const f4 hT, f4 (&acc)[NWV]) -> f4 {
+#ifndef PSNODE_K4F_DEFER_DW
+#define PSNODE_K4F_DEFER_DW 1        // <= 4 waves: the weight-gradient MFMAs of a layer are issued behind the NEXT exchange's LDS write, in front of its
+                                     // barrier -- one wave per SIMD has nothing else to keep the MFMA pipe busy while the tile travels
+#endif
+#ifndef PSNODE_K4F_TREAD_AHEAD
+#define PSNODE_K4F_TREAD_AHEAD 1
+#endif
+    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1);
+    f4 pendT[DEFER ? NWV : 1], pend_h = f4{0.f, 0.f, 0.f, 0.f};      // transposed tiles / own activations of the layer whose gradient is still owed
+    auto flush = [&](f4 (&pacc)[NWV]) {
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < NWV; ++c) pacc[c] = fm4(pendT[c][kk], pend_h[kk], pacc[c]);
+        }
+    };
+    // pacc: the accumulators of the layer handled by the previous call (its gradient MFMAs run here, between this layer's LDS write and barrier)
+    auto midT = [&](const int layer, const f4 d, const f4 hT, f4 (&acc)[NWV], f4 (*pacc)[NWV] = nullptr) -> f4 {
         put(tile(p, w), d);
         const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
         f4 wq = wl[0];
         f4 accA = fm4(wq[0], d[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], d[1], f4{0.f, 0.f, 0.f, 0.f});
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
+        if constexpr (DEFER) { if (pacc) flush(*pacc); }
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
 #ifndef PSNODE_K4F_TREAD_AHEAD
@@ -267,10 +286,16 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
                 accA = fm4(wqq[c][0], vq[c][0], accA); accB = fm4(wqq[c][1], vq[c][1], accB);
                 accA = fm4(wqq[c][2], vq[c][2], accA); accB = fm4(wqq[c][3], vq[c][3], accB);
             }
+            if constexpr (DEFER) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int c = 0; c < NWV; ++c) pendT[c] = dTq[c];
+                pend_h = hT;
+            } else {
 #pragma unroll
-                for (int c = 0; c < NWV; ++c) acc[c] = fm4(dTq[c][kk], hT[kk], acc[c]);      // NWV independent chains
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int c = 0; c < NWV; ++c) acc[c] = fm4(dTq[c][kk], hT[kk], acc[c]);      // NWV independent chains
+            }
             p ^= 1;
             return accA + accB;
         }
@@ -332,9 +357,10 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         return accA + accB;
     };
     // 8-byte all-reduce of rows r < 2 over the waves (fixed order)
-    auto allreduce2 = [&](const f2 part, const f2 init) -> f2 {
+    auto allreduce2 = [&](const f2 part, const f2 init, f4 (*pacc)[NWV] = nullptr) -> f2 {
         f2* xb2 = reinterpret_cast<f2*>(tile(p, 0));
         xb2[w * 64 + l] = part;
+        if constexpr (DEFER) { if (pacc) flush(*pacc); }
         lds_barrier();
         f2 out = init;
 #pragma unroll
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             S2 += d2;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 1); }     // W3's region: forward image for the next step
             const f4 h1T = transpose(a1);
-            const f4 d1 = midT(0, d2, h1T, accW2) * elu_grad_quad(a1);
+            const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             S1 += d1;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
             const f4 ft = own4(fT, d1);           // rows 0..1: gX partial, rows 2..3: gz partial
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
             }
-            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
+            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
             {   // dW1 (`s` columns) += delta1 (x) s
                 const f4 dT = transpose(d1);
                 put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, (NZM > 0 && g < ne) ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});

@@ -283,17 +283,31 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     };
     // transposed DE layer (image in LDS) + the weight gradient of that layer from the very tiles the all-gather published:
     // acc[c] += delta(block (w+c) % NWV)^T (x) hT, hT = this wave's own input activations in operand layout (K4f: midT)
-    auto midT = [&](const int layer, const f4 d, const f4 hT, f4 (&acc)[NWV]) -> f4 {
+#ifndef PSNODE_K7F_TREAD_AHEAD
+#define PSNODE_K7F_TREAD_AHEAD 1     // <= 4 waves: every LDS read of the layer in flight before the first MFMA that needs one (K4f: PSNODE_K4F_TREAD_AHEAD)
+#endif
+#ifndef PSNODE_K7F_DEFER_DW
+#define PSNODE_K7F_DEFER_DW 1        // <= 4 waves: a layer's weight-gradient MFMAs run behind the NEXT exchange's LDS write (K4f: PSNODE_K4F_DEFER_DW)
+#endif
+    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD && PSNODE_K7F_DEFER_DW;
+    f4 pendT[DEFER ? NWV : 1], pend_h = zero4;
+    auto flush = [&](f4 (&pacc)[NWV]) {
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < NWV; ++c) pacc[c] = fm4(pendT[c][kk], pend_h[kk], pacc[c]);
+        }
+    };
+    auto midT = [&](const int layer, const f4 d, const f4 hT, f4 (&acc)[NWV], f4 (*pacc)[NWV] = nullptr) -> f4 {
         put(tile(p, w), d);
         const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
         f4 wq = wl[0];
         f4 accA = fm4(wq[0], d[0], zero4), accB = fm4(wq[1], d[1], zero4);
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
+        if constexpr (DEFER) { if (pacc) flush(*pacc); }
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
-#ifndef PSNODE_K7F_TREAD_AHEAD
-#define PSNODE_K7F_TREAD_AHEAD 1     // <= 4 waves: every LDS read of the layer in flight before the first MFMA that needs one (K4f: PSNODE_K4F_TREAD_AHEAD)
-#endif
         if constexpr (PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD) {
             f4 vq[NWV], wqq[NWV], dTq[NWV];
 #pragma unroll
@@ -306,10 +320,16 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 accA = fm4(wqq[c][0], vq[c][0], accA); accB = fm4(wqq[c][1], vq[c][1], accB);
                 accA = fm4(wqq[c][2], vq[c][2], accA); accB = fm4(wqq[c][3], vq[c][3], accB);
             }
+            if constexpr (DEFER) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int c = 0; c < NWV; ++c) pendT[c] = dTq[c];
+                pend_h = hT;
+            } else {
 #pragma unroll
-                for (int c = 0; c < NWV; ++c) acc[c] = fm4(dTq[c][kk], hT[kk], acc[c]);      // NWV independent chains
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int c = 0; c < NWV; ++c) acc[c] = fm4(dTq[c][kk], hT[kk], acc[c]);      // NWV independent chains
+            }
             p ^= 1;
             return accA + accB;
         }
@@ -375,9 +395,10 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         return accA + accB;
     };
     // all-reduce of the output rows over the waves (fixed order): 2 rows (x-layout) or 4 rows (slot layout)
-    auto allreduce2 = [&](const f2 part, const f2 init) -> f2 {
+    auto allreduce2 = [&](const f2 part, const f2 init, f4 (*pacc)[NWV] = nullptr) -> f2 {
         f2* xb2 = reinterpret_cast<f2*>(tile(p, 0));
         xb2[w * 64 + l] = part;
+        if constexpr (DEFER) { if (pacc) flush(*pacc); }
         lds_barrier();
         f2 out = init;
 #pragma unroll
@@ -674,7 +695,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             S2 += d2;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 1); }     // W3's region: forward image for the next step
             const f4 h1T = transpose(a1);
-            const f4 d1 = midT(0, d2, h1T, accW2) * elu_grad_quad(a1);
+            const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             D1 += d1;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
             const f4 ft = own4(fT, d1);
@@ -690,7 +711,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
             }
-            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
+            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
             {   // dW1 (`s` columns) += delta1 (x) s, s = (X_s | ext)
                 const f4 dT = transpose(d1);
                 put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, g < ne ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
