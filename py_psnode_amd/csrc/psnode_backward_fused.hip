@@ -250,7 +250,30 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #endif
     constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1);
     f4 pendT[DEFER ? NWV : 1], pend_h = f4{0.f, 0.f, 0.f, 0.f};      // transposed tiles / own activations of the layer whose gradient is still owed
+#ifndef PSNODE_K4F_DEFER8
+#define PSNODE_K4F_DEFER8 1         // 8 waves: the same deferral without holding the transposed tiles: they are re-read from the previous exchange's parity
+#endif
+#ifndef PSNODE_K4F_DW_PAIR
+#define PSNODE_K4F_DW_PAIR 4
+#endif
+    constexpr bool DEFER8 = NWV >= 8 && PSNODE_K4F_DEFER8 && PSNODE_K4F_DW_PAIR && !REC;
+    int pend_par = 0;
+    auto dw_groups = [&](const int par, const f4 hT, f4 (&acc)[NWV]) {
+        constexpr int DG = PSNODE_K4F_DW_PAIR <= 1 ? 2 : PSNODE_K4F_DW_PAIR;      // chunks per group
+#pragma unroll
+        for (int c = 0; c < NWV; c += DG) {
+            f4 dTg[DG];
+#pragma unroll
+            for (int q = 0; q < DG; ++q) dTg[q] = get_row(tile(par, (w + c + q) & (NWV - 1)), roff);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < DG; ++q) acc[c + q] = fm4(dTg[q][kk], hT[kk], acc[c + q]);
+            if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto flush = [&](f4 (&pacc)[NWV]) {
+        if constexpr (DEFER8) dw_groups(pend_par, pend_h, pacc);
         if constexpr (DEFER) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         f4 wq = wl[0];
         f4 accA = fm4(wq[0], d[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], d[1], f4{0.f, 0.f, 0.f, 0.f});
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
-        if constexpr (DEFER) { if (pacc) flush(*pacc); }
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
 #ifndef PSNODE_K4F_TREAD_AHEAD
@@ -331,18 +354,8 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #endif
         if constexpr (!(PSNODE_K4F_ABLATE & 1)) {
         if constexpr (PSNODE_K4F_DW_PAIR && NWV >= 8 && !REC) {      // (recompute instance at RK4: 48.2 -> 50.3 ms with it, profiles/r03y_dw_pair_ab.txt)
-            constexpr int DG = PSNODE_K4F_DW_PAIR == 1 ? 2 : PSNODE_K4F_DW_PAIR;      // chunks per group
-#pragma unroll
-            for (int c = 0; c < NWV; c += DG) {
-                f4 dTg[DG];
-#pragma unroll
-                for (int q = 0; q < DG; ++q) dTg[q] = get_row(tile(p, (w + c + q) & (NWV - 1)), roff);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int q = 0; q < DG; ++q) acc[c + q] = fm4(dTg[q][kk], hT[kk], acc[c + q]);
-                if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
-            }
+            if constexpr (DEFER8) { pend_par = p; pend_h = hT; }      // (the tiles of this parity stay intact until the exchange after next)
+            else dw_groups(p, hT, acc);
         } else {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     auto allreduce2 = [&](const f2 part, const f2 init, f4 (*pacc)[NWV] = nullptr) -> f2 {
         f2* xb2 = reinterpret_cast<f2*>(tile(p, 0));
         xb2[w * 64 + l] = part;
-        if constexpr (DEFER) { if (pacc) flush(*pacc); }
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
         lds_barrier();
         f2 out = init;
 #pragma unroll

@@ -291,7 +291,30 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #endif
     constexpr bool DEFER = PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD && PSNODE_K7F_DEFER_DW;
     f4 pendT[DEFER ? NWV : 1], pend_h = zero4;
+#ifndef PSNODE_K7F_DEFER8
+#define PSNODE_K7F_DEFER8 1         // 8 waves: the same deferral without holding the transposed tiles: they are re-read from the previous exchange's parity
+#endif
+#ifndef PSNODE_K7F_DW_PAIR
+#define PSNODE_K7F_DW_PAIR 4
+#endif
+    constexpr bool DEFER8 = NWV >= 8 && PSNODE_K7F_DEFER8 && PSNODE_K7F_DW_PAIR;
+    int pend_par = 0;
+    auto dw_groups = [&](const int par, const f4 hT, f4 (&acc)[NWV]) {
+        constexpr int DG = PSNODE_K7F_DW_PAIR <= 1 ? 2 : PSNODE_K7F_DW_PAIR;      // chunks per group
+#pragma unroll
+        for (int c = 0; c < NWV; c += DG) {
+            f4 dTg[DG];
+#pragma unroll
+            for (int q = 0; q < DG; ++q) dTg[q] = get_row(tile(par, (w + c + q) & (NWV - 1)), roff);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < DG; ++q) acc[c + q] = fm4(dTg[q][kk], hT[kk], acc[c + q]);
+            if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto flush = [&](f4 (&pacc)[NWV]) {
+        if constexpr (DEFER8) dw_groups(pend_par, pend_h, pacc);
         if constexpr (DEFER) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         f4 wq = wl[0];
         f4 accA = fm4(wq[0], d[0], zero4), accB = fm4(wq[1], d[1], zero4);
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
-        if constexpr (DEFER) { if (pacc) flush(*pacc); }
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
         if constexpr (PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD) {
@@ -364,18 +387,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #define PSNODE_K7F_DW_PAIR 4     // 8 waves: the weight-gradient MFMAs of two chunks interleaved (K4f: PSNODE_K4F_DW_PAIR)
 #endif
         if constexpr (PSNODE_K7F_DW_PAIR && NWV >= 8) {
-            constexpr int DG = PSNODE_K7F_DW_PAIR == 1 ? 2 : PSNODE_K7F_DW_PAIR;      // chunks per group
-#pragma unroll
-            for (int c = 0; c < NWV; c += DG) {
-                f4 dTg[DG];
-#pragma unroll
-                for (int q = 0; q < DG; ++q) dTg[q] = get_row(tile(p, (w + c + q) & (NWV - 1)), roff);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int q = 0; q < DG; ++q) acc[c + q] = fm4(dTg[q][kk], hT[kk], acc[c + q]);
-                if constexpr (BOUND) __builtin_amdgcn_sched_barrier(0);
-            }
+            if constexpr (DEFER8) { pend_par = p; pend_h = hT; }      // (the tiles of this parity stay intact until the exchange after next)
+            else dw_groups(p, hT, acc);
         } else {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) {
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     auto allreduce2 = [&](const f2 part, const f2 init, f4 (*pacc)[NWV] = nullptr) -> f2 {
         f2* xb2 = reinterpret_cast<f2*>(tile(p, 0));
         xb2[w * 64 + l] = part;
-        if constexpr (DEFER) { if (pacc) flush(*pacc); }
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
         lds_barrier();
         f2 out = init;
 #pragma unroll
