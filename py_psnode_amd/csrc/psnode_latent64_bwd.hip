@@ -216,9 +216,15 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         mm(wr, x, accA, accB);
         return accA + accB;
     };
-    auto reduce_scatter = [&](const f4 (&part)[4]) -> f4 {
+#ifndef PSNODE_K9_HOOK
+#define PSNODE_K9_HOOK 1      // the outer products (weight gradients) that precede a reduce-scatter are issued between its LDS writes and its barrier:
+                              // one wave per SIMD has nothing else to keep the MFMA pipe busy while the partial sums travel (K4f: PSNODE_K4F_DEFER_DW)
+#endif
+    auto no_hook = [] {};
+    auto reduce_scatter = [&](const f4 (&part)[4], auto&& hook) -> f4 {
 #pragma unroll
         for (int c = 1; c < 4; ++c) rsbuf[((q * NW9 + ((w + c) & 3)) * NW9 + w) * 64 + l] = part[c];
+        hook();
         lds_barrier();
         f4 out = part[0];
 #pragma unroll
@@ -233,20 +239,20 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         acc = m9(w4[2], dl[2], acc);
         return m9(w4[3], dl[3], acc);
     };
-    auto blkT_reg = [&](const float (&wt)[16], const f4 dl) -> f4 {
+    auto blkT_reg = [&](const float (&wt)[16], const f4 dl, auto&& hook) -> f4 {
         f4 part[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) part[c] = mulT(f4{wt[4 * c], wt[4 * c + 1], wt[4 * c + 2], wt[4 * c + 3]}, dl);
-        return reduce_scatter(part);
+        return reduce_scatter(part, hook);
     };
-    auto blkT_lds = [&](const int qb, const f4 dl) -> f4 {
+    auto blkT_lds = [&](const int qb, const f4 dl, auto&& hook) -> f4 {
         f4 part[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if constexpr (TREG) part[c] = mulT(f4{tq[qb][4 * c], tq[qb][4 * c + 1], tq[qb][4 * c + 2], tq[qb][4 * c + 3]}, dl);
             else part[c] = mulT(wlp[(qb * 4 + c) * 256], dl);
         }
-        return reduce_scatter(part);
+        return reduce_scatter(part, hook);
     };
     auto partT_mem = [&](const float* src, const f4 dl, f4 (&part)[4], const bool accumulate) {
 #pragma unroll
@@ -384,15 +390,16 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         ae_hidden(xo, zv);
         publish(3, ah1);
         ASB2 += gi;
-        const f4 d1 = blkT_lds(LQ_AW2T, gi) * dact9(ah1);          // the barrier inside publishes slots 0..3
+        const f4 d1 = blkT_lds(LQ_AW2T, gi, no_hook) * dact9(ah1);          // the barrier inside publishes slots 0..3
         AS1 += d1;
-        outer(accW2a, transpose(gi), 3);
+        const f4 giT = transpose(gi);
         const f4 dT = transpose(d1);
         f4 gx = z9();
 #pragma unroll
         for (int bb = 0; bb < NAE; ++bb) {
-            outer(accAF[bb], dT, bb);                              // every read of the slots precedes the last barrier
-            const f4 gb = blkT_lds(LQ_AFT + bb, d1);
+            auto grads = [&] { if (bb == 0) outer(accW2a, giT, 3); outer(accAF[bb], dT, bb); };      // every read of the slots precedes the last barrier
+            if constexpr (!PSNODE_K9_HOOK) grads();
+            const f4 gb = PSNODE_K9_HOOK ? blkT_lds(LQ_AFT + bb, d1, grads) : blkT_lds(LQ_AFT + bb, d1, no_hook);
             if (bb == 0) gx = gb;
             else gzv.b[bb - 1] = gb;
         }
@@ -481,11 +488,12 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
             SB2 += gk;
             publish(0, h1[s]);
             publish(1, xst[s]);
-            const f4 d1 = blkT_reg(w2t, gk) * dact9(h1[s]);        // barrier inside: slots 0, 1 visible afterwards
+            const f4 d1 = blkT_reg(w2t, gk, no_hook) * dact9(h1[s]);        // barrier inside: slots 0, 1 visible afterwards
             D1 += d1;
-            outer(accW2, transpose(gk), 0);
-            outer(accF[0], transpose(d1), 1);
-            const f4 gx = blkT_reg(wftx, d1);                       // barrier after every read of slots 0, 1
+            const f4 gkT = transpose(gk), d1T = transpose(d1);
+            auto grads = [&] { outer(accW2, gkT, 0); outer(accF[0], d1T, 1); };
+            if constexpr (!PSNODE_K9_HOOK) grads();
+            const f4 gx = PSNODE_K9_HOOK ? blkT_reg(wftx, d1, grads) : blkT_reg(wftx, d1, no_hook);      // barrier after every read of slots 0, 1
             gx0 += gx;
 #pragma unroll
             for (int jj = 0; jj < s; ++jj) gks[jj] += (h_ * rk_a(METHOD, s, jj)) * gx;
@@ -499,9 +507,15 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         f4 gext[NBE];
 #pragma unroll
         for (int e = 0; e < NBE; ++e) {
-            outer(accF[1 + e], DT, e);
-            if constexpr (DAE) gext[e] = e < NZV ? blkT_lds(LQ_DFT + e, D1) : blkT_reg(wfti, D1);
-            else gext[e] = blkT_reg(wftz, D1);
+            auto grads = [&] { outer(accF[1 + e], DT, e); };
+            if constexpr (!PSNODE_K9_HOOK) grads();
+            if constexpr (PSNODE_K9_HOOK) {
+                if constexpr (DAE) gext[e] = e < NZV ? blkT_lds(LQ_DFT + e, D1, grads) : blkT_reg(wfti, D1, grads);
+                else gext[e] = blkT_reg(wftz, D1, grads);
+            } else {
+                if constexpr (DAE) gext[e] = e < NZV ? blkT_lds(LQ_DFT + e, D1, no_hook) : blkT_reg(wfti, D1, no_hook);
+                else gext[e] = blkT_reg(wftz, D1, no_hook);
+            }
         }
         if constexpr (DAE) {
             if (ev >= 0) {
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
         f4 part[4];
         partT_mem(pw + (D_A0T + 16 * blk) * 64, S1, part, false);
         if constexpr (DAE) partT_mem(pwa + (A_A0T + 16 * blk) * 64, AS1, part, true);
-        const f4 ga = reduce_scatter(part);
+        const f4 ga = reduce_scatter(part, no_hook);
         if (valid) *reinterpret_cast<f4*>(d.ga0 + b * n + H9 * blk + own) = ga;
     }
     // ---- parameter-gradient partials of this workgroup: [DE | AE], nn.Linear order [W1, b1, W2, b2]
