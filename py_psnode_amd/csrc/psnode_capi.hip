@@ -203,7 +203,9 @@ extern "C" {
 
 int32_t psnode_abi_version(void) { return PSNODE_ABI_VERSION; }
 
-const char* psnode_build_info(void) { return "psnode_hip abi " "1" " gfx950 (generic + mfma kernels), built " __DATE__; }
+#define PSNODE_STR2(x) #x
+#define PSNODE_STR(x) PSNODE_STR2(x)
+const char* psnode_build_info(void) { return "psnode_hip abi " PSNODE_STR(PSNODE_ABI_VERSION) " gfx950 (generic + mfma kernels), built " __DATE__; }
 
 const char* psnode_status_string(int32_t s) {
     switch (s) {
