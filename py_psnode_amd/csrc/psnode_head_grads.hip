@@ -31,9 +31,19 @@ struct HeadDev {
     const float* aw1;               // AW1 [hreal, k1a]; columns zv0 .. zv0+nzv-1 multiply z | v
     int k1a, zv0;
     float* gza;                     // [R, B, 8] or null
-    float* sa1;                     // [B, H]
-    float* wpart;                   // [workgroups][NP]
+    float* sa1;                     // [gridDim.y][B, H]: per row-split partial (summed in a fixed order afterwards when gridDim.y > 1)
+    float* wpart;                   // [gridDim.y * gridDim.x][NP]
 };
+
+// rows are independent: at <= 4 waves (one wave per SIMD and workgroup, LDS and registers for three or four workgroups per CU) the rows are
+// split over blockIdx.y so that a CU holds several workgroups whose exchanges overlap
+__global__ void sum_splits_kernel(const float* __restrict__ part, float* __restrict__ out, const long long n, const int splits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = part[i];
+    for (int q = 1; q < splits; ++q) acc += part[(long long)q * n + i];
+    out[i] = acc;
+}
 
 constexpr int HTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (K4f: FTILE)
 
@@ -93,11 +103,12 @@ __global__ __launch_bounds__(64 * NWV) void head_grads_kernel(const HeadDev a) {
         return q;
     };
     int p = 0;
-    Row nx = load_row(0);
-    for (long long r = 0; r < a.R; ++r) {
+    const long long rlo = a.R * blockIdx.y / gridDim.y, rhi = a.R * (blockIdx.y + 1) / gridDim.y;      // this workgroup's rows
+    Row nx = load_row(rlo < a.R ? rlo : a.R - 1);
+    for (long long r = rlo; r < rhi; ++r) {
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the row requested a whole iteration ago
         Row q = nx;
-        nx = load_row(r + 1 < a.R ? r + 1 : r);       // unconditional (clamped): no phis behind the loads
+        nx = load_row(r + 1 < rhi ? r + 1 : r);       // unconditional (clamped): no phis behind the loads
         if (!valid) { q.d1 = zero4; q.d2 = zero4; q.d3 = zero4; q.gs = zero4; }     // padding trajectories duplicate the last one
         put(tile(p, 0, w), q.d2);
         put(tile(p, 1, w), q.d3);
@@ -165,8 +176,8 @@ __global__ __launch_bounds__(64 * NWV) void head_grads_kernel(const HeadDev a) {
     }
 
     // ---- epilogue: sa1 (per trajectory), per-workgroup partials [dAW2 | dAW3 | dAW4 slots (16 x HR) | dAW1 u-columns (HR x 16) | db1 db2 db3 | sum gi (16)]
-    if (valid) *reinterpret_cast<f4*>(a.sa1 + b * H + 16 * w + 4 * g) = S1;
-    float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
+    if (valid) *reinterpret_cast<f4*>(a.sa1 + ((size_t)blockIdx.y * a.B + b) * H + 16 * w + 4 * g) = S1;
+    float* wp = a.wpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.NP;
     const int oW3 = HR * HR, oP3 = 2 * HR * HR, oP0 = oP3 + 16 * HR, oB = oP0 + HR * 16, oG = oB + 3 * HR;
     const int v = 16 * w + j;        // own column
 #pragma unroll
@@ -216,10 +227,19 @@ extern "C" {
 
 int32_t psnode_dae_head_grads_out_floats(int32_t hidden) { return hidden >= 1 && hidden <= 128 ? head_np(hidden) : 0; }
 
+#ifndef PSNODE_K7H_SPLITS
+#define PSNODE_K7H_SPLITS 4
+#endif
+static int head_splits(const psnode_dae_head_grads_args_f32* a) {
+    const int nw = padded_hidden(a->hidden) / 16;
+    if (nw > 4 || a->R < 64) return 1;
+    return PSNODE_K7H_SPLITS;
+}
+
 size_t psnode_dae_head_grads_workspace_bytes(const psnode_dae_head_grads_args_f32* a) {
-    if (!a || a->hidden < 1 || a->hidden > 128 || a->B < 1) return 0;
-    const size_t nwg = (size_t)((a->B + TBM - 1) / TBM);
-    return (nwg * head_np(a->hidden) + 64) * sizeof(float);
+    if (!a || a->hidden < 1 || a->hidden > 128 || a->B < 1 || !padded_hidden(a->hidden)) return 0;
+    const size_t nwg = (size_t)((a->B + TBM - 1) / TBM), rs = (size_t)head_splits(a);
+    return (rs * nwg * head_np(a->hidden) + (rs > 1 ? rs * (size_t)a->B * padded_hidden(a->hidden) : 0) + 128) * sizeof(float);
 }
 
 int32_t psnode_dae_head_grads_f32(const psnode_dae_head_grads_args_f32* p, void* workspace, size_t workspace_bytes, void* stream) {
@@ -239,9 +259,12 @@ int32_t psnode_dae_head_grads_f32(const psnode_dae_head_grads_args_f32* p, void*
     for (int l = 0; l < 3; ++l) { a.h[l] = p->act[l]; a.d[l] = p->delta[l]; }
     a.h_rs = p->act_row_stride;
     a.gi = p->gi; a.u = p->u; a.aw1 = p->aw1; a.k1a = p->aw1_cols; a.zv0 = p->zv_col0;
-    a.gza = p->grad_zv; a.sa1 = p->sa1; a.wpart = static_cast<float*>(workspace);
     const size_t nwg = (size_t)((p->B + TBM - 1) / TBM);
-    const dim3 grid((unsigned)nwg), block(64 * nw);
+    const int rs = head_splits(p);
+    a.gza = p->grad_zv; a.wpart = static_cast<float*>(workspace);
+    float* sa1_part = a.wpart + (((size_t)rs * nwg * a.NP + 63) / 64) * 64;
+    a.sa1 = rs > 1 ? sa1_part : p->sa1;
+    const dim3 grid((unsigned)nwg, (unsigned)rs), block(64 * nw);
     const size_t lds = (size_t)7 * nw * HTILE * sizeof(float);
     hipError_t e = hipSuccess;
     switch (nw) {
@@ -255,7 +278,12 @@ int32_t psnode_dae_head_grads_f32(const psnode_dae_head_grads_args_f32* p, void*
         }
     }
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
-    return launch_reduce_partials(a.wpart, p->out, nullptr, a.NP, 0, (int)nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    if (rs > 1) {
+        const long long n = p->B * (long long)H;
+        hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sa1_part, p->sa1, n, rs);
+        if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    }
+    return launch_reduce_partials(a.wpart, p->out, nullptr, a.NP, 0, (int)(nwg * rs), s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
 
 }  // extern "C"
