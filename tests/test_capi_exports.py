@@ -80,3 +80,21 @@ def test_recogniser():
     assert fused.de_layers_of(extra, 10, 8) is None
     ae = models.AE_Func(26, (64, 64, 64), 2)
     assert len(fused.ae_layers_of(ae, 14, 12, 2)) == 4
+
+
+def test_integration_md_binding_example_matches_the_abi():
+    """The ctypes structs a maintainer would copy out of INTEGRATION.md must have the layout of include/psnode_hip.h (here: of the
+    binding this package itself uses): a struct that stops short of the trailing fields makes the library read past its end."""
+    import ctypes
+    import os
+    import re
+    from py_psnode_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = text[text.index("# neural_dae/_psnode.py"):]
+    block = block[:block.index("lib = ctypes.CDLL")]
+    ns = {}
+    exec("import ctypes\nfrom ctypes import c_int32, c_int64, c_uint32, c_void_p, c_size_t\n" + re.sub(r"^import ctypes, torch$", "", block, flags=re.M), ns)
+    assert ctypes.sizeof(ns["Mlp"]) == ctypes.sizeof(_lib.MlpF32)
+    assert ctypes.sizeof(ns["View"]) == ctypes.sizeof(_lib.ViewF32)
+    assert ctypes.sizeof(ns["OdeArgs"]) == ctypes.sizeof(_lib.OdeArgsF32)
+    assert [f[0] for f in ns["OdeArgs"]._fields_] == [f[0] for f in _lib.OdeArgsF32._fields_]
