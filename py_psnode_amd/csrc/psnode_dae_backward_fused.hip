@@ -553,7 +553,18 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     };
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
     float svx[NX] = {};
-    if constexpr (!REC) { if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx); }
+#ifndef PSNODE_K7F_HEAD_AHEAD
+#define PSNODE_K7F_HEAD_AHEAD 1      // REC = false: the saved rows of the next grid point's head are requested late in the step's last stage (next to
+                                     // the next stage's rows) instead of at the top of the next step, where the head needs them at once
+#endif
+    // (<= 4 waves only: hidden-64 training step 20.9 -> 20.6 ms; at 8 waves the twelve registers cost more in spills than the latency they
+    //  hide -- RK4 49.9 -> 56.3 ms, profiles/r03y_head_ahead_ab.txt)
+    constexpr bool HEAD_AHEAD = !REC && NWV <= 4 && PSNODE_K7F_HEAD_AHEAD;
+    f4 hn1 = zero4, hn2 = zero4, hn3 = zero4;
+    if constexpr (!REC) {
+        if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx);
+        if constexpr (HEAD_AHEAD) load_head(nT - 1, hn1, hn2, hn3);
+    }
     for (long long k = nT - 2; k >= 0; --k) {
         const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
         // ---- (1) AE head at grid point k+1 (my_solvers.py:121): adjoint = dL/dis[k+1] + the algebraic adjoint of step k+1's DE
@@ -563,6 +574,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 float x1[NX];
                 load_x2(a.xs, k + 1, x1);
                 ae_hidden(x1, k + 1, -1, a1, a2, a3);
+            } else if constexpr (HEAD_AHEAD) {
+                a1 = hn1; a2 = hn2; a3 = hn3;
             } else {
                 load_head(k + 1, a1, a2, a3);
             }
@@ -723,6 +736,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             if constexpr (!REC) {      // the next stage's rows, requested late in this one (K4f: PSNODE_K4F_SAVED_AHEAD)
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+                if constexpr (HEAD_AHEAD) { if (s == 0) load_head(k, hn1, hn2, hn3); }      // grid point k: the head of the next iteration (or the one behind the loop)
             }
             const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
             {   // dW1 (`s` columns) += delta1 (x) s, s = (X_s | ext)
@@ -785,6 +799,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             float x1[NX];
             load_x2(a.xs, 0, x1);
             ae_hidden(x1, 0, -1, a1, a2, a3);
+        } else if constexpr (HEAD_AHEAD) {
+            if (nT >= 2) { a1 = hn1; a2 = hn2; a3 = hn3; }
+            else load_head(0, a1, a2, a3);
         } else {
             load_head(0, a1, a2, a3);
         }
