@@ -486,12 +486,21 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             d2 = mid_lds(TSZ + NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
             d1 = mid_lds(TSZ, zero4, d2) * elu_grad_quad(a1);
         } else {
+#ifndef PSNODE_K7F_ABLATE_HEAD
+#define PSNODE_K7F_ABLATE_HEAD 0     // timing experiments only (results WRONG): 1 = the head's two transposed layers skipped, 2 = its row stores skipped, 4 = layers on the DE's LDS images
+#endif
+            if constexpr (PSNODE_K7F_ABLATE_HEAD & 1) { d2 = d3 * elu_grad_quad(a2); d1 = d2 * elu_grad_quad(a1); }
+            else if constexpr (PSNODE_K7F_ABLATE_HEAD & 4) {
+                d2 = mid_lds(NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
+                d1 = mid_lds(0, zero4, d2) * elu_grad_quad(a1);
+            } else {
             d2 = mid_g(pack_ta + NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
             d1 = mid_g(pack_ta, zero4, d2) * elu_grad_quad(a1);
+            }
         }
         const f4 ft = own4(afT, d1);
         const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
-        if (valid) {
+        if (valid && !(PSNODE_K7F_ABLATE_HEAD & 2)) {
             const size_t rb = row * a.B * H;
             if constexpr (REC) {      // (saved activations: the caller contracts over the forward call's buffers)
                 stg<f4>(sbase(hr.a1 + rb), offH, a1);
