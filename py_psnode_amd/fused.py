@@ -765,6 +765,13 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         free, _ = torch.cuda.mem_get_info(dev)
         if (6 * H + 40) * 4 * T * B > free // 2:
             fuse_de = False
+    if gi_c is None:
+        # grad_is = NULL: the recompute instances of one register class (z+v+i = 4: NZM = 2, NZA = 1) at hidden 64 / RK4 -- K7w and K7f alike
+        # -- returned wrong AE gradients (found by profiles/scripts/fuzz_backward.py at the end of round 3; an explicit zero tensor is
+        # right on every instance, the cause is not visible in the source): these kernels always get the explicit tensor
+        gi_c = torch.zeros_like(is_c)
+        keep.append(gi_c)
+        a.grad_is = gi_c.data_ptr()
     if fuse_de:
         if saved is not None:
             s_act, s_xst, s_ae, s_ev, s_evi = saved

@@ -203,6 +203,33 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
         _close(a_, b_.double().cpu(), f"auto vs split param {k}")
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("H,xd", [(128, 8), (100, 8), (128, 5), (64, 8), (32, 3)])
+def test_wide_backward_without_external_inputs_at_hidden_128(method, H, xd):
+    """z_dim = 0 (no external-input slots: the NZM = 0 instances) on K4f, recompute and saved, against K5 -- the recompute instance
+    <Midpoint, NZM = 0, 8 waves> returned a wrong dL/dall_initial / dW1 until the end of round 3 (found by the shape fuzz)."""
+    from py_psnode_amd import fused
+    g = torch.Generator().manual_seed(300 + H + xd)
+    torch.manual_seed(300 + H + xd)
+    B, Tn, zd = 48, 7, 0
+    lin = [nn.Linear(a_, b_) for a_, b_ in zip([3 * (xd + zd), H, H, H], [H, H, H, xd])]
+    layers = [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1).cuda()
+    r = lambda *s_: (0.1 * torch.randn(*s_, generator=g)).cuda()
+    x_in, z = torch.zeros(Tn, B, xd, device="cuda"), r(Tn, B, zd)
+    x_in[0] = r(B, xd)
+    a0 = torch.cat((x_in[0], z[0]), -1)
+    G = torch.randn(Tn, B, xd, generator=g).cuda()
+    xs, saved = fused.ode_integrate(method, layers, t, x_in, z, a0, save=True)
+    b = fused.ode_backward(method, layers, t, z, a0, xs, G, kernel="generic")
+    for name, kw in (("K4f", {}), ("K4f saved", {"saved": saved})):
+        a = fused.ode_backward(method, layers, t, z, a0, xs, G, kernel="wide", **kw)
+        _close(a[0], b[0].double().cpu(), f"{name} grad x0")
+        _close(a[3], b[3].double().cpu(), f"{name} grad all_initial")
+        for k, (p_, q_) in enumerate(zip(a[4], b[4])):
+            _close(p_, q_.double().cpu(), f"{name} grad param {k}")
+
+
 def test_hidden128_training_takes_the_one_launch_backward():
     """ODE_Model at --hidden 128 (the scripts' argparse default) under autograd with fused='require': forward K1, backward K4f in ONE
     launch -- not round 2's split (adjoint sweep + library GEMMs over stored rows)."""
@@ -620,6 +647,26 @@ def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):
     if chunk is not None:      # the same cases on the one-launch form (K7f)
         _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True)
         _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False)
+
+
+@pytest.mark.parametrize("xd,zd,vd,idim", [(4, 0, 1, 3), (4, 1, 1, 2), (3, 2, 0, 2)])
+def test_dae_wide_backward_without_grad_is_on_the_four_slot_classes(xd, zd, vd, idim):
+    """grad_is = None on the shapes with z + v + i = 4 (found by profiles/scripts/fuzz_backward.py: round 2's split kernel K7w got the AE
+    gradients wrong there; the host now always hands it an explicit zero tensor): K7f, K7f(saved) and the split form against K5."""
+    for H, method in ((64, "euler"), (64, "rk4"), (32, "midpoint"), (128, "rk4")):
+        _dae_wide_vs_generic(method, H, 24, 5, xd, zd, vd, idim, seed=900 + xd, events=False, with_gi=False)
+        _dae_wide_vs_generic(method, H, 9, 3, xd, zd, vd, idim, seed=901 + xd, events=False, with_gi=False, chunk_steps=2)
+    # ... and the one-launch kernel K7 (hidden 64) on the same shapes
+    from py_psnode_amd import fused
+    for method in ("euler", "rk4"):
+        de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(9, 3, xd, zd, vd, idim, 902 + xd, False, H=64)
+        xe, ie = torch.zeros(3, 9, 0, device="cuda"), torch.zeros(3, 9, idim, device="cuda")
+        xs, is_ = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0)
+        b = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, None, kernel="generic")
+        a = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, None, kernel="mfma")
+        for grp in ("de", "ae"):
+            for k, (p, q) in enumerate(zip(a[grp], b[grp])):
+                _close(p, q.double().cpu(), f"K7 grad_is=None grad {grp} {k}")
 
 
 @pytest.mark.parametrize("B,Tn", [(1, 2), (3, 1), (17, 2), (33, 3), (16, 5)])
