@@ -11,6 +11,7 @@ import os
 VERBOSE = os.environ.get("FUZZ_VERBOSE", "0") == "1"
 FROM = int(os.environ.get("FUZZ_FROM", "0"))
 OLD = os.environ.get("FUZZ_OLD", "0") == "1"
+BMAX, TMAX = int(os.environ.get("FUZZ_BMAX", "70")), int(os.environ.get("FUZZ_TMAX", "14"))
 def close(a, b, what, tag):
     global bad
     if b is None:
@@ -21,7 +22,7 @@ def close(a, b, what, tag):
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     H = random.choice([8, 24, 32, 40, 64, 96, 128])
     method = random.choice(["euler", "midpoint", "rk4"])
-    B, Tn = random.randint(1, 70), random.randint(2, 14)
+    B, Tn = random.randint(1, BMAX), random.randint(2, TMAX)
     events = Tn > 4 and random.random() < 0.6
     chunk = random.choice([None, 1, 3, 5])
     use_gi = True if OLD else random.random() < 0.8

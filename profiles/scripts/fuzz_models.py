@@ -2,6 +2,7 @@
 no_encode models at random hidden widths: gradients of the default training route (forward saves its activations where the kernels can)
 against the recompute route (PSNODE_SAVE_ACTIVATIONS=0, pinned to the reference gradients by tests/test_grad_goldens.py), same fp32 inputs.
 usage (GPU box, repo root): python profiles/scripts/fuzz_models.py [seed] [iterations]"""
+import os
 import random
 import sys
 
@@ -17,7 +18,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     H = random.choice([16, 64]) if tag.endswith("02") else random.choice([8, 32, 40, 64, 100, 128])
     zd = random.choice([0, 2]) if tag == "dae02" else random.choice([1, 2, 4])
     method = random.choice(["euler", "midpoint", "rk4"])
-    B, T = random.randint(1, 40), random.randint(1, 12)
+    B, T = random.randint(1, int(os.environ.get("FUZZ_BMAX", "40"))), random.randint(1, int(os.environ.get("FUZZ_TMAX", "12")))
     events = T > 7 and random.random() < 0.5
     torch.manual_seed(it)
     g = torch.Generator().manual_seed(1000 + it)
