@@ -157,7 +157,10 @@ def bytes_per_state_step(w):
     return rd + wr
 
 
-def cpu_baseline(w, p_cpu, method, budget_s=12.0):
+def cpu_baseline(w, p_cpu, method, budget_s=12.0, gpu_out=None):
+    """The CPU oracle on the node's host cores (bounded sample).  gpu_out = the fused path's first output [T,B,D] for the same batch:
+    its error against the oracle's sample is reported under BOTH metrics of tests/helpers.py (north_star's per-trajectory one and
+    SURVEY 8(d)'s elementwise one)."""
     from oracle import psnode_oracle as O
     T_s = min(101, w["T"])               # bounded sample: same batch, first 100 grid steps
     # The path is ~300 small ATen ops per step: all host threads is far from the fastest setting on a many-core
@@ -177,16 +180,31 @@ def cpu_baseline(w, p_cpu, method, budget_s=12.0):
     torch.set_num_threads(n_threads)
     times = []
     t_start = time.perf_counter()
+    ref = None
     while len(times) < 9 and (time.perf_counter() - t_start < budget_s or not times):
         t0 = time.perf_counter()
-        run_oracle(O, w, p_cpu, method, T_s)
+        ref = run_oracle(O, w, p_cpu, method, T_s)
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": w["B"] * (T_s - 1) / med, "unit": "state-steps/s", "cores": n_threads, "kind": "port",
-            "sample": f"oracle/psnode_oracle.py (PyTorch-CPU fp32, reference op order), same batch B={w['B']}, first {T_s - 1} of "
-                      f"{w['T'] - 1} steps, median of {len(times)} runs ({med:.3f} s each), torch threads={n_threads}, "
-                      f"host cpus={os.cpu_count()}"}
+    out = {"value": w["B"] * (T_s - 1) / med, "unit": "state-steps/s", "cores": n_threads, "kind": "port",
+           "sample": f"oracle/psnode_oracle.py (PyTorch-CPU fp32, reference op order), same batch B={w['B']}, first {T_s - 1} of "
+                     f"{w['T'] - 1} steps, median of {len(times)} runs ({med:.3f} s each), torch threads={n_threads}, "
+                     f"host cpus={os.cpu_count()}"}
+    if gpu_out is not None and ref is not None:
+        r = (ref[0] if isinstance(ref, (tuple, list)) else ref).double()
+        y = gpu_out[:r.shape[0]].double().cpu() if gpu_out.shape[0] >= r.shape[0] and gpu_out.shape[1] == r.shape[1] else None
+        if y is None and gpu_out.dim() == 3 and gpu_out.shape[0] == r.shape[1]:      # model outputs are [B,T,D]
+            y = gpu_out.permute(1, 0, 2)[:r.shape[0]].double().cpu()
+        if y is not None and y.shape == r.shape:
+            d = (y - r).abs()
+            out["gpu_vs_oracle"] = {
+                "sample": f"all {r.shape[1]} trajectories x first {r.shape[0] - 1} steps of the timed batch",
+                "per_trajectory_rel_err": float((d.amax((0, 2)) / r.abs().amax((0, 2)).clamp_min(1e-3)).max()),
+                "elementwise_rel_err": float((d / r.abs().clamp_min(1e-3)).max()),
+                "tolerance": "1e-5 per trajectory (north_star); the elementwise figure is SURVEY 8(d)'s metric, under which the "
+                             "reference's own fp32 result is 1.5e-5..7e-5 from fp64 (DESIGN.md 'Accuracy gate')"}
+    return out
 
 
 def kernel_name_for(lib, _lib, fused, w, p, method, kernel, dev):
@@ -257,13 +275,144 @@ def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10):
     flops, bts = flops_per_state_step(w, p_cpu, method), bytes_per_state_step(w)
     kname = kernel_name_for(lib, _lib, fused, w, p, method, "auto", dev)
     ach = flops * ss / (avg * 1e-3) / 1e12
+    bound = "valu_fp32" if kname == "valu_dpp" else "mfma"     # K3f issues no MFMA: it is priced against the same fp32 datapath peak
     return {"workload": f"{workload} {method}: B={B} x {T - 1} steps, H{w['H']}", "kernel": kname, "steps": steps, "warmup": warmup,
             "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
             "outputs_finite": bool(torch.isfinite(outs[0]).all()),
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": traffic_for(workload, method, kname, B, T, None), "kernel_ms": avg, "kernel_ms_median": med,
+            "roofline": {"bound": bound, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                         "traffic": traffic_for(workload, method, kname, B, T, None), "traffic_source": "profiles/pmc_traffic.json",
+                         "kernel_ms": avg, "kernel_ms_median": med,
                          "flop_per_state_step": flops, "bytes_per_state_step": bts,
                          "hbm_achieved_GBs": bts * ss / (avg * 1e-3) / 1e9}}
+
+
+class Trainer:
+    """One training step of the fused autograd route on a resident batch: forward (saving activations where the policy of
+    py_psnode_amd/autograd.py says so) + the scripts' masked-MSE loss + fused backward (+ the sharded reductions at N > 1).
+    neural_00_ODE_01_no_encode.py:350-360, neural_01_DAE_01_no_encode.py:405-424."""
+
+    def __init__(self, w, p, method, kernel, loss, dev, dist=None):
+        from py_psnode_amd import autograd as pag
+        from py_psnode_amd import loss as ploss
+        from py_psnode_amd import sharded
+        assert w["kind"] in ("ode", "dae"), "training covers the ode01 / dae01 workloads"
+        self.w, self.p, self.method, self.kernel, self.loss, self.dev, self.dist = w, p, method, kernel, loss, dev, dist
+        self.pag, self.ploss, self.sharded = pag, ploss, sharded
+        B, T = w["B"], w["T"]
+        mk = lambda ls: [q.clone().requires_grad_(True) for wb in ls for q in wb]
+        pair = lambda ps: [(ps[k], ps[k + 1]) for k in range(0, len(ps), 2)]
+        self.params = mk(p["de"]) + (mk(p["ae"]) if w["kind"] == "dae" else [])
+        nde = 2 * len(p["de"])
+        self.layers, self.ae_layers = pair(self.params[:nde]), pair(self.params[nde:])
+        self.G = torch.randn(T, B, w["xd"], device=dev)
+        # the scripts' datasets: ODE mask defaults to ones like x (neural_base.py:14-32), DAE mask is [N,T,1]
+        gm = torch.Generator().manual_seed(11)
+        mshape = (B, T, w["xd"]) if w["kind"] == "ode" else (B, T, 1)
+        self.mask = (torch.rand(mshape, generator=gm) > 0.1).float().to(dev)
+
+    def loss_of(self, xs, is_=None):
+        """The scripts' loss on the [B,T,D] predictions (neural_00_ODE_01_no_encode.py:353-355, neural_01_DAE_01_no_encode.py:414-419)."""
+        w, p, m, ploss, sharded = self.w, self.p, self.mask, self.ploss, self.sharded
+        mse = torch.nn.functional.mse_loss
+        if self.loss == "weighted-sum":
+            return (xs * self.G).sum() + (is_.sum() if is_ is not None else 0.0)
+        xp = xs.permute(1, 0, 2)
+        if self.dist is not None and self.loss == "mse-fused":
+            # data-parallel step: global 1/sum(mask) by a scalar all-reduce, local share of the global loss, no gather
+            if is_ is None:
+                return sharded.masked_mse_sharded(xp, p["x"], m)[0]
+            wx = [10.0 if d == 1 else 1.0 for d in range(w["xd"])]
+            return (sharded.masked_mse_sharded(xp, p["x"], m, col_weight=wx, t0_weight=1.0)[0]
+                    + sharded.masked_mse_sharded(is_.permute(1, 0, 2), p["i"], m, t0_weight=1.0)[0])
+        if is_ is None:
+            if self.loss == "mse-fused":
+                return ploss.ode_loss(xp, p["x"], m)[0]
+            return torch.sum(torch.sum(torch.sum(mse(xp, p["x"], reduction="none") * m, dim=1), dim=0) / torch.sum(m))
+        ip = is_.permute(1, 0, 2)
+        if self.loss == "mse-fused":
+            return ploss.dae_loss(xp, p["x"], ip, p["i"], m)[0]
+        x, i = p["x"], p["i"]
+        x_loss = (torch.sum(mse(xp, x, reduction="none") * m) + torch.sum(mse(xp[:, :, 1:2], x[:, :, 1:2], reduction="none") * m) * 9) / torch.sum(m)
+        i_loss = torch.sum(mse(ip, i, reduction="none") * m) / torch.sum(m)
+        return x_loss + i_loss + mse(x[:, 0, :], xp[:, 0, :]) + mse(i[:, 0, :], ip[:, 0, :])
+
+    def step(self, marks=None):
+        """marks: three more HIP events recorded behind the forward, the loss and the backward (kernel time per family)."""
+        w, p, pag = self.w, self.p, self.pag
+        for q in self.params:
+            q.grad = None
+        if w["kind"] == "dae":
+            xs, is_ = pag.fused_dae_integrate(self.method, self.kernel, self.layers, self.ae_layers, p["x_init"], tmv(p["t"]),
+                                              tmv(p["z"]), tmv(p["v"]), tmv(p["i"]), p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
+            outs = (xs.detach(), is_.detach())
+        else:
+            xs, is_ = pag.fused_ode_integrate(self.method, self.kernel, self.layers, tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
+                                              p["event_t"], p["z_jump"]), None
+            outs = (xs.detach(),)
+        if marks:
+            marks[0].record()
+        loss = self.loss_of(xs, is_)
+        if marks:
+            marks[1].record()
+        loss.backward()
+        if marks:
+            marks[2].record()
+        if self.dist is not None:
+            self.sharded.all_reduce_param_grads(self.params)
+        return outs
+
+
+# The training step (SURVEY 8(f1)) of the no_encode models on the driver's clock: RK4 and the solver the scripts ship with (Euler) at the
+# scripts' hidden 64 constructor default... and the argparse default --hidden 128 (neural_00_ODE_01_no_encode.py:245-246)
+TRAIN_EXTRAS = [("ode01", "rk4", 64), ("dae01", "rk4", 64), ("ode01", "euler", 64), ("dae01", "euler", 64), ("ode01", "rk4", 128), ("dae01", "rk4", 128)]
+
+
+def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
+    """One training workload on the driver's clock: `steps` forward + loss + backward passes at B=4096 x 1000 steps.  roofline.frac on
+    the 3x-forward flop convention (forward + data gradients + weight gradients); kernel time per family from HIP events between the
+    three parts of the step; saved_bytes = the stage activations the forward kept for the backward (0: the backward recomputes)."""
+    w = dict(WORKLOADS[workload])
+    w["H"] = hidden
+    B, T = w["B"], w["T"]
+    p_cpu = make_problem(w, B, T)
+    p = to_dev(p_cpu, dev)
+    tr = Trainer(w, p, method, "auto", "mse-fused", dev)
+    for _ in range(warmup):
+        tr.step()
+    torch.cuda.synchronize(dev)
+    E = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [(E(), E(), E(), E()) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        outs = tr.step(ev[k][1:])
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    part = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in ev) / steps
+    whole = sorted(e[0].elapsed_time(e[3]) for e in ev)
+    avg, med = sum(whole) / steps, whole[steps // 2]
+    ss = B * (T - 1)
+    flops = 3 * flops_per_state_step(w, p_cpu, method)
+    ach = flops * ss / (avg * 1e-3) / 1e12
+    grads_ok = all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in tr.params)
+    res = {"workload": f"{workload} {method} TRAIN (forward + masked-MSE loss + fused backward): B={B} x {T - 1} steps, H{hidden}",
+           "steps": steps, "warmup": warmup, "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
+           "outputs_finite": bool(torch.isfinite(outs[0]).all()), "grads_finite": grads_ok,
+           "saved_bytes": int(tr.pag.last_saved_bytes),
+           "host_enqueue_ms": None,
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                        "flop_convention": "3 x forward flops per state-step", "flop_per_state_step": flops,
+                        "kernel_ms": avg, "kernel_ms_median": med,
+                        "kernel_ms_by_family": {"forward": part(0, 1), "loss": part(1, 2), "backward": part(2, 3)}}}
+    # host-side enqueue cost of one step (no device wait inside the step: the difference to the GPU time is what the host may hide)
+    torch.cuda.synchronize(dev)
+    th = time.perf_counter()
+    tr.step()
+    res["host_enqueue_ms"] = (time.perf_counter() - th) * 1e3
+    torch.cuda.synchronize(dev)
+    del tr, p, outs
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(n):
@@ -297,6 +446,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=None, help="override the MLPs' hidden width (the scripts' --hidden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="default run: skip the extra workloads (configs 3, 4, Euler) timed after the headline")
+    ap.add_argument("--no-train-extras", action="store_true", help="default run: skip the training-step workloads among the extras")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather (integrate-only scaling)")
     ap.add_argument("--train", action="store_true", help="time forward + backward (fused autograd route) instead of the forward alone")
     ap.add_argument("--loss", default="mse-fused", choices=["mse-fused", "mse-torch", "weighted-sum"],
@@ -356,72 +506,14 @@ def main():
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
         gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
 
-    train_state = {}
-    if args.train:
-        assert w["kind"] in ("ode", "dae"), "--train covers the ode01 / dae01 workloads"
-        from py_psnode_amd import autograd as pag
-        mk = lambda ls: [q.clone().requires_grad_(True) for wb in ls for q in wb]
-        pair = lambda ps: [(ps[k], ps[k + 1]) for k in range(0, len(ps), 2)]
-        train_state["params"] = mk(p["de"]) + (mk(p["ae"]) if w["kind"] == "dae" else [])
-        nde = 2 * len(p["de"])
-        train_state["layers"] = pair(train_state["params"][:nde])
-        train_state["ae_layers"] = pair(train_state["params"][nde:])
-        train_state["G"] = torch.randn(T, B, w["xd"], device=dev)
-        # the scripts' datasets: ODE mask defaults to ones like x (neural_base.py:14-32), DAE mask is [N,T,1]
-        gm = torch.Generator().manual_seed(11)
-        mshape = (B, T, w["xd"]) if w["kind"] == "ode" else (B, T, 1)
-        train_state["mask"] = (torch.rand(mshape, generator=gm) > 0.1).float().to(dev)
-        from py_psnode_amd import loss as ploss
-        mse = torch.nn.functional.mse_loss
-
-    def train_loss(xs, is_=None):
-        """The scripts' loss on the [B,T,D] predictions (neural_00_ODE_01_no_encode.py:353-355, neural_01_DAE_01_no_encode.py:414-419)."""
-        m = train_state["mask"]
-        if args.loss == "weighted-sum":
-            return (xs * train_state["G"]).sum() + (is_.sum() if is_ is not None else 0.0)
-        xp = xs.permute(1, 0, 2)
-        if dist is not None and args.loss == "mse-fused":
-            # data-parallel step: global 1/sum(mask) by a scalar all-reduce, local share of the global loss, no gather
-            if is_ is None:
-                return sharded.masked_mse_sharded(xp, p["x"], m)[0]
-            wx = [10.0 if d == 1 else 1.0 for d in range(w["xd"])]
-            return (sharded.masked_mse_sharded(xp, p["x"], m, col_weight=wx, t0_weight=1.0)[0]
-                    + sharded.masked_mse_sharded(is_.permute(1, 0, 2), p["i"], m, t0_weight=1.0)[0])
-        if is_ is None:
-            if args.loss == "mse-fused":
-                return ploss.ode_loss(xp, p["x"], m)[0]
-            return torch.sum(torch.sum(torch.sum(mse(xp, p["x"], reduction="none") * m, dim=1), dim=0) / torch.sum(m))
-        ip = is_.permute(1, 0, 2)
-        if args.loss == "mse-fused":
-            return ploss.dae_loss(xp, p["x"], ip, p["i"], m)[0]
-        x, i = p["x"], p["i"]
-        x_loss = (torch.sum(mse(xp, x, reduction="none") * m) + torch.sum(mse(xp[:, :, 1:2], x[:, :, 1:2], reduction="none") * m) * 9) / torch.sum(m)
-        i_loss = torch.sum(mse(ip, i, reduction="none") * m) / torch.sum(m)
-        return x_loss + i_loss + mse(x[:, 0, :], xp[:, 0, :]) + mse(i[:, 0, :], ip[:, 0, :])
-
-    def train_step():
-        for q in train_state["params"]:
-            q.grad = None
-        if w["kind"] == "dae":
-            xs, is_ = pag.fused_dae_integrate(args.method, args.kernel, train_state["layers"], train_state["ae_layers"], p["x_init"], tmv(p["t"]),
-                                              tmv(p["z"]), tmv(p["v"]), tmv(p["i"]), p["a0"], p["event_t"], p["z_jump"], p["v_jump"])
-            train_loss(xs, is_).backward()
-            if dist is not None:
-                sharded.all_reduce_param_grads(train_state["params"])
-            return (xs.detach(), is_.detach())
-        xs = pag.fused_ode_integrate(args.method, args.kernel, train_state["layers"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
-                                     p["event_t"], p["z_jump"])
-        train_loss(xs).backward()
-        if dist is not None:
-            sharded.all_reduce_param_grads(train_state["params"])
-        return (xs.detach(),)
+    trainer = Trainer(w, p, args.method, args.kernel, args.loss, dev, dist) if args.train else None
 
     def one_step(ev_pair=None):
         """One pass of the hot path (+ the all-gather at N>1).  ev_pair brackets the compute-stream kernels only."""
         if ev_pair:
             ev_pair[0].record()
         if args.train:
-            outs = train_step()
+            outs = trainer.step()
             if ev_pair:
                 ev_pair[1].record()
             return outs
@@ -520,8 +612,9 @@ def main():
                        "collective": ((f"rccl all_gather of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration"
                                        if pipelined else "rccl all_gather of the output shards [T,B,D]") if do_gather else "none"),
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "kernel_ms": kern_avg_ms, "kernel_ms_median": kern_med_ms,
+            "roofline": {"bound": "valu_fp32" if kname == "valu_dpp" else "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic is not None else None,
+                         "kernel_ms": kern_avg_ms, "kernel_ms_median": kern_med_ms,
                          "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1], "flop_per_state_step": flops,
                          "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
                          "bytes_per_state_step": bts},
@@ -542,7 +635,7 @@ def main():
                 def walk():
                     de.zero_grad()
                     xs = solver.integrate_ODE(x_func=de, t=tmv(p["t"])[:Ts], x=tmv(p["x"])[:Ts], z=tmv(p["z"])[:Ts], all_initial=p["a0"])
-                    (xs * train_state["G"][:Ts]).sum().backward()
+                    (xs * trainer.G[:Ts]).sum().backward()
                 walk(); torch.cuda.synchronize(dev)
                 t0 = time.perf_counter(); walk(); torch.cuda.synchronize(dev)
                 dtw = time.perf_counter() - t0
@@ -550,11 +643,19 @@ def main():
                                             "fused_over_walk": value / (B * (Ts - 1) / dtw)}
         headline = (args.workload, args.method, B, T, w["H"], args.kernel) == ("ode01", "rk4", 4096, 1001, 64, "auto")
         if world == 1 and dist is None and headline and not args.train and not args.no_extras:
+            out0 = outs[0]
             del outs
             res["extra"] = [extra_line(lib, _lib, fused, wl, m, dev) for wl, m in EXTRAS]
+            if not args.no_train_extras:
+                res["extra"] += [train_extra_line(fused, wl, m, h, dev) for wl, m, h in TRAIN_EXTRAS]
+            outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method)
+            res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method, gpu_out=None if args.train else outs[0])
             res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            if "gpu_vs_oracle" in res["cpu_baseline"]:
+                acc = res["cpu_baseline"]["gpu_vs_oracle"]
+                res["config"]["rel_err_vs_oracle"] = {"per_trajectory": acc["per_trajectory_rel_err"], "elementwise": acc["elementwise_rel_err"],
+                                                      "sample": acc["sample"]}
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line on stdout
         import ctypes
         sys.stdout.flush()

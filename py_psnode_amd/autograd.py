@@ -14,6 +14,8 @@ from . import fused
 # 17.5 -> 14.3, 32 10.4 -> 9.6; DAE_01 77.0 -> 52.2, 23.0 -> 21.4, 16.9 -> 14.7) whenever the rows (6 KB per state-step at 128: 25 GB for
 # that batch; 3.1 KB / 13 GB at 64) fit into half of the free HBM; "1" / "0" force it on / off.
 SAVE_ACTIVATIONS = os.environ.get("PSNODE_SAVE_ACTIVATIONS", "auto")
+# bytes of stage activations the most recent training forward kept for its backward (0: the backward recomputes) -- bench.py reports it
+last_saved_bytes = 0
 
 
 def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
@@ -67,6 +69,8 @@ class _FusedOde(torch.autograd.Function):
         res = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
                                   save=save)
         xs, saved = res if save else (res, None)
+        global last_saved_bytes
+        last_saved_bytes = sum(q.numel() * q.element_size() for q in saved) if saved is not None else 0
         ctx.method = method
         ctx.has_jump = z_jump is not None
         ctx.has_saved = saved is not None
@@ -116,6 +120,8 @@ class _FusedDae(torch.autograd.Function):
                                   event_idx=event_idx, kernel=kernel, save=save)
         xs, is_ = res[0], res[1]
         acts = [q for q in res[2] if q is not None] if save else []
+        global last_saved_bytes
+        last_saved_bytes = sum(q.numel() * q.element_size() for q in acts)
         ctx.method, ctx.n_de, ctx.event_idx = method, n_de, event_idx
         ctx.has_zj, ctx.has_vj = z_jump is not None, v_jump is not None
         ctx.n_saved = len(acts)

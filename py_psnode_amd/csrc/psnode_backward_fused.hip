@@ -94,14 +94,12 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
     constexpr bool STREAM = NWV >= 8 && REC;     // forward / transposed images swapped in LDS per phase; activations through the ring
     constexpr int BMODE = REC ? PSNODE_K4F_BOUND : PSNODE_K4F_BOUND_SAVED;
-#ifndef PSNODE_K4F_NO_WORKAROUND
-#define PSNODE_K4F_NO_WORKAROUND 0
-#endif
-    // (not for the recompute instance <Midpoint, NZM = 0, 8 waves>: with the sched_barriers in place that one instance returned a wrong
-    //  dL/dall_initial and dW1 -- every other output, and every other instance, right -- and sometimes faulted; found by
-    //  profiles/scripts/fuzz_backward.py at the end of round 3, cause not found in the source (an extra fence in front of the epilogue does
-    //  not help, removing the scheduling bounds does); pinned by test_wide_backward_without_external_inputs_at_hidden_128)
-    constexpr bool BOUND = NWV >= 8 && (BMODE == 1 || (BMODE == 2 && S >= 4) || (BMODE == 3 && S >= 2)) && !(REC && NZM == 0 && S == 2 && !PSNODE_K4F_NO_WORKAROUND);
+    // (rounds 3's exception for the recompute instance <Midpoint, NZM = 0, 8 waves> is gone: its wrong dL/dall_initial / dW1 were a VGPR
+    //  spill -- of `l & 15`, live from the prologue to the epilogue -- that the register allocator had placed inside the `4 + g < x_dim`
+    //  arm of load_x2, a divergent region whose EXEC is EMPTY at x_dim = 8: nothing was saved, and the epilogue's `i < n` predicates read
+    //  whatever the scratch slot held (zeros: every lane acted as column 0).  Dropping the sched_barriers only moved the spill.  load_x2
+    //  is branch-free now (psnode_common.h: ldg_sel); profiles/scripts/isa_lint.py check A watches for the pattern.  DESIGN.md, round 4.)
+    constexpr bool BOUND = NWV >= 8 && (BMODE == 1 || (BMODE == 2 && S >= 4) || (BMODE == 3 && S >= 2));
     constexpr int EVERY = REC ? PSNODE_K4F_EVERY : PSNODE_K4F_EVERY_SAVED;
     float w1xs[NX], w1z[NZ], w2r[STREAM ? 1 : 4 * NWV], w3r[STREAM ? 1 : 4 * NWV], w4[4];
     f4 b1r, b2, b3, b4;
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             const unsigned long long base = ((unsigned long long)hi << 32) | lo;
             const unsigned dst = __builtin_amdgcn_readfirstlane(wT_lds + (unsigned)slot * 1024u);
             unsigned keep;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+            asm volatile(PSNODE_LDS_DMA_ASM
                          : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(base) : "memory");
         }
     };
@@ -398,6 +396,9 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     // addressing: sbase(uniform row base) + 32-bit per-lane BYTE offset (psnode_common.h: ldg / stg)
     const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);
     const unsigned offX = 4u * ((unsigned)(b * xd) + g);
+    unsigned offXc[NX];                                                    // the same with the column clamped into the row (ldg_sel)
+#pragma unroll
+    for (int r = 0; r < NX; ++r) offXc[r] = 4u * ((unsigned)(b * xd) + (4 * r + g < xd ? 4 * r + g : 0));
     const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offZJ = 4u * (unsigned)(b * a.zjb);
     auto load_ext = [&, offZ, offZJ](const long long k, const int ev, float (&dst)[NZ]) {
         if constexpr (NZM > 0) {
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = ldg_sel(row, offXc[r], 4 * r + g < xd);      // branch-free (psnode_common.h: ldg_sel)
     };
     // clock and event index of a step are RAW prefetched values (one grid point / one table entry per step, requested a step ahead);
     // the difference and the readfirstlane happen a step later, at the consumer.  Subtracting / broadcasting right behind the load --

@@ -181,19 +181,22 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_wide_kernel(const WideD
     // addressing: sbase(uniform row base) + 32-bit per-lane BYTE offset (psnode_common.h: ldg / stg)
     const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);      // rows of H floats: this lane's 4 units of its trajectory
     const unsigned offX = 4u * ((unsigned)(b * xd) + g);                  // rows of x_dim floats (+ 16 r)
+    unsigned offXc[NX];                                                    // the same with the column clamped into the row (ldg_sel)
+#pragma unroll
+    for (int r = 0; r < NX; ++r) offXc[r] = 4u * ((unsigned)(b * xd) + (4 * r + g < xd ? 4 * r + g : 0));
     const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offZJ = 4u * (unsigned)(b * a.zjb);
     auto load_ext = [&, offZ, offZJ](const long long k, const int ev, float (&dst)[NZM > 0 ? NZM : 1]) {
         if constexpr (NZM > 0) {
             const gptr<const float> row = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
             const unsigned m_ = ev >= 0 ? ~0u : 0u, zo = (offZJ & m_) | (offZ & ~m_);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) dst[m] = eon[m] ? ldg<float>(row, zo + 4u * ecol[m]) : 0.0f;
+            for (int m = 0; m < NZM; ++m) dst[m] = ldg_sel(row, zo + 4u * ecol[m], eon[m]);      // (ecol is 0 on padding slots)
         }
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = ldg_sel(row, offXc[r], 4 * r + g < xd);      // branch-free (psnode_common.h: ldg_sel)
     };
     auto load_dt = [&](const long long k) -> float { return ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT); };
 

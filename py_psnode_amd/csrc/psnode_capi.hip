@@ -250,9 +250,10 @@ int32_t psnode_ode_integrate_f32(const psnode_ode_args_f32* args, void* workspac
     IntegrateDev d;
     const int rc = fill_ode(args, d);
     if (rc) return rc;
-    if (d.sact) {      // only K1 proper writes the training side outputs
-        bind_dims(args->de, d.de);
-        if (args->kernel == PSNODE_KERNEL_GENERIC || !mfma_ode_save_hidden(d)) return PSNODE_ERR_UNSUPPORTED;
+    if (d.sact) {      // only K1 proper / K3c write the training side outputs (checked with the pointers in place: alignment counts)
+        IntegrateDev q = d;
+        bind_dims(args->de, q.de);
+        if (args->kernel == PSNODE_KERNEL_GENERIC || !mfma_ode_save_hidden(q)) return PSNODE_ERR_UNSUPPORTED;
     }
     return dispatch(d, false, args->kernel, &args->de, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }

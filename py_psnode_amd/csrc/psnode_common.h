@@ -156,10 +156,33 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ src, flo
 // LDS-only workgroup barrier: waits for this wave's LDS traffic (lgkmcnt), not for its outstanding global prefetches --
 // a plain __syncthreads() would also drain vmcnt and serialise the one-step-ahead loads of the MFMA kernels.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef PSNODE_LDS_BARRIER_SYNC      // discriminator builds only (round 4 defect chase): the full barrier, draining vmcnt too
+    __syncthreads();
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+// LDS-DMA of 64 lanes x 16 B (K4f / K7f image swaps): `global_load_lds_dwordx4 <lane*16>, <uniform 64-bit base>` with the LDS
+// destination in M0 (saved / restored around it).  The instruction sits in inline asm, where the compiler's hazard recognizer does not
+// look, so the asm has to carry its own wait states:
+//   * SALU write of M0 -> LDS-DMA reads M0: 1 wait state;
+//   * VALU write of an SGPR (v_readlane / v_readfirstlane: how the spilled, loop-invariant slot bases come back) -> VMEM reads that SGPR
+//     as its scalar address: FIVE wait states (gfx9 `VmemSgprWaitStates`), or the load may go out with the OLD register contents.
+// Rounds 2-3 had `s_nop 0` here: s_waitcnt + 2 s_mov + s_nop 0 = 4 wait states when the compiler schedules the v_readlane of the
+// base's high half directly in front of the asm -- 237 such sites in the 15 recompute 8-wave instances of K4f alone
+// (profiles/scripts/isa_asm_hazards.py, profiles/r04_dma_hazard_*.txt).  `s_nop 2` makes the asm self-sufficient (2 s_mov + 3 = 5
+// without counting the s_waitcnt).  PSNODE_DMA_NOP=0 rebuilds the old sequence.
+#ifndef PSNODE_DMA_NOP
+#define PSNODE_DMA_NOP 2
+#endif
+#define PSNODE_STR2(x) #x
+#define PSNODE_STR(x) PSNODE_STR2(x)
+#define PSNODE_LDS_DMA_ASM                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop " PSNODE_STR(PSNODE_DMA_NOP)            \
+    "\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
 
 // fp32(1/3): the reference multiplies fp32 tensors by the python double 1/3, which ATen rounds to fp32
 // (my_fixed_grid.py:8,43-44).
@@ -303,6 +326,16 @@ template <bool NT, typename V>
 __device__ __forceinline__ void store_nt(V* p, const V v) {
     if constexpr (NT && PSNODE_SAVED_NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+}
+// Predicated row element WITHOUT control flow: the load is unconditional from an offset the caller has clamped into the row, the
+// predicate only selects the value (v_cndmask).  Written `cond ? ldg(..) : 0.0f` the load sits in one arm of a branch, and every such arm
+// in a time-loop kernel is a divergent EXEC region in which the register allocator may place a spill: the spill then saves only the
+// lanes active THERE (none at all when the predicate is false for the whole wave) and a reload outside of the region hands the other
+// lanes garbage -- round 3's defect (a), DESIGN.md "Round 4: the two fenced defects".
+template <typename T>
+__device__ __forceinline__ float ldg_sel(gptr<const T> base, unsigned safe_byte_off, bool on) {
+    const float v = ldg<float>(base, safe_byte_off);
+    return on ? v : 0.0f;
 }
 template <typename V, typename T>
 __device__ __forceinline__ void stg(gptr<T> base, unsigned byte_off, V v) {

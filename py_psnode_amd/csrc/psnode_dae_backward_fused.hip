@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             const unsigned long long base = ((unsigned long long)hi << 32) | lo;
             const unsigned dst = __builtin_amdgcn_readfirstlane(wT_lds + (unsigned)slot * 1024u);
             unsigned keep;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+            asm volatile(PSNODE_LDS_DMA_ASM
                          : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(base) : "memory");
         }
     };
@@ -432,6 +432,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     // per-lane BYTE offsets next to a scalar row base (psnode_common.h: sbase / ldg / stg)
     const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);      // rows of H floats: this lane's 4 units of its trajectory
     const unsigned offX = 4u * ((unsigned)(b * xd) + g);                  // rows of x_dim floats (+ 16 r)
+    unsigned offXc[NX];                                                    // the same with the column clamped into the row (ldg_sel)
+#pragma unroll
+    for (int r = 0; r < NX; ++r) offXc[r] = 4u * ((unsigned)(b * xd) + (4 * r + g < xd ? 4 * r + g : 0));
     const unsigned offI = 4u * (unsigned)(b * idim);                      // rows of i_dim floats (+ 4 column)
     const unsigned offS = 4u * ((unsigned)(b * 16) + g);                  // slot rows (+ 16 m)
     const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offV = 4u * (unsigned)(b * a.v.sb);
@@ -440,22 +443,24 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     struct RowZV { gptr<const float> z, v; unsigned zo, vo; };
     auto zv_rows = [&, offZ, offV, offZJ, offVJ](const long long k, const int ev) -> RowZV {
         RowZV r;
-        r.z = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
-        r.v = sbase(ev >= 0 ? a.vj + (long long)ev * a.vje : a.v.p + k * a.v.st);
+        // (without z / v inputs the row is the clock's: zv_val loads unconditionally -- no branch, not even a uniform one, in front of
+        //  the head's MFMAs: psnode_common.h, ldg_sel)
+        r.z = sbase(zd > 0 ? (ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st) : a.t.p);
+        r.v = sbase(vd > 0 ? (ev >= 0 ? a.vj + (long long)ev * a.vje : a.v.p + k * a.v.st) : a.t.p);
         const unsigned m = ev >= 0 ? ~0u : 0u;     // (bit select: a ?: between the two captured offsets becomes a select between their ADDRESSES)
-        r.zo = (offZJ & m) | (offZ & ~m);
-        r.vo = (offVJ & m) | (offV & ~m);
+        r.zo = zd > 0 ? ((offZJ & m) | (offZ & ~m)) : 0u;
+        r.vo = vd > 0 ? ((offVJ & m) | (offV & ~m)) : 0u;
         return r;
     };
     auto zv_val = [&](const RowZV& r, const int kind, const int col) -> float {
-        const float zr = zd > 0 ? ldg<float>(r.z, r.zo + 4u * (kind == 0 ? col : 0)) : 0.0f;
-        const float vr = vd > 0 ? ldg<float>(r.v, r.vo + 4u * (kind == 1 ? col : 0)) : 0.0f;
+        const float zr = ldg<float>(r.z, r.zo + 4u * (kind == 0 ? col : 0));
+        const float vr = ldg<float>(r.v, r.vo + 4u * (kind == 1 ? col : 0));
         return kind == 0 ? zr : (kind == 1 ? vr : 0.0f);
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = ldg_sel(row, offXc[r], 4 * r + g < xd);      // branch-free (psnode_common.h: ldg_sel)
     };
     // AE head, hidden activations of g(xa; z|v of grid point k or of event ev)
     auto ae_hidden = [&](const float (&xa)[NX], const long long k, const int ev, f4& a1, f4& a2, f4& a3) {
@@ -520,11 +525,13 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     };
     // dL/dis[k] enters through the `s`-block slot of its i-dim (one slot per i-dim); padding trajectories carry no adjoint at all
     auto add_gis = [&](const long long k, float (&gs)[NZM]) {
-        if (a.gis) {
-            const gptr<const float> row = sbase(a.gis + k * a.B * idim);
+        // grad_is == NULL reads the rows of `is` instead (same shape) and masks them out: no branch (psnode_dae_backward_wide.hip: add_gis)
+        const bool has = a.gis != nullptr;
+        const gptr<const float> row = sbase((has ? a.gis : a.is) + k * a.B * idim);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m)
-                if (ekind[m] == 2 && 4 * m + g >= ne) { const float q = ldg<float>(row, offI + 4u * ecol[m]); gs[m] += valid ? q : 0.0f; }
+        for (int m = 0; m < NZM; ++m) {
+            const float q = ldg<float>(row, offI + 4u * (ekind[m] == 2 ? ecol[m] : 0));
+            gs[m] += (has && valid && ekind[m] == 2 && 4 * m + g >= ne) ? q : 0.0f;
         }
     };
 

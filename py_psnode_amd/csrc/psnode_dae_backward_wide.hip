@@ -274,6 +274,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     // per-lane BYTE offsets (psnode_common.h: at)
     const unsigned offH = 4u * ((unsigned)(b * H) + 16 * w + 4 * g);      // rows of H floats: this lane's 4 units of its trajectory
     const unsigned offX = 4u * ((unsigned)(b * xd) + g);                  // rows of x_dim floats (+ 16 r)
+    unsigned offXc[NX];                                                    // the same with the column clamped into the row (ldg_sel)
+#pragma unroll
+    for (int r = 0; r < NX; ++r) offXc[r] = 4u * ((unsigned)(b * xd) + (4 * r + g < xd ? 4 * r + g : 0));
     const unsigned offI = 4u * (unsigned)(b * idim);                      // rows of i_dim floats (+ 4 column)
     const unsigned offS = 4u * ((unsigned)(b * 16) + g);                  // slot rows (+ 16 m)
     const unsigned offT = 4u * (unsigned)(b * a.t.sb), offZ = 4u * (unsigned)(b * a.z.sb), offV = 4u * (unsigned)(b * a.v.sb);
@@ -282,22 +285,24 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     struct RowZV { gptr<const float> z, v; unsigned zo, vo; };
     auto zv_rows = [&, offZ, offV, offZJ, offVJ](const long long k, const int ev) -> RowZV {
         RowZV r;
-        r.z = sbase(ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st);
-        r.v = sbase(ev >= 0 ? a.vj + (long long)ev * a.vje : a.v.p + k * a.v.st);
+        // (without z / v inputs the row is the clock's: zv_val loads unconditionally -- no branch, not even a uniform one, in front of
+        //  the head's MFMAs: psnode_common.h, ldg_sel)
+        r.z = sbase(zd > 0 ? (ev >= 0 ? a.zj + (long long)ev * a.zje : a.z.p + k * a.z.st) : a.t.p);
+        r.v = sbase(vd > 0 ? (ev >= 0 ? a.vj + (long long)ev * a.vje : a.v.p + k * a.v.st) : a.t.p);
         const unsigned m = ev >= 0 ? ~0u : 0u;     // (bit select: a ?: between the two captured offsets becomes a select between
-        r.zo = (offZJ & m) | (offZ & ~m);          //  their ADDRESSES, which puts them on the stack)
-        r.vo = (offVJ & m) | (offV & ~m);
+        r.zo = zd > 0 ? ((offZJ & m) | (offZ & ~m)) : 0u;
+        r.vo = vd > 0 ? ((offVJ & m) | (offV & ~m)) : 0u;
         return r;
     };
     auto zv_val = [&](const RowZV& r, const int kind, const int col) -> float {
-        const float zr = zd > 0 ? ldg<float>(r.z, r.zo + 4u * (kind == 0 ? col : 0)) : 0.0f;
-        const float vr = vd > 0 ? ldg<float>(r.v, r.vo + 4u * (kind == 1 ? col : 0)) : 0.0f;
+        const float zr = ldg<float>(r.z, r.zo + 4u * (kind == 0 ? col : 0));
+        const float vr = ldg<float>(r.v, r.vo + 4u * (kind == 1 ? col : 0));
         return kind == 0 ? zr : (kind == 1 ? vr : 0.0f);
     };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = (4 * r + g < xd) ? ldg<float>(row, offX + 16u * r) : 0.0f;
+        for (int r = 0; r < NX; ++r) dst[r] = ldg_sel(row, offXc[r], 4 * r + g < xd);      // branch-free (psnode_common.h: ldg_sel)
     };
     // AE head, hidden activations of g(xa; z|v of grid point k or of event ev)
     auto ae_hidden = [&](const float (&xa)[NX], const long long k, const int ev, f4& a1, f4& a2, f4& a3) {
@@ -361,11 +366,17 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_wide_kernel(const WideD
     };
     // dL/dis[k] enters through the `s`-block slot of its i-dim (one slot per i-dim)
     auto add_gis = [&](const long long k, float (&gs)[NZM]) {
-        if (a.gis) {
-            const gptr<const float> row = sbase(a.gis + k * a.B * idim);
+        // grad_is == NULL (no loss term on the algebraic outputs) reads the rows of `is` instead -- same shape -- and masks them out:
+        // NO branch here.  Rounds 2-3 had `if (a.gis) { .. }`: the compiler moved that uniform branch between the last MFMA of the head's
+        // third layer and the v_pk_add that sums its two accumulator chains; the hazard recognizer pads the fall-through path with
+        // s_nop but not the taken edge, so with NULL the add read registers 2..3 of the accumulator one instruction behind the MFMA that
+        // writes them (wrong a3 in half of the units -> wrong AE gradients; profiles/r04_defect_b_*.txt).
+        const bool has = a.gis != nullptr;
+        const gptr<const float> row = sbase((has ? a.gis : a.is) + k * a.B * idim);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m)
-                if (ekind[m] == 2 && 4 * m + g >= ne) gs[m] += ldg<float>(row, offI + 4u * ecol[m]);
+        for (int m = 0; m < NZM; ++m) {
+            const float q = ldg<float>(row, offI + 4u * (ekind[m] == 2 ? ecol[m] : 0));
+            gs[m] += (has && ekind[m] == 2 && 4 * m + g >= ne) ? q : 0.0f;
         }
     };
 

@@ -6,6 +6,7 @@ exactly as nn.Linear stores them; `plan_ode` / `plan_dae` do the recognition for
 in py_psnode_amd.neural_dae.  Nothing here computes on the CPU and nothing here imports oracle/.
 """
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -18,6 +19,23 @@ Layers = Sequence[Tuple[torch.Tensor, torch.Tensor]]
 
 METHOD_ID = {"euler": _lib.EULER, "midpoint": _lib.MIDPOINT, "rk4": _lib.RK4_38}
 KERNEL_ID = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "mfma": _lib.KERNEL_MFMA, "wide": _lib.KERNEL_MFMA_WIDE}
+
+# PSNODE_POISON=1 (debug / `pytest -m gpu` leg of tests/test_gpu_fuzz.py): every buffer this module hands a kernel uninitialised --
+# outputs, stored rows, workspaces -- is filled with NaN bit patterns first, so that a kernel (or a host-side contraction) that consumes
+# memory nobody wrote shows up as NaN instead of as whatever the caching allocator happened to recycle.
+_POISON = os.environ.get("PSNODE_POISON", "0") == "1"
+
+
+def _empty(*size, **kw) -> torch.Tensor:
+    t = torch.empty(*size, **kw)
+    if _POISON and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        elif t.dtype == torch.uint8:
+            t.fill_(0xFF)            # 0xFFFFFFFF read as fp32 is a NaN
+        else:
+            t.fill_(-(1 << 30))
+    return t
 
 
 # ----------------------------------------------------------------------------- recognition
@@ -219,7 +237,7 @@ def event_table(t: torch.Tensor, event_t: Optional[torch.Tensor], check_duplicat
     t_arg, event_arg = t, event_t          # the caller's objects: what the duplicate-check memo is keyed on (detach() makes new ones)
     t = _f32_dev(t, dev, "t")
     event_t = _f32_dev(event_t, dev, "event_t")
-    tab = torch.empty(T - 1, dtype=torch.int32, device=dev)
+    tab = _empty(T - 1, dtype=torch.int32, device=dev)
     dup = torch.zeros(1, dtype=torch.int32, device=dev)
     n_ev = event_t.shape[1]
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -261,7 +279,7 @@ def _dup_check_remember(t, event_t):
 
 def _workspace(lib, de: _lib.MlpF32, ae, dev) -> torch.Tensor:
     nbytes = lib.psnode_workspace_bytes(ctypes.byref(de), ctypes.byref(ae) if ae is not None else None)
-    return torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    return _empty(nbytes + 256, dtype=torch.uint8, device=dev)
 
 
 def _aligned_ptr(ws: torch.Tensor):
@@ -318,7 +336,7 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
             a.event_idx = event_idx.data_ptr()
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
         if out is None:
-            out = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+            out = _empty((T, B, xd), dtype=torch.float32, device=dev)
         elif out.shape != (T, B, xd) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != dev:
             raise ValueError("out must be a contiguous fp32 [T,B,xd] tensor on the inputs' device")
         a.x_out = out.data_ptr()
@@ -329,8 +347,8 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
                 raise _lib.UnsupportedShapeError("ode_integrate(save=True): the MFMA integrator K1 does not take this shape")
             S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
             L = len(de_layers) - 1       # hidden layers: 3 for the no_encode MLPs (K1), 1 for the latent ones at hidden 64 (K3c)
-            saved = (torch.empty((max(T - 1, 0), S, L, B, Hp), dtype=torch.float32, device=dev),
-                     torch.empty((max(T - 1, 0), S, B, xd), dtype=torch.float32, device=dev))
+            saved = (_empty((max(T - 1, 0), S, L, B, Hp), dtype=torch.float32, device=dev),
+                     _empty((max(T - 1, 0), S, B, xd), dtype=torch.float32, device=dev))
             if T >= 2:
                 a.save_act, a.save_xstage = saved[0].data_ptr(), saved[1].data_ptr()
         ws = _workspace(lib, a.de, None, dev)
@@ -410,8 +428,8 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
             a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
             a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
         if out is None:
-            xs = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
-            is_ = torch.empty((T, B, idim), dtype=torch.float32, device=dev)
+            xs = _empty((T, B, xd), dtype=torch.float32, device=dev)
+            is_ = _empty((T, B, idim), dtype=torch.float32, device=dev)
         else:
             xs, is_ = out
             if xs.shape != (T, B, xd) or is_.shape != (T, B, idim) or not (xs.is_contiguous() and is_.is_contiguous()):
@@ -426,13 +444,13 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
             f32 = dict(dtype=torch.float32, device=dev)
             n_ev = (z_jump if z_jump is not None else v_jump).shape[1] if event_idx is not None else 0
             L = len(de_layers) - 1       # hidden layers: 3 (K2), 1 for the latent shapes at hidden 64 (K3c; i0 rows are then i_dim wide)
-            saved = (torch.empty((max(T - 1, 0), S, L, B, Hp), **f32), torch.empty((max(T - 1, 0), S, B, xd), **f32),
-                     torch.empty((L, T, B, Hp), **f32),
+            saved = (_empty((max(T - 1, 0), S, L, B, Hp), **f32), _empty((max(T - 1, 0), S, B, xd), **f32),
+                     _empty((L, T, B, Hp), **f32),
                      torch.zeros((n_ev, L, B, Hp), **f32) if n_ev else None,
                      torch.zeros((n_ev, B, 16 if L == 3 else idim), **f32) if n_ev else None)
             a.save_act, a.save_xstage, a.save_ae_act = saved[0].data_ptr(), saved[1].data_ptr(), saved[2].data_ptr()
             if T < 2:       # no step: nothing but the head at grid point 0 is written; the struct wants all three or none
-                dummy = torch.empty(16, **f32)
+                dummy = _empty(16, **f32)
                 keep.append(dummy)
                 a.save_act = a.save_xstage = dummy.data_ptr()
             if n_ev:
@@ -547,17 +565,17 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
         Fz = _pad_rows(W1[:, 2 * n + xd:3 * n] + W1[:, n + xd:2 * n], H) if zd > 0 else None   # (Ws + Wd)[:, z columns]
         with torch.cuda.device(dev):
             nbytes = lib.psnode_ode_backward_wide_workspace_bytes(ctypes.byref(a))
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
             wp, wn = _aligned_ptr(ws)
             st = torch.cuda.current_stream(dev).cuda_stream
             zt = z.detach() if zd > 0 else None
             for k1 in range(T - 1, 0, -chunk_steps):
                 k0 = max(0, k1 - chunk_steps)
                 Tc = k1 - k0
-                rows = [torch.empty((Tc, S, B, H), dtype=torch.float32, device=dev) for _ in range(6)]
-                gk = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
-                Xs = torch.empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
-                dsum = [torch.empty((Tc, B, H), dtype=torch.float32, device=dev) for _ in range(3)]
+                rows = [_empty((Tc, S, B, H), dtype=torch.float32, device=dev) for _ in range(6)]
+                gk = _empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
+                Xs = _empty((Tc, S, B, xd), dtype=torch.float32, device=dev)
+                dsum = [_empty((Tc, B, H), dtype=torch.float32, device=dev) for _ in range(3)]
                 a.k0, a.k1 = k0, k1
                 for q in range(3):
                     a.act[q], a.delta[q], a.dsum[q] = rows[q].data_ptr(), rows[3 + q].data_ptr(), dsum[q].data_ptr()
@@ -687,9 +705,19 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
     Sa1 = torch.zeros((B, H), **f32)                            # sum over the heads of the AE's delta_1
     carry_x, carry_i = torch.zeros((B, xd), **f32), torch.zeros((B, 16), **f32)
     a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
+    if saved is not None and not fuse_de:
+        raise ValueError("saved activations are read by the fused-DE form only")
+    if fuse_de and saved is None:
+        # one launch over the whole grid stores the AE head's rows of EVERY grid point (6 x [T,B,H] + [T,B,16] + the u rows of K7h): a very
+        # long grid on a full card goes through the time-chunked split form instead (bounded at ~3 GB of rows per chunk).  Decided HERE,
+        # before the fused-only fields of the argument struct are filled: psnode_dae_backward_wide_f32 picks K7f on grad_params_de != NULL
+        # (round 3 cleared the flag after filling them -- every chunk but the first then failed with PSNODE_ERR_DIMS)
+        free, _ = torch.cuda.mem_get_info(dev)
+        if (6 * H + 40) * 4 * T * B > free // 2:
+            fuse_de = False
     if fuse_de:
-        gp_de = torch.empty(sum(w.numel() + w.shape[0] for w in (W1, W2, W3, W4)), **f32)
-        ga0_de = torch.empty((B, n), **f32)
+        gp_de = _empty(sum(w.numel() + w.shape[0] for w in (W1, W2, W3, W4)), **f32)
+        ga0_de = _empty((B, n), **f32)
         a.grad_params_de, a.grad_all_initial_de = gp_de.data_ptr(), ga0_de.data_ptr()
         a.grad_zv = gzv.data_ptr()
         a.grad_jump = gjump.data_ptr() if gjump is not None else None
@@ -732,13 +760,13 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         h.gi, h.u = gi_slots.data_ptr(), u.data_ptr()
         A1c = A1.contiguous()
         h.aw1, h.aw1_cols, h.zv_col0 = A1c.data_ptr(), A1c.shape[1], n + xd
-        gza = torch.empty((R, B, 8), **f32) if nzv > 0 else None
-        sa1 = torch.empty((B, H), **f32)
-        out = torch.empty(lib.psnode_dae_head_grads_out_floats(Hr), **f32)
+        gza = _empty((R, B, 8), **f32) if nzv > 0 else None
+        sa1 = _empty((B, H), **f32)
+        out = _empty(lib.psnode_dae_head_grads_out_floats(Hr), **f32)
         h.grad_zv = gza.data_ptr() if gza is not None else None
         h.sa1, h.out = sa1.data_ptr(), out.data_ptr()
         nb = lib.psnode_dae_head_grads_workspace_bytes(ctypes.byref(h))
-        hws = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+        hws = _empty(nb + 256, dtype=torch.uint8, device=dev)
         hp_, hn_ = _aligned_ptr(hws)
         _lib.check(lib.psnode_dae_head_grads_f32(ctypes.byref(h), hp_, hn_, torch.cuda.current_stream(dev).cuda_stream),
                    "psnode_dae_head_grads_f32")
@@ -757,21 +785,10 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         Sa1 += sa1
         return gza[..., :nzv] if gza is not None else None
 
-    if saved is not None and not fuse_de:
-        raise ValueError("saved activations are read by the fused-DE form only")
-    if fuse_de and saved is None:
-        # one launch over the whole grid stores the AE head's rows of EVERY grid point (6 x [T,B,H] + [T,B,16] + the u rows of K7h): a very
-        # long grid on a full card goes through the time-chunked split form instead (bounded at ~3 GB of rows per chunk)
-        free, _ = torch.cuda.mem_get_info(dev)
-        if (6 * H + 40) * 4 * T * B > free // 2:
-            fuse_de = False
-    if gi_c is None:
-        # grad_is = NULL: the recompute instances of one register class (z+v+i = 4: NZM = 2, NZA = 1) at hidden 64 / RK4 -- K7w and K7f alike
-        # -- returned wrong AE gradients (found by profiles/scripts/fuzz_backward.py at the end of round 3; an explicit zero tensor is
-        # right on every instance, the cause is not visible in the source): these kernels always get the explicit tensor
-        gi_c = torch.zeros_like(is_c)
-        keep.append(gi_c)
-        a.grad_is = gi_c.data_ptr()
+    # (grad_is = None goes to the kernels as NULL: they read the rows of `is` instead and mask them out, branch-free.  Round 3 passed an
+    #  explicit zero tensor here because NULL gave wrong AE gradients on one register class; round 4 found the cause -- a uniform
+    #  `if (grad_is)` branch scheduled between an MFMA and the consumer of its result, psnode_dae_backward_wide.hip:add_gis -- and removed
+    #  the branch, so the C ABI's documented NULL is safe for every caller)
     if fuse_de:
         if saved is not None:
             s_act, s_xst, s_ae, s_ev, s_evi = saved
@@ -783,17 +800,17 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
                 for q in range(3):
                     ev_rows[q] = s_ev[:, q]
-            arows = [s_ae[0], s_ae[1], s_ae[2]] + [torch.empty((T, B, H), **f32) for _ in range(3)]
+            arows = [s_ae[0], s_ae[1], s_ae[2]] + [_empty((T, B, H), **f32) for _ in range(3)]
         else:
-            arows = [torch.empty((T, B, H), **f32) for _ in range(6)]
-        agi = torch.empty((T, B, 16), **f32)
+            arows = [_empty((T, B, H), **f32) for _ in range(6)]
+        agi = _empty((T, B, 16), **f32)
         a.k0, a.k1 = 0, T - 1
         for q in range(3):
             a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
         a.ae_gi = agi.data_ptr()
         with torch.cuda.device(dev):
             nbytes = lib.psnode_dae_backward_wide_workspace_bytes(ctypes.byref(a))
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
             wp, wn = _aligned_ptr(ws)
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
@@ -825,18 +842,18 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         chunk_steps = max(1, min(T - 1, int(3e9 // ((6 * S + 6) * 4 * B * H))))
     with torch.cuda.device(dev):
         nbytes = lib.psnode_dae_backward_wide_workspace_bytes(ctypes.byref(a))
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)
         st = torch.cuda.current_stream(dev).cuda_stream
         for k1 in range(T - 1, 0, -chunk_steps):
             k0 = max(0, k1 - chunk_steps)
             Tc = k1 - k0
-            rows = [torch.empty((Tc, S, B, H), **f32) for _ in range(6)]
-            arows = [torch.empty((Tc + 1, B, H), **f32) for _ in range(6)]
-            agi = torch.empty((Tc + 1, B, 16), **f32)
-            gk = torch.empty((Tc, S, B, xd), **f32)
-            Xs = torch.empty((Tc, S, B, xd), **f32)
-            dsum = [torch.empty((Tc, B, H), **f32) for _ in range(3)]
+            rows = [_empty((Tc, S, B, H), **f32) for _ in range(6)]
+            arows = [_empty((Tc + 1, B, H), **f32) for _ in range(6)]
+            agi = _empty((Tc + 1, B, 16), **f32)
+            gk = _empty((Tc, S, B, xd), **f32)
+            Xs = _empty((Tc, S, B, xd), **f32)
+            dsum = [_empty((Tc, B, H), **f32) for _ in range(3)]
             a.k0, a.k1 = k0, k1
             for q in range(3):
                 a.act[q], a.delta[q], a.dsum[q] = rows[q].data_ptr(), rows[3 + q].data_ptr(), dsum[q].data_ptr()
@@ -949,14 +966,14 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
             g["v_jump"] = torch.zeros((B, n_ev, vd), dtype=torch.float32, device=dev)
             a.grad_v_jump = g["v_jump"].data_ptr()
     with torch.cuda.device(dev):
-        g["x_init"] = torch.empty((B, xd), dtype=torch.float32, device=dev)
-        g["all_initial"] = torch.empty((B, xd + zd + vd + idim), dtype=torch.float32, device=dev)
-        g["z"] = torch.empty((T, B, zd), dtype=torch.float32, device=dev) if zd > 0 else None
-        g["v"] = torch.empty((T, B, vd), dtype=torch.float32, device=dev) if vd > 0 else None
+        g["x_init"] = _empty((B, xd), dtype=torch.float32, device=dev)
+        g["all_initial"] = _empty((B, xd + zd + vd + idim), dtype=torch.float32, device=dev)
+        g["z"] = _empty((T, B, zd), dtype=torch.float32, device=dev) if zd > 0 else None
+        g["v"] = _empty((T, B, vd), dtype=torch.float32, device=dev) if vd > 0 else None
         npd = sum(w.numel() + b.numel() for w, b in de_layers)
         npa = sum(w.numel() + b.numel() for w, b in ae_layers)
-        gde = torch.empty(npd, dtype=torch.float32, device=dev)
-        gae = torch.empty(npa, dtype=torch.float32, device=dev)
+        gde = _empty(npd, dtype=torch.float32, device=dev)
+        gae = _empty(npa, dtype=torch.float32, device=dev)
         a.grad_x_init, a.grad_all_initial = g["x_init"].data_ptr(), g["all_initial"].data_ptr()
         a.grad_z = g["z"].data_ptr() if g["z"] is not None else None
         a.grad_v = g["v"].data_ptr() if g["v"] is not None else None
@@ -968,7 +985,7 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
             if event_idx is not None:
                 a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
         nbytes = lib.psnode_dae_backward_workspace_bytes(ctypes.byref(a))
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_dae_backward_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_dae_backward_f32")
@@ -1011,18 +1028,18 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
             gzj = torch.zeros((B, z_jump.shape[1], zd), dtype=torch.float32, device=dev)
             a.grad_z_jump = gzj.data_ptr()
     with torch.cuda.device(dev):
-        gx0 = torch.empty((B, xd), dtype=torch.float32, device=dev)
-        ga0 = torch.empty((B, xd + zd), dtype=torch.float32, device=dev)
-        gz = torch.empty((T, B, zd), dtype=torch.float32, device=dev) if (need_grad_z and zd > 0) else None
+        gx0 = _empty((B, xd), dtype=torch.float32, device=dev)
+        ga0 = _empty((B, xd + zd), dtype=torch.float32, device=dev)
+        gz = _empty((T, B, zd), dtype=torch.float32, device=dev) if (need_grad_z and zd > 0) else None
         npar = lib.psnode_ode_backward_param_count(ctypes.byref(a))
-        gpar = torch.empty(npar, dtype=torch.float32, device=dev)
+        gpar = _empty(npar, dtype=torch.float32, device=dev)
         a.grad_x0, a.grad_all_initial, a.grad_params = gx0.data_ptr(), ga0.data_ptr(), gpar.data_ptr()
         a.grad_z = gz.data_ptr() if gz is not None else None
         if saved is not None and T >= 2:
             keep += [saved[0], saved[1]]
             a.saved_act, a.saved_xstage = saved[0].data_ptr(), saved[1].data_ptr()
         nbytes = lib.psnode_ode_backward_workspace_bytes(ctypes.byref(a))
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_ode_backward_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_ode_backward_f32")
@@ -1044,7 +1061,7 @@ def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
-    out = torch.empty((*x.shape[:-1], layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
+    out = _empty((*x.shape[:-1], layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.psnode_mlp_rows_f32(ctypes.byref(m), x2.shape[0], x2.data_ptr(), x2.stride(0), out.data_ptr(), out.shape[-1],
                                      torch.cuda.current_stream(dev).cuda_stream)
@@ -1102,14 +1119,14 @@ def ode_encoded_integrate(method: str, x_encoder: Layers, z_encoder: Layers, x_d
         keep.append(event_idx)
         a.event_idx = event_idx.data_ptr()
         a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
-    x_pred = torch.empty((T, B, xd), dtype=torch.float32, device=dev)
+    x_pred = _empty((T, B, xd), dtype=torch.float32, device=dev)
     a.x_pred = x_pred.data_ptr()
     x_re = xh = None
     if want_recon:
-        x_re = torch.empty((B, T, xd), dtype=torch.float32, device=dev)
+        x_re = _empty((B, T, xd), dtype=torch.float32, device=dev)
         a.x_re, a.xre_stride_t, a.xre_stride_b = x_re.data_ptr(), xd, T * xd
     if want_latent:
-        xh = torch.empty((T, B, 16), dtype=torch.float32, device=dev)
+        xh = _empty((T, B, 16), dtype=torch.float32, device=dev)
         a.xh_out = xh.data_ptr()
     with torch.cuda.device(dev):
         rc = lib.psnode_ode_encoded_integrate_f32(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
@@ -1135,11 +1152,11 @@ def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor,
         raise ValueError(f"mlp_rows_backward: grad_out {tuple(grad_out.shape)} does not match input {tuple(inp.shape)}")
     rows = x2.shape[0]
     with torch.cuda.device(dev):
-        gin = torch.empty((*inp.shape[:-1], inp.shape[-1]), dtype=torch.float32, device=dev) if need_grad_in else None
+        gin = _empty((*inp.shape[:-1], inp.shape[-1]), dtype=torch.float32, device=dev) if need_grad_in else None
         npar = sum(w.numel() + b.numel() for w, b in layers)
-        gp = torch.empty(npar, dtype=torch.float32, device=dev)
+        gp = _empty(npar, dtype=torch.float32, device=dev)
         nbytes = lib.psnode_mlp_rows_backward_workspace_bytes(ctypes.byref(m), rows)
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_mlp_rows_backward_f32(ctypes.byref(m), rows, x2.data_ptr(), x2.stride(0), g2.data_ptr(), g2.stride(0),
                                               gin.data_ptr() if gin is not None else None, inp.shape[-1], gp.data_ptr(), wp, wn,

@@ -19,6 +19,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
+from .fused import _empty
 
 
 def _view_bt(t: torch.Tensor, dev, name: str, keep: list) -> _lib.ViewF32:
@@ -76,12 +77,12 @@ def masked_mse_terms(pred, target, mask=None, col_weight=None, inv_norm: Optiona
         keep.append(inv_norm)
         a.inv_norm = inv_norm.data_ptr()
     a.scale, a.t0_coef = float(scale), float(t0_coef)
-    out = torch.empty(D + 2, dtype=torch.float32, device=dev)
-    grad = torch.empty((T, B, D), dtype=torch.float32, device=dev) if want_grad else None
+    out = _empty(D + 2, dtype=torch.float32, device=dev)
+    grad = _empty((T, B, D), dtype=torch.float32, device=dev) if want_grad else None
     a.out = out.data_ptr()
     a.grad_pred = grad.data_ptr() if want_grad else None
     nbytes = lib.psnode_masked_mse_workspace_bytes(ctypes.byref(a))
-    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
     p = (ws.data_ptr() + 255) // 256 * 256
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream

@@ -56,7 +56,17 @@ def test_default_bench_line_carries_the_extra_workloads():
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     names = [e["workload"].split(":")[0] for e in d["extra"]]
-    assert names == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"]
+    train = ["ode01 rk4 TRAIN", "dae01 rk4 TRAIN", "ode01 euler TRAIN", "dae01 euler TRAIN", "ode01 rk4 TRAIN", "dae01 rk4 TRAIN"]
+    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train
     for e in d["extra"]:
         assert e["outputs_finite"] and 0.05 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_median"] > 0
+    # round 4: the training steps (row f1) ride on the driver's clock too -- hidden 64 (RK4, Euler) and the scripts' --hidden 128
+    tr = d["extra"][4:]
+    assert [("H64" in e["workload"], "H128" in e["workload"]) for e in tr] == [(True, False)] * 4 + [(False, True)] * 2
+    for e in tr:
+        fam = e["roofline"]["kernel_ms_by_family"]
+        assert e["grads_finite"] and fam["forward"] > 0 and fam["backward"] > fam["forward"] and e["host_enqueue_ms"] > 0
+        assert e["roofline"]["flop_convention"].startswith("3 x forward")
+    assert tr[0]["saved_bytes"] > 0 and tr[3]["saved_bytes"] == 0          # RK4 reads saved activations, DAE_01 Euler at hidden 64 recomputes
+    assert [e["roofline"]["bound"] for e in d["extra"][:4]] == ["mfma", "valu_fp32", "mfma", "mfma"]      # K3f issues no MFMA
     assert d["roofline"]["kernel_ms_median"] > 0
