@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 4
+#define PSNODE_ABI_VERSION 5
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
 
@@ -229,6 +229,10 @@ typedef struct {
     float* grad_params;              /* flat, psnode_ode_backward_param_count() floats */
     const float* saved_act;          /* ABI 3, optional: what the forward call wrote to save_act / save_xstage (same method, T, B, MLP).  With them the */
     const float* saved_xstage;       /* one-launch backward K4f skips the recompute of the stage evaluations; both NULL = recompute */
+    uint32_t flags;                  /* ABI 5: PSNODE_FLAG_INPUT_TRUE_X = backward of a teacher-forced call (my_solvers.py:72-74: every step starts
+                                        from the dataset row x[k]): `xs` then holds the DATASET x [T,B,x_dim] contiguous (the forward result is not
+                                        needed), no adjoint is carried from step to step, grad_x0 = dL/dxs[0] + the start adjoint of step 0.
+                                        K4f only (hidden <= 128, x_dim <= 8, recompute form: saved_* must be NULL) */
 } psnode_ode_bwd_args_f32;
 
 int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* args);
@@ -389,6 +393,14 @@ typedef struct {
     const float* saved_ae_act;
     const float* saved_ev_act;
     const float* saved_ev_i;
+    /* ABI 5, fused-DE recompute form only (saved_* NULL): backward of a teacher-forced integrate_DAE (my_solvers.py:111-121).
+     * PSNODE_FLAG_INPUT_TRUE_X: the DE of step k starts from x_true[k] and the head at grid point j reads x_true[j] (dataset rows
+     * [T,B,x_dim] contiguous) -- no adjoint flows from step to step through x except through an event's recomputed i0, whose head reads
+     * the RUNNING state xs[k]; PSNODE_FLAG_INPUT_TRUE_I: the DE reads i_true[k] ([T,B,i_dim] contiguous) instead of the head's value --
+     * the DE's algebraic adjoint is dropped (the AE -> DE link is cut).  Gradients w.r.t. the dataset rows themselves are not formed. */
+    uint32_t flags;
+    const float* x_true;
+    const float* i_true;
 } psnode_dae_bwd_wide_args_f32;
 
 int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* args);   /* dims only */

@@ -15,10 +15,11 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 4          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 5          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
-                         #     psnode_dae_save_hidden)
+                         #     psnode_dae_save_hidden;
+                         #  5: flags (+ x_true / i_true) in psnode_ode_bwd_args_f32 / psnode_dae_bwd_wide_args_f32: teacher-forced backward)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -85,7 +86,7 @@ class OdeBwdArgsF32(ctypes.Structure):
                 ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("n_events", c_int32), ("xs", c_void_p), ("grad_xs", c_void_p),
                 ("grad_x0", c_void_p), ("grad_z", c_void_p), ("grad_z_jump", c_void_p), ("grad_all_initial", c_void_p),
-                ("grad_params", c_void_p), ("saved_act", c_void_p), ("saved_xstage", c_void_p)]
+                ("grad_params", c_void_p), ("saved_act", c_void_p), ("saved_xstage", c_void_p), ("flags", ctypes.c_uint32)]
 
 
 class DaeBwdArgsF32(ctypes.Structure):
@@ -129,7 +130,7 @@ class DaeBwdWideArgsF32(ctypes.Structure):
                 ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p),
                 ("grad_params_de", c_void_p), ("grad_zv", c_void_p), ("grad_jump", c_void_p), ("grad_all_initial_de", c_void_p),
                 ("saved_act", c_void_p), ("saved_xstage", c_void_p), ("saved_ae_act", c_void_p), ("saved_ev_act", c_void_p),
-                ("saved_ev_i", c_void_p)]
+                ("saved_ev_i", c_void_p), ("flags", ctypes.c_uint32), ("x_true", c_void_p), ("i_true", c_void_p)]
 
 
 class DaeHeadGradsArgsF32(ctypes.Structure):

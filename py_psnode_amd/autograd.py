@@ -65,6 +65,14 @@ class _FusedOde(torch.autograd.Function):
     @staticmethod
     def forward(ctx, method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params):
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
+        ctx.x_true = None
+        if x0.dim() == 3:        # teacher forcing (my_solvers.py:72-74): x0 is the whole dataset x [T,B,xd]; nothing is saved, K4f recomputes
+            ctx.x_true = x0.detach().contiguous()
+            xs = fused.ode_integrate(method, layers, t, ctx.x_true, z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
+                                     input_true_x=True)
+            ctx.method, ctx.has_jump, ctx.has_saved, ctx.event_idx = method, z_jump is not None, False, event_idx
+            ctx.save_for_backward(t, z, all_initial, xs, *((z_jump,) if z_jump is not None else ()), *params)
+            return xs
         save = _want_saved(method, kernel, layers, x0.shape[-1], z.shape[-1], t.shape[0], t.shape[1])
         res = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
                                   save=save)
@@ -91,6 +99,12 @@ class _FusedOde(torch.autograd.Function):
         params = saved[pos:]
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
         need_z = ctx.needs_input_grad[5]
+        if ctx.x_true is not None:   # teacher forcing: every step started from a dataset row -- K4f with the dataset as `xs`, no carried adjoint
+            gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, ctx.x_true, grad_xs, event_idx=ctx.event_idx,
+                                                         z_jump=z_jump, need_grad_z=need_z, kernel="wide", input_true_x=True)
+            if gz is None and need_z:
+                gz = torch.zeros_like(z)
+            return (None, None, None, None, None, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)   # (no gradient for the dataset x)
         gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, xs, grad_xs, event_idx=ctx.event_idx, z_jump=z_jump,
                                                      need_grad_z=need_z, saved=acts)
         if gz is None and need_z:
@@ -98,14 +112,16 @@ class _FusedOde(torch.autograd.Function):
         return (None, None, None, None, gx0, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)
 
 
-def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None, check_events=False):
-    """Differentiable fused integrate_ODE (no teacher forcing): gradients flow to x[0], z, all_initial, z_jump and the MLP."""
+def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None, check_events=False, input_true_x=False):
+    """Differentiable fused integrate_ODE: gradients flow to x[0], z, all_initial, z_jump and the MLP.  input_true_x (teacher forcing,
+    my_solvers.py:72-74): every step starts from the dataset row x[k]; gradients flow to z, all_initial, z_jump and the MLP (the dataset
+    x gets none: callers whose x requires grad take the callback walk)."""
     with torch.no_grad():
         event_idx = fused.event_table(t, event_t, check_events)
     if event_idx is None:
         z_jump = None
     params = [p for wb in layers for p in wb]
-    return _FusedOde.apply(method, kernel, event_idx, t, x[0], z, all_initial, z_jump, *params)
+    return _FusedOde.apply(method, kernel, event_idx, t, x.detach() if input_true_x else x[0], z, all_initial, z_jump, *params)
 
 
 class _FusedDae(torch.autograd.Function):
@@ -153,10 +169,47 @@ class _FusedDae(torch.autograd.Function):
                 g["z_jump"] if ctx.needs_input_grad[10] else None, g["v_jump"] if ctx.needs_input_grad[11] else None, *g["de"], *g["ae"])
 
 
+class _FusedDaeTeacherForced(torch.autograd.Function):
+    """integrate_DAE with input_true_x and / or input_true_i (my_solvers.py:111-121): forward K2 with the flags (nothing saved), backward
+    K7f in its recompute form with the dataset rows (psnode_dae_bwd_wide_args_f32::x_true / i_true).  The dataset rows get no gradient."""
+
+    @staticmethod
+    def forward(ctx, method, kernel, event_idx, n_de, tx, ti, t, x_init, x, z, v, i, all_initial, z_jump, v_jump, *params):
+        de = [(params[k], params[k + 1]) for k in range(0, 2 * n_de, 2)]
+        ae = [(params[k], params[k + 1]) for k in range(2 * n_de, len(params), 2)]
+        xs, is_ = fused.dae_integrate(method, de, ae, x_init, t, x, z, v, i, all_initial, z_jump=z_jump, v_jump=v_jump, event_idx=event_idx,
+                                      kernel=kernel, input_true_x=tx, input_true_i=ti)[:2]
+        ctx.method, ctx.n_de, ctx.event_idx, ctx.tx, ctx.ti = method, n_de, event_idx, tx, ti
+        ctx.has_zj, ctx.has_vj = z_jump is not None, v_jump is not None
+        ctx.save_for_backward(t, z, v, all_initial, xs, is_, x, i, *((z_jump,) if z_jump is not None else ()),
+                              *((v_jump,) if v_jump is not None else ()), *params)
+        return xs, is_
+
+    @staticmethod
+    def backward(ctx, grad_xs, grad_is):
+        sv = list(ctx.saved_tensors)
+        t, z, v, a0, xs, is_, x, i = sv[:8]
+        k = 8
+        z_jump = sv[k] if ctx.has_zj else None
+        k += int(ctx.has_zj)
+        v_jump = sv[k] if ctx.has_vj else None
+        k += int(ctx.has_vj)
+        params = sv[k:]
+        de = [(params[q], params[q + 1]) for q in range(0, 2 * ctx.n_de, 2)]
+        ae = [(params[q], params[q + 1]) for q in range(2 * ctx.n_de, len(params), 2)]
+        g = fused.dae_backward_wide(ctx.method, de, ae, t, z, v, a0, xs, is_, grad_xs, grad_is, event_idx=ctx.event_idx, z_jump=z_jump,
+                                    v_jump=v_jump, x_true=x if ctx.tx else None, i_true=i if ctx.ti else None)
+        gz = g["z"] if g["z"] is not None else (torch.zeros_like(z) if ctx.needs_input_grad[9] else None)
+        gv = g["v"] if g["v"] is not None else (torch.zeros_like(v) if ctx.needs_input_grad[10] else None)
+        return (None, None, None, None, None, None, None, g["x_init"], None, gz, gv, None, g["all_initial"],
+                g["z_jump"] if ctx.needs_input_grad[13] else None, g["v_jump"] if ctx.needs_input_grad[14] else None, *g["de"], *g["ae"])
+
+
 def fused_dae_integrate(method, kernel, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None,
-                        check_events=False):
-    """Differentiable fused integrate_DAE (no teacher forcing): gradients flow to x_init, z, v, all_initial, the jump inputs and
-    both MLPs.  `i` only provides the width of the algebraic variable (the dataset values are unused without teacher forcing)."""
+                        check_events=False, x=None, input_true_x=False, input_true_i=False):
+    """Differentiable fused integrate_DAE: gradients flow to x_init, z, v, all_initial, the jump inputs and both MLPs.  Without teacher
+    forcing `i` only provides the width of the algebraic variable.  input_true_x / input_true_i: `x` / `i` are the dataset rows the DE
+    and the heads are fed (my_solvers.py:111-121); they get no gradient."""
     with torch.no_grad():
         event_idx = fused.event_table(t, event_t, check_events)
     if event_idx is None:
@@ -165,4 +218,8 @@ def fused_dae_integrate(method, kernel, de_layers, ae_layers, x_init, t, z, v, i
         z_jump = z_jump if (z_jump is not None and z_jump.shape[-1] > 0) else None
         v_jump = v_jump if (v_jump is not None and v_jump.shape[-1] > 0) else None
     params = [p for wb in list(de_layers) + list(ae_layers) for p in wb]
+    if input_true_x or input_true_i:
+        xd_ = x.detach() if input_true_x else x_init.new_zeros((1, t.shape[1], 0))
+        return _FusedDaeTeacherForced.apply(method, kernel, event_idx, len(de_layers), bool(input_true_x), bool(input_true_i), t, x_init, xd_,
+                                            z, v, i.detach(), all_initial, z_jump, v_jump, *params)
     return _FusedDae.apply(method, kernel, event_idx, len(de_layers), t, x_init, z, v, i.detach(), all_initial, z_jump, v_jump, *params)

@@ -594,6 +594,11 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     if ((a->saved_act != nullptr) != (a->saved_xstage != nullptr)) return PSNODE_ERR_NULL;
     if (a->saved_act && !use_fused_bwd(a) && !use_latent64_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4f and K9 read them
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a->flags & ~PSNODE_FLAG_INPUT_TRUE_X) return PSNODE_ERR_UNSUPPORTED;
+    if (a->flags & PSNODE_FLAG_INPUT_TRUE_X) {      // teacher-forced backward: K4f (recompute form) is the kernel that has it
+        if (a->kernel == PSNODE_KERNEL_GENERIC || a->saved_act || !fused_bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;
+        return fused_bwd_launch(a, static_cast<float*>(workspace), s);
+    }
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_fused_bwd(a)) return fused_bwd_launch(a, static_cast<float*>(workspace), s);

@@ -36,6 +36,7 @@ __device__ __forceinline__ f4 fm4(float a, float b, f4 c) { return __builtin_amd
 
 struct FusedDev {
     int method, xd, zd, hreal, n_events, NP;
+    int true_x;                           // teacher-forced call: `xs` = the dataset rows, no adjoint carried from step to step (my_solvers.py:72-74)
     long long T, B;
     const float *w1, *w4;                 // raw nn.Linear tensors for the small transposed operands
     ViewDev t, z;
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
         float gks[S][NX], gx0[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-            const float g1 = gcar[r] + (valid ? gin[r] : 0.0f);
+            const float g1 = (a.true_x ? 0.0f : gcar[r]) + (valid ? gin[r] : 0.0f);      // (teacher forcing: x[k+1] is an output only)
             gx0[r] = g1;
 #pragma unroll
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
@@ -847,6 +848,8 @@ int fused_bwd_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStre
     a.xs = p->xs; a.gout = p->grad_xs; a.gx0 = p->grad_x0; a.gz = p->grad_z; a.gzj = p->grad_z_jump; a.ga0 = p->grad_all_initial;
     a.wpart = wpart; a.ring = ring;
     a.sact = p->saved_act; a.sxst = p->saved_xstage;
+    a.true_x = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0;
+    if (a.true_x && a.sact) return PSNODE_ERR_UNSUPPORTED;     // a teacher-forced forward saves nothing: recompute form only
     hipError_t e;
     switch (nw) {
         case 2: e = launch_fused_method<2>(a, NZM, pde, pt, pf, NA, s); break;

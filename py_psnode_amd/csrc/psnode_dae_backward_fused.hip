@@ -34,6 +34,8 @@ struct FusedDaeDev {
     const float *zj, *vj;
     long long zjb, zje, vjb, vje;
     const float *xs, *is, *gxs, *gis;
+    const float *xtrue, *itrue;           // teacher forcing (recompute form only; my_solvers.py:111-121): dataset rows [T,B,xd] / [T,B,id]
+    int tx, ti;                           //   tx: DE starts and grid heads read xtrue, no x adjoint from step to step; ti: DE reads itrue, AE -> DE link cut
     float* carry_x;                       // [B, xd]: adjoint of x at grid point 0 (without dL/dxs[0])
     float *gzv, *gjump, *ga0;             // [T, B, nzv] (DE part), [B, n_events, nzv] (DE part), [B, n] (DE part)
     float* wpart;                         // [workgroups][NP]
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             f4 a1, a2, a3;
             if constexpr (REC) {
                 float x1[NX];
-                load_x2(a.xs, k + 1, x1);
+                load_x2(a.tx ? a.xtrue : a.xs, k + 1, x1);
                 ae_hidden(x1, k + 1, -1, a1, a2, a3);
             } else if constexpr (HEAD_AHEAD) {
                 a1 = hn1; a2 = hn2; a3 = hn3;
@@ -597,16 +599,16 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             }
             add_gis(k + 1, gsl);
             const f2 gxa = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)(k + 1));
-            gcar[0] += gxa[0];
-            if constexpr (NX > 1) gcar[1] += gxa[1];
+            gcar[0] += (REC && a.tx) ? 0.0f : gxa[0];          // (teacher-forced x: the head read a dataset row)
+            if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : gxa[1];
         }
         // ---- (2) DE step k
         float x0[NX] = {}, gin[NX], ext[NZM];
-        if constexpr (REC) load_x2(a.xs, k, x0);
+        if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, k, x0);
         load_x2(a.gxs, k + 1, gin);
         {
             const RowZV zr = zv_rows(k, ev);
-            const gptr<const float> irow = sbase(a.is + k * a.B * idim);
+            const gptr<const float> irow = sbase(((REC && a.ti) ? a.itrue : a.is) + k * a.B * idim);
 #pragma unroll
             for (int m = 0; m < NZM; ++m) {
                 ext[m] = zv_val(zr, ekind[m], ecol[m]);
@@ -622,7 +624,11 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         } else
         if (ev >= 0) {   // event: i0 = g(x0; z_jump, v_jump) (my_solvers.py:108-110); its rows travel through the event buffers
             f4 e1, e2, e3;
-            ae_hidden(x0, k, ev, e1, e2, e3);
+            float xe[NX];      // the event's head reads the RUNNING state, teacher forcing or not (my_solvers.py:108-110)
+#pragma unroll
+            for (int r = 0; r < NX; ++r) xe[r] = x0[r];
+            if (a.tx) load_x2(a.xs, k, xe);
+            ae_hidden(xe, k, ev, e1, e2, e3);
             f4 sb4 = ab4;
             float sw4[4] = {aw4[0], aw4[1], aw4[2], aw4[3]};
             if constexpr (AEG) {        // event steps are rare: their output layer is read where it is used, not kept for the whole launch
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             }
             const f4 i0 = allreduce4(own4(sw4, e3), sb4);
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) if (ekind[m] == 2) ext[m] = i0[m];
+            for (int m = 0; m < NZM; ++m) if (ekind[m] == 2 && !a.ti) ext[m] = i0[m];      // (teacher-forced i: the DE keeps the dataset row)
             if (valid) {
                 const size_t rb = (size_t)ev * a.B * H;
                 stg<f4>(sbase(a.eact[0] + rb), offH, e1);
@@ -773,9 +779,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         S1 += D1;
         const f4 gE = allreduce4(own4(fE, D1), zero4);       // adjoint of this step's external inputs, slot layout
 #pragma unroll
-        for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];
+        for (int r = 0; r < NX; ++r) gcar[r] = (REC && a.tx) ? 0.0f : gx0[r];        // (the step started from a dataset row)
 #pragma unroll
-        for (int m = 0; m < NZM; ++m) gsl[m] = gE[m];
+        for (int m = 0; m < NZM; ++m) gsl[m] = (REC && a.ti) ? 0.0f : gE[m];           // (the DE read a dataset row of i)
         if (w == 0 && valid) {       // z | v columns: final layout (an event step's belong to the jump values)
 #pragma unroll
             for (int m = 0; m < NZM; ++m) {
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         f4 a1, a2, a3;
         if constexpr (REC) {
             float x1[NX];
-            load_x2(a.xs, 0, x1);
+            load_x2(a.tx ? a.xtrue : a.xs, 0, x1);
             ae_hidden(x1, 0, -1, a1, a2, a3);
         } else if constexpr (HEAD_AHEAD) {
             if (nT >= 2) { a1 = hn1; a2 = hn2; a3 = hn3; }
@@ -823,8 +829,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         }
         add_gis(0, gsl);
         const f2 gxa = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)0);
-        gcar[0] += gxa[0];
-        if constexpr (NX > 1) gcar[1] += gxa[1];
+        gcar[0] += (REC && a.tx) ? 0.0f : gxa[0];
+        if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : gxa[1];
     }
 
     // ---- epilogue
@@ -1015,6 +1021,10 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
     a.vj = p->v_jump; a.vjb = p->vj_stride_b; a.vje = p->vj_stride_e;
     a.xs = p->xs; a.is = p->is; a.gxs = p->grad_xs; a.gis = p->grad_is;
+    a.tx = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0; a.ti = (p->flags & PSNODE_FLAG_INPUT_TRUE_I) ? 1 : 0;
+    a.xtrue = p->x_true; a.itrue = p->i_true;
+    if ((a.tx || a.ti) && p->saved_act) return PSNODE_ERR_UNSUPPORTED;      // a teacher-forced forward saves nothing: recompute form only
+    if ((a.tx && !a.xtrue) || (a.ti && !a.itrue)) return PSNODE_ERR_NULL;
     a.carry_x = p->carry_x;
     a.gzv = p->grad_zv; a.gjump = p->grad_jump; a.ga0 = p->grad_all_initial_de;
     a.wpart = wpart; a.ring = ring;

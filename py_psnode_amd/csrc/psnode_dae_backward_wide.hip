@@ -676,6 +676,7 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
     if (p->T < 2 || p->B < 1 || p->k0 < 0 || p->k1 <= p->k0 || p->k1 > p->T - 1) return PSNODE_ERR_DIMS;
     for (int l = 0; l < 4; ++l) if (!p->de.weight[l] || !p->de.bias[l] || !p->ae.weight[l] || !p->ae.bias[l]) return PSNODE_ERR_NULL;
     const bool fused = p->grad_params_de != nullptr;
+    if ((p->flags & ~(PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I)) || (p->flags && !fused)) return PSNODE_ERR_UNSUPPORTED;   // teacher forcing: K7f only
     if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || !p->ae_gi) return PSNODE_ERR_NULL;
     if (fused) {
         if (p->k0 != 0 || p->k1 != p->T - 1) return PSNODE_ERR_DIMS;

@@ -616,6 +616,17 @@ def ode_backward_wide(method: str, de_layers: Layers, t, z, all_initial, xs, gra
     return gx0, gz, gzj, ga0, [gW[0], gb[0], gW[1], gb[1], gW[2], gb[2], gW[3], gb[3]]
 
 
+def _check_saved(act, xst, T, B, xd, S, L, dev):
+    """The saved stage activations / stage inputs reach the kernels as raw pointers: a tuple from another call (other T, B, method or
+    width) would be read out of bounds, so its shape is checked here ([T-1,S,L,B,Hp] / [T-1,S,B,xd], contiguous, on this device)."""
+    ok = (act.dim() == 5 and tuple(act.shape[:4]) == (T - 1, S, L, B) and tuple(xst.shape) == (T - 1, S, B, xd)
+          and act.is_contiguous() and xst.is_contiguous() and act.device == dev and xst.device == dev
+          and act.dtype == torch.float32 and xst.dtype == torch.float32)
+    if not ok:
+        raise ValueError(f"saved activations do not belong to this call: got {tuple(act.shape)} / {tuple(xst.shape)}, "
+                         f"expected [{T - 1},{S},{L},{B},Hp] / [{T - 1},{S},{B},{xd}] contiguous fp32 on {dev}")
+
+
 def _split_grads(flat, layers):
     out, off = [], 0
     for w, b in layers:
@@ -650,13 +661,15 @@ def dae_backward_wide_supported(method: str, de_layers: Layers, ae_layers: Layer
 
 
 def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all_initial, xs, is_, grad_xs, grad_is, event_idx=None,
-                      z_jump=None, v_jump=None, chunk_steps: Optional[int] = None, fuse_de: bool = True, saved=None):
+                      z_jump=None, v_jump=None, chunk_steps: Optional[int] = None, fuse_de: bool = True, saved=None, x_true=None, i_true=None):
     """Backward of `dae_integrate` for hidden widths <= 128 other than the one-launch kernel's (K7, hidden 64): the sequential adjoint
     sweep -- DE stages, AE head per grid point, event-time recompute -- on an MFMA kernel (psnode_dae_backward_wide_f32).
     fuse_de (default): ONE launch over the whole grid (K7f) that also forms the DE's parameter gradients and the DE's share of the
     input gradients; only the AE head's rows (one set per grid point) are contracted here.  fuse_de=False: round 2's split (K7w in time
     chunks, every contraction a library GEMM over stored rows).  saved = what `dae_integrate(save=True)` returned for the same call
-    (fuse_de only): the kernel evaluates nothing forwards.  Same return value as `dae_backward`."""
+    (fuse_de only): the kernel evaluates nothing forwards.  x_true / i_true [T,B,.]: backward of a teacher-forced call
+    (input_true_x / input_true_i, my_solvers.py:111-121) -- the dataset rows the forward call fed the DE / the heads; K7f recompute form
+    only.  Same return value as `dae_backward`."""
     lib = _lib.load()
     dev = xs.device
     T, B, xd = xs.shape
@@ -707,7 +720,19 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
     a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
     if saved is not None and not fuse_de:
         raise ValueError("saved activations are read by the fused-DE form only")
-    if fuse_de and saved is None:
+    xt_c = it_c = None
+    if x_true is not None or i_true is not None:
+        if saved is not None or not fuse_de:
+            raise ValueError("teacher forcing: the fused-DE recompute form only")
+        xt_c = _f32_dev(x_true, dev, "x_true").contiguous() if x_true is not None else None
+        it_c = _f32_dev(i_true, dev, "i_true").contiguous() if i_true is not None else None
+        if (xt_c is not None and tuple(xt_c.shape) != (T, B, xd)) or (it_c is not None and tuple(it_c.shape) != (T, B, idim)):
+            raise ValueError("x_true / i_true must be [T,B,x_dim] / [T,B,i_dim]")
+        keep += [xt_c, it_c]
+        a.flags = (_lib.FLAG_INPUT_TRUE_X if xt_c is not None else 0) | (_lib.FLAG_INPUT_TRUE_I if it_c is not None else 0)
+        a.x_true = xt_c.data_ptr() if xt_c is not None else None
+        a.i_true = it_c.data_ptr() if it_c is not None else None
+    if fuse_de and saved is None and x_true is None and i_true is None:
         # one launch over the whole grid stores the AE head's rows of EVERY grid point (6 x [T,B,H] + [T,B,16] + the u rows of K7h): a very
         # long grid on a full card goes through the time-chunked split form instead (bounded at ~3 GB of rows per chunk).  Decided HERE,
         # before the fused-only fields of the argument struct are filled: psnode_dae_backward_wide_f32 picks K7f on grad_params_de != NULL
@@ -815,7 +840,8 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
             # the AE head's rows -> its parameter gradients and its share of the input gradients (K7h)
-            gza = head_grads_hip(arows[:3], B * H, arows[3:], agi, xs_c, zv_all)
+            # (the heads at the grid points read the dataset rows under input_true_x; the event heads below always the running state)
+            gza = head_grads_hip(arows[:3], B * H, arows[3:], agi, xt_c if x_true is not None else xs_c, zv_all)
             if nzv > 0:
                 gzv += gza
             del arows, agi
@@ -980,9 +1006,16 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
         a.grad_params_de, a.grad_params_ae = gde.data_ptr(), gae.data_ptr()
         if saved is not None and T >= 2:        # (K9 reads them; the C side refuses them for the kernels that recompute)
             s_act, s_xst, s_ae, s_ev, s_evi = saved
+            L = len(de_layers) - 1
+            _check_saved(s_act, s_xst, T, B, xd, {"euler": 1, "midpoint": 2, "rk4": 4}[method], L, dev)
+            if tuple(s_ae.shape[:3]) != (L, T, B) or s_ae.shape[-1] != s_act.shape[-1] or not s_ae.is_contiguous() or s_ae.device != dev:
+                raise ValueError("saved AE activations do not belong to this call (shape / device)")
             keep += [s_act, s_xst, s_ae, s_ev, s_evi]
             a.saved_act, a.saved_xstage, a.saved_ae_act = s_act.data_ptr(), s_xst.data_ptr(), s_ae.data_ptr()
             if event_idx is not None:
+                n_ev_ = (z_jump if z_jump is not None else v_jump).shape[1]
+                if s_ev is None or s_evi is None or s_ev.shape[0] != n_ev_ or s_ev.shape[2] != B or s_evi.shape[:2] != (n_ev_, B):
+                    raise ValueError("saved event activations do not belong to this call (shape)")
                 a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
         nbytes = lib.psnode_dae_backward_workspace_bytes(ctypes.byref(a))
         ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
@@ -994,9 +1027,10 @@ def dae_backward(method: str, de_layers: Layers, ae_layers: Layers, t, z, v, all
 
 
 def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True,
-                 kernel: str = "auto", saved=None):
-    """Backward pass of `ode_integrate` (input_true_x=False) in one launch.  `saved` = what `ode_integrate(save=True)` returned next to
-    xs: K4f then skips the recompute of the stage evaluations.
+                 kernel: str = "auto", saved=None, input_true_x: bool = False):
+    """Backward pass of `ode_integrate` in one launch.  `saved` = what `ode_integrate(save=True)` returned next to
+    xs: K4f then skips the recompute of the stage evaluations.  input_true_x: backward of a teacher-forced call (my_solvers.py:72-74) --
+    `xs` must then be the DATASET x the forward call started every step from; K4f (hidden <= 128, x_dim <= 8) only.
     Returns (grad_x0 [B,xd], grad_z [T,B,zd] | None, grad_z_jump | None, grad_all_initial [B,n], [grad W1, b1, ..., W4, b4])."""
     lib = _lib.load()
     dev = xs.device
@@ -1010,6 +1044,10 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
                                  need_grad_z=need_grad_z)
     keep: list = []
     a = _bwd_args(method, de_layers, xd, zd, T, B, dev, keep, kernel)
+    if input_true_x:
+        if saved is not None:
+            raise ValueError("a teacher-forced forward saves no activations")
+        a.flags = _lib.FLAG_INPUT_TRUE_X
     z, z_jump = _aligned16(z), _aligned16(z_jump)
     a.t = _view(t, dev, "t", keep)
     a.z = _view(z, dev, "z", keep)
@@ -1036,6 +1074,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
         a.grad_x0, a.grad_all_initial, a.grad_params = gx0.data_ptr(), ga0.data_ptr(), gpar.data_ptr()
         a.grad_z = gz.data_ptr() if gz is not None else None
         if saved is not None and T >= 2:
+            _check_saved(saved[0], saved[1], T, B, xd, {"euler": 1, "midpoint": 2, "rk4": 4}[method], len(de_layers) - 1, dev)
             keep += [saved[0], saved[1]]
             a.saved_act, a.saved_xstage = saved[0].data_ptr(), saved[1].data_ptr()
         nbytes = lib.psnode_ode_backward_workspace_bytes(ctypes.byref(a))

@@ -103,6 +103,12 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     from ..autograd import fused_ode_integrate
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
                                                check_events=self._check_events_now(event_t))
+                # teacher-forced training (my_solvers.py:72-74): K4f in its recompute form; the dataset x gets no gradient
+                elif input_true_x and not x.requires_grad and self.kernel in ("auto", "mfma") and \
+                        _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1], "wide"):
+                    from ..autograd import fused_ode_integrate
+                    return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
+                                               check_events=self._check_events_now(event_t), input_true_x=True)
             if self.fused == "require":
                 raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style ELU-MLP "
                                       "`x_dot`, ODE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
@@ -144,9 +150,17 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     from ..autograd import fused_dae_integrate
                     return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump,
                                                check_events=self._check_events_now(event_t))
+                # teacher-forced training (my_solvers.py:111-121): K7f in its recompute form; the dataset rows get no gradient
+                elif (input_true_x or input_true_i) and not (input_true_x and x.requires_grad) and not (input_true_i and i.requires_grad) \
+                        and x.shape[-1] == x_init.shape[-1] and self.kernel in ("auto", "mfma") and t.shape[0] >= 2 and \
+                        _fused.dae_backward_wide_supported(self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]):
+                    from ..autograd import fused_dae_integrate
+                    return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump,
+                                               check_events=self._check_events_now(event_t), x=x, input_true_x=input_true_x,
+                                               input_true_i=input_true_i)
             if self.fused == "require":
                 raise NotFusableError("integrate_DAE: call is not fusable (needs fp32 HIP tensors, DE_Func/AE_Func-style "
-                                      "ELU-MLPs, DAE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
+                                      "ELU-MLPs, DAE_Event callbacks; with autograd: a shape with a backward kernel; teacher forcing: hidden <= 128, dataset rows without grad)")
             self._note_walk("integrate_DAE", z if z.numel() else v)
         return self._walk_dae(x_init, x_func, i_func, t, x, z, v, i, all_initial, event_fn, jump_change_fn,
                               input_true_x, input_true_i)

@@ -800,3 +800,63 @@ def test_full_size_backward_two_implementations_agree(kind):
         for grp in ("de", "ae"):
             for k, (p, q) in enumerate(zip(a[grp], b[grp])):
                 _close(p, q.double().cpu(), f"grad {grp} {k}")
+
+
+@pytest.mark.parametrize("events", [False, True])
+def test_dae_wide_low_memory_fallback_takes_the_split_route(monkeypatch, events):
+    """dae_backward_wide falls back from the one-launch K7f to the time-chunked split route when the AE head's rows of the whole grid
+    would not fit half of the free HBM.  Round 3 cleared the flag AFTER filling the fused-only fields of the argument struct (the C side
+    picks K7f on grad_params_de != NULL): every chunk but the first failed with PSNODE_ERR_DIMS, and a single chunk ran K7f while the host
+    contracted buffers K7f never writes.  Forced here through torch.cuda.mem_get_info; gradients equal K7f's."""
+    from py_psnode_amd import fused
+    de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(37, 9, 8, 2, 2, 2, 4242, events, H=128)
+    xe, ie = torch.zeros(9, 37, 0, device="cuda"), torch.zeros(9, 37, 2, device="cuda")
+    xs, is_ = fused.dae_integrate("rk4", de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj)
+    tab = fused.event_table(t, ev) if ev is not None else None
+    kw = dict(event_idx=tab, z_jump=zj, v_jump=vj)
+    ref = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, **kw)                   # K7f
+    calls = []
+    real = fused._lib.load().psnode_dae_backward_wide_f32
+
+    class Spy:                                                                                          # counts the kernel calls of the fallback
+        def __call__(self, *a_):
+            calls.append(1)
+            return real(*a_)
+    lib = fused._lib.load()
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a_, **k_: (1 << 16, 1 << 40))
+    monkeypatch.setattr(lib, "psnode_dae_backward_wide_f32", Spy(), raising=False)
+    try:
+        got = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, chunk_steps=3, **kw)
+    finally:
+        monkeypatch.undo()
+    assert len(calls) == 3, "8 steps in chunks of 3 on the split route"
+    for key in ("x_init", "all_initial", "z", "v", "z_jump", "v_jump"):
+        if ref[key] is not None:
+            _close(got[key], ref[key].double().cpu(), f"fallback {key}")
+    for grp in ("de", "ae"):
+        for k, (p, q) in enumerate(zip(got[grp], ref[grp])):
+            _close(p, q.double().cpu(), f"fallback grad {grp} {k}")
+
+
+def test_saved_activations_of_another_call_are_refused():
+    """The saved rows reach the kernels as raw pointers: a tuple from a call with another grid / batch / method must raise, not be read
+    out of bounds."""
+    from py_psnode_amd import fused
+    torch.manual_seed(5)
+    H, xd, zd, B = 64, 8, 2, 20
+    lin = [nn.Linear(a_, b_) for a_, b_ in zip([3 * (xd + zd), H, H, H], [H, H, H, xd])]
+    layers = [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin]
+    mk = lambda Tn: ((torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1).cuda(), (0.1 * torch.randn(Tn, B, xd)).cuda(),
+                     (0.1 * torch.randn(Tn, B, zd)).cuda())
+    t, x, z = mk(6)
+    a0 = torch.cat((x[0], z[0]), -1)
+    xs, saved = fused.ode_integrate("rk4", layers, t, x, z, a0, save=True)
+    t9, x9, z9 = mk(9)
+    xs9, saved9 = fused.ode_integrate("rk4", layers, t9, x9, z9, torch.cat((x9[0], z9[0]), -1), save=True)
+    G = torch.randn(6, B, xd).cuda()
+    fused.ode_backward("rk4", layers, t, z, a0, xs, G, saved=saved)                                     # the right tuple is fine
+    with pytest.raises(ValueError, match="saved activations do not belong"):
+        fused.ode_backward("rk4", layers, t, z, a0, xs, G, saved=saved9)                                # other grid
+    _, saved_e = fused.ode_integrate("euler", layers, t, x, z, a0, save=True)
+    with pytest.raises(ValueError, match="saved activations do not belong"):
+        fused.ode_backward("rk4", layers, t, z, a0, xs, G, saved=saved_e)                               # other method (S = 1 vs 4)
