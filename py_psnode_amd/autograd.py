@@ -46,10 +46,9 @@ def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
         S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
         free, _ = torch.cuda.mem_get_info(de[0][0].device)
         return ((T - 1) * S * 2 + T) * 64 * B * 4 <= free // 2
-    # hidden 64 has the one-launch kernel K7 (recompute): the saved form beats it at RK4 and Midpoint (training step at 4096 x 1000:
-    # 20.8 vs 23.0 ms, 14.3 vs 14.7), not at Euler (11.0 vs 10.65: profiles/r03z_h64.txt)
-    if de[0][0].shape[0] == 64 and not (method in ("rk4", "midpoint") or SAVE_ACTIVATIONS == "1"):
-        return False
+    # hidden 64 also has the one-launch kernel K7 (recompute).  The saved form beats it at every method since round 4 (K7f requests its
+    # per-step inputs a step ahead: training step at 4096 x 1000 RK4 19.7 vs 23.0 ms, Euler 9.6 vs 10.6 -- gpurun_out/r04g.log; round 3:
+    # Euler 11.0 vs 10.65, which kept K7 for Euler)
     Hp = fused.dae_save_hidden(method, de, ae, x_dim, z_dim, v_dim, i_dim, kernel)
     if Hp <= 0 or not fused.dae_backward_wide_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim):
         return False

@@ -409,10 +409,12 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             for (int m = 0; m < NZM; ++m) dst[m] = ldg<float>(row, zo + 4u * ecol[m]);     // padding slots read column 0 against a zero weight
         }
     };
+    auto x2on = [&](const int r) -> bool { return 4 * r + g < xd; };
     auto load_x2 = [&](const float* base, const long long k, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k * a.B * xd);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = ldg_sel(row, offXc[r], 4 * r + g < xd);      // branch-free (psnode_common.h: ldg_sel)
+        for (int r = 0; r < NX; ++r) dst[r] = ldg<float>(row, offXc[r]);      // RAW and branch-free (clamped column, psnode_common.h: ldg_sel):
+                                                                                // every caller is a request a step / stage ahead, x2on() masks at the consumer
     };
     // clock and event index of a step are RAW prefetched values (one grid point / one table entry per step, requested a step ahead);
     // the difference and the readfirstlane happen a step later, at the consumer.  Subtracting / broadcasting right behind the load --
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     for (long long k = nT - 2; k >= 0; --k) {
         float x0[NX], gin[NX], ext[NZ];
 #pragma unroll
-        for (int r = 0; r < NX; ++r) { x0[r] = x0n[r]; gin[r] = ginn[r]; }
+        for (int r = 0; r < NX; ++r) { x0[r] = x2on(r) ? x0n[r] : 0.0f; gin[r] = x2on(r) ? ginn[r] : 0.0f; }
 #pragma unroll
         for (int m = 0; m < NZ; ++m) ext[m] = extn[m];
         const float h_ = t_hi - t_lo;
@@ -558,12 +560,12 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
                 if constexpr (PSNODE_K4F_SAVED_AHEAD) {
                     a1 = sv1; a2 = sv2; a3 = sv3;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                    for (int r = 0; r < NX; ++r) X[s][r] = x2on(r) ? svx[r] : 0.0f;
                     if constexpr (PSNODE_K4F_SAVED_AHEAD == 1) load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
                 } else {
                     load_saved(idx, a1, a2, a3, svx);
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                    for (int r = 0; r < NX; ++r) X[s][r] = x2on(r) ? svx[r] : 0.0f;
                 }
             } else if constexpr (STREAM) {
 #ifndef PSNODE_K4F_RING_LATE

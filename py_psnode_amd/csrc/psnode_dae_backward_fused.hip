@@ -567,7 +567,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         q1 = ldg_nt<f4, (NWV >= 8)>(sbase(rb), offH);
         q2 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + act_layer), offH);
         q3 = ldg_nt<f4, (NWV >= 8)>(sbase(rb + 2 * act_layer), offH);
-        load_x2(a.sxst, idx, xq);
+        const gptr<const float> xrow = sbase(a.sxst + idx * a.B * xd);       // RAW (requested a stage ahead): masked where X[s] is formed
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xq[r] = ldg<float>(xrow, offXc[r]);
     };
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
     float svx[NX] = {};
@@ -583,45 +585,135 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx);
         if constexpr (HEAD_AHEAD) load_head(nT - 1, hn1, hn2, hn3);
     }
+#ifndef PSNODE_K7F_INPUTS_AHEAD
+#define PSNODE_K7F_INPUTS_AHEAD 1
+#endif
+    // Round 4, <= 4 waves: the per-step inputs -- event index, dL/dis and dL/dxs rows, the z | v | i rows, the clock, (recompute form) the
+    // state row -- are requested one step AHEAD, in the middle of the previous step, and stay raw until the step consumes them.  Rounds
+    // 2-3 loaded each of them where it was used: six `global_load ..; s_waitcnt vmcnt(0)` round trips per step, each of which also waited
+    // for the head's row stores issued just before (vmcnt counts stores) -- SQ_WAIT_ANY 48 % of the saved-activation Euler instance
+    // (profiles/r04_train_h64_sq_table.txt).  The z | v gradient store of a step is deferred to the next step (in front of the requests)
+    // so that the wait at the top of a step only sees loads.  (8 waves: the ~14 registers would be spills; unchanged there.)
+    constexpr bool AHEAD = NWV <= 4 && PSNODE_K7F_INPUTS_AHEAD;
+    const bool has_gis = a.gis != nullptr;
+    auto load_t = [&](const long long kk) -> float { return ldg<float>(sbase(a.t.p + kk * a.t.st), offT); };
+    // RAW inputs of step k: dL/dis row k+1 (row of `is` when grad_is is NULL: masked out at the consumer), dL/dxs row k+1, the z / v / i
+    // candidates of every ext slot of step k.  No select, mask or subtraction in here: an operation on a freshly loaded value is scheduled
+    // next to the load, with the wait for it (DESIGN.md "what the ISA said about waits"); finish_step() applies them a step later.
+    struct StepRaw { float gq[NZM], gin[NX], zr[NZM], vr[NZM], ir[NZM], xr[NX]; };
+    auto load_x2_raw = [&](const float* base, const long long k_, float (&dst)[NX]) {
+        const gptr<const float> row = sbase(base + k_ * a.B * xd);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) dst[r] = ldg<float>(row, offXc[r]);
+    };
+    auto fetch_step = [&](const long long k_, const int ev_, StepRaw& q) {
+        const gptr<const float> grow = sbase((has_gis ? a.gis : a.is) + (k_ + 1) * a.B * idim);
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) q.gq[m] = ldg<float>(grow, offI + 4u * (ekind[m] == 2 ? ecol[m] : 0));
+        load_x2_raw(a.gxs, k_ + 1, q.gin);
+        const RowZV zr = zv_rows(k_, ev_);
+        // (saved form, event step: i0 as the forward call computed it, slot layout [nE,B,16] -- the row POINTER and the lane offset are
+        //  selected, the load is one and unconditional: a branch around it would put a wait behind the join of every step)
+        const bool evs = !REC && ev_ >= 0;
+        const gptr<const float> irow = sbase(evs ? a.sevi + (size_t)(evs ? ev_ : 0) * a.B * 16 : ((REC && a.ti) ? a.itrue : a.is) + k_ * a.B * idim);
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) {
+            q.zr[m] = ldg<float>(zr.z, zr.zo + 4u * (ekind[m] == 0 ? ecol[m] : 0));
+            q.vr[m] = ldg<float>(zr.v, zr.vo + 4u * (ekind[m] == 1 ? ecol[m] : 0));
+            q.ir[m] = ldg<float>(irow, evs ? offS + 16u * m : offI + 4u * (ekind[m] == 2 ? ecol[m] : 0));
+        }
+        if constexpr (REC) load_x2_raw(a.tx ? a.xtrue : a.xs, k_, q.xr);
+    };
+    auto finish_step = [&](const StepRaw& q, float (&gq_)[NZM], float (&gin_)[NX], float (&ext_)[NZM], float (&x0_)[NX]) {
+#pragma unroll
+        for (int m = 0; m < NZM; ++m) {
+            gq_[m] = q.gq[m];
+            ext_[m] = ekind[m] == 0 ? q.zr[m] : (ekind[m] == 1 ? q.vr[m] : (ekind[m] == 2 ? q.ir[m] : 0.0f));
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { gin_[r] = (4 * r + g < xd) ? q.gin[r] : 0.0f; x0_[r] = (REC && 4 * r + g < xd) ? q.xr[r] : 0.0f; }
+    };
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;      // per-lane load: the entry stays in a VGPR until it is used
+    StepRaw nxt = {};                        // raw inputs of the step about to run (requested a step ago)
+    float x1_c[NX] = {};                     // recompute form: the state row of grid point k+1 (= the previous step's start row)
+    float t_hi = 0.0f, t_lo = 0.0f;
+    int ev_n = -1, ev_r = -1;
+    float gz_pend[NZM] = {};                 // z | v gradient of the previous step, stored at the next one
+    int ev_pend = -1;
+    long long k_pend = -1;
+    auto flush_gzv = [&]() {
+        if (k_pend >= 0 && w == 0 && valid) {
+#pragma unroll
+            for (int m = 0; m < NZM; ++m) {
+                const int q = 4 * m + g;
+                if (q < nzv) {
+                    if (ev_pend >= 0) a.gjump[(b * a.n_events + ev_pend) * nzv + q] = gz_pend[m];
+                    a.gzv[(k_pend * a.B + b) * nzv + q] = ev_pend >= 0 ? 0.0f : gz_pend[m];
+                }
+            }
+        }
+    };
+    if constexpr (AHEAD) {
+        if (nT >= 2) {
+            ev_n = has_ev ? __builtin_amdgcn_readfirstlane(a.ev[nT - 2]) : -1;
+            ev_r = evp[nT >= 3 ? nT - 3 : 0];
+            fetch_step(nT - 2, ev_n, nxt);
+            t_hi = load_t(nT - 1);
+            t_lo = load_t(nT - 2);
+            if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, nT - 1, x1_c);
+        }
+    }
     for (long long k = nT - 2; k >= 0; --k) {
-        const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
+        int ev;
+        float gq[NZM], gin[NX], ext[NZM], x0[NX] = {}, x1[NX] = {}, h_;
+        if constexpr (AHEAD) {
+            ev = ev_n;
+            finish_step(nxt, gq, gin, ext, x0);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) x1[r] = x1_c[r];
+            h_ = t_hi - t_lo;
+        } else {
+            ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
+            if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, k + 1, x1);
+            StepRaw now;
+            fetch_step(k, ev, now);
+            finish_step(now, gq, gin, ext, x0);
+            h_ = load_t(k + 1) - load_t(k);
+        }
         // ---- (1) AE head at grid point k+1 (my_solvers.py:121): adjoint = dL/dis[k+1] + the algebraic adjoint of step k+1's DE
         {
             f4 a1, a2, a3;
             if constexpr (REC) {
-                float x1[NX];
-                load_x2(a.tx ? a.xtrue : a.xs, k + 1, x1);
                 ae_hidden(x1, k + 1, -1, a1, a2, a3);
             } else if constexpr (HEAD_AHEAD) {
                 a1 = hn1; a2 = hn2; a3 = hn3;
             } else {
                 load_head(k + 1, a1, a2, a3);
             }
-            add_gis(k + 1, gsl);
+#pragma unroll
+            for (int m = 0; m < NZM; ++m) gsl[m] += (has_gis && valid && ekind[m] == 2 && 4 * m + g >= ne) ? gq[m] : 0.0f;      // (add_gis, on the raw row)
             const f2 gxa = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)(k + 1));
             gcar[0] += (REC && a.tx) ? 0.0f : gxa[0];          // (teacher-forced x: the head read a dataset row)
             if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : gxa[1];
         }
-        // ---- (2) DE step k
-        float x0[NX] = {}, gin[NX], ext[NZM];
-        if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, k, x0);
-        load_x2(a.gxs, k + 1, gin);
-        {
-            const RowZV zr = zv_rows(k, ev);
-            const gptr<const float> irow = sbase(((REC && a.ti) ? a.itrue : a.is) + k * a.B * idim);
+        if constexpr (AHEAD) {       // behind the head's row stores: last step's z | v gradient, then the requests for the next step
+            flush_gzv();
+            const long long kq = k > 0 ? k - 1 : 0;
+            ev_n = has_ev ? __builtin_amdgcn_readfirstlane(ev_r) : -1;      // requested a step ago
+            ev_r = evp[k >= 2 ? k - 2 : 0];
+            fetch_step(kq, ev_n, nxt);
+            t_hi = t_lo;
+            t_lo = load_t(kq);
+            if constexpr (REC) {
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) {
-                ext[m] = zv_val(zr, ekind[m], ecol[m]);
-                if (ekind[m] == 2) ext[m] = ldg<float>(irow, offI + 4u * ecol[m]);
+                for (int r = 0; r < NX; ++r) x1_c[r] = x0[r];       // this step's start row is the next head's grid point
             }
         }
-        if constexpr (!REC) {
-            if (ev >= 0) {   // event: i0 as the forward call computed it
-                const gptr<const float> er = sbase(a.sevi + (size_t)ev * a.B * 16);
-#pragma unroll
-                for (int m = 0; m < NZM; ++m) if (ekind[m] == 2) ext[m] = ldg<float>(er, offS + 16u * m);
-            }
-        } else
+        // ---- (2) DE step k
+        if constexpr (REC)
         if (ev >= 0) {   // event: i0 = g(x0; z_jump, v_jump) (my_solvers.py:108-110); its rows travel through the event buffers
             f4 e1, e2, e3;
             float xe[NX];      // the event's head reads the RUNNING state, teacher forcing or not (my_solvers.py:108-110)
@@ -653,7 +745,6 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 }
             }
         }
-        const float h_ = ldg<float>(sbase(a.t.p + (k + 1) * a.t.st), offT) - ldg<float>(sbase(a.t.p + k * a.t.st), offT);
         f4 cz = c0;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) cz = fm4(w1z[m], ext[m] - a0e[m], cz);
@@ -721,7 +812,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             if constexpr (!REC) {
                 a1 = sv1; a2 = sv2; a3 = sv3;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) X[s][r] = svx[r];
+                for (int r = 0; r < NX; ++r) X[s][r] = (4 * r + g < xd) ? svx[r] : 0.0f;
             } else if constexpr (STREAM) { a1 = na1; a2 = na2; a3 = na3; }
             else { a1 = h1[s]; a2 = h2[s]; a3 = h3[s]; }
             const f2 gk = f2{gks[s][0], NX > 1 ? gks[s][1] : 0.0f};
@@ -782,16 +873,12 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         for (int r = 0; r < NX; ++r) gcar[r] = (REC && a.tx) ? 0.0f : gx0[r];        // (the step started from a dataset row)
 #pragma unroll
         for (int m = 0; m < NZM; ++m) gsl[m] = (REC && a.ti) ? 0.0f : gE[m];           // (the DE read a dataset row of i)
-        if (w == 0 && valid) {       // z | v columns: final layout (an event step's belong to the jump values)
+        // z | v columns: final layout (an event step's belong to the jump values); AHEAD: stored at the next step, in front of its requests
 #pragma unroll
-            for (int m = 0; m < NZM; ++m) {
-                const int q = 4 * m + g;
-                if (q < nzv) {
-                    if (ev >= 0) a.gjump[(b * a.n_events + ev) * nzv + q] = gE[m];
-                    a.gzv[(k * a.B + b) * nzv + q] = ev >= 0 ? 0.0f : gE[m];
-                }
-            }
-        }
+        for (int m = 0; m < NZM; ++m) gz_pend[m] = gE[m];
+        ev_pend = ev;
+        k_pend = k;
+        if constexpr (!AHEAD) flush_gzv();
         // ---- (3) event: that adjoint belongs to the recomputed i0, whose head is run backwards here; grid point k's own head
         //          (is[k], un-jumped) then only sees dL/dis[k]
         if (ev >= 0) {
@@ -814,6 +901,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             for (int m = 0; m < NZM; ++m) gsl[m] = 0.0f;
         }
     }
+    if constexpr (AHEAD) flush_gzv();
     if constexpr (STREAM) dma_wait();
     {   // the head at grid point 0 (my_solvers.py:95): i_0 = g(x_init; z_0, v_0)
         f4 a1, a2, a3;
