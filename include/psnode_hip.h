@@ -401,9 +401,18 @@ typedef struct {
     uint32_t flags;
     const float* x_true;
     const float* i_true;
+    /* ABI 5, fused-DE form at hidden <= 64 WITH saved activations (psnode_dae_backward_wide_ae_floats(args) > 0; then REQUIRED): the AE head's gradients are
+     * formed in the kernel as well -- nothing is left to contract, no head row is written (ae_act / ae_delta / ae_gi / ev_delta / ev_gi may
+     * be NULL; ev_act / ev_i are still scratch of the recompute form).  Flat output, h = the MLPs' hidden width, K1a = n + x + z + v:
+     *     [ dAW1 (h x K1a) | db1 (h) | dAW2 (h x h) | db2 | dAW3 (h x h) | db3 | P3 (16 x h) | sg (16) ]
+     * P3 / sg are per ext SLOT (slot q < ne: the `s - a0` block, ne <= q < 2 ne: the `s` block; an algebraic variable d owns slots
+     * nzv + d and ne + nzv + d): dAW4[d] = P3[nzv + d] + P3[ne + nzv + d], db4[d] likewise from sg.  grad_all_initial_de then holds the WHOLE
+     * dL/dall_initial and grad_zv / grad_jump the whole dL/d(z|v) (DE + head). */
+    float* grad_params_ae_raw;
 } psnode_dae_bwd_wide_args_f32;
 
 int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* args);   /* dims only */
+size_t psnode_dae_backward_wide_ae_floats(const psnode_dae_bwd_wide_args_f32* args);     /* floats of grad_params_ae_raw; 0 = head rows + K7h */
 size_t psnode_dae_backward_wide_workspace_bytes(const psnode_dae_bwd_wide_args_f32* args);
 int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -36,6 +36,7 @@ EXPORTS = (
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
     "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
     "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
+    "psnode_dae_backward_wide_ae_floats",
 )
 
 
@@ -130,7 +131,8 @@ class DaeBwdWideArgsF32(ctypes.Structure):
                 ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p),
                 ("grad_params_de", c_void_p), ("grad_zv", c_void_p), ("grad_jump", c_void_p), ("grad_all_initial_de", c_void_p),
                 ("saved_act", c_void_p), ("saved_xstage", c_void_p), ("saved_ae_act", c_void_p), ("saved_ev_act", c_void_p),
-                ("saved_ev_i", c_void_p), ("flags", ctypes.c_uint32), ("x_true", c_void_p), ("i_true", c_void_p)]
+                ("saved_ev_i", c_void_p), ("flags", ctypes.c_uint32), ("x_true", c_void_p), ("i_true", c_void_p),
+                ("grad_params_ae_raw", c_void_p)]
 
 
 class DaeHeadGradsArgsF32(ctypes.Structure):
@@ -243,6 +245,8 @@ def load():
     lib.psnode_dae_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
     lib.psnode_dae_backward_wide_f32.restype = c_int32
     lib.psnode_dae_backward_wide_f32.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
+    lib.psnode_dae_backward_wide_ae_floats.restype = c_size_t
+    lib.psnode_dae_backward_wide_ae_floats.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
     _lib = lib
     return lib
 

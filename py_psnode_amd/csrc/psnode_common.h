@@ -227,6 +227,7 @@ int fused_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStre
 // K7f (psnode_dae_backward_fused.hip): the DAE backward at hidden <= 128 with the DE's parameter gradients formed in the kernel
 size_t dae_fused_bwd_workspace_floats(const psnode_dae_bwd_wide_args_f32* a);
 int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* a, float* workspace, hipStream_t s);
+size_t dae_fused_bwd_ae_floats(const psnode_dae_bwd_wide_args_f32* a);
 // K8 (psnode_latent_bwd.hip): backward of the latent ODE integrator at hidden 16
 bool latent16_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 bool latent16_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);

@@ -39,6 +39,8 @@ struct FusedDaeDev {
     float* carry_x;                       // [B, xd]: adjoint of x at grid point 0 (without dL/dxs[0])
     float *gzv, *gjump, *ga0;             // [T, B, nzv] (DE part), [B, n_events, nzv] (DE part), [B, n] (DE part)
     float* wpart;                         // [workgroups][NP]
+    float* wpart_ae;                      // <= 4 waves: [workgroups][NPA] partials of the AE head's gradients (formed in the kernel: round 4)
+    int NPA;
     float* ring;                          // NWV >= 8: [S][3][B][H] stage activations of the step in flight
     float *aact[3], *adelta[3], *agi;     // AE head rows per grid point [T, B, H] / [T, B, 16]
     float *eact[3], *edelta[3], *egi, *ei;
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     //             `s - a0` slot and nothing on the other, so that slot q < nzv IS dL/d(z|v)[q]
     //   aw4T[m] = AW4[i-dim of slot 4m+g][16w+i]          g3a = AW4^T (slot adjoints): both slots of an i-dim carry its row
     //   afT[r]  = AW1[16w+4g+r][n + x-dim of row i]
-    float w4T[NX], fT[4], fE[4], aw4T[NZM], afT[4];
+    //   afZ[r]  = AW1[16w+4g+r][n + x + ext slot of row i], slots < nzv: the head's dL/d(z|v) in the slot layout gE has (<= 4 waves)
+    float w4T[NX], fT[4], fE[4], aw4T[NZM], afT[4], afZ[4];
     {
         const int u = 16 * w + i, K1 = 3 * n, K1a = n + xd + nzv;
 #pragma unroll
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             }
             fE[r] = fe;
             afT[r] = (o < xd && on) ? a.aw1[(size_t)uu * K1a + n + o] : 0.0f;
+            afZ[r] = (o < nzv && on) ? a.aw1[(size_t)uu * K1a + n + xd + o] : 0.0f;
         }
     }
     // bias + W1[:, a0 columns] . a0
@@ -202,7 +206,13 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     }
     // row of a padded tile that holds column i of the DE's stage input s = (x dims | ext): x-dim d in row 4(d&3) + (d>>2) (registers 0..1
     // of lane group d&3), ext e in row 4(e&3) + 2 + (e>>2) (registers 2..3 of lane group e&3)
-    const int srow = i < xd ? 4 * (i & 3) + (i >> 2) : (i < n ? 4 * ((i - xd) & 3) + 2 + ((i - xd) >> 2) : -1);
+    // (mask arithmetic, not ?: -- the nested conditional became two divergent branches, and the register allocator parked the result in
+    //  an AGPR from inside one of them: the spill-under-EXEC pattern of round 3's defect (a), caught by isa_lint.py on the first build)
+    const int rowx_ = 4 * (i & 3) + (i >> 2), rowe_ = 4 * ((i - xd) & 3) + 2 + ((i - xd) >> 2);
+    const int inx_ = -(int)(i < xd), ins_ = -(int)(i < n), ina_ = -(int)(i < xd + nzv);
+    const int srow = (inx_ & rowx_) | (~inx_ & ((ins_ & rowe_) | ~ins_));          // -1 outside of (x | ext)
+    // ... and the same for the AE head's first-layer input behind all_initial, u = (x dims | z | v)
+    const int arow = (inx_ & rowx_) | (~inx_ & ((ina_ & rowe_) | ~ina_));
 
     // ---- LDS tiles
     const int toff = 4 * l + 8 * g;                                   // own slot of a tile
@@ -421,8 +431,9 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         p ^= 1;
         return out;
     };
-    auto allreduce4 = [&](const f4 part, const f4 init) -> f4 {
+    auto allreduce4 = [&](const f4 part, const f4 init, f4 (*pacc)[NWV] = nullptr) -> f4 {
         put(tile(p, w), part);
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
         lds_barrier();
         f4 out = init;
 #pragma unroll
@@ -481,13 +492,57 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             a3 = elu_quad(mid(aw3r, ab3, a2));
         }
     };
-    // AE head backwards: output adjoint gs (slot layout), rows written at row index `row` of (ract, rdelta, rgi); returns dL/dxa
+#ifndef PSNODE_K7F_AE_GRADS
+#define PSNODE_K7F_AE_GRADS 1
+#endif
+    // Round 4, <= 4 waves (hidden <= 64: 512 registers per lane, the AE's transposed images already in LDS): everything that rounds 2-3
+    // contracted over the head's STORED rows -- K7h, one more launch, 6 x [T,B,H] rows written here and read back there, ~1.6 ms + ~0.8 ms
+    // of host glue per 4096 x 1000 batch -- is formed in this kernel, by the means the DE's gradients are: the transposed layers run
+    // through midT (weight gradient of the layer from the tiles the all-gather published), dAW4 / dAW1 from one in-wave transpose each,
+    // the head's dL/d(z|v) rides on the all-reduce of its dL/dx, sums for the biases / all_initial stay in registers.  No head row is stored.
+    // (saved-activation form only: in the recompute instances -- forward weights of both MLPs in registers on top -- hipcc 7.2's
+    //  `AMDGPU Rewrite AGPR-Copy-MFMA` pass segfaults on <RK4, NZM = 4, NZA = 2, 4 waves>; they keep the head rows + K7h)
+    constexpr bool AEW = NWV <= 4 && !REC && PSNODE_K7F_AE_GRADS;
+    f4 accA3[AEW ? NWV : 1], accA2[AEW ? NWV : 1], accAP3 = zero4, accA1u = zero4, SA1 = zero4, SA2 = zero4, SA3 = zero4, SGi = zero4;
+#pragma unroll
+    for (int c = 0; c < (AEW ? NWV : 1); ++c) { accA3[c] = zero4; accA2[c] = zero4; }
+    // AE head backwards: output adjoint gs (slot layout); xa / zva = the head's inputs (x rows, z | v in the AE's slot layout) for dAW1.
+    // Returns dL/dxa and (AEW) the head's dL/d(z|v), slot layout.  Without AEW the rows are written at row index `row` of (ract, rdelta, rgi).
     struct HeadRows { float *a1, *a2, *a3, *d1, *d2, *d3, *gi; };
-    auto ae_adjoint = [&](const f4 a1, const f4 a2, const f4 a3, const float (&gs)[NZM], const HeadRows hr, const size_t row) -> f2 {
+    struct HeadOut { f2 gx, gz; };
+    auto ae_adjoint = [&](const f4 a1, const f4 a2, const f4 a3, const float (&gs)[NZM], const HeadRows hr, const size_t row,
+                          const float (&xa)[NX], const float (&zva)[NZA]) -> HeadOut {
         f4 g3 = zero4;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) g3 = fm4(aw4T[m], gs[m], g3);
         const f4 d3 = g3 * elu_grad_quad(a3);
+        if constexpr (AEW) {
+            SA3 += d3;
+            const f4 gs4 = f4{gs[0], NZM > 1 ? gs[NZM > 1 ? 1 : 0] : 0.0f, NZM > 2 ? gs[NZM > 2 ? 2 : 0] : 0.0f, NZM > 3 ? gs[NZM > 3 ? 3 : 0] : 0.0f};
+            SGi += gs4;
+            {   // dAW4[slot of row][own unit] += gs (x) h3, contracted over the tile's trajectories (rows (g, r) <-> slot 4r+g)
+                const f4 gT = transpose(gs4);
+                const f4 hT = transpose(a3);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accAP3 = fm4(gT[kk], hT[kk], accAP3);
+            }
+            const f4 h2T = transpose(a2);
+            const f4 d2 = midT(3, d3, h2T, accA3) * elu_grad_quad(a2);           // the AE's W3^T (layer 3 of wT), dAW3 from the published tiles
+            SA2 += d2;
+            const f4 h1T = transpose(a1);
+            const f4 d1 = midT(2, d2, h1T, accA2, &accA3) * elu_grad_quad(a1);
+            SA1 += d1;
+            const f4 ft = own4(afT, d1), fz = own4(afZ, d1);
+            const f4 red = allreduce4(f4{ft[0], ft[1], fz[0], fz[1]}, zero4, &accA2);
+            {   // dAW1 (u columns) += delta1 (x) u, u = (x | z | v) of the head
+                const f4 dT = transpose(d1);
+                put(scr, f4{xa[0], NX > 1 ? xa[NX > 1 ? 1 : 0] : 0.0f, zva[0], NZA > 1 ? zva[NZA > 1 ? 1 : 0] : 0.0f});
+                const f4 sT = arow >= 0 ? get_row(scr, 72 * (arow >> 2) + 4 * g + (arow & 3)) : zero4;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accA1u = fm4(dT[kk], sT[kk], accA1u);
+            }
+            return HeadOut{f2{red[0], red[1]}, f2{red[2], red[3]}};
+        }
         f4 d2, d1;
         if constexpr (AET_LDS) {
             d2 = mid_lds(TSZ + NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
@@ -523,7 +578,13 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 for (int m = 0; m < NZM; ++m) stg<float>(gr, offS + 16u * m, gs[m]);
             }
         }
-        return gx;
+        return HeadOut{gx, f2{0.f, 0.f}};
+    };
+    // the head's z | v inputs at grid point kk (un-jumped) or at event ev, AE slot layout
+    auto head_zv = [&](const long long kk, const int ev_, float (&zva)[NZA]) {
+        const RowZV zr = zv_rows(kk, ev_);
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) zva[m] = zv_val(zr, akind[m], acol[m]);
     };
     // dL/dis[k] enters through the `s`-block slot of its i-dim (one slot per i-dim); padding trajectories carry no adjoint at all
     auto add_gis = [&](const long long k, float (&gs)[NZM]) {
@@ -600,7 +661,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     // RAW inputs of step k: dL/dis row k+1 (row of `is` when grad_is is NULL: masked out at the consumer), dL/dxs row k+1, the z / v / i
     // candidates of every ext slot of step k.  No select, mask or subtraction in here: an operation on a freshly loaded value is scheduled
     // next to the load, with the wait for it (DESIGN.md "what the ISA said about waits"); finish_step() applies them a step later.
-    struct StepRaw { float gq[NZM], gin[NX], zr[NZM], vr[NZM], ir[NZM], xr[NX]; };
+    struct StepRaw { float gq[NZM], gin[NX], zr[NZM], vr[NZM], ir[NZM], xr[NX], hx[NX], hz[NZA], hv[NZA]; };
     auto load_x2_raw = [&](const float* base, const long long k_, float (&dst)[NX]) {
         const gptr<const float> row = sbase(base + k_ * a.B * xd);
 #pragma unroll
@@ -623,8 +684,22 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             q.ir[m] = ldg<float>(irow, evs ? offS + 16u * m : offI + 4u * (ekind[m] == 2 ? ecol[m] : 0));
         }
         if constexpr (REC) load_x2_raw(a.tx ? a.xtrue : a.xs, k_, q.xr);
+        if constexpr (AEW) {     // the inputs of the head at grid point k+1 (for dAW1): its x row and the un-jumped z | v rows
+            load_x2_raw((REC && a.tx) ? a.xtrue : a.xs, k_ + 1, q.hx);
+            const RowZV zh = zv_rows(k_ + 1, -1);
+#pragma unroll
+            for (int m = 0; m < NZA; ++m) {
+                q.hz[m] = ldg<float>(zh.z, zh.zo + 4u * (akind[m] == 0 ? acol[m] : 0));
+                q.hv[m] = ldg<float>(zh.v, zh.vo + 4u * (akind[m] == 1 ? acol[m] : 0));
+            }
+        }
     };
-    auto finish_step = [&](const StepRaw& q, float (&gq_)[NZM], float (&gin_)[NX], float (&ext_)[NZM], float (&x0_)[NX]) {
+    auto finish_step = [&](const StepRaw& q, float (&gq_)[NZM], float (&gin_)[NX], float (&ext_)[NZM], float (&x0_)[NX], float (&xh_)[NX],
+                           float (&zvh_)[NZA]) {
+#pragma unroll
+        for (int m = 0; m < NZA; ++m) zvh_[m] = AEW ? (akind[m] == 0 ? q.hz[m] : (akind[m] == 1 ? q.hv[m] : 0.0f)) : 0.0f;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) xh_[r] = (AEW && 4 * r + g < xd) ? q.hx[r] : 0.0f;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) {
             gq_[m] = q.gq[m];
@@ -643,15 +718,16 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     int ev_n = -1, ev_r = -1;
     float gz_pend[NZM] = {};                 // z | v gradient of the previous step, stored at the next one
     int ev_pend = -1;
-    long long k_pend = -1;
-    auto flush_gzv = [&]() {
-        if (k_pend >= 0 && w == 0 && valid) {
+    long long k_pend = AEW ? a.T - 1 : -1;   // (AEW: grid point T-1 has no DE part, only its head's)
+    // gzh: (AEW) the share of the head at grid point k_pend, slot layout -- un-jumped rows, whatever the step did
+    auto flush_gzv = [&](const f2 gzh) {
+        if (k_pend >= 0 && w == 0 && valid && (a.gzv != nullptr)) {
 #pragma unroll
             for (int m = 0; m < NZM; ++m) {
                 const int q = 4 * m + g;
                 if (q < nzv) {
                     if (ev_pend >= 0) a.gjump[(b * a.n_events + ev_pend) * nzv + q] = gz_pend[m];
-                    a.gzv[(k_pend * a.B + b) * nzv + q] = ev_pend >= 0 ? 0.0f : gz_pend[m];
+                    a.gzv[(k_pend * a.B + b) * nzv + q] = (ev_pend >= 0 ? 0.0f : gz_pend[m]) + (m < 2 ? gzh[m < 2 ? m : 0] : 0.0f);
                 }
             }
         }
@@ -668,10 +744,10 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     }
     for (long long k = nT - 2; k >= 0; --k) {
         int ev;
-        float gq[NZM], gin[NX], ext[NZM], x0[NX] = {}, x1[NX] = {}, h_;
+        float gq[NZM], gin[NX], ext[NZM], x0[NX] = {}, x1[NX] = {}, xh[NX], zvh[NZA], h_;
         if constexpr (AHEAD) {
             ev = ev_n;
-            finish_step(nxt, gq, gin, ext, x0);
+            finish_step(nxt, gq, gin, ext, x0, xh, zvh);
 #pragma unroll
             for (int r = 0; r < NX; ++r) x1[r] = x1_c[r];
             h_ = t_hi - t_lo;
@@ -680,10 +756,11 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, k + 1, x1);
             StepRaw now;
             fetch_step(k, ev, now);
-            finish_step(now, gq, gin, ext, x0);
+            finish_step(now, gq, gin, ext, x0, xh, zvh);
             h_ = load_t(k + 1) - load_t(k);
         }
         // ---- (1) AE head at grid point k+1 (my_solvers.py:121): adjoint = dL/dis[k+1] + the algebraic adjoint of step k+1's DE
+        f2 gzh_k = f2{0.f, 0.f};
         {
             f4 a1, a2, a3;
             if constexpr (REC) {
@@ -695,12 +772,13 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             }
 #pragma unroll
             for (int m = 0; m < NZM; ++m) gsl[m] += (has_gis && valid && ekind[m] == 2 && 4 * m + g >= ne) ? gq[m] : 0.0f;      // (add_gis, on the raw row)
-            const f2 gxa = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)(k + 1));
-            gcar[0] += (REC && a.tx) ? 0.0f : gxa[0];          // (teacher-forced x: the head read a dataset row)
-            if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : gxa[1];
+            const HeadOut ho = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)(k + 1), xh, zvh);
+            gcar[0] += (REC && a.tx) ? 0.0f : ho.gx[0];          // (teacher-forced x: the head read a dataset row)
+            if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : ho.gx[1];
+            gzh_k = ho.gz;
         }
         if constexpr (AHEAD) {       // behind the head's row stores: last step's z | v gradient, then the requests for the next step
-            flush_gzv();
+            flush_gzv(gzh_k);
             const long long kq = k > 0 ? k - 1 : 0;
             ev_n = has_ev ? __builtin_amdgcn_readfirstlane(ev_r) : -1;      // requested a step ago
             ev_r = evp[k >= 2 ? k - 2 : 0];
@@ -878,7 +956,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         for (int m = 0; m < NZM; ++m) gz_pend[m] = gE[m];
         ev_pend = ev;
         k_pend = k;
-        if constexpr (!AHEAD) flush_gzv();
+        if constexpr (!AHEAD) flush_gzv(f2{0.f, 0.f});
         // ---- (3) event: that adjoint belongs to the recomputed i0, whose head is run backwards here; grid point k's own head
         //          (is[k], un-jumped) then only sees dL/dis[k]
         if (ev >= 0) {
@@ -894,14 +972,23 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                 e2 = ldg<f4>(sbase(rb + a.B * H), offH);
                 e3 = ldg<f4>(sbase(rb + 2 * a.B * H), offH);
             }
-            const f2 gxa = ae_adjoint(e1, e2, e3, gsl, event_rows, (size_t)ev);
-            gcar[0] += gxa[0];
-            if constexpr (NX > 1) gcar[1] += gxa[1];
+            float xev[NX] = {}, zvev[NZA] = {};
+            if constexpr (AEW) {      // the event head's inputs (for dAW1): the RUNNING state of step k and the jump values
+                load_x2(a.xs, k, xev);
+                head_zv(k, ev, zvev);
+            }
+            const HeadOut he = ae_adjoint(e1, e2, e3, gsl, event_rows, (size_t)ev, xev, zvev);
+            gcar[0] += he.gx[0];
+            if constexpr (NX > 1) gcar[1] += he.gx[1];
+            if constexpr (AEW) {      // its dL/d(z|v) belongs to the jump values, like the step's own
+                gz_pend[0] += he.gz[0];
+                if constexpr (NZM > 1) gz_pend[1] += he.gz[1];
+            }
 #pragma unroll
             for (int m = 0; m < NZM; ++m) gsl[m] = 0.0f;
         }
     }
-    if constexpr (AHEAD) flush_gzv();
+    if constexpr (AHEAD && !AEW) flush_gzv(f2{0.f, 0.f});
     if constexpr (STREAM) dma_wait();
     {   // the head at grid point 0 (my_solvers.py:95): i_0 = g(x_init; z_0, v_0)
         f4 a1, a2, a3;
@@ -916,9 +1003,12 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             load_head(0, a1, a2, a3);
         }
         add_gis(0, gsl);
-        const f2 gxa = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)0);
-        gcar[0] += (REC && a.tx) ? 0.0f : gxa[0];
-        if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : gxa[1];
+        float xh0[NX] = {}, zvh0[NZA] = {};
+        if constexpr (AEW) { load_x2((REC && a.tx) ? a.xtrue : a.xs, 0, xh0); head_zv(0, -1, zvh0); }
+        const HeadOut ho = ae_adjoint(a1, a2, a3, gsl, grid_rows, (size_t)0, xh0, zvh0);
+        gcar[0] += (REC && a.tx) ? 0.0f : ho.gx[0];
+        if constexpr (NX > 1) gcar[1] += (REC && a.tx) ? 0.0f : ho.gx[1];
+        if constexpr (AEW) flush_gzv(ho.gz);       // grid point 0: step 0's DE part (pending) + this head's
     }
 
     // ---- epilogue
@@ -934,7 +1024,17 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             const int uu = 16 * w + 4 * g + r;
             at[r] = (i < n && uu < HR) ? a.w1[(size_t)uu * K1 + i] - a.w1[(size_t)uu * K1 + n + i] : 0.0f;
         }
-        const f4 ga = allreduce4(own4(at, S1), zero4);
+        f4 ga = allreduce4(own4(at, S1), zero4);
+        if constexpr (AEW) {      // + the AE's share: sum_u AW1[u][c] SA1[u] (its first-layer input starts with all_initial, no difference term)
+            const int K1a = n + xd + nzv;
+            float ata[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int uu = 16 * w + 4 * g + r;
+                ata[r] = (i < n && uu < HR) ? a.aw1[(size_t)uu * K1a + i] : 0.0f;
+            }
+            ga += allreduce4(own4(ata, SA1), zero4);
+        }
         if (w == 0 && valid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (4 * g + r < n) a.ga0[b * n + 4 * g + r] = ga[r];
@@ -1007,11 +1107,74 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             for (int r = 0; r < NX; ++r) if (4 * r + g < xd) wp[oB4 + 4 * r + g] = sb4[r];
         }
     }
+    if constexpr (AEW) {
+        // the AE head's partials: [dAW1 (HR x K1a) | db1 | dAW2 | db2 | dAW3 | db3 | P3 (16 slots x HR) | sum gi (16 slots)] -- the caller
+        // folds the two slots of an i-dim (P3, sum gi) into dAW4 / db4 as it did with K7h's output
+        float* wa = a.wpart_ae + (size_t)blockIdx.x * a.NPA;
+        const int K1a = n + xd + nzv;
+        const int aB1 = HR * K1a, aW2 = aB1 + HR, aB2 = aW2 + HR * HR, aW3 = aB2 + HR, aB3 = aW3 + HR * HR, aP3 = aB3 + HR, aSG = aP3 + 16 * HR;
+        {
+            const f4 sT = transpose(SA1);
+            f4 ca0 = zero4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const long long tb = b0 + 4 * kk + g;
+                const float av = (i < n && tb < a.B) ? a.a0[tb * n + i] : 0.0f;
+                ca0 = fm4(sT[kk], av, ca0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = 16 * w + 4 * g + r;
+                if (u < HR) {
+                    float* row = wa + (size_t)u * K1a;
+                    if (j < n) row[j] = ca0[r];
+                    if (j < xd + nzv) row[n + j] = accA1u[r];
+                }
+            }
+        }
+        {
+            const int v = 16 * w + j;        // own column
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) {
+                const int ub = 16 * ((w + c) & (NWV - 1)) + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ub + r < HR && v < HR) {
+                        wa[aW2 + (size_t)(ub + r) * HR + v] = accA2[c][r];
+                        wa[aW3 + (size_t)(ub + r) * HR + v] = accA3[c][r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (v < HR) wa[aP3 + (size_t)(4 * r + g) * HR + v] = accAP3[r];      // rows (g, r) <-> slot 4r+g
+        }
+        f4 s1 = SA1, s2 = SA2, s3 = SA3, sg = SGi;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[r] += __shfl_xor(s1[r], m, 64); s2[r] += __shfl_xor(s2[r], m, 64); s3[r] += __shfl_xor(s3[r], m, 64);
+                sg[r] += __shfl_xor(sg[r], m, 64);
+            }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = 16 * w + 4 * g + r;
+                if (u < HR) { wa[aB1 + u] = s1[r]; wa[aB2 + u] = s2[r]; wa[aB3 + u] = s3[r]; }
+                if (w == 0) wa[aSG + 4 * r + g] = sg[r];         // (the slot adjoints are the same in every wave)
+            }
+        }
+    }
 }
 
 size_t k7f_lds_bytes(int nw) { return (wide_t_floats(nw) * (aet_in_lds(nw) ? 2 : 1) + (size_t)3 * nw * FTILE) * sizeof(float); }
 size_t k7f_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
 int k7f_np(int hr, int xd, int ne) { const int n = xd + ne; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
+// <= 4 waves: the AE head's partials [dAW1 | db1 | dAW2 | db2 | dAW3 | db3 | P3 (16 x h) | sum gi (16)]
+int k7f_npa(int nw, bool saved, int hr, int xd, int nzv, int ne) {
+    return (nw <= 4 && saved) ? hr * (xd + ne + xd + nzv) + hr + 2 * (hr * hr + hr) + 16 * hr + 16 : 0;
+}
 size_t k7f_fwd_floats(int nw, int n) { return ((wide_fwd_floats(nw, n) + 63) / 64) * 64; }
 
 template <int METHOD, int NWV>
@@ -1056,7 +1219,12 @@ size_t dae_fused_bwd_workspace_floats(const psnode_dae_bwd_wide_args_f32* p) {
     const int nw = wide_hidden(p->de) / 16, ne = p->z_dim + p->v_dim + p->i_dim, n = p->x_dim + ne;
     const size_t nwg = (size_t)((p->B + TBM - 1) / TBM);
     return 2 * k7f_fwd_floats(nw, n) + 4 * wide_t_floats(nw) + ((nwg * k7f_np(p->de.out_dim[0], p->x_dim, ne) + 63) / 64) * 64 +
-           k7f_ring_floats(nw, p->method, p->B) + 256;
+           ((nwg * k7f_npa(nw, p->saved_act != nullptr, p->de.out_dim[0], p->x_dim, p->z_dim + p->v_dim, ne) + 63) / 64) * 64 + k7f_ring_floats(nw, p->method, p->B) + 256;
+}
+// floats of psnode_dae_bwd_wide_args_f32::grad_params_ae_raw (0: this width leaves the AE head's contractions to the caller, K7h)
+size_t dae_fused_bwd_ae_floats(const psnode_dae_bwd_wide_args_f32* p) {
+    const int nw = wide_hidden(p->de) / 16;
+    return (size_t)k7f_npa(nw, p->saved_act != nullptr, p->de.out_dim[0], p->x_dim, p->z_dim + p->v_dim, p->z_dim + p->v_dim + p->i_dim);
 }
 
 int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace, hipStream_t s) {
@@ -1071,8 +1239,10 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     f4* pfa = pta + wide_t_floats(nw) / 4;
     float* wpart = reinterpret_cast<float*>(pfa + wide_t_floats(nw) / 4);
     const size_t nwg = (size_t)((p->B + TBM - 1) / TBM);
-    const int NP = k7f_np(HR, xd, ne);
-    float* ring = wpart + ((nwg * NP + 63) / 64) * 64;
+    const int NP = k7f_np(HR, xd, ne), NPA = k7f_npa(nw, p->saved_act != nullptr, HR, xd, nzv, ne);
+    float* wpart_ae = wpart + ((nwg * NP + 63) / 64) * 64;
+    float* ring = wpart_ae + ((nwg * NPA + 63) / 64) * 64;
+    if (NPA > 0 && !p->grad_params_ae_raw) return PSNODE_ERR_NULL;
     PackMfma f;
     memset(&f, 0, sizeof(f));
     f.ae = 0; f.nw = nw; f.xd = xd; f.ne = ne; f.n = n; f.nzv = nzv; f.NX = kNXc; f.NB = 0; f.NE = NZM; f.NA = NA; f.fold = 1;
@@ -1115,7 +1285,7 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     if ((a.tx && !a.xtrue) || (a.ti && !a.itrue)) return PSNODE_ERR_NULL;
     a.carry_x = p->carry_x;
     a.gzv = p->grad_zv; a.gjump = p->grad_jump; a.ga0 = p->grad_all_initial_de;
-    a.wpart = wpart; a.ring = ring;
+    a.wpart = wpart; a.ring = ring; a.wpart_ae = wpart_ae; a.NPA = NPA;
     for (int l = 0; l < 3; ++l) {
         a.aact[l] = p->ae_act[l]; a.adelta[l] = p->ae_delta[l];
         a.eact[l] = p->ev_act[l]; a.edelta[l] = p->ev_delta[l];
@@ -1130,7 +1300,9 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     }
     if (e == hipErrorNotSupported) return PSNODE_ERR_UNSUPPORTED;
     if (e != hipSuccess) return PSNODE_ERR_HIP;
-    return launch_reduce_partials(wpart, p->grad_params_de, nullptr, NP, 0, (int)nwg, s) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+    if (launch_reduce_partials(wpart, p->grad_params_de, nullptr, NP, 0, (int)nwg, s) != hipSuccess) return PSNODE_ERR_HIP;
+    if (NPA > 0 && launch_reduce_partials(wpart_ae, p->grad_params_ae_raw, nullptr, NPA, 0, (int)nwg, s) != hipSuccess) return PSNODE_ERR_HIP;
+    return PSNODE_OK;
 }
 
 }  // namespace psnode

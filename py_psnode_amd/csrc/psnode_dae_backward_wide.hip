@@ -662,6 +662,11 @@ int32_t psnode_dae_backward_wide_supported(const psnode_dae_bwd_wide_args_f32* a
     return a->de.in_dim == 3 * n && a->de.out_dim[3] == xd && a->ae.in_dim == n + xd + nzv && a->ae.out_dim[3] == id;
 }
 
+size_t psnode_dae_backward_wide_ae_floats(const psnode_dae_bwd_wide_args_f32* a) {
+    if (!psnode_dae_backward_wide_supported(a) || !a->grad_params_de) return 0;
+    return dae_fused_bwd_ae_floats(a);
+}
+
 size_t psnode_dae_backward_wide_workspace_bytes(const psnode_dae_bwd_wide_args_f32* a) {
     if (!psnode_dae_backward_wide_supported(a)) return 0;
     if (a->grad_params_de) return dae_fused_bwd_workspace_floats(a) * sizeof(float);
@@ -677,7 +682,8 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
     for (int l = 0; l < 4; ++l) if (!p->de.weight[l] || !p->de.bias[l] || !p->ae.weight[l] || !p->ae.bias[l]) return PSNODE_ERR_NULL;
     const bool fused = p->grad_params_de != nullptr;
     if ((p->flags & ~(PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I)) || (p->flags && !fused)) return PSNODE_ERR_UNSUPPORTED;   // teacher forcing: K7f only
-    if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || !p->ae_gi) return PSNODE_ERR_NULL;
+    const bool ae_in_kernel = fused && dae_fused_bwd_ae_floats(p) > 0;      // hidden <= 64: no head rows are written at all
+    if (!p->t.ptr || !p->all_initial || !p->xs || !p->is || !p->grad_xs || !p->carry_x || (!ae_in_kernel && !p->ae_gi)) return PSNODE_ERR_NULL;
     if (fused) {
         if (p->k0 != 0 || p->k1 != p->T - 1) return PSNODE_ERR_DIMS;
         const bool sv = p->saved_act != nullptr;
@@ -688,13 +694,14 @@ int32_t psnode_dae_backward_wide_f32(const psnode_dae_bwd_wide_args_f32* p, void
         return PSNODE_ERR_NULL;
     }
     for (int l = 0; l < 3; ++l) {
-        if (!p->ae_act[l] || !p->ae_delta[l]) return PSNODE_ERR_NULL;
+        if (!ae_in_kernel && (!p->ae_act[l] || !p->ae_delta[l])) return PSNODE_ERR_NULL;
         if (!fused && (!p->act[l] || !p->delta[l] || !p->dsum[l])) return PSNODE_ERR_NULL;
     }
     if ((p->z_dim > 0 && !p->z.ptr) || (p->v_dim > 0 && !p->v.ptr)) return PSNODE_ERR_NULL;
     if (p->event_idx) {
-        if (p->n_events < 1 || (p->z_dim > 0 && !p->z_jump) || (p->v_dim > 0 && !p->v_jump) || !p->ev_gi || !p->ev_i) return PSNODE_ERR_NULL;
-        for (int l = 0; l < 3; ++l) if (!p->ev_act[l] || !p->ev_delta[l]) return PSNODE_ERR_NULL;
+        if (p->n_events < 1 || (p->z_dim > 0 && !p->z_jump) || (p->v_dim > 0 && !p->v_jump) || !p->ev_i) return PSNODE_ERR_NULL;
+        if (!ae_in_kernel && !p->ev_gi) return PSNODE_ERR_NULL;
+        for (int l = 0; l < 3; ++l) if (!p->ev_act[l] || (!ae_in_kernel && !p->ev_delta[l])) return PSNODE_ERR_NULL;
     }
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_dae_backward_wide_workspace_bytes(p))
         return PSNODE_ERR_WORKSPACE;

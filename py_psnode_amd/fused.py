@@ -825,20 +825,52 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 a.saved_ev_act, a.saved_ev_i = s_ev.data_ptr(), s_evi.data_ptr()
                 for q in range(3):
                     ev_rows[q] = s_ev[:, q]
-            arows = [s_ae[0], s_ae[1], s_ae[2]] + [_empty((T, B, H), **f32) for _ in range(3)]
+            # > 0 (hidden <= 64, saved activations): the AE head's gradients are formed in the kernel too -- no head rows, no K7h
+            n_ae_raw = int(lib.psnode_dae_backward_wide_ae_floats(ctypes.byref(a)))
+            arows = None if n_ae_raw else [s_ae[0], s_ae[1], s_ae[2]] + [_empty((T, B, H), **f32) for _ in range(3)]
         else:
-            arows = [_empty((T, B, H), **f32) for _ in range(6)]
-        agi = _empty((T, B, 16), **f32)
+            n_ae_raw = int(lib.psnode_dae_backward_wide_ae_floats(ctypes.byref(a)))
+            arows = None if n_ae_raw else [_empty((T, B, H), **f32) for _ in range(6)]
         a.k0, a.k1 = 0, T - 1
-        for q in range(3):
-            a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
-        a.ae_gi = agi.data_ptr()
+        gae_raw = agi = None
+        if n_ae_raw:
+            gae_raw = _empty(n_ae_raw, **f32)
+            a.grad_params_ae_raw = gae_raw.data_ptr()
+        else:
+            agi = _empty((T, B, 16), **f32)
+            for q in range(3):
+                a.ae_act[q], a.ae_delta[q] = arows[q].data_ptr(), arows[3 + q].data_ptr()
+            a.ae_gi = agi.data_ptr()
         with torch.cuda.device(dev):
             nbytes = lib.psnode_dae_backward_wide_workspace_bytes(ctypes.byref(a))
             ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
             wp, wn = _aligned_ptr(ws)
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.psnode_dae_backward_wide_f32(ctypes.byref(a), wp, wn, st), "psnode_dae_backward_wide_f32")
+            if n_ae_raw:
+                # one launch did everything: unpack [dAW1 | db1 | dAW2 | db2 | dAW3 | db3 | P3 (16 slots x h) | sg (16 slots)]
+                K1a, o = n + xd + nzv, 0
+                gA[0] = gae_raw[o:o + Hr * K1a].view(Hr, K1a); o += Hr * K1a
+                gab[0] = gae_raw[o:o + Hr]; o += Hr
+                gA[1] = gae_raw[o:o + Hr * Hr].view(Hr, Hr); o += Hr * Hr
+                gab[1] = gae_raw[o:o + Hr]; o += Hr
+                gA[2] = gae_raw[o:o + Hr * Hr].view(Hr, Hr); o += Hr * Hr
+                gab[2] = gae_raw[o:o + Hr]; o += Hr
+                P3 = gae_raw[o:o + 16 * Hr].view(16, Hr); o += 16 * Hr
+                sg = gae_raw[o:o + 16]
+                gA[3] = P3[nzv:ne] + P3[ne + nzv:2 * ne]
+                gab[3] = sg[nzv:ne] + sg[ne + nzv:2 * ne]
+                g = {"z_jump": None, "v_jump": None}
+                g["x_init"] = carry_x + gx_c[0]
+                g["all_initial"] = ga0_de                      # (the kernel added the AE's share)
+                g["z"] = gzv[..., :zd].contiguous() if zd > 0 else None
+                g["v"] = gzv[..., zd:].contiguous() if vd > 0 else None
+                if n_ev:
+                    g["z_jump"] = gjump[..., :zd].contiguous() if zd > 0 else None
+                    g["v_jump"] = gjump[..., zd:].contiguous() if vd > 0 else None
+                g["de"] = _split_grads(gp_de, de_layers)
+                g["ae"] = [gA[0], gab[0], gA[1], gab[1], gA[2], gab[2], gA[3], gab[3]]
+                return g
             # the AE head's rows -> its parameter gradients and its share of the input gradients (K7h)
             # (the heads at the grid points read the dataset rows under input_true_x; the event heads below always the running state)
             gza = head_grads_hip(arows[:3], B * H, arows[3:], agi, xt_c if x_true is not None else xs_c, zv_all)
