@@ -402,7 +402,7 @@ def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
            "host_enqueue_ms": None,
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                         "flop_convention": "3 x forward flops per state-step", "flop_per_state_step": flops,
-                        "kernel_ms": avg, "kernel_ms_median": med,
+                        "kernel_ms": avg, "kernel_ms_median": med, "kernel_ms_each": [round(e[0].elapsed_time(e[3]), 3) for e in ev],
                         "kernel_ms_by_family": {"forward": part(0, 1), "loss": part(1, 2), "backward": part(2, 3)}}}
     # host-side enqueue cost of one step (no device wait inside the step: the difference to the GPU time is what the host may hide)
     torch.cuda.synchronize(dev)

@@ -252,6 +252,8 @@ size_t dae_mfma_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
 int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
 hipError_t launch_mfma_h32(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);    // psnode_mfma_h32.hip
 hipError_t launch_mfma_h128(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h128.hip
+hipError_t launch_mfma_h192(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h192.hip (forward only)
+hipError_t launch_mfma_h256(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h256.hip (forward only)
 
 // psnode_generic_bwd.hip (K5: generic fused backward, ODE and DAE)
 size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B);

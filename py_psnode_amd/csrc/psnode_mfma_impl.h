@@ -44,6 +44,23 @@ __global__ void pack_mfma_kernel(const PackMfma p) {
         p.out[idx] = pack_fwd_value(p, (idx >> 6) / R, (idx >> 6) % R, idx & 63);
 }
 
+// Stream image of the H->H layers for the widths whose weights no CU can hold (hidden 129..256: 12 / 16 waves per tile):
+// [layer 2|3][wave w][chunk c][lane] f4 -- component r is forward-image register W2|W3 + 4c + r -- so that chunk c of a wave is ONE
+// coalesced 1 KB global_load_dwordx4 and a wave's layer is one contiguous 16 KB run: scalar base + one lane offset + immediates
+// (the image stays in L2: 0.5 MB per MLP at hidden 256).
+__global__ void pack_stream_kernel(const PackMfma p, f4* __restrict__ out) {
+    const int W2 = p.NX + p.NB + p.NE + 4, W3 = W2 + 4 * p.nw + 4;
+    const int n = 2 * p.nw * p.nw * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, c = (idx >> 6) % p.nw, w = ((idx >> 6) / p.nw) % p.nw, layer = (idx >> 6) / (p.nw * p.nw);
+        f4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = pack_fwd_value(p, w, (layer ? W3 : W2) + 4 * c + r, lane);
+        out[idx] = v;
+    }
+}
+__host__ __device__ constexpr size_t stream_image_floats(int nwv) { return nwv > 8 ? (size_t)2 * nwv * nwv * 64 * 4 : 0; }
+
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ f4 elu4(f4 v) { return elu_quad(v); }
@@ -53,22 +70,33 @@ template <int NWV>
 struct Tail {
     float w2[4 * NWV], w3[4 * NWV], w4[4];
     f4 b2, b3, b4;
+    int m;             // NWV > 8: 0 = DE, 1 = AE -- which set of the LDS-parked layer constants (tw4 / tb in the kernel) is this MLP's
+    const float* gw;   // NWV > 8: this WAVE's run of the stream image (pack_stream_kernel; wave-uniform), layer 2 at +0, layer 3 at + NWV * NWV * 256 floats
 };
 
-__host__ __device__ constexpr bool ae_weights_in_lds(bool dae, int nwv) { return dae && nwv >= 8; }
+__host__ __device__ constexpr bool ae_weights_in_lds(bool dae, int nwv) { return dae && nwv == 8; }
+__host__ __device__ constexpr bool weights_streamed(int nwv) { return nwv > 8; }
+// Which shape classes the streamed widths carry: the ones that compile WITHOUT spills at 168 (12 waves) / 128 (16 waves) VGPRs per lane
+// (a spill in a kernel with divergent regions is what round 4's defect (a) was; the ISA lint gates the build on it).  16 waves: the ODE
+// with x_dim <= 8; 12 waves: the ODE at every x_dim, the DAE with 2 (z+v+i) <= 12.  Everything else at these widths takes K0.
+__host__ __device__ constexpr bool streamed_class_ok(int nwv, bool dae, bool wide_x, int nzm) {
+    return nwv <= 8 || (nwv == 12 ? (!dae || nzm <= 3) : (!dae && !wide_x));
+}
 __host__ __device__ constexpr size_t ae_lds_bytes(int nwv) { return (size_t)2 * nwv * nwv * 64 * sizeof(f4); }
 
-template <int NX, int NB, int NE, int NWV, bool MID = true>
+template <int NX, int NB, int NE, int NWV, bool MID = true, bool SMALL = true>
 __device__ __forceinline__ void load_tail(const float* pw, Tail<NWV>& t) {
     using R = Regs<NX, NB, NE, NWV>;
     if constexpr (MID) {
 #pragma unroll
         for (int k = 0; k < 4 * NWV; ++k) { t.w2[k] = pw[(R::W2 + k) * 64]; t.w3[k] = pw[(R::W3 + k) * 64]; }
     }
+    if constexpr (SMALL) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        t.w4[r] = pw[(R::W4 + r) * 64];
-        t.b2[r] = pw[(R::B2 + r) * 64]; t.b3[r] = pw[(R::B3 + r) * 64]; t.b4[r] = pw[(R::B4 + r) * 64];
+        for (int r = 0; r < 4; ++r) {
+            t.w4[r] = pw[(R::W4 + r) * 64];
+            t.b2[r] = pw[(R::B2 + r) * 64]; t.b3[r] = pw[(R::B3 + r) * 64]; t.b4[r] = pw[(R::B4 + r) * 64];
+        }
     }
 }
 
@@ -88,10 +116,32 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     // AE's H->H weights live in (dynamic) LDS, each lane reading back exactly the A-operand values it wrote.
     constexpr bool AE_LDS = ae_weights_in_lds(DAE, NWV);
     extern __shared__ f4 aew[];   // AE_LDS: [layer 2|3][chunk][wave][lane]
+    // 12 / 16 waves (hidden 129..256): 3 / 4 waves per SIMD, 168 / 128 VGPRs per lane, and one H->H matrix is 144 / 256 KB -- neither
+    // registers nor LDS hold the weights.  Every H->H layer streams its A operands from the L2-resident stream image (one coalesced
+    // dwordx4 per chunk); the other waves of the SIMD cover the latency.
+    constexpr bool W_GLB = weights_streamed(NWV);
+    constexpr int MODE_DE = W_GLB ? 2 : 0, MODE_AE = W_GLB ? 2 : (AE_LDS ? 1 : 0);
+    // ... and at 128 / 168 VGPRs per lane the 16 registers per MLP of layer constants (b2, b3, b4, this wave's L4 slice) are the
+    // difference between spilling and not: they are parked in LDS and read where a layer starts (one ds_read_b128 each)
+    __shared__ f4 tw4[W_GLB ? (DAE ? 2 : 1) : 1][W_GLB ? NWV : 1][W_GLB ? 64 : 1];
+    __shared__ f4 tb[W_GLB ? (DAE ? 2 : 1) : 1][3][W_GLB ? NWV : 1][4];
 
     const int l = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = l >> 4, j = l & 15;
+    auto park_tail = [&](const float* pwl, const int m, const int w4r, const int b2r, const int b3r, const int b4r) {
+        f4 q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = pwl[(w4r + r) * 64];
+        tw4[m][w][l] = q;
+        const int regs[3] = {b2r, b3r, b4r};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = pwl[(regs[i] + r) * 64];
+            if ((l & 15) == 0) tb[m][i][w][l >> 4] = q;
+        }
+    };
     const long long b0 = (long long)blockIdx.x * TBM;
     const bool valid = b0 + j < a.B;
     const long long b = valid ? b0 + j : a.B - 1;
@@ -111,7 +161,10 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     for (int m = 0; m < NZM; ++m) w1z.v[m] = pw[(RD::W1E + m) * 64];
 #pragma unroll
     for (int r = 0; r < 4; ++r) b1r[r] = pw[(RD::B1 + r) * 64];
-    load_tail<NX, 0, NZM, NWV>(pw, de);
+    load_tail<NX, 0, NZM, NWV, !W_GLB, !W_GLB>(pw, de);
+    de.m = 0;
+    if constexpr (W_GLB) park_tail(pw, 0, RD::W4, RD::B2, RD::B3, RD::B4);
+    de.gw = W_GLB ? pack_de + (size_t)NWV * (RD::COUNT + NA) * 64 + (size_t)w * NWV * 256 : nullptr;
 
     const float* pwa = pack_ae + (size_t)w * (RA::COUNT + NA) * 64 + l;
     float aw1x[NX];
@@ -125,7 +178,10 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         for (int m = 0; m < NZA; ++m) aw1e.v[m] = pwa[(RA::W1E + m) * 64];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ab1r[r] = pwa[(RA::B1 + r) * 64];
-        load_tail<NX, 0, NZA, NWV, !AE_LDS>(pwa, ae);
+        load_tail<NX, 0, NZA, NWV, !AE_LDS && !W_GLB, !W_GLB>(pwa, ae);
+        ae.m = 1;
+        if constexpr (W_GLB) park_tail(pwa, 1, RA::W4, RA::B2, RA::B3, RA::B4);
+        ae.gw = W_GLB ? pack_ae + (size_t)NWV * (RA::COUNT + NA) * 64 + (size_t)w * NWV * 256 : nullptr;
         if constexpr (AE_LDS) {
 #pragma unroll
             for (int c = 0; c < NWV; ++c) {
@@ -261,7 +317,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         f4 vq[NWV];
         if constexpr (PREFETCH_ALL) {
 #pragma unroll
-            for (int c = 1; c < NWV; ++c) vq[c] = xbuf[p][(w + c) & (NWV - 1)][l];
+            for (int c = 1; c < NWV; ++c) vq[c] = xbuf[p][wrap_wave(w + c, NWV)][l];
             if constexpr (PRE < 4) asm volatile("" : "+v"(accA), "+v"(accB));      // the remaining own-quarter MFMAs stay behind the read issue
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -271,7 +327,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         if constexpr (PRE < 4) accB = mfma4(wm[3], h[3], accB);
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
-            const f4 v = PREFETCH_ALL ? vq[c] : xbuf[p][(w + c) & (NWV - 1)][l];
+            const f4 v = PREFETCH_ALL ? vq[c] : xbuf[p][wrap_wave(w + c, NWV)][l];
             accA = mfma4(wm[4 * c + 0], v[0], accA);
             accB = mfma4(wm[4 * c + 1], v[1], accB);
             accA = mfma4(wm[4 * c + 2], v[2], accA);
@@ -294,7 +350,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         lds_barrier();
 #pragma unroll
         for (int c = 1; c < NWV; ++c) {
-            const f4 v = xbuf[p][(w + c) & (NWV - 1)][l];
+            const f4 v = xbuf[p][wrap_wave(w + c, NWV)][l];
             wq = wl[c * NWV * 64];
             accA = mfma4(wq[0], v[0], accA);
             accB = mfma4(wq[1], v[1], accB);
@@ -304,16 +360,61 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         p ^= 1;
         return elu4(accA + accB);
     };
+    // the same layer with the A operands streamed from the stream image (`wl` = this lane's f4 of chunk 0 of the layer): all NWV chunk
+    // loads are requested first -- they travel while the tile publishes / gathers the activations
+    auto mid_glb = [&](const float* __restrict__ lay, const f4 bias, const f4 h) -> f4 {
+        // `lay`: the wave's run of this layer (uniform).  The lane offset goes through an empty asm: these loads are loop-invariant to
+        // the compiler, and hoisted out of the time loop they would be the register-resident weights that do not fit (first build:
+        // 330 spilled VGPRs).  Laundering the POINTER instead made every load a flat_load behind 64-bit per-lane address arithmetic.
+        int loff = 4 * l;
+        asm volatile("" : "+v"(loff));
+        const f4* wl = reinterpret_cast<const f4*>(lay + loff);
+        // a ring of WD chunk slots: chunk c + WD is requested into the slot chunk c just left, the gathered activations of chunk c + 1
+        // are read while chunk c multiplies -- the order is pinned per chunk (left alone the scheduler hoists every read and every
+        // load to the top of the layer and spills ~100 VGPRs at 16 waves)
+#ifndef PSNODE_STREAM_DEPTH
+#define PSNODE_STREAM_DEPTH 4
+#endif
+        constexpr int WD = PSNODE_STREAM_DEPTH < NWV ? PSNODE_STREAM_DEPTH : NWV;
+        f4 wq[WD];
+#pragma unroll
+        for (int c = 0; c < WD; ++c) wq[c] = wl[c * 64];
+        xbuf[p][w][l] = h;
+        f4 accA = bias, accB = f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        f4 vn = xbuf[p][wrap_wave(w + 1, NWV)][l];
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) {
+            const f4 v = c == 0 ? h : vn;
+            if (c >= 1 && c + 1 < NWV) vn = xbuf[p][wrap_wave(w + c + 1, NWV)][l];
+            const f4 wc = wq[c % WD];
+            accA = mfma4(wc[0], v[0], accA);
+            accB = mfma4(wc[1], v[1], accB);
+            accA = mfma4(wc[2], v[2], accA);
+            accB = mfma4(wc[3], v[3], accB);
+            if (c + WD < NWV) wq[c % WD] = wl[(c + WD) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p ^= 1;
+        return elu4(accA + accB);
+    };
     // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows.
     // ROWS2: only rows r < 2 of the output carry data (the DE with x_dim <= 8): all-reduce 8 bytes per lane instead of 16.
-    auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto from_lds, auto&& keep) -> f4 {
+    // `wmode`: where the H->H weights are -- 0 registers, 1 LDS (the AE at 8 waves), 2 the stream image (more than 8 waves)
+    auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto wmode, auto&& keep) -> f4 {
         constexpr bool ROWS2 = decltype(rows2)::value;
         f4 h = elu4(pre1);
         keep(0, h);
-        if constexpr (decltype(from_lds)::value) {
+        if constexpr (decltype(wmode)::value == 1) {
             h = mid_lds(0, t.b2, h);
             keep(1, h);
             h = mid_lds(1, t.b3, h);
+            keep(2, h);
+        } else if constexpr (decltype(wmode)::value == 2) {
+            h = mid_glb(t.gw, tb[t.m][0][w][g], h);
+            keep(1, h);
+            h = mid_glb(t.gw + (size_t)NWV * NWV * 256, tb[t.m][1][w][g], h);
             keep(2, h);
         } else {
             h = mid(t.w2, t.b2, h);
@@ -321,24 +422,32 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             h = mid(t.w3, t.b3, h);
             keep(2, h);
         }
-        f4 accA = mfma4(t.w4[0], h[0], f4{0.f, 0.f, 0.f, 0.f});
-        f4 accB = mfma4(t.w4[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
-        accA = mfma4(t.w4[2], h[2], accA);
-        accB = mfma4(t.w4[3], h[3], accB);
+        f4 w4v, out;
+        if constexpr (decltype(wmode)::value == 2) { w4v = tw4[t.m][w][l]; out = tb[t.m][2][w][g]; }
+        else { w4v = f4{t.w4[0], t.w4[1], t.w4[2], t.w4[3]}; out = t.b4; }
+        f4 accA = mfma4(w4v[0], h[0], f4{0.f, 0.f, 0.f, 0.f});
+        f4 accB = mfma4(w4v[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        accA = mfma4(w4v[2], h[2], accA);
+        accB = mfma4(w4v[3], h[3], accB);
         const f4 part = accA + accB;
-        f4 out = t.b4;
         if constexpr (ROWS2) {
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2* xb2 = reinterpret_cast<f2*>(&xbuf[2][0][0]);
             xb2[w * 64 + l] = f2{part[0], part[1]};
             lds_barrier();
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) { const f2 q = xb2[c * 64 + l]; out[0] += q[0]; out[1] += q[1]; }
+            for (int c = 0; c < NWV; ++c) {
+                const f2 q = xb2[c * 64 + l]; out[0] += q[0]; out[1] += q[1];
+                if constexpr (W_GLB) { if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0); }    // four reads in flight, not NWV (registers)
+            }
         } else {
             xbuf[2][w][l] = part;
             lds_barrier();
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) out += xbuf[2][c][l];
+            for (int c = 0; c < NWV; ++c) {
+                out += xbuf[2][c][l];
+                if constexpr (W_GLB) { if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         return out;
     };
@@ -364,12 +473,12 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
                 for (int r = 0; r < NX; ++r) if (4 * r + g < xd) sx_run[4 * r + g] = xs[r];
             }
             sx_run += sx_step;
-            const f4 out = tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{},
+            const f4 out = tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::integral_constant<int, MODE_DE>{},
                                 [&](const int q, const f4 hq) { if (valid) store_nt<(NWV >= 8)>(reinterpret_cast<f4*>(sa_run + (size_t)q * sa_layer), hq); });
             sa_run += 3 * sa_layer;
             return out;
         }
-        return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::false_type{}, [](int, f4) {});
+        return tail(NX > 1 ? accA + accB : accA, de, std::integral_constant<bool, (NX <= 2)>{}, std::integral_constant<int, MODE_DE>{}, [](int, f4) {});
     };
     // AE head g(xa; zv): rows (g, m) of the result carry the i-dim that DE ext slot (m, g) consumes
     // SAVE: `rows` = this lane's four units in layer 0 of the head's saved activations, `lstride` floats to the next layer (null: not saved)
@@ -381,9 +490,9 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
 #pragma unroll
             for (int m = 0; m < NZA; ++m) acc = mfma4(aw1e.v[m], zv.v[m], acc);
             if constexpr (SAVE)
-                return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{},
+                return tail(acc, ae, std::false_type{}, std::integral_constant<int, MODE_AE>{},
                             [&](const int q, const f4 hq) { if (valid) store_nt<(NWV >= 8)>(reinterpret_cast<f4*>(rows + (size_t)q * lstride), hq); });
-            return tail(acc, ae, std::false_type{}, std::integral_constant<bool, AE_LDS>{}, [](int, f4) {});
+            return tail(acc, ae, std::false_type{}, std::integral_constant<int, MODE_AE>{}, [](int, f4) {});
         }
         return acc;
     };
@@ -413,6 +522,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     };
     auto store_i = [&](long long k, const f4 iv) { if constexpr (DAE) store_i_at(a.io + (k * a.B + b) * idim, iv); };
 
+    if constexpr (W_GLB) __syncthreads();      // the LDS-parked layer constants are in place
     store_x(0);
     f4 icur = f4{0.f, 0.f, 0.f, 0.f};
     Arr<NZA> zaz_nxt = {}, zav_nxt = {};      // raw z / v reads of grid point k+1 for the AE head (selected at use)
@@ -605,7 +715,7 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, NA);                                                    \
         return hipGetLastError();                                                                                          \
     }
-    if constexpr (!TRUE_X && NXR == kNXc) {
+    if constexpr (!TRUE_X && NXR == kNXc && !weights_streamed(NWV)) {      // the training forwards exist where a fused backward does (hidden <= 128)
         if (!dae && a.sact) {
 #define PSNODE_LAUNCH_SAVE(NZM_)                                                                                           \
     {                                                                                                                      \
@@ -623,7 +733,7 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
 #undef PSNODE_LAUNCH_SAVE
         }
     }
-    if constexpr (!TRUE_X && NXR == kNXc) {
+    if constexpr (!TRUE_X && NXR == kNXc && !weights_streamed(NWV)) {
         if (dae && a.sact) {
             if (a.flags & PSNODE_FLAG_INPUT_TRUE_I) return hipErrorNotSupported;
 #define PSNODE_LAUNCH_SAVE(NZM_, NZA_)                                                                                     \
@@ -651,7 +761,10 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
         }
     }
     if (a.sact) return hipErrorNotSupported;
+    if (!streamed_class_ok(NWV, dae, NXR != kNXc, NZM)) return hipErrorNotSupported;
     if (!dae) {
+        if constexpr (!streamed_class_ok(NWV, false, NXR != kNXc, 0)) return hipErrorNotSupported;
+        else
         switch (NZM) {
             case 0: PSNODE_LAUNCH(0, 0, false)
             case 1: PSNODE_LAUNCH(1, 0, false)
@@ -661,16 +774,22 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
             default: return hipErrorNotSupported;
         }
     }
-    if constexpr (NXR != kNXc) return hipErrorNotSupported;     // the DAE kernels hold two register-resident MLPs: x_dim <= 8
+    if constexpr (NXR != kNXc || !streamed_class_ok(NWV, true, false, 1)) return hipErrorNotSupported;     // the DAE kernels hold two register-resident MLPs: x_dim <= 8
     else
     switch (NZM * 10 + NZA) {
         case 11: PSNODE_LAUNCH(1, 1, true)
         case 21: PSNODE_LAUNCH(2, 1, true)
         case 31: PSNODE_LAUNCH(3, 1, true)
-        case 41: PSNODE_LAUNCH(4, 1, true)
         case 32: PSNODE_LAUNCH(3, 2, true)
-        case 42: PSNODE_LAUNCH(4, 2, true)
-        default: return hipErrorNotSupported;
+        default:
+            if constexpr (streamed_class_ok(NWV, true, false, 4)) {
+                switch (NZM * 10 + NZA) {
+                    case 41: PSNODE_LAUNCH(4, 1, true)
+                    case 42: PSNODE_LAUNCH(4, 2, true)
+                    default: return hipErrorNotSupported;
+                }
+            }
+            return hipErrorNotSupported;
     }
 #undef PSNODE_LAUNCH
 }
@@ -698,7 +817,11 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     p.out_dim = a.xd;
     p.out = pack;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, p);
-    float* pack_ae = pack + (size_t)NWV * (max_regs(NWV) + NA) * 64;
+    const size_t one = (size_t)NWV * (max_regs(NWV) + NA) * 64 + stream_image_floats(NWV);
+    if constexpr (weights_streamed(NWV))     // the stream image sits right behind the register image of its MLP (Tail::gw)
+        hipLaunchKernelGGL(pack_stream_kernel, dim3(64), dim3(256), 0, stream, p,
+                           reinterpret_cast<f4*>(pack + (size_t)NWV * (pack_fwd_count(p)) * 64));
+    float* pack_ae = pack + one;
     if (dae) {
         PackMfma q = p;
         q.ae = 1; q.NB = 0; q.NE = nza_of(a); q.fold = 0;
@@ -707,6 +830,9 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
         q.out_dim = a.id;
         q.out = pack_ae;
         hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, q);
+        if constexpr (weights_streamed(NWV))
+            hipLaunchKernelGGL(pack_stream_kernel, dim3(64), dim3(256), 0, stream, q,
+                               reinterpret_cast<f4*>(pack_ae + (size_t)NWV * (pack_fwd_count(q)) * 64));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -55,6 +55,11 @@ struct PackMfma {
 
 // the hidden width the MFMA kernels run a width-h MLP at (0: none)
 __host__ __device__ inline int padded_hidden(int h) { return h < 1 ? 0 : (h <= 32 ? 32 : (h <= 64 ? 64 : (h <= 128 ? 128 : 0))); }
+// ... and the FORWARD kernels K1 / K2 alone (round 4): 129..192 -> 12 waves, 193..256 -> 16 waves per tile, the H->H weights of these
+// two classes streamed from the L2-resident image every layer (no CU holds them: two 256 x 256 fp32 matrices are the whole register file)
+__host__ __device__ inline int padded_hidden_fwd(int h) { return h <= 128 ? padded_hidden(h) : (h <= 192 ? 192 : (h <= 256 ? 256 : 0)); }
+// source wave of chunk c in wave w: (w + c) mod nw  (w, c < nw; nw need not be a power of two: 12 waves at hidden 192)
+__host__ __device__ constexpr int wrap_wave(int x, int nw) { return (nw & (nw - 1)) == 0 ? (x & (nw - 1)) : (x >= nw ? x - nw : x); }
 
 __host__ __device__ inline int pack_fwd_count(const PackMfma& p) { return p.NX + p.NB + p.NE + 20 + 8 * p.nw + p.NA; }
 
@@ -89,13 +94,13 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
         const int uu = 16 * w + 4 * g + (reg - B1);
         if (uu < H) v = p.b1[uu];
     } else if (reg < B2) {
-        const int kk = reg - W2, ws = (w + (kk >> 2)) & (p.nw - 1), col = 16 * ws + 4 * g + (kk & 3);
+        const int kk = reg - W2, ws = wrap_wave(w + (kk >> 2), p.nw), col = 16 * ws + 4 * g + (kk & 3);
         if (urow && col < H) v = p.w2[u * H + col];
     } else if (reg < W3) {
         const int uu = 16 * w + 4 * g + (reg - B2);
         if (uu < H) v = p.b2[uu];
     } else if (reg < B3) {
-        const int kk = reg - W3, ws = (w + (kk >> 2)) & (p.nw - 1), col = 16 * ws + 4 * g + (kk & 3);
+        const int kk = reg - W3, ws = wrap_wave(w + (kk >> 2), p.nw), col = 16 * ws + 4 * g + (kk & 3);
         if (urow && col < H) v = p.w3[u * H + col];
     } else if (reg < W4) {
         const int uu = 16 * w + 4 * g + (reg - B3);

@@ -287,6 +287,38 @@ def _aligned_ptr(ws: torch.Tensor):
     return p, ws.numel() - (p - ws.data_ptr())
 
 
+_MFMA_CLASSES = ("MFMA integrators K1 / K2 cover `in -> H -> H -> H -> out` ELU-MLPs with H <= 128 (any x_dim <= 16 for the ODE, "
+                 "x_dim <= 8 and z+v+i <= 8 for the DAE), and -- weights streamed from L2 -- the ODE up to H = 192 at any x_dim <= 16 and "
+                 "up to H = 256 at x_dim <= 8, the DAE up to H = 192 with z+v+i <= 6")
+_k0_warned = False
+
+
+def _mfma_miss(rc: int, kernel: str, what: str, de_layers: Layers):
+    """kernel='mfma' on a shape the MFMA integrators do not carry: say which shapes they do, and what the fallback costs."""
+    if rc == -5 and kernel == "mfma":
+        widths = [int(w.shape[0]) for w, _ in de_layers[:-1]]
+        raise _lib.UnsupportedShapeError(
+            f"{what}: no MFMA integrator for hidden widths {widths}.  {_MFMA_CLASSES}.  kernel='auto' runs this shape on the generic "
+            "kernel K0 (any width that fits the 160 KB LDS), at roughly 10x the time per state-step (40.5 vs 3.9 ms per 4096 x 1000 "
+            "RK4 batch at hidden 64; DESIGN.md 'Shapes without an MFMA specialisation')")
+
+
+def _note_k0(lib, args, dae: bool, de_layers: Layers):
+    """AUTO landing on K0 with a no_encode-style MLP wider than the MFMA classes: never silently ~10x slower."""
+    global _k0_warned
+    if _k0_warned or len(de_layers) != 4:
+        return
+    widths = [int(w.shape[0]) for w, _ in de_layers[:-1]]
+    if len(set(widths)) != 1 or widths[0] <= 128:
+        return
+    k = (lib.psnode_dae_kernel_for if dae else lib.psnode_ode_kernel_for)(ctypes.byref(args))
+    if k == _lib.KERNEL_GENERIC:
+        _k0_warned = True
+        import warnings
+        warnings.warn(f"hidden width {widths[0]} runs on the generic kernel K0, roughly 10x the time per state-step of the MFMA "
+                      f"integrators.  {_MFMA_CLASSES}", RuntimeWarning, stacklevel=3)
+
+
 def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=None, z_jump=None,
                   input_true_x: bool = False, kernel: str = "auto", event_idx: Optional[torch.Tensor] = None,
                   check_events: bool = False, out: Optional[torch.Tensor] = None, save: bool = False):
@@ -354,7 +386,10 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
         ws = _workspace(lib, a.de, None, dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_ode_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _mfma_miss(rc, kernel, "psnode_ode_integrate_f32", de_layers)
     _lib.check(rc, "psnode_ode_integrate_f32")
+    if kernel == "auto":
+        _note_k0(lib, a, False, de_layers)
     # the stream-ordered caching allocator keeps `keep`/`ws` storage valid until the kernel has run
     return (out, saved) if save else out
 
@@ -458,7 +493,10 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
         ws = _workspace(lib, a.de, a.ae, dev)
         wp, wn = _aligned_ptr(ws)
         rc = lib.psnode_dae_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _mfma_miss(rc, kernel, "psnode_dae_integrate_f32", de_layers)
     _lib.check(rc, "psnode_dae_integrate_f32")
+    if kernel == "auto":
+        _note_k0(lib, a, True, de_layers)
     return (xs, is_, saved) if save else (xs, is_)
 
 

@@ -67,6 +67,6 @@ def test_default_bench_line_carries_the_extra_workloads():
         fam = e["roofline"]["kernel_ms_by_family"]
         assert e["grads_finite"] and fam["forward"] > 0 and fam["backward"] > fam["forward"] and e["host_enqueue_ms"] > 0
         assert e["roofline"]["flop_convention"].startswith("3 x forward")
-    assert tr[0]["saved_bytes"] > 0 and tr[3]["saved_bytes"] == 0          # RK4 reads saved activations, DAE_01 Euler at hidden 64 recomputes
+    assert all(e["saved_bytes"] > 0 for e in tr)       # every hidden-64 / 128 training step reads saved activations (DAE_01 Euler too since round 4)
     assert [e["roofline"]["bound"] for e in d["extra"][:4]] == ["mfma", "valu_fp32", "mfma", "mfma"]      # K3f issues no MFMA
     assert d["roofline"]["kernel_ms_median"] > 0

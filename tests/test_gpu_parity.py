@@ -161,6 +161,71 @@ def test_mfma_kernel_hidden_widths(xd, zd, method, H):
     _check_mfma_ode(xd, zd, method, H)
 
 
+@pytest.mark.parametrize("H", [192, 256, 130, 200])
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd", [(8, 2), (3, 0), (8, 8)])
+def test_mfma_kernel_streamed_hidden_widths(xd, zd, method, H):
+    """--hidden 129..256 (round 4): 12 / 16 waves per tile, the H->H weights streamed from the L2-resident stream image every layer
+    (psnode_mfma_impl.h `weights_streamed`); in-between widths zero-padded to 192 / 256.  Forced with kernel='mfma': events, ragged
+    clocks, teacher forcing."""
+    _check_mfma_ode(xd, zd, method, H)
+
+
+@pytest.mark.parametrize("method", ["euler", "rk4"])
+def test_mfma_kernel_streamed_widths_wide_state_and_dae(method):
+    """At 12 waves (hidden 129..192) the ODE carries x_dim 9..16 and the DAE runs streamed as well (z+v+i <= 6)."""
+    _check_mfma_ode(12, 2, method, 192)
+    _check_mfma_ode(16, 4, method, 160)
+    _check_mfma_dae(8, 2, 2, 2, method, 192)
+    _check_mfma_dae(5, 1, 1, 1, method, 144)
+    _check_mfma_dae(8, 0, 2, 2, method, 192)
+
+
+def test_streamed_width_classes_that_fall_back_are_reported_and_still_right():
+    """What the streamed widths do NOT carry (they would spill at 128 VGPRs per lane): the DAE and x_dim > 8 above hidden 192, the DAE
+    with z+v+i > 6 above 128.  kernel_for says GENERIC, kernel='mfma' refuses, AUTO runs K0 and matches the oracle."""
+    import ctypes
+    from py_psnode_amd import _lib
+    lib = _lib.load()
+    a = _lib.OdeArgsF32()
+    a.method, a.x_dim, a.z_dim, a.T, a.B = _lib.RK4_38, 8, 2, 11, 16
+    a.de.n_layers, a.de.in_dim = 4, 30
+    for H, want in ((192, _lib.KERNEL_MFMA), (256, _lib.KERNEL_MFMA), (257, _lib.KERNEL_GENERIC)):
+        for k, o in enumerate((H, H, H, 8)):
+            a.de.out_dim[k] = o
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == want, H
+    a.x_dim, a.de.in_dim, a.de.out_dim[3] = 12, 3 * 14, 12
+    for H, want in ((192, _lib.KERNEL_MFMA), (256, _lib.KERNEL_GENERIC)):
+        for k in range(3):
+            a.de.out_dim[k] = H
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == want, H
+    d = _lib.DaeArgsF32()
+    d.method, d.x_dim, d.z_dim, d.v_dim, d.i_dim, d.T, d.B = _lib.RK4_38, 8, 2, 2, 2, 11, 16
+    d.de.n_layers, d.de.in_dim, d.ae.n_layers, d.ae.in_dim = 4, 42, 4, 26
+    for H, want in ((192, _lib.KERNEL_MFMA), (256, _lib.KERNEL_GENERIC)):
+        for k, (o1, o2) in enumerate(zip((H, H, H, 8), (H, H, H, 2))):
+            d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
+        assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == want, H
+    de, ae, t, x, z, v, i, xi, a0, ev, zj, vj = _synthetic_dae(9, 7, 8, 2, 2, 2, seed=23, H=256)
+    c = lambda q: q.cuda()
+    with pytest.raises(ValueError):
+        fused().dae_integrate("rk4", dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), kernel="mfma")
+    ref_x, ref_i = O.integrate_dae("rk4", de, ae, xi, t, x, z, v, i, a0)
+    xs, is_ = fused().dae_integrate("rk4", dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0))
+    assert rel_err(xs.cpu(), ref_x) <= TOL_GPU and rel_err(is_.cpu(), ref_i) <= TOL_GPU
+
+
+def test_streamed_width_full_batch_subset_vs_oracle():
+    """hidden 256 at the headline batch (B=4096 x 200 steps, RK4): 16 waves per tile on every CU, 20 trajectories against the oracle."""
+    B, Tn = 4096, 201
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, seed=2, H=256)
+    out = fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
+    idx = torch.tensor(sorted(set(range(0, B, 230)) | {B - 1, 17}))
+    ref = O.integrate_ode("rk4", ls, t[:, idx], x[:, idx], z[:, idx], a0[idx])
+    assert torch.isfinite(out).all()
+    assert rel_err(out[:, idx.cuda()].cpu(), ref) <= TOL_GPU
+
+
 @pytest.mark.parametrize("H", [7, 20, 48, 100, 127])
 @pytest.mark.parametrize("method", METHODS)
 def test_mfma_kernel_other_hidden_widths_run_zero_padded(method, H):
@@ -396,8 +461,8 @@ def test_auto_picks_mfma_for_reference_shape():
         assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
     a.x_dim, a.de.in_dim, a.de.out_dim[3] = 17, 3 * 19, 17
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
-    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=160)
-    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel above hidden 128
+    ls, t, x, z, a0 = _synthetic_ode(4, 3, H=300)
+    with pytest.raises(ValueError):      # PSNODE_ERR_UNSUPPORTED: no MFMA kernel above hidden 256
         fused().ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="mfma")
 
 
