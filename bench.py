@@ -45,6 +45,9 @@ WORKLOADS = {
     # BASELINE's literal "enc/dec 64 -> 16 latent": encoders / decoder of hidden 64 on the MFMA row kernels (K3b) around the 16-wide
     # latent integrator (K3f); an extension kwarg of models.ODE_Model -- upstream has ONE hidden_dim for all three
     "ode02_enc64": dict(kind="ode02_model", B=4096, T=1001, xd=8, zd=2, H=16, E=64, nh=1),
+    # the whole DAE_02 direct_encode forward as the script ships it (hidden 64, neural_01_DAE_02_direct_encode.py:267):
+    # Init_Func, four encoders, latent integrate_DAE, both decoders of the solution, both reconstructions -- one launch behind Init_Func (K3g)
+    "dae02": dict(kind="dae02_model", B=4096, T=1001, xd=8, zd=2, vd=2, id=2, H=64, nh=1),
 }
 
 
@@ -71,6 +74,15 @@ def make_problem(w, B, T, seed_offset=0):
         model = models.ODE_Model(xd, zd, w["H"], direct_encode=True, solver=nd.RK4(), enc_hidden=w.get("E"))
         model.solver.fused = "require"
         p = dict(model=model, de=[(l.weight.detach(), l.bias.detach()) for l in model.de_func.x_dot if isinstance(l, torch.nn.Linear)])
+    elif w["kind"] == "dae02_model":
+        from py_psnode_amd import models
+        from py_psnode_amd import neural_dae as nd
+        torch.manual_seed(0)
+        model = models.DAE_Model(xd, zd, vd, idim, w["H"], direct_encode=True, solver=nd.RK4())
+        model.solver.fused = "require"
+        model.one_launch = os.environ.get("PSNODE_DAE02_ONE_LAUNCH", "1") == "1"     # this workload times K3g unless told otherwise
+        lin = lambda seq: [(l.weight.detach(), l.bias.detach()) for l in seq if isinstance(l, torch.nn.Linear)]
+        p = dict(model=model, de=lin(model.de_func.x_dot), ae=lin(model.ae_func.i_calculator))
     else:
         p = dict(de=mlp([3 * n] + [w["H"]] * w["nh"] + [xd], 0))
     p["t"] = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
@@ -81,6 +93,12 @@ def make_problem(w, B, T, seed_offset=0):
     p["z_jump"] = torch.zeros(B, 2, zd)
     if w["kind"] == "ode02_model":
         p["a0"] = torch.zeros(1)
+    elif w["kind"] == "dae02_model":
+        p["a0"] = torch.zeros(1)
+        p["x"] = 0.1 * torch.randn(B, T, xd, generator=g)           # the reconstruction reads every row
+        p["v"] = 0.1 * torch.randn(B, T, vd, generator=g)
+        p["i"] = 0.1 * torch.randn(B, T, idim, generator=g)
+        p["v_jump"] = torch.zeros(B, 2, vd)
     elif w["kind"] == "dae":
         p["ae"] = mlp([n + xd + zd + vd] + [w["H"]] * w["nh"] + [idim], 7)
         p["v"] = 0.1 * torch.randn(B, T, vd, generator=g)
@@ -112,6 +130,9 @@ def run_fused(fused, w, p, method, kernel):
     if w["kind"] == "ode02_model":
         with torch.no_grad():
             return p["model"](t=p["t"], x=p["x"], z=p["z"], event_t=p["event_t"], z_jump=p["z_jump"])[:1]
+    if w["kind"] == "dae02_model":
+        with torch.no_grad():
+            return p["model"](t=p["t"], x=p["x"], z=p["z"], v=p["v"], i=p["i"], event_t=p["event_t"], z_jump=p["z_jump"], v_jump=p["v_jump"])
     if w["kind"] == "ode":
         return (fused.ode_integrate(method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                     event_t=p["event_t"], z_jump=p["z_jump"], kernel=kernel),)
@@ -131,6 +152,21 @@ def run_oracle(O, w, p, method, T):
             de = [(l.weight, l.bias) for l in m.de_func.x_dot if isinstance(l, torch.nn.Linear)]
             sol = O.integrate_ode(method, de, sl(p["t"]), Xh, Zh, torch.cat((Xh[0], Zh[0]), -1), p["event_t"], seq(m.z_encoder, p["z_jump"]))
             return seq(m.x_decoder, sol), seq(m.x_decoder, Xh)
+    if w["kind"] == "dae02_model":
+        import torch.nn.functional as F
+        m = p["model"]
+        seq = lambda s, a: F.linear(F.elu(F.linear(a, s[0].weight, s[0].bias)), s[2].weight, s[2].bias)
+        lin = lambda s: [(l.weight, l.bias) for l in s if isinstance(l, torch.nn.Linear)]
+        with torch.no_grad():
+            x, z, v, i = (p[k][:, :T] for k in "xzvi")
+            x0 = m.init_func(z0=z[:, 0], v0=v[:, 0], i0=i[:, 0])
+            Xh0, Xh, Zh, Vh, Ih = seq(m.x_encoder, x0), tmv(seq(m.x_encoder, x)), tmv(seq(m.z_encoder, z)), tmv(seq(m.v_encoder, v)), tmv(seq(m.i_encoder, i))
+            Xs, Is = O.integrate_dae(method, lin(m.de_func.x_dot), lin(m.ae_func.i_calculator), Xh0, sl(p["t"]), Xh, Zh, Vh, Ih,
+                                     torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), -1), p["event_t"], seq(m.z_encoder, p["z_jump"]),
+                                     seq(m.v_encoder, p["v_jump"]))
+            xp = seq(m.x_decoder, Xs)
+            xp[0] = x0
+            return xp, seq(m.i_decoder, Is), seq(m.x_decoder, Xh), seq(m.i_decoder, Ih)
     if w["kind"] == "ode":
         return O.integrate_ode(method, p["de"], sl(p["t"]), sl(p["x"]), sl(p["z"]), p["a0"], p["event_t"], p["z_jump"])
     return O.integrate_dae(method, p["de"], p["ae"], p["x_init"], sl(p["t"]), sl(p["x"]), sl(p["z"]), sl(p["v"]), sl(p["i"]),
@@ -143,8 +179,11 @@ def flops_per_state_step(w, p, method):
     if w["kind"] == "ode02_model":   # + enc x, enc z, 2x dec per grid point (2 880 flop at H=16)
         H, xd, zd, E = w["H"], w["xd"], w["zd"], w.get("E", w["H"])
         f += 2 * ((xd * E + E * H) + (zd * E + E * H) + 2 * (H * E + E * xd))
-    if w["kind"] == "dae":
+    if w["kind"] in ("dae", "dae02_model"):
         f += 2 * mlp_macs(p["ae"])
+    if w["kind"] == "dae02_model":   # + enc z, enc v, enc x, enc i, 2 x dec x, 2 x dec i per grid point (dense count, as SURVEY 8(d) does for ODE_02)
+        H, xd, zd, vd, idim = w["H"], w["xd"], w["zd"], w["vd"], w["id"]
+        f += 2 * (sum(d * H + H * H for d in (xd, zd, vd, idim)) + 2 * (H * H + H * xd) + 2 * (H * H + H * idim))
     return f
 
 
@@ -152,6 +191,8 @@ def bytes_per_state_step(w):
     """Compulsory HBM traffic per state-step: read t + external inputs, write the outputs."""
     if w["kind"] == "ode02_model":   # fully fused ideal: read x, z, t; write x_pred, x_re
         return 4 * (w["xd"] + w["zd"] + 1 + 2 * w["xd"])
+    if w["kind"] == "dae02_model":   # fully fused: read t, x, z, v, i; write x_pred, i_pred, x_re, i_re
+        return 4 * (1 + w["xd"] + w["zd"] + w["vd"] + w["id"] + 2 * w["xd"] + 2 * w["id"])
     rd = 4 * (1 + w["zd"] + w.get("vd", 0))
     wr = 4 * (w["xd"] + w.get("id", 0))
     return rd + wr
@@ -210,7 +251,7 @@ def cpu_baseline(w, p_cpu, method, budget_s=12.0, gpu_out=None):
 def kernel_name_for(lib, _lib, fused, w, p, method, kernel, dev):
     """Which kernel family `auto` resolves to for this workload (what `config.kernel` and the pmc_traffic.json key say)."""
     B, T = w["B"], w["T"]
-    if w["kind"] == "ode02_model":
+    if w["kind"] in ("ode02_model", "dae02_model"):
         auto_kernel = 2
     elif w["kind"] == "ode":
         a = _lib.OdeArgsF32()
@@ -254,7 +295,7 @@ def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10):
     B, T = w["B"], w["T"]
     p_cpu = make_problem(w, B, T)
     p = to_dev(p_cpu, dev)
-    if w["kind"] == "ode02_model":
+    if w["kind"] in ("ode02_model", "dae02_model"):
         from py_psnode_amd import neural_dae as nd
         p["model"].solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
         p["model"].solver.fused, p["model"].solver.kernel = "require", "auto"
@@ -492,12 +533,12 @@ def main():
     B, T = w["B"], w["T"]
     p_cpu = make_problem(w, B, T, seed_offset=rank)
     p = to_dev(p_cpu, dev)
-    if w["kind"] == "ode02_model":
+    if w["kind"] in ("ode02_model", "dae02_model"):
         from py_psnode_amd import neural_dae as nd
         for mdl in (p["model"], p_cpu["model"]):
             mdl.solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[args.method]()
             mdl.solver.fused, mdl.solver.kernel = "require", args.kernel
-    n_out = 1 if w["kind"] == "ode" else 2
+    n_out = 1 if w["kind"] == "ode" else (4 if w["kind"] == "dae02_model" else 2)
     from py_psnode_amd import sharded
     do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train   # training never gathers (sharded loss)
     pipelined = do_gather and w["kind"] in ("ode", "dae") and args.chunks > 1

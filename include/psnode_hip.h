@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 5
+#define PSNODE_ABI_VERSION 6
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
 
@@ -508,6 +508,40 @@ typedef struct {
 
 int32_t psnode_ode_encoded_supported(const psnode_ode_encoded_args_f32* args);   /* 1 / 0, dims only */
 int32_t psnode_ode_encoded_integrate_f32(const psnode_ode_encoded_args_f32* args, void* stream);
+
+/* The whole DAE_Model.forward of neural_01_DAE_02_direct_encode.py:125-153 at its shipped hidden_dim 64 in ONE launch (K3g; ABI 6):
+ *   Xh0 = x_encoder(x0)                                   x0 = Init_Func(z[0], v[0], i[0]), computed by the caller (once per batch)
+ *   Zh = z_encoder(z) (absent when z_dim == 0), Vh = v_encoder(v), Xh = x_encoder(x), Ih = i_encoder(i)
+ *   all_initial = cat(Xh0, Zh[0], Vh[0], Ih[0]);  jumps = z_encoder(z_jump) | v_encoder(v_jump)
+ *   (Xh_sol, Ih_sol) = integrate_DAE(x_init = Xh0, latent DE 12H|9H -> H -> H, latent AE 7H|5H -> H -> H)      (my_solvers.py:82-131)
+ *   x_pred = x_decoder(Xh_sol), x_pred[0] = x0;  i_pred = i_decoder(Ih_sol);  x_re = x_decoder(Xh);  i_re = i_decoder(Ih)
+ * t, x, z, v, i are the scripts' RAW tensors as time-major views; z_jump / v_jump the RAW [B,nE,*] tensors; event_idx as produced by
+ * psnode_event_table_f32.  Every encoder is Linear(in,64) ELU Linear(64,64) (x_dim <= 16; z_dim, v_dim, i_dim <= 8), every decoder
+ * Linear(64,64) ELU Linear(64,out).  None of the six latent [T,B,64] tensors reaches memory.  x_re / i_re: both or neither (NULL: the
+ * reconstruction and the x / i encoders' per-row work are skipped; x may then be NULL too).  Workspace: the packed weight images. */
+typedef struct {
+    int32_t method;                  /* psnode_method */
+    int32_t x_dim, z_dim, v_dim, i_dim;
+    int64_t T, B;
+    psnode_mlp_f32 x_encoder, z_encoder, v_encoder, i_encoder, x_decoder, i_decoder, de, ae;
+    psnode_view_f32 t, x, z, v, i;   /* [T,B,1], [T,B,x_dim], [T,B,z_dim], [T,B,v_dim], [T,B,i_dim] */
+    const float* x0;                 /* [B, x_dim] contiguous */
+    const int32_t* event_idx;        /* int32[T-1] or NULL */
+    const float* z_jump;             /* raw [B,nE,z_dim] */
+    int64_t zj_stride_b, zj_stride_e;
+    const float* v_jump;             /* raw [B,nE,v_dim] */
+    int64_t vj_stride_b, vj_stride_e;
+    float* x_pred;                   /* [T,B,x_dim] contiguous */
+    float* i_pred;                   /* [T,B,i_dim] contiguous */
+    float* x_re;                     /* x_re[t*xre_stride_t + b*xre_stride_b + d], or NULL */
+    int64_t xre_stride_t, xre_stride_b;
+    float* i_re;                     /* i_re[t*ire_stride_t + b*ire_stride_b + d], or NULL */
+    int64_t ire_stride_t, ire_stride_b;
+} psnode_dae_encoded_args_f32;
+
+int32_t psnode_dae_encoded_supported(const psnode_dae_encoded_args_f32* args);   /* 1 / 0, dims only */
+size_t psnode_dae_encoded_workspace_bytes(const psnode_dae_encoded_args_f32* args);
+int32_t psnode_dae_encoded_integrate_f32(const psnode_dae_encoded_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row width Hp of save_act for these dims (32 / 64 / 128) if an AUTO / MFMA call can save its activations, else 0 (dims only). */
 int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);

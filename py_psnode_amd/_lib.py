@@ -15,11 +15,12 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 5          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 6          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
                          #     psnode_dae_save_hidden;
-                         #  5: flags (+ x_true / i_true) in psnode_ode_bwd_args_f32 / psnode_dae_bwd_wide_args_f32: teacher-forced backward)
+                         #  5: flags (+ x_true / i_true) in psnode_ode_bwd_args_f32 / psnode_dae_bwd_wide_args_f32: teacher-forced backward;
+                         #  6: psnode_dae_encoded_*: the DAE_02 model forward in one launch)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -34,6 +35,7 @@ EXPORTS = (
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
+    "psnode_dae_encoded_supported", "psnode_dae_encoded_workspace_bytes", "psnode_dae_encoded_integrate_f32",
     "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
     "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
     "psnode_dae_backward_wide_ae_floats",
@@ -109,6 +111,19 @@ class OdeEncodedArgsF32(ctypes.Structure):
                 ("t", ViewF32), ("x", ViewF32), ("z", ViewF32), ("event_idx", c_void_p), ("z_jump", c_void_p),
                 ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("x_pred", c_void_p), ("x_re", c_void_p),
                 ("xre_stride_t", c_int64), ("xre_stride_b", c_int64), ("xh_out", c_void_p)]
+
+
+class DaeEncodedArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
+                ("T", c_int64), ("B", c_int64),
+                ("x_encoder", MlpF32), ("z_encoder", MlpF32), ("v_encoder", MlpF32), ("i_encoder", MlpF32),
+                ("x_decoder", MlpF32), ("i_decoder", MlpF32), ("de", MlpF32), ("ae", MlpF32),
+                ("t", ViewF32), ("x", ViewF32), ("z", ViewF32), ("v", ViewF32), ("i", ViewF32), ("x0", c_void_p),
+                ("event_idx", c_void_p), ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
+                ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64),
+                ("x_pred", c_void_p), ("i_pred", c_void_p),
+                ("x_re", c_void_p), ("xre_stride_t", c_int64), ("xre_stride_b", c_int64),
+                ("i_re", c_void_p), ("ire_stride_t", c_int64), ("ire_stride_b", c_int64)]
 
 
 class OdeBwdWideArgsF32(ctypes.Structure):
@@ -233,6 +248,12 @@ def load():
     lib.psnode_ode_encoded_supported.argtypes = [ctypes.POINTER(OdeEncodedArgsF32)]
     lib.psnode_ode_encoded_integrate_f32.restype = c_int32
     lib.psnode_ode_encoded_integrate_f32.argtypes = [ctypes.POINTER(OdeEncodedArgsF32), c_void_p]
+    lib.psnode_dae_encoded_supported.restype = c_int32
+    lib.psnode_dae_encoded_supported.argtypes = [ctypes.POINTER(DaeEncodedArgsF32)]
+    lib.psnode_dae_encoded_workspace_bytes.restype = c_size_t
+    lib.psnode_dae_encoded_workspace_bytes.argtypes = [ctypes.POINTER(DaeEncodedArgsF32)]
+    lib.psnode_dae_encoded_integrate_f32.restype = c_int32
+    lib.psnode_dae_encoded_integrate_f32.argtypes = [ctypes.POINTER(DaeEncodedArgsF32), c_void_p, c_size_t, c_void_p]
     lib.psnode_ode_backward_wide_supported.restype = c_int32
     lib.psnode_ode_backward_wide_supported.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
     lib.psnode_ode_backward_wide_workspace_bytes.restype = c_size_t

@@ -11,6 +11,9 @@
 // L1's `s - a0` and `s` column groups are folded:  Ws.s + Wd.(s - a0) = (Ws+Wd).s - Wd.a0, the a0 terms (+ bias, + the a0
 // column group) become a per-trajectory constant; external blocks (z, v, and the algebraic i) a per-step constant.
 // This halves L1's MFMAs; (Ws+Wd) is rounded once (relative 6e-8), far inside the 1e-5 gate (tests compare with the oracle).
+#include <cstdlib>
+#include <cstring>
+
 #include "psnode_common.h"
 
 namespace psnode {
@@ -311,6 +314,818 @@ __global__ __launch_bounds__(256) void latent64_kernel(const IntegrateDev a, con
     }
 }
 
+// =====================================================================================================================================
+// K3g -- the whole DAE_Model.forward of neural_01_DAE_02_direct_encode.py:125-153 at its shipped hidden_dim 64 in ONE launch:
+//   Xh0 = x_encoder(x0);  Zh = z_encoder(z), Vh = v_encoder(v), (Xh, Ih) = (x_encoder(x), i_encoder(i));  a0 = cat(Xh0, Zh[0], Vh[0], Ih[0])
+//   (Xh_sol, Ih_sol) = integrate_DAE(latent DE / AE, jumps = encoders of the RAW z_jump / v_jump)
+//   x_pred = x_decoder(Xh_sol), x_pred[0] = x0;  i_pred = i_decoder(Ih_sol);  x_re = x_decoder(Xh);  i_re = i_decoder(Ih)
+// The latent tensors (six [T,B,64] arrays, ~1 KB per state-step through HBM on the K3b + K3c route) never reach memory: a step reads the
+// RAW rows (t, z, v and -- for the reconstructions -- x, i) and writes the four decoded rows.  Same decomposition as K3c (4 waves per
+// 16-trajectory tile, wave w owns hidden units and latent dims 16w..16w+15, 64x64 blocks in the mid-layer register format); per step the
+// tile additionally runs
+//   * the four encoders on the rows of grid point k+1: L1 (in <= 16 -> 64: 2..4 MFMAs), ELU, ONE exchange for the four hidden vectors,
+//     L2 (one 64x64 block each), ONE exchange for the four outputs -- Zh | Vh feed the AE head now and the DE's per-step constant next
+//     step, Xh | Ih go to the decoders (the reconstruction);
+//   * the two decoders on four vectors (solution x, solution i, reconstruction x, reconstruction i): L1 = one block on the gathered
+//     vector, ELU, L2 split-K over the waves' own units (4 MFMAs), ONE exchange in which wave d collects output d from the four waves,
+//     adds the bias and stores it -- x_pred, i_pred, x_re, i_re are written by waves 0..3.
+// => 13 exchanges and ~390 MFMAs per wave and RK4 step (K3c: 10 and 240; the K3b row kernels it replaces ran the same 150 MFMAs per
+// 16 rows plus ~1 KB per row of HBM traffic).  Event steps encode the RAW jump rows on the spot.
+struct EncW { float w1[4]; f4 b1; float w2[16]; f4 b2; };        // encoder in -> 64 -> 64 (in <= 16)
+struct DecW { float w1[16]; f4 b1; float w2s[4]; f4 b2; };       // decoder 64 -> 64 -> out (out <= 16): L2 = this wave's K slice
+constexpr int kEncRegs = 28, kDecRegs = 28, kEncDecRegs = 4 * kEncRegs + 2 * kDecRegs;
+
+struct PackEncDec {
+    const float *w1[6], *b1[6], *w2[6], *b2[6];    // x_enc, z_enc, v_enc, i_enc, x_dec, i_dec  (z_enc may be all-null: z_dim == 0)
+    int in_dim[6], out_dim[6];
+    float* out;                                     // [wave][reg][lane]
+};
+
+__global__ void pack_encdec_kernel(const PackEncDec p) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NW64 * kEncDecRegs * 64; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, reg = (idx >> 6) % kEncDecRegs, w = (idx >> 6) / kEncDecRegs, i = lane & 15, g = lane >> 4, u = 16 * w + i;
+        const int m = reg / 28, q = reg % 28;
+        auto col = [&](int kk) { return 16 * ((w + (kk >> 2)) & 3) + 4 * g + (kk & 3); };
+        float v = 0.0f;
+        if (p.w1[m]) {
+            if (m < 4) {            // encoder
+                if (q < 4) { const int c = 4 * q + g; if (c < p.in_dim[m]) v = p.w1[m][(size_t)u * p.in_dim[m] + c]; }
+                else if (q < 8) v = p.b1[m][16 * w + 4 * g + (q - 4)];
+                else if (q < 24) v = p.w2[m][(size_t)u * H64 + col(q - 8)];
+                else v = p.b2[m][16 * w + 4 * g + (q - 24)];
+            } else {                // decoder
+                if (q < 16) v = p.w1[m][(size_t)u * H64 + col(q)];
+                else if (q < 20) v = p.b1[m][16 * w + 4 * g + (q - 16)];
+                else if (q < 24) { if (i < p.out_dim[m]) v = p.w2[m][(size_t)i * H64 + 16 * w + 4 * g + (q - 20)]; }
+                else { const int o = 4 * g + (q - 24); if (o < p.out_dim[m]) v = p.b2[m][o]; }
+            }
+        }
+        p.out[idx] = v;
+    }
+}
+
+struct ModelDev {
+    IntegrateDev a;          // method, T, B, raw dims xd | zd | vd | id, raw views t | x | z | v | i, ev, zj, vj, xo = x_pred, io = i_pred
+    const float* x0;         // [B, xd]: Init_Func's output
+    float* xre; long long xre_st, xre_sb;       // x_re[t * st + b * sb + d] or null
+    float* ire; long long ire_st, ire_sb;
+};
+
+template <int METHOD, bool HASZ>
+__global__ __launch_bounds__(256) void latent64_model_kernel(const ModelDev md, const float* __restrict__ pack_de,
+                                                              const float* __restrict__ pack_ae, const float* __restrict__ pack_ed) {
+    constexpr int NBE = HASZ ? 3 : 2, NBLK = 1 + NBE, NZV = NBE - 1;
+    constexpr int RDE = 16 * NBLK + 24 + 16 * NBLK, RAE = 16 * NBE + 24 + 16 * NBLK;
+    const IntegrateDev& a = md.a;
+    __shared__ f4 xbuf[2][NW64][64];
+    __shared__ f4 gbuf[2][4][NW64][64];
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = l >> 4, j = l & 15;
+    const long long b0 = (long long)blockIdx.x * 16;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const bool recon = md.xre != nullptr;
+
+    // ---- weights -> registers (latent DE / AE as K3c; encoders / decoders from the enc/dec image)
+    const float* pw = pack_de + (size_t)w * RDE * 64 + l;
+    float wf[NBLK][16], w2[16];
+    f4 b1r, b2r;
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wf[blk][k] = pw[(16 * blk + k) * 64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w2[k] = pw[(16 * NBLK + 4 + k) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b1r[r] = pw[(16 * NBLK + r) * 64]; b2r[r] = pw[(16 * NBLK + 20 + r) * 64]; }
+    const float* pwa = pack_ae + (size_t)w * RAE * 64 + l;
+    float af[NBE][16], aw2[16];
+    f4 ab1r, ab2r;
+#pragma unroll
+    for (int blk = 0; blk < NBE; ++blk)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) af[blk][k] = pwa[(16 * blk + k) * 64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) aw2[k] = pwa[(16 * NBE + 4 + k) * 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ab1r[r] = pwa[(16 * NBE + r) * 64]; ab2r[r] = pwa[(16 * NBE + 20 + r) * 64]; }
+    const float* pe = pack_ed + (size_t)w * kEncDecRegs * 64 + l;
+    auto load_enc = [&](const int m, EncW& e) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e.w1[q] = pe[(28 * m + q) * 64]; e.b1[q] = pe[(28 * m + 4 + q) * 64]; e.b2[q] = pe[(28 * m + 24 + q) * 64]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e.w2[q] = pe[(28 * m + 8 + q) * 64];
+    };
+    auto load_dec = [&](const int m, DecW& d) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d.w1[q] = pe[(28 * m + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d.b1[q] = pe[(28 * m + 16 + q) * 64]; d.w2s[q] = pe[(28 * m + 20 + q) * 64]; d.b2[q] = pe[(28 * m + 24 + q) * 64]; }
+    };
+    EncW ex, ez, evv, ei;
+    DecW dx, di;
+    load_enc(0, ex); load_enc(1, ez); load_enc(2, evv); load_enc(3, ei);
+    load_dec(4, dx); load_dec(5, di);
+
+    // 16 MFMAs of one 64x64 block against a chunk-layout vector, two accumulator chains
+    auto mm = [&](const float (&wr)[16], const V4& x, f4& accA, f4& accB) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            accA = mf(wr[4 * c + 0], x.v[c][0], accA); accB = mf(wr[4 * c + 1], x.v[c][1], accB);
+            accA = mf(wr[4 * c + 2], x.v[c][2], accA); accB = mf(wr[4 * c + 3], x.v[c][3], accB);
+        }
+    };
+    int p = 0, q2 = 0;
+    auto gather = [&](const f4 own) -> V4 {
+        xbuf[p][w][l] = own;
+        lds_barrier();
+        V4 o;
+        o.v[0] = own;
+#pragma unroll
+        for (int c = 1; c < 4; ++c) o.v[c] = xbuf[p][(w + c) & 3][l];
+        __builtin_amdgcn_sched_barrier(0);
+        p ^= 1;
+        return o;
+    };
+    // N vectors in one exchange (one barrier)
+    auto gather4 = [&](const f4 (&own)[4], V4 (&o)[4], const int n) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) if (s < n) gbuf[q2][s][w][l] = own[s];
+        lds_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < n) {
+                o[s].v[0] = own[s];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) o[s].v[c] = gbuf[q2][s][(w + c) & 3][l];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        q2 ^= 1;
+    };
+    auto layer = [&](const float (&wr)[16], const f4 init, const f4 own) -> f4 {
+        xbuf[p][w][l] = own;
+        f4 accA = init, accB = {0.f, 0.f, 0.f, 0.f};
+        accA = mf(wr[0], own[0], accA); accB = mf(wr[1], own[1], accB);
+        accA = mf(wr[2], own[2], accA); accB = mf(wr[3], own[3], accB);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        f4 vq[4];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) vq[c] = xbuf[p][(w + c) & 3][l];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f4 v = vq[c];
+            accA = mf(wr[4 * c + 0], v[0], accA); accB = mf(wr[4 * c + 1], v[1], accB);
+            accA = mf(wr[4 * c + 2], v[2], accA); accB = mf(wr[4 * c + 3], v[3], accB);
+        }
+        p ^= 1;
+        return accA + accB;
+    };
+
+    // ---- raw rows: lane (g, j) holds column 4m + g of trajectory j's row (the B operand of encoder L1's MFMA m), 0 beyond the width
+    struct Raw { float x[4], z[2], v[2], i[2]; };
+    const int xd = a.xd, zd = a.zd, vd = a.vd, idm = a.id;
+    const float* tp = a.t.p + b * a.t.sb;
+    const float* xp = a.x.p ? a.x.p + b * a.x.sb : tp;
+    const float* zp = HASZ ? a.z.p + b * a.z.sb : tp;
+    const float* vp = a.v.p + b * a.v.sb;
+    const float* ip = a.i.p ? a.i.p + b * a.i.sb : tp;
+    const long long xst = a.x.p ? a.x.st : 0, zst = HASZ ? a.z.st : 0, vst = a.v.st, ist = a.i.p ? a.i.st : 0;
+    auto colv = [&](const float* row, const int m, const int width) -> float {       // branch-free: clamped load, value select
+        const int c = 4 * m + g;
+        const float v = row[c < width ? c : 0];
+        return c < width ? v : 0.0f;
+    };
+    auto load_raw = [&](const long long k, Raw& r) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) r.x[m] = recon ? colv(xp + k * xst, m, xd) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r.z[m] = HASZ ? colv(zp + k * zst, m, zd) : 0.0f;
+            r.v[m] = colv(vp + k * vst, m, vd);
+            r.i[m] = recon ? colv(ip + k * ist, m, idm) : 0.0f;
+        }
+    };
+    auto enc_l1 = [&](const EncW& e, const float* raw, const int nm) -> f4 {      // ELU(b1 + W1 . raw)
+        f4 acc = e.b1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < nm) acc = mf(e.w1[m], raw[m], acc);
+        return elu4l(acc);
+    };
+    auto enc_l2 = [&](const EncW& e, const V4& h) -> f4 {
+        f4 accA = e.b2, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(e.w2, h, accA, accB);
+        return accA + accB;
+    };
+    const int nmx = (xd + 3) >> 2, nmz = (zd + 3) >> 2, nmv = (vd + 3) >> 2, nmi = (idm + 3) >> 2;
+    // the four encoders on one grid point's raw rows: out[0] = Xh (reconstruction), [1] = Zh, [2] = Vh, [3] = Ih (reconstruction), gathered
+    auto encode_rows = [&](const Raw& r, V4 (&out)[4]) {
+        f4 h[4];
+        h[0] = recon ? enc_l1(ex, r.x, nmx) : f4{0.f, 0.f, 0.f, 0.f};
+        h[1] = HASZ ? enc_l1(ez, r.z, nmz) : f4{0.f, 0.f, 0.f, 0.f};
+        h[2] = enc_l1(evv, r.v, nmv);
+        h[3] = recon ? enc_l1(ei, r.i, nmi) : f4{0.f, 0.f, 0.f, 0.f};
+        V4 hg[4];
+        gather4(h, hg, 4);
+        f4 o[4];
+        o[0] = recon ? enc_l2(ex, hg[0]) : h[0];
+        o[1] = HASZ ? enc_l2(ez, hg[1]) : h[1];
+        o[2] = enc_l2(evv, hg[2]);
+        o[3] = recon ? enc_l2(ei, hg[3]) : h[3];
+        gather4(o, out, 4);
+    };
+    // the z | v encoders alone (event steps: the RAW jump rows)
+    auto encode_zv = [&](const float (&rz)[2], const float (&rv)[2], V4 (&out)[4]) {
+        f4 h[4] = {};
+        h[0] = HASZ ? enc_l1(ez, rz, nmz) : f4{0.f, 0.f, 0.f, 0.f};
+        h[1] = enc_l1(evv, rv, nmv);
+        V4 hg[4];
+        gather4(h, hg, 2);
+        f4 o[4] = {};
+        o[0] = HASZ ? enc_l2(ez, hg[0]) : h[0];
+        o[1] = enc_l2(evv, hg[1]);
+        gather4(o, out, 2);
+    };
+    // ---- decoders: four vectors in, wave d stores output d (0: x_pred, 1: i_pred, 2: x_re, 3: i_re)
+    const bool is_i = (w & 1) != 0, is_re = w >= 2;
+    float* const obase = is_re ? (is_i ? md.ire : md.xre) : (is_i ? a.io : a.xo);
+    const int odim = is_i ? idm : xd;
+    const long long ost = is_re ? (is_i ? md.ire_st : md.xre_st) : a.B * odim, osb = is_re ? (is_i ? md.ire_sb : md.xre_sb) : odim;
+    const f4 ob2 = is_i ? di.b2 : dx.b2;
+    auto dec_part = [&](const DecW& d, const V4& vin) -> f4 {
+        f4 accA = d.b1, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(d.w1, vin, accA, accB);
+        const f4 h = elu4l(accA + accB);
+        f4 pa = mf(d.w2s[0], h[0], f4{0.f, 0.f, 0.f, 0.f}), pb = mf(d.w2s[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        pa = mf(d.w2s[2], h[2], pa); pb = mf(d.w2s[3], h[3], pb);
+        return pa + pb;
+    };
+    // first (grid point 0): wave 0's row is the raw x0 instead of the decoded one (neural_01_DAE_02_direct_encode.py:150).
+    // Returns this wave's output row (lane (g, j): dims 4g..4g+3 of trajectory j); the caller stores it at the top of the NEXT step, behind
+    // the loop-top s_waitcnt vmcnt(0) -- stores count in vmcnt on gfx9, and issued at the end of their own step the whole tile waited out
+    // their round trip every step (first build: 10.8 ms per 4096 x 1000 RK4 batch, slower than the five launches it replaces)
+    auto decode_rows = [&](const V4& xs, const V4& is_, const V4& xr, const V4& ir, const bool first) -> f4 {
+        gbuf[q2][0][w][l] = dec_part(dx, xs);
+        gbuf[q2][1][w][l] = dec_part(di, is_);
+        if (recon) { gbuf[q2][2][w][l] = dec_part(dx, xr); gbuf[q2][3][w][l] = dec_part(di, ir); }
+        lds_barrier();
+        f4 o = ob2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o += gbuf[q2][w][c][l];
+        q2 ^= 1;
+        if (first && w == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int d = 4 * g + r; o[r] = md.x0[b * xd + (d < xd ? d : 0)]; }
+        }
+        return o;
+    };
+    const bool storing = valid && (recon || !is_re);
+    float* orow = obase + b * osb + 4 * g;          // running output row pointer (this lane's first dim)
+    auto store_row = [&](const f4 o) {
+        if (storing) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < odim) orow[r] = o[r];
+        }
+        orow += ost;
+    };
+
+    // ---- grid point 0: encoders, all_initial, the constants c0 (DE) / c0a (AE), i_0
+    Raw r0;
+    load_raw(0, r0);
+    float x0raw[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) x0raw[m] = colv(md.x0 + b * xd, m, xd);
+    V4 enc0[4];
+    encode_rows(r0, enc0);                         // Xh[0] (reconstruction), Zh[0], Vh[0], Ih[0]
+    V4 ih0g = enc0[3];
+    // Xh0 = x_encoder(x0): own dims + gathered
+    f4 x;
+    V4 xg;
+    {
+        const f4 h = enc_l1(ex, x0raw, nmx);
+        const V4 hg = gather(h);
+        x = enc_l2(ex, hg);
+        xg = gather(x);
+    }
+    if (!recon) {       // i_encoder(i[0]) for all_initial (the raw i row is read only here)
+        float ri[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) ri[m] = colv(a.i.p + b * a.i.sb, m, idm);
+        const f4 h = enc_l1(ei, ri, nmi);
+        const V4 hg = gather(h);
+        ih0g = gather(enc_l2(ei, hg));
+    }
+    f4 c0A = b1r, c0B = {0.f, 0.f, 0.f, 0.f}, caA = ab1r, caB = c0B;
+    auto a0_block = [&](const int blk, const V4& a0v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 4 * c + r;
+                if (q & 1) { c0B = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0B); caB = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caB); }
+                else { c0A = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0A); caA = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caA); }
+            }
+    };
+    a0_block(0, xg);
+    if constexpr (HASZ) a0_block(1, enc0[1]);
+    a0_block(NBLK - 2, enc0[2]);
+    a0_block(NBLK - 1, ih0g);
+    const f4 c0 = c0A + c0B, c0a = caA + caB;
+
+    struct Ext { V4 b[2]; };       // Zh | Vh gathered (b[0] unused without z)
+    auto ae_eval = [&](const V4& xgv, const Ext& zv) -> f4 {
+        f4 accA = c0a, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(af[0], xgv, accA, accB);
+        if constexpr (HASZ) mm(af[1], zv.b[0], accA, accB);
+        mm(af[NBE - 1], zv.b[1], accA, accB);
+        const f4 h1 = elu4l(accA + accB);
+        return layer(aw2, ab2r, h1);
+    };
+    Ext ext_cur;
+    ext_cur.b[0] = enc0[1]; ext_cur.b[1] = enc0[2];
+    V4 ig = gather(ae_eval(xg, ext_cur));          // i_0 = g(x_0; z[0], v[0])  (my_solvers.py:95)
+    f4 o_prev = decode_rows(xg, ig, enc0[0], ih0g, true);
+    const long long nT = a.T, tst = a.t.st;
+    if (nT < 2) { store_row(o_prev); return; }
+
+    auto rhs_from_gathered = [&](const V4& xgv, const f4 cz) -> f4 {
+        f4 accA = cz, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(wf[0], xgv, accA, accB);
+        return layer(w2, b2r, elu4l(accA + accB));
+    };
+    auto rhs = [&](const f4 xs_own, const f4 cz) -> f4 { return layer(w2, b2r, elu4l(layer(wf[0], cz, xs_own))); };
+
+    float t_cur = tp[0], t_nxt = tp[tst];
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const bool has_ev = a.ev != nullptr;
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
+    int ev_cur = has_ev ? a.ev[0] : -1;
+    int ev_raw = evp[nT > 2 ? 1 : 0];
+    Raw rn;                                         // raw rows of grid point k+1, requested a step ahead
+    load_raw(1, rn);
+
+    for (long long k = 0; k + 1 < nT; ++k) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): everything in flight was requested a step ago
+        const float h_ = t_nxt - t_cur;
+        t_cur = t_nxt;
+        const Raw rk1 = rn;
+        const int ev_now = ev_cur;
+        const bool more = k + 2 < nT;
+        store_row(o_prev);                          // grid point k's outputs: a whole step to drain
+        {
+            const long long kn = more ? k + 2 : k + 1;          // the last step re-reads its own rows (unused)
+            t_nxt = tp[kn * tst];
+            ev_cur = (has_ev && more) ? ev_raw : -1;
+            load_raw(kn, rn);
+            ev_raw = evp[k + 3 < nT ? k + 2 : 0];
+        }
+        Ext ext_step = ext_cur;
+        if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {      // jump: encode the RAW jump rows, i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)
+            float rz[2], rv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                rz[m] = HASZ ? colv(a.zj + b * a.zjb + (long long)ev_now * a.zje, m, zd) : 0.0f;
+                rv[m] = colv(a.vj + b * a.vjb + (long long)ev_now * a.vje, m, vd);
+            }
+            V4 ej[4];
+            encode_zv(rz, rv, ej);
+            ext_step.b[0] = ej[0]; ext_step.b[1] = ej[1];
+            ig = gather(ae_eval(xg, ext_step));
+        }
+        // per-step constant: c0 + F_z . Zh + F_v . Vh + F_i . Ih
+        f4 czA = c0, czB = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HASZ) mm(wf[1], ext_step.b[0], czA, czB);
+        mm(wf[NBLK - 2], ext_step.b[1], czA, czB);
+        mm(wf[NBLK - 1], ig, czA, czB);
+        const f4 cz = czA + czB;
+
+        const f4 k1 = rhs_from_gathered(xg, cz);
+        if constexpr (METHOD == PSNODE_EULER) {
+            x = x + h_ * k1;
+        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+            const f4 k2 = rhs(x + k1 * (0.5f * h_), cz);
+            x = x + h_ * k2;
+        } else {
+            const f4 k2 = rhs(x + h_ * k1 * kOneThird, cz);
+            const f4 k3 = rhs(x + h_ * (k2 - k1 * kOneThird), cz);
+            const f4 k4 = rhs(x + h_ * (k1 - k2 + k3), cz);
+            x = x + (k1 + 3.0f * (k2 + k3) + k4) * h_ * 0.125f;
+        }
+        xg = gather(x);
+        V4 en[4];
+        encode_rows(rk1, en);                       // grid point k+1: Xh (reconstruction), Zh, Vh, Ih (reconstruction)
+        ext_cur.b[0] = en[1]; ext_cur.b[1] = en[2];
+        ig = gather(ae_eval(xg, ext_cur));          // i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]) with the un-jumped rows  (my_solvers.py:121)
+        o_prev = decode_rows(xg, ig, en[0], en[3], false);
+    }
+    store_row(o_prev);
+}
+
+constexpr size_t kModel2Lds = 18 * sizeof(f4) * NW64 * 64;       // xbuf[2] + slotA[4] + slotB[4] + slotC[4] + slotJ[2] vectors of 4 KB
+// K3g, two-role form (the default): 8 waves per 16-trajectory tile, 2 per SIMD, ONE barrier sequence.
+//   waves 0..3  "chain":  exactly K3c's work -- per-step constant, RK stages, AE head -- 240 MFMAs and 10 exchanges per RK4 step;
+//   waves 4..7  "rows":   the four encoders of grid point k+1 and the two decoders on the four vectors of grid point k -- 150 MFMAs per
+//                         step, cut into ten pieces that sit between the chain's ten barriers.
+// A barrier is a workgroup barrier, so both roles execute the SAME number of them per step; what differs is the work between them.
+// Data crosses roles through LDS at those barriers: the rows waves publish Zh | Vh of grid point k+1 (slot B) before the chain's AE
+// head needs them; the chain's own all-gathers of x_{k+1} and i_{k+1} are read by the rows waves as well (they decode them a step later).
+// Why two roles: (1) the straight fusion above holds 500 registers per lane, and everything beyond 256 is an AGPR that costs a
+// v_accvgpr_read per MFMA operand (318 per step); split in two, each role fits 256.  (2) K3c runs one wave per SIMD and idles through
+// every exchange (42 % of its cycles): the rows wave on the same SIMD issues its independent MFMAs exactly there.
+template <int METHOD, bool HASZ>
+__global__ __launch_bounds__(512) void latent64_model2_kernel(const ModelDev md, const float* __restrict__ pack_de,
+                                                               const float* __restrict__ pack_ae, const float* __restrict__ pack_ed) {
+    constexpr int NBE = HASZ ? 3 : 2, NBLK = 1 + NBE;
+    constexpr int RDE = 16 * NBLK + 24 + 16 * NBLK, RAE = 16 * NBE + 24 + 16 * NBLK;
+    constexpr int S = METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4);
+    constexpr int NBAR = 2 * S + 2;            // exchanges of the chain per step: (2S - 1) stage exchanges, gather x, AE hidden, gather i
+    const IntegrateDev& a = md.a;
+    typedef f4 Vec[NW64][64];                  // one 64-wide vector per trajectory, 16 dims per wave of a role
+    extern __shared__ f4 smem2[];              // 72 KB (kModel2Lds)
+    Vec* const xbuf = reinterpret_cast<Vec*>(smem2);        // [2]  the chain's exchanges (parity: an even number per step)
+    Vec* const slotA = xbuf + 2;               // [4]  rows: encoder hidden vectors x | z | v | i (jump steps: z | v of the jump rows first)
+    Vec* const slotB = slotA + 4;              // [4]  rows: encoder outputs Xh | Zh | Vh | Ih (own dims per rows-wave)
+    Vec* const slotC = slotB + 4;              // [4]  rows: decoder partials [output][wave]
+    Vec* const slotJ = slotC + 4;              // [2]  rows: encoder outputs of the jump rows z | v (read by the chain until barrier 1 of the step)
+    const int l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool chain = wave < NW64;
+    const int w = wave & 3;                    // unit / dim slice 16w..16w+15 inside the role
+    const int g = l >> 4, j = l & 15;
+    const long long b0 = (long long)blockIdx.x * 16;
+    const bool valid = b0 + j < a.B;
+    const long long b = valid ? b0 + j : a.B - 1;
+    const bool recon = md.xre != nullptr;
+    const long long nT = a.T, tst = a.t.st;
+    const int xd = a.xd, zd = a.zd, vd = a.vd, idm = a.id;
+    const float* tp = a.t.p + b * a.t.sb;
+    const bool has_ev = a.ev != nullptr;
+
+    auto mm = [&](const float (&wr)[16], const V4& x, f4& accA, f4& accB) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            accA = mf(wr[4 * c + 0], x.v[c][0], accA); accB = mf(wr[4 * c + 1], x.v[c][1], accB);
+            accA = mf(wr[4 * c + 2], x.v[c][2], accA); accB = mf(wr[4 * c + 3], x.v[c][3], accB);
+        }
+    };
+    auto read_gathered = [&](const Vec& buf) -> V4 {      // chunk layout of a vector the four waves of a role published
+        V4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o.v[c] = buf[(w + c) & 3][l];
+        return o;
+    };
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
+    auto colv = [&](const float* row, const int m, const int width) -> float {
+        const int c = 4 * m + g;
+        const float v = row[c < width ? c : 0];
+        return c < width ? v : 0.0f;
+    };
+
+    if (chain) {
+        // ================================================================ chain role (K3c's work)
+        const float* pw = pack_de + (size_t)w * RDE * 64 + l;
+        float wf[NBLK][16], w2[16];
+        f4 b1r, b2r;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wf[blk][k] = pw[(16 * blk + k) * 64];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w2[k] = pw[(16 * NBLK + 4 + k) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b1r[r] = pw[(16 * NBLK + r) * 64]; b2r[r] = pw[(16 * NBLK + 20 + r) * 64]; }
+        const float* pwa = pack_ae + (size_t)w * RAE * 64 + l;
+        float af[NBE][16], aw2[16];
+        f4 ab1r, ab2r;
+#pragma unroll
+        for (int blk = 0; blk < NBE; ++blk)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) af[blk][k] = pwa[(16 * blk + k) * 64];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) aw2[k] = pwa[(16 * NBE + 4 + k) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ab1r[r] = pwa[(16 * NBE + r) * 64]; ab2r[r] = pwa[(16 * NBE + 20 + r) * 64]; }
+
+        int p = 0;
+        auto gather = [&](const f4 own) -> V4 {
+            xbuf[p][w][l] = own;
+            lds_barrier();
+            V4 o;
+            o.v[0] = own;
+#pragma unroll
+            for (int c = 1; c < 4; ++c) o.v[c] = xbuf[p][(w + c) & 3][l];
+            __builtin_amdgcn_sched_barrier(0);
+            p ^= 1;
+            return o;
+        };
+        auto layer = [&](const float (&wr)[16], const f4 init, const f4 own) -> f4 {
+            xbuf[p][w][l] = own;
+            f4 accA = init, accB = {0.f, 0.f, 0.f, 0.f};
+            accA = mf(wr[0], own[0], accA); accB = mf(wr[1], own[1], accB);
+            accA = mf(wr[2], own[2], accA); accB = mf(wr[3], own[3], accB);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            f4 vq[4];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) vq[c] = xbuf[p][(w + c) & 3][l];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const f4 v = vq[c];
+                accA = mf(wr[4 * c + 0], v[0], accA); accB = mf(wr[4 * c + 1], v[1], accB);
+                accA = mf(wr[4 * c + 2], v[2], accA); accB = mf(wr[4 * c + 3], v[3], accB);
+            }
+            p ^= 1;
+            return accA + accB;
+        };
+        // ---- prologue (5 barriers, mirrored by the rows role): P1 hidden of enc(x0) | P2 Xh0 | P3 encoder hiddens of row 0 | P4 their outputs
+        //      | then the AE head of grid point 0 (2 exchanges)
+        lds_barrier();                                     // P1 (rows: hidden of x_encoder(x0) in slotA[0])
+        lds_barrier();                                     // P2 (rows: Xh0 own dims in slotB[0])
+        f4 x = slotB[0][w][l];
+        V4 xg = read_gathered(slotB[0]);
+        lds_barrier();                                     // P3 (rows: hiddens of row 0)
+        lds_barrier();                                     // P4 (rows: outputs of row 0 in slotB[0..3])
+        f4 c0A = b1r, c0B = {0.f, 0.f, 0.f, 0.f}, caA = ab1r, caB = c0B;
+        auto a0_block = [&](const int blk, const V4& a0v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 4 * c + r;
+                    if (q & 1) { c0B = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0B); caB = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caB); }
+                    else { c0A = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0A); caA = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caA); }
+                }
+        };
+        a0_block(0, xg);
+        if constexpr (HASZ) a0_block(1, read_gathered(slotB[1]));
+        a0_block(NBLK - 2, read_gathered(slotB[2]));
+        a0_block(NBLK - 1, read_gathered(slotB[3]));
+        const f4 c0 = c0A + c0B, c0a = caA + caB;
+        // AE head on the encoder outputs of the grid point the rows waves published last (slotB[1] = Zh, slotB[2] = Vh)
+        auto ae_eval = [&](const V4& xgv) -> f4 {
+            f4 accA = c0a, accB = {0.f, 0.f, 0.f, 0.f};
+            mm(af[0], xgv, accA, accB);
+            if constexpr (HASZ) { const V4 zg = read_gathered(slotB[1]); mm(af[1], zg, accA, accB); }
+            { const V4 vg = read_gathered(slotB[2]); mm(af[NBE - 1], vg, accA, accB); }
+            return layer(aw2, ab2r, elu4l(accA + accB));
+        };
+        // the DE's i block of the per-step constant is formed right behind the gather of i (F_i . Ih: 4 registers carried instead of the
+        // gathered vector's 16 -- the chain role lives at 256 registers per lane)
+        auto fi_of = [&](const V4& igv) -> f4 {
+            f4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
+            mm(wf[NBLK - 1], igv, accA, accB);
+            return accA + accB;
+        };
+        f4 czi = fi_of(gather(ae_eval(xg)));               // 2 exchanges: i_0 = g(x_0; z[0], v[0])  (my_solvers.py:95)
+        if (nT < 2) { lds_barrier(); return; }             // (rows: partials of grid point 0)
+
+        auto rhs_from_gathered = [&](const V4& xgv, const f4 cz) -> f4 {
+            f4 accA = cz, accB = {0.f, 0.f, 0.f, 0.f};
+            mm(wf[0], xgv, accA, accB);
+            return layer(w2, b2r, elu4l(accA + accB));
+        };
+        auto rhs = [&](const f4 xs_own, const f4 cz) -> f4 { return layer(w2, b2r, elu4l(layer(wf[0], cz, xs_own))); };
+        float t_cur = tp[0], t_nxt = tp[tst];
+        int ev_cur = has_ev ? a.ev[0] : -1;
+        int ev_raw = evp[nT > 2 ? 1 : 0];
+        for (long long k = 0; k + 1 < nT; ++k) {
+            const float h_ = t_nxt - t_cur;
+            t_cur = t_nxt;
+            const int ev_now = ev_cur;
+            const bool more = k + 2 < nT;
+            t_nxt = tp[(more ? k + 2 : k + 1) * tst];
+            ev_cur = (has_ev && more) ? ev_raw : -1;
+            ev_raw = evp[k + 3 < nT ? k + 2 : 0];
+            // per-step constant from Zh | Vh of grid point k (slot B holds them since the previous step) or, at a jump, of the jump rows
+            const bool jump = __builtin_amdgcn_readfirstlane(ev_now) >= 0;
+            if (jump) {          // 4 barriers, mirrored: E1 hiddens of the jump rows | E2 their outputs (slotJ: own dims) | AE head (2)
+                lds_barrier();
+                lds_barrier();
+                f4 accA = c0a, accB = {0.f, 0.f, 0.f, 0.f};
+                mm(af[0], xg, accA, accB);
+                if constexpr (HASZ) { const V4 zg = read_gathered(slotJ[0]); mm(af[1], zg, accA, accB); }
+                { const V4 vg = read_gathered(slotJ[1]); mm(af[NBE - 1], vg, accA, accB); }
+                czi = fi_of(gather(layer(aw2, ab2r, elu4l(accA + accB))));        // i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)
+            }
+            f4 czA = c0, czB = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (HASZ) { const V4 zg = read_gathered(jump ? slotJ[0] : slotB[1]); mm(wf[1], zg, czA, czB); }
+            { const V4 vg = read_gathered(jump ? slotJ[1] : slotB[2]); mm(wf[NBLK - 2], vg, czA, czB); }
+            const f4 cz = (czA + czB) + czi;
+            const f4 k1 = rhs_from_gathered(xg, cz);                       // 1 exchange
+            if constexpr (METHOD == PSNODE_EULER) {
+                x = x + h_ * k1;
+            } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+                const f4 k2 = rhs(x + k1 * (0.5f * h_), cz);              // 2 exchanges per further stage
+                x = x + h_ * k2;
+            } else {
+                const f4 k2 = rhs(x + h_ * k1 * kOneThird, cz);
+                const f4 k3 = rhs(x + h_ * (k2 - k1 * kOneThird), cz);
+                const f4 k4 = rhs(x + h_ * (k1 - k2 + k3), cz);
+                x = x + (k1 + 3.0f * (k2 + k3) + k4) * h_ * 0.125f;
+            }
+            xg = gather(x);                                                // exchange 2S: the rows waves read it too
+            czi = fi_of(gather(ae_eval(xg)));                              // exchanges 2S + 1, 2S + 2 (Zh | Vh of grid point k+1 from slot B)
+        }
+        lds_barrier();                                     // (rows: partials of the last grid point)
+        return;
+    }
+
+    // ==================================================================== rows role: encoders one grid point ahead, decoders one behind
+    const float* pe = pack_ed + (size_t)w * kEncDecRegs * 64 + l;
+    auto load_enc = [&](const int m, EncW& e) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e.w1[q] = (m == 0 || q < 2) ? pe[(28 * m + q) * 64] : 0.0f; e.b1[q] = pe[(28 * m + 4 + q) * 64]; e.b2[q] = pe[(28 * m + 24 + q) * 64]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e.w2[q] = pe[(28 * m + 8 + q) * 64];
+    };
+    auto load_dec = [&](const int m, DecW& d) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d.w1[q] = pe[(28 * m + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d.b1[q] = pe[(28 * m + 16 + q) * 64]; d.w2s[q] = pe[(28 * m + 20 + q) * 64]; d.b2[q] = pe[(28 * m + 24 + q) * 64]; }
+    };
+    EncW ex, ez, evv, ei;
+    DecW dx, di;
+    load_enc(0, ex); load_enc(1, ez); load_enc(2, evv); load_enc(3, ei);
+    load_dec(4, dx); load_dec(5, di);
+    struct Raw { float x[4], z[2], v[2], i[2]; };
+    const float* xp = a.x.p ? a.x.p + b * a.x.sb : tp;
+    const float* zp = HASZ ? a.z.p + b * a.z.sb : tp;
+    const float* vp = a.v.p + b * a.v.sb;
+    const float* ip = a.i.p + b * a.i.sb;
+    const long long xst = a.x.p ? a.x.st : 0, zst = HASZ ? a.z.st : 0, vst = a.v.st, ist = a.i.st;
+    auto load_raw = [&](const long long k, Raw& r) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) r.x[m] = recon ? colv(xp + k * xst, m, xd) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r.z[m] = HASZ ? colv(zp + k * zst, m, zd) : 0.0f;
+            r.v[m] = colv(vp + k * vst, m, vd);
+            r.i[m] = colv(ip + k * ist, m, idm);
+        }
+    };
+    auto enc_l1x = [&](const EncW& e, const float* raw, const int nm) -> f4 {       // x: up to 16 columns
+        f4 acc = e.b1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (m < nm) acc = mf(e.w1[m], raw[m], acc);
+        return elu4l(acc);
+    };
+    auto enc_l1 = [&](const EncW& e, const float* raw, const int nm) -> f4 {        // z | v | i: up to 8 columns (two L1 registers held)
+        f4 acc = mf(e.w1[0], raw[0], e.b1);
+        if (nm > 1) acc = mf(e.w1[1], raw[1], acc);
+        return elu4l(acc);
+    };
+    auto enc_l2 = [&](const EncW& e, const V4& h) -> f4 {
+        f4 accA = e.b2, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(e.w2, h, accA, accB);
+        return accA + accB;
+    };
+    const int nmx = (xd + 3) >> 2, nmz = (zd + 3) >> 2, nmv = (vd + 3) >> 2, nmi = (idm + 3) >> 2;
+    // output d of this tile is written by rows-wave d: 0 x_pred, 1 i_pred, 2 x_re, 3 i_re
+    const bool is_i = (w & 1) != 0, is_re = w >= 2;
+    float* const obase = is_re ? (is_i ? md.ire : md.xre) : (is_i ? a.io : a.xo);
+    const int odim = is_i ? idm : xd;
+    const long long ost = is_re ? (is_i ? md.ire_st : md.xre_st) : a.B * odim, osb = is_re ? (is_i ? md.ire_sb : md.xre_sb) : odim;
+    const f4 ob2 = is_i ? di.b2 : dx.b2;
+    const bool storing = valid && (recon || !is_re);
+    float* orow = obase + (storing ? b * osb + 4 * g : 0);
+    auto dec_part = [&](const DecW& d, const V4& vin) -> f4 {
+        f4 accA = d.b1, accB = {0.f, 0.f, 0.f, 0.f};
+        mm(d.w1, vin, accA, accB);
+        const f4 h = elu4l(accA + accB);
+        f4 pa = mf(d.w2s[0], h[0], f4{0.f, 0.f, 0.f, 0.f}), pb = mf(d.w2s[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
+        pa = mf(d.w2s[2], h[2], pa); pb = mf(d.w2s[3], h[3], pb);
+        return pa + pb;
+    };
+    auto reduce_store = [&](const bool first) {       // after the barrier behind the slotC writes
+        f4 o = ob2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o += slotC[w][c][l];
+        if (first && w == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int d = 4 * g + r; o[r] = md.x0[b * xd + (d < xd ? d : 0)]; }     // x_pred[0] = x0 (:150)
+        }
+        if (storing) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < odim) orow[r] = o[r];
+        }
+        orow += ost;
+    };
+
+    // ---- prologue (mirrors the chain's): Xh0, the encoders of row 0, then row 0's decoders inside the chain's two AE exchanges
+    Raw r0;
+    load_raw(0, r0);
+    {
+        float x0raw[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) x0raw[m] = colv(md.x0 + b * xd, m, xd);
+        slotA[0][w][l] = enc_l1x(ex, x0raw, nmx);
+    }
+    lds_barrier();                                         // P1
+    slotB[0][w][l] = enc_l2(ex, read_gathered(slotA[0]));
+    lds_barrier();                                         // P2: Xh0
+    const V4 xh0g = read_gathered(slotB[0]);
+    // hiddens of row 0
+    slotA[0][w][l] = recon ? enc_l1x(ex, r0.x, nmx) : f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HASZ) slotA[1][w][l] = enc_l1(ez, r0.z, nmz);
+    slotA[2][w][l] = enc_l1(evv, r0.v, nmv);
+    slotA[3][w][l] = enc_l1(ei, r0.i, nmi);
+    lds_barrier();                                         // P3
+    {
+        const f4 ox = recon ? enc_l2(ex, read_gathered(slotA[0])) : f4{0.f, 0.f, 0.f, 0.f};
+        f4 oz = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HASZ) oz = enc_l2(ez, read_gathered(slotA[1]));
+        const f4 ov = enc_l2(evv, read_gathered(slotA[2]));
+        const f4 oi = enc_l2(ei, read_gathered(slotA[3]));
+        slotB[0][w][l] = ox; slotB[1][w][l] = oz; slotB[2][w][l] = ov; slotB[3][w][l] = oi;
+    }
+    lds_barrier();                                         // P4: outputs of row 0
+    // decode grid point 0 (its solution row is x0 itself: output 0 is overwritten by reduce_store(first))
+    slotC[0][w][l] = dec_part(dx, xh0g);
+    if (recon) { slotC[2][w][l] = dec_part(dx, read_gathered(slotB[0])); slotC[3][w][l] = dec_part(di, read_gathered(slotB[3])); }
+    lds_barrier();                                         // chain: AE hidden of grid point 0
+    lds_barrier();                                         // chain: gather i_0 (the chain's second exchange of the prologue: parity 1)
+    slotC[1][w][l] = dec_part(di, read_gathered(xbuf[1]));
+    if (nT < 2) { lds_barrier(); reduce_store(true); return; }
+
+    int ev_cur = has_ev ? a.ev[0] : -1;
+    int ev_raw = evp[nT > 2 ? 1 : 0];
+    Raw rn;
+    load_raw(1, rn);
+    bool first = true;
+    // Per step k the rows waves (a) finish the decode of grid point k (partials were written last step: barrier 1 of this step is
+    // the one behind them), (b) encode grid point k+1, (c) start the decode of grid point k+1 behind the chain's gathers.
+    for (long long k = 0; k + 1 < nT; ++k) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the rows requested a step ago
+        const Raw rk1 = rn;
+        const int ev_now = ev_cur;
+        const bool more = k + 2 < nT;
+        ev_cur = (has_ev && more) ? ev_raw : -1;
+        ev_raw = evp[k + 3 < nT ? k + 2 : 0];
+        if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {   // jump rows: encoded on the spot (hiddens through slotA, free here) into slotJ, 4 barriers
+            float rz[2], rv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                rz[m] = HASZ ? colv(a.zj + b * a.zjb + (long long)ev_now * a.zje, m, zd) : 0.0f;
+                rv[m] = colv(a.vj + b * a.vjb + (long long)ev_now * a.vje, m, vd);
+            }
+            if constexpr (HASZ) slotA[1][w][l] = enc_l1(ez, rz, nmz);
+            slotA[2][w][l] = enc_l1(evv, rv, nmv);
+            lds_barrier();                                 // E1
+            f4 oz = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (HASZ) oz = enc_l2(ez, read_gathered(slotA[1]));
+            const f4 ov = enc_l2(evv, read_gathered(slotA[2]));
+            slotJ[0][w][l] = oz; slotJ[1][w][l] = ov;
+            lds_barrier();                                 // E2
+            lds_barrier();                                 // chain: AE hidden
+            lds_barrier();                                 // chain: gather i0
+        }
+        // barrier 1 (chain: stage-1 hidden): encoder hiddens of grid point k+1 out, decode of grid point k completes behind it
+        load_raw(more ? k + 2 : k + 1, rn);
+        slotA[0][w][l] = recon ? enc_l1x(ex, rk1.x, nmx) : f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (HASZ) slotA[1][w][l] = enc_l1(ez, rk1.z, nmz);
+        slotA[2][w][l] = enc_l1(evv, rk1.v, nmv);
+        slotA[3][w][l] = recon ? enc_l1(ei, rk1.i, nmi) : f4{0.f, 0.f, 0.f, 0.f};
+        lds_barrier();                                     // 1
+        reduce_store(first);
+        first = false;
+        f4 oz = {0.f, 0.f, 0.f, 0.f}, ov, ox = oz, oi = oz;
+        if constexpr (S == 1) {
+            // Euler: 4 barriers per step -- everything between 1 and 2
+            if constexpr (HASZ) oz = enc_l2(ez, read_gathered(slotA[1]));
+            ov = enc_l2(evv, read_gathered(slotA[2]));
+            if (recon) { ox = enc_l2(ex, read_gathered(slotA[0])); oi = enc_l2(ei, read_gathered(slotA[3])); }
+        } else {
+            if constexpr (HASZ) oz = enc_l2(ez, read_gathered(slotA[1]));
+            lds_barrier();                                 // 2
+            ov = enc_l2(evv, read_gathered(slotA[2]));
+            lds_barrier();                                 // 3
+            if (recon) ox = enc_l2(ex, read_gathered(slotA[0]));
+            if constexpr (S == 4) lds_barrier();           // 4
+            if (recon) oi = enc_l2(ei, read_gathered(slotA[3]));
+            if constexpr (S == 4) { lds_barrier(); lds_barrier(); lds_barrier(); }      // 5, 6, 7
+        }
+        // the chain last read Zh | Vh of grid point k (slot B) for its per-step constant, in front of barrier 1: free to overwrite
+        slotB[0][w][l] = ox; slotB[1][w][l] = oz; slotB[2][w][l] = ov; slotB[3][w][l] = oi;
+        lds_barrier();                                     // 2S: chain gathers x_{k+1} -- exchange 2S of an even count: parity 1
+        slotC[0][w][l] = dec_part(dx, read_gathered(xbuf[1]));
+        if (recon) slotC[2][w][l] = dec_part(dx, read_gathered(slotB[0]));
+        lds_barrier();                                     // 2S + 1: chain's AE hidden
+        if (recon) slotC[3][w][l] = dec_part(di, read_gathered(slotB[3]));
+        lds_barrier();                                     // 2S + 2: chain gathers i_{k+1} (parity 1 again)
+        slotC[1][w][l] = dec_part(di, read_gathered(xbuf[1]));
+    }
+    lds_barrier();                                         // behind the last partials
+    reduce_store(first);
+}
+
 bool two64(const MlpDev& m, int in_dim) { return m.n_layers == 2 && m.in_dim == in_dim && m.out_dim[0] == H64 && m.out_dim[1] == H64; }
 bool al4(const ViewDev& v) { return v.p && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0 && v.st % 4 == 0 && v.sb % 4 == 0; }
 
@@ -377,4 +1192,116 @@ hipError_t launch_latent64(const IntegrateDev& a, bool dae, float* pack, hipStre
     }
 }
 
+
+namespace {
+template <int METHOD>
+hipError_t launch_model_method(const ModelDev& md, const float* pde, const float* pae, const float* ped, hipStream_t s) {
+    const dim3 grid((unsigned)((md.a.B + 15) / 16));
+    static const bool one_role = [] { const char* e = getenv("PSNODE_K3G_ONE_ROLE"); return e && e[0] == '1'; }();      // the straight fusion (A/B arm)
+    if (one_role) {
+        if (md.a.zd) hipLaunchKernelGGL((latent64_model_kernel<METHOD, true>), grid, dim3(256), 0, s, md, pde, pae, ped);
+        else hipLaunchKernelGGL((latent64_model_kernel<METHOD, false>), grid, dim3(256), 0, s, md, pde, pae, ped);
+        return hipGetLastError();
+    }
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kModel2Lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), kModel2Lds, s, md, pde, pae, ped);
+        return hipGetLastError();
+    };
+    return md.a.zd ? go(&latent64_model2_kernel<METHOD, true>) : go(&latent64_model2_kernel<METHOD, false>);
+}
+bool enc_ok(const psnode_mlp_f32& m, int in, int maxin) {
+    return m.n_layers == 2 && m.in_dim == in && in >= 1 && in <= maxin && m.out_dim[0] == H64 && m.out_dim[1] == H64;
+}
+bool dec_ok(const psnode_mlp_f32& m, int out) { return m.n_layers == 2 && m.in_dim == H64 && m.out_dim[0] == H64 && m.out_dim[1] == out && out >= 1 && out <= 16; }
+bool lat_ok(const psnode_mlp_f32& m, int in) { return m.n_layers == 2 && m.in_dim == in && m.out_dim[0] == H64 && m.out_dim[1] == H64; }
+}  // namespace
 }  // namespace psnode
+
+using namespace psnode;
+
+extern "C" {
+
+int32_t psnode_dae_encoded_supported(const psnode_dae_encoded_args_f32* p) {
+    if (!p) return 0;
+    const int nblk = p->z_dim ? 4 : 3;
+    if (p->z_dim < 0 || p->z_dim > 8) return 0;
+    return enc_ok(p->x_encoder, p->x_dim, 16) && (p->z_dim == 0 || enc_ok(p->z_encoder, p->z_dim, 8)) && enc_ok(p->v_encoder, p->v_dim, 8) &&
+           enc_ok(p->i_encoder, p->i_dim, 8) && dec_ok(p->x_decoder, p->x_dim) && dec_ok(p->i_decoder, p->i_dim) &&
+           lat_ok(p->de, 3 * nblk * H64) && lat_ok(p->ae, (2 * nblk - 1) * H64);
+}
+
+size_t psnode_dae_encoded_workspace_bytes(const psnode_dae_encoded_args_f32* p) {
+    if (!p) return 0;
+    return (latent64_pack_floats() + (size_t)NW64 * kEncDecRegs * 64 + 64) * sizeof(float);
+}
+
+int32_t psnode_dae_encoded_integrate_f32(const psnode_dae_encoded_args_f32* p, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p) return PSNODE_ERR_NULL;
+    if (p->method < PSNODE_EULER || p->method > PSNODE_RK4_38) return PSNODE_ERR_METHOD;
+    if (p->T < 1 || p->B < 1 || p->x_dim < 1 || p->v_dim < 1 || p->i_dim < 1 || p->z_dim < 0) return PSNODE_ERR_DIMS;
+    if (!p->t.ptr || !p->v.ptr || !p->i.ptr || (p->z_dim && !p->z.ptr) || !p->x0 || !p->x_pred || !p->i_pred) return PSNODE_ERR_NULL;
+    if ((p->x_re == nullptr) != (p->i_re == nullptr)) return PSNODE_ERR_NULL;       // both reconstructions or neither
+    if (p->x_re && !p->x.ptr) return PSNODE_ERR_NULL;
+    if (p->event_idx && (!p->v_jump || (p->z_dim && !p->z_jump))) return PSNODE_ERR_NULL;
+    if (!psnode_dae_encoded_supported(p)) return PSNODE_ERR_UNSUPPORTED;
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < psnode_dae_encoded_workspace_bytes(p)) return PSNODE_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* pack = static_cast<float*>(workspace);
+    ModelDev md;
+    memset(&md, 0, sizeof(md));
+    IntegrateDev& a = md.a;
+    a.method = p->method; a.xd = p->x_dim; a.zd = p->z_dim; a.vd = p->v_dim; a.id = p->i_dim; a.T = p->T; a.B = p->B;
+    auto bind = [](const psnode_mlp_f32& m, MlpDev& d) {
+        d.n_layers = m.n_layers; d.in_dim = m.in_dim;
+        for (int l = 0; l < m.n_layers; ++l) { d.out_dim[l] = m.out_dim[l]; d.w[l] = m.weight[l]; d.bias[l] = m.bias[l]; }
+    };
+    bind(p->de, a.de); bind(p->ae, a.ae);
+    a.t = ViewDev{p->t.ptr, p->t.stride_t, p->t.stride_b};
+    a.x = ViewDev{p->x.ptr, p->x.stride_t, p->x.stride_b};
+    a.z = ViewDev{p->z.ptr, p->z.stride_t, p->z.stride_b};
+    a.v = ViewDev{p->v.ptr, p->v.stride_t, p->v.stride_b};
+    a.i = ViewDev{p->i.ptr, p->i.stride_t, p->i.stride_b};
+    a.ev = p->event_idx; a.zj = p->z_jump; a.zjb = p->zj_stride_b; a.zje = p->zj_stride_e;
+    a.vj = p->v_jump; a.vjb = p->vj_stride_b; a.vje = p->vj_stride_e;
+    a.xo = p->x_pred; a.io = p->i_pred;
+    md.x0 = p->x0;
+    md.xre = p->x_re; md.xre_st = p->xre_stride_t; md.xre_sb = p->xre_stride_b;
+    md.ire = p->i_re; md.ire_st = p->ire_stride_t; md.ire_sb = p->ire_stride_b;
+    // packed images: latent DE | AE (as K3c), then the encoders / decoders
+    const int nblk = a.zd ? 4 : 3;
+    Pack64 pk;
+    pk.ae = 0; pk.nblk = nblk; pk.nfront = nblk; pk.k1 = 3 * nblk * H64;
+    pk.w1 = a.de.w[0]; pk.b1 = a.de.bias[0]; pk.w2 = a.de.w[1]; pk.b2 = a.de.bias[1];
+    pk.out = pack;
+    hipLaunchKernelGGL(pack64_kernel, dim3(32), dim3(256), 0, s, pk);
+    float* pack_ae = pack + latent64_pack_floats() / 2;
+    Pack64 qk = pk;
+    qk.ae = 1; qk.nfront = nblk - 1; qk.k1 = (2 * nblk - 1) * H64;
+    qk.w1 = a.ae.w[0]; qk.b1 = a.ae.bias[0]; qk.w2 = a.ae.w[1]; qk.b2 = a.ae.bias[1];
+    qk.out = pack_ae;
+    hipLaunchKernelGGL(pack64_kernel, dim3(32), dim3(256), 0, s, qk);
+    float* pack_ed = pack + latent64_pack_floats();
+    PackEncDec pe;
+    memset(&pe, 0, sizeof(pe));
+    const psnode_mlp_f32* ms[6] = {&p->x_encoder, p->z_dim ? &p->z_encoder : nullptr, &p->v_encoder, &p->i_encoder, &p->x_decoder, &p->i_decoder};
+    for (int m = 0; m < 6; ++m) {
+        if (!ms[m]) continue;
+        pe.w1[m] = ms[m]->weight[0]; pe.b1[m] = ms[m]->bias[0]; pe.w2[m] = ms[m]->weight[1]; pe.b2[m] = ms[m]->bias[1];
+        pe.in_dim[m] = ms[m]->in_dim; pe.out_dim[m] = ms[m]->out_dim[1];
+        if (!pe.w1[m] || !pe.b1[m] || !pe.w2[m] || !pe.b2[m]) return PSNODE_ERR_NULL;
+    }
+    pe.out = pack_ed;
+    hipLaunchKernelGGL(pack_encdec_kernel, dim3(32), dim3(256), 0, s, pe);
+    if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    hipError_t e;
+    switch (a.method) {
+        case PSNODE_EULER: e = launch_model_method<PSNODE_EULER>(md, pack, pack_ae, pack_ed, s); break;
+        case PSNODE_MIDPOINT: e = launch_model_method<PSNODE_MIDPOINT>(md, pack, pack_ae, pack_ed, s); break;
+        default: e = launch_model_method<PSNODE_RK4_38>(md, pack, pack_ae, pack_ed, s); break;
+    }
+    return e == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+}  // extern "C"

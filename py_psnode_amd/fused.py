@@ -1243,6 +1243,95 @@ def ode_encoded_integrate(method: str, x_encoder: Layers, z_encoder: Layers, x_d
     return x_pred.permute(1, 0, 2), x_re, xh
 
 
+def _dae_encoded_args(mlps, dev, keep, xd, zd, vd, idim):
+    a = _lib.DaeEncodedArgsF32()
+    a.x_dim, a.z_dim, a.v_dim, a.i_dim = xd, zd, vd, idim
+    names = ("x_encoder", "z_encoder", "v_encoder", "i_encoder", "x_decoder", "i_decoder", "de", "ae")
+    for name, m in zip(names, mlps):
+        if m is not None:
+            setattr(a, name, _mlp(m, dev, name, keep))
+    return a
+
+
+def dae_encoded_supported(x_encoder, z_encoder, v_encoder, i_encoder, x_decoder, i_decoder, de_layers, ae_layers) -> bool:
+    """Shapes of the fused direct_encode DAE forward (psnode_dae_encoded_integrate_f32, hidden_dim 64; z_encoder None = z_dim 0)."""
+    mlps = (x_encoder, z_encoder, v_encoder, i_encoder, x_decoder, i_decoder, de_layers, ae_layers)
+    try:
+        if any(m is not None and len(m) != 2 for m in mlps) or any(m is None for k, m in enumerate(mlps) if k != 1):
+            return False
+        dev = x_encoder[0][0].device
+        if dev.type != "cuda":
+            return False
+        xd, vd, idim = x_encoder[0][0].shape[1], v_encoder[0][0].shape[1], i_encoder[0][0].shape[1]
+        zd = z_encoder[0][0].shape[1] if z_encoder is not None else 0
+        a = _dae_encoded_args(mlps, dev, [], xd, zd, vd, idim)
+    except (IndexError, TypeError, ValueError):
+        return False
+    return bool(_lib.load().psnode_dae_encoded_supported(ctypes.byref(a)))
+
+
+def dae_encoded_integrate(method: str, x_encoder, z_encoder, v_encoder, i_encoder, x_decoder, i_decoder, de_layers, ae_layers,
+                          x0, t, x, z, v, i, event_t=None, z_jump=None, v_jump=None, event_idx=None, want_recon: bool = True,
+                          check_events: bool = False):
+    """The whole DAE_Model.forward of neural_01_DAE_02_direct_encode.py:125-153 in ONE launch (hidden_dim 64): the four encoders,
+    all_initial, the latent integrate_DAE, both decoders of the solution and the two reconstructions.  x0 [B,xd] is Init_Func's output;
+    t, x, z, v, i are the scripts' B-major tensors [B,T,*] (z of width 0 when the model has no z_encoder); z_jump / v_jump the RAW
+    [B,nE,*] tensors.  Returns (x_pred, i_pred, x_re, i_re), each [B,T,*] as the permuted view of a time-major buffer for the
+    predictions (like the script) and B-major contiguous for the reconstructions (None without want_recon)."""
+    lib = _lib.load()
+    dev = v.device
+    keep: list = []
+    B, T, vd = v.shape
+    xd, idim, zd = x0.shape[-1], i.shape[-1], (z.shape[-1] if z is not None else 0)
+    if z_encoder is None:
+        zd = 0
+    mlps = (x_encoder, z_encoder, v_encoder, i_encoder, x_decoder, i_decoder, de_layers, ae_layers)
+    a = _dae_encoded_args(mlps, dev, keep, xd, zd, vd, idim)
+    a.method, a.T, a.B = METHOD_ID[method], T, B
+    if not lib.psnode_dae_encoded_supported(ctypes.byref(a)):
+        raise _lib.UnsupportedShapeError("dae_encoded_integrate: needs encoders in->64->64 (x <= 16, z | v | i <= 8 wide), decoders "
+                                         "64->64->out, de 12H|9H->64->64, ae 7H|5H->64->64")
+    for name, q, wdt in (("t", t, 1), ("x", x, xd), ("v", v, vd), ("i", i, idim)) + ((("z", z, zd),) if zd else ()):
+        if q is None or q.shape[:2] != (B, T) or q.shape[-1] != wdt:
+            raise ValueError(f"dae_encoded_integrate: {name} {None if q is None else tuple(q.shape)} does not match [B={B}, T={T}, {wdt}]")
+    a.t = _view(t.permute(1, 0, 2), dev, "t", keep)
+    a.x = _view(x.permute(1, 0, 2), dev, "x", keep)
+    a.v = _view(v.permute(1, 0, 2), dev, "v", keep)
+    a.i = _view(i.permute(1, 0, 2), dev, "i", keep)
+    if zd:
+        a.z = _view(z.permute(1, 0, 2), dev, "z", keep)
+    x0c = _f32_dev(x0, dev, "x0").contiguous()
+    if x0c.shape != (B, xd):
+        raise ValueError(f"dae_encoded_integrate: x0 {tuple(x0c.shape)} does not match [B={B}, xd={xd}]")
+    keep.append(x0c)
+    a.x0 = x0c.data_ptr()
+    if event_idx is None and event_t is not None and event_t.shape[1] > 0 and T > 1:
+        event_idx = event_table(t.permute(1, 0, 2), event_t, check_duplicates=check_events)
+    if event_idx is not None:
+        _check_jump("v_jump", v_jump, B, vd, event_idx)
+        keep.append(event_idx)
+        a.event_idx = event_idx.data_ptr()
+        a.v_jump, a.vj_stride_b, a.vj_stride_e = _jump(v_jump, dev, "v_jump", keep)
+        if zd:
+            _check_jump("z_jump", z_jump, B, zd, event_idx)
+            a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
+    with torch.cuda.device(dev):
+        x_pred = _empty((T, B, xd), dtype=torch.float32, device=dev)
+        i_pred = _empty((T, B, idim), dtype=torch.float32, device=dev)
+        a.x_pred, a.i_pred = x_pred.data_ptr(), i_pred.data_ptr()
+        x_re = i_re = None
+        if want_recon:
+            x_re = _empty((B, T, xd), dtype=torch.float32, device=dev)
+            i_re = _empty((B, T, idim), dtype=torch.float32, device=dev)
+            a.x_re, a.xre_stride_t, a.xre_stride_b = x_re.data_ptr(), xd, T * xd
+            a.i_re, a.ire_stride_t, a.ire_stride_b = i_re.data_ptr(), idim, T * idim
+        ws = _empty(lib.psnode_dae_encoded_workspace_bytes(ctypes.byref(a)) + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_dae_encoded_integrate_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_dae_encoded_integrate_f32")
+    return x_pred.permute(1, 0, 2), i_pred.permute(1, 0, 2), x_re, i_re
+
+
 def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor, need_grad_in: bool = True):
     """Backward of `mlp_rows`: returns (grad_in or None, [dW1, db1, dW2, db2]) from the saved input and grad_out (row kernel)."""
     lib = _lib.load()

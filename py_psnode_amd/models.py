@@ -11,6 +11,8 @@ Sub-module and parameter names equal the scripts' (`de_func.x_dot.0.weight`, `x_
 [B,T,D]; the solver gets permute(1,0,2) views and the result is permuted back, as upstream.
 The scripts hard-code Euler(); pass `solver=` or assign `model.solver = RK4()`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -292,6 +294,9 @@ class DAE_Model(nn.Module):
                                                 event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
                                                 input_true_x=input_true_x, input_true_i=input_true_i)
             return _tm(xs), _tm(is_)
+        fused_out = self._forward_encoded(x0, t, x, z, v, i, event_t, z_jump, v_jump)
+        if fused_out is not None:
+            return fused_out
         enc_z = (lambda a: a) if self.z_encoder is None else (lambda a: _rows(self.z_encoder, a))
         Xh0 = _rows(self.x_encoder, x0)
         if _time_major_route(x):      # HIP route: time-major latent tensors, first row re-encoded for all_initial (see ODE_Model.forward)
@@ -315,6 +320,52 @@ class DAE_Model(nn.Module):
         x_pred = _rows(self.x_decoder, Xh_sol)
         x_pred[0] = x0                                             # neural_01_DAE_02_direct_encode.py:150
         return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _rows(self.x_decoder, Xh_bt), _rows(self.i_decoder, Ih_bt)
+
+    one_launch = None      # True / False: take / never take the one-launch forward K3g; None: PSNODE_DAE02_ONE_LAUNCH (default off, see below)
+
+    def _forward_encoded(self, x0, t, x, z, v, i, event_t, z_jump, v_jump):
+        """The whole direct_encode forward behind Init_Func in ONE HIP launch (psnode_dae_encoded_integrate_f32, K3g: four encoders,
+        all_initial, latent integrate_DAE, both decoders, both reconstructions -- none of the six latent [T,B,64] tensors reaches
+        memory) when nothing needs autograd, the tensors are fp32 on a HIP device, hidden_dim is 64 and the solver is one of this
+        package's with fusing allowed; None otherwise (row kernels + solver route: also the training route)."""
+        from . import fused
+        from .neural_dae.my_solvers import FixedGridODESolver
+        solver = self.solver
+        if not isinstance(solver, FixedGridODESolver) or getattr(solver, "fused", "off") == "off" or not solver.method:
+            return None
+        if getattr(solver, "kernel", "auto") == "generic":
+            return None
+        # Measured (profiles/r04m_dae02_routes.txt, 4096 x 1000 steps): the one launch moves 140 B per state-step instead of ~1.7 KB and needs
+        # none of the six [T,B,64] latent tensors (6.3 GB at that size), but at hidden 64 the encoders / decoders are MFMA work that the
+        # row kernels run at full occupancy, and it is 8 % (RK4) / 12 % (Euler) SLOWER than the row kernels + K3c: opt-in
+        # (model.one_launch = True or PSNODE_DAE02_ONE_LAUNCH=1), the row-kernel route stays the default.
+        want = self.one_launch if self.one_launch is not None else os.environ.get("PSNODE_DAE02_ONE_LAUNCH", "0") == "1"
+        if not want:
+            return None
+        mods = [self.x_encoder, self.z_encoder, self.v_encoder, self.i_encoder, self.x_decoder, self.i_decoder, self.de_func.x_dot,
+                self.ae_func.i_calculator]
+        if any(m is not None and fused._overrides_forward_hooks(m) for m in [self, self.de_func, self.ae_func] + mods):
+            return None
+        if v.device.type != "cuda" or any(q.dtype != torch.float32 for q in (t, x, z, v, i, x0)) or v.dim() != 3 or v.shape[1] < 1:
+            return None
+        if not getattr(type(self.event), "_psnode_event", False) or type(self.de_func) is not DAE_DE_Func or type(self.ae_func) is not AE_Func:
+            return None
+        if (self.z_encoder is None) != (z.shape[-1] == 0) or x.shape[-1] != x0.shape[-1]:
+            return None
+        mlps = [None if m is None else fused.sequential_layers(m) for m in mods]
+        if any(m is None for k, m in enumerate(mlps) if k != 1) or (self.z_encoder is not None and mlps[1] is None):
+            return None
+        if not fused.dae_encoded_supported(*mlps):
+            return None
+        if fused._needs_autograd([x0, x, z, v, i, z_jump, v_jump] + [p for m in mlps if m is not None for wb in m for p in wb]):
+            return None
+        if event_t is not None and (event_t.dtype != torch.float32 or v_jump is None or v_jump.dtype != torch.float32
+                                    or (self.z_encoder is not None and (z_jump is None or z_jump.dtype != torch.float32))):
+            return None
+        # as ODE_Model._forward_encoded: the event object holds the RAW jump tensors afterwards (nothing reads them after forward)
+        self.event.set_event(t=event_t, z=z_jump, v=v_jump)
+        return fused.dae_encoded_integrate(solver.method, *mlps, x0, t, x, z, v, i, event_t=event_t, z_jump=z_jump, v_jump=v_jump,
+                                           check_events=solver._check_events_now(event_t))
 
     _EXPORTS = ("x_encoder", "x_decoder", "z_encoder", "v_encoder", "i_encoder", "i_decoder", "init_func", "de_func", "ae_func")
 
