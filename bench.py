@@ -175,15 +175,21 @@ def run_oracle(O, w, p, method, T):
 
 def flops_per_state_step(w, p, method):
     stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    if w["kind"] == "dae02_model":
+        # EXECUTED flops: with z | v | i frozen over a step (zero-order hold) and the a0 group constant over the batch, only the x block of
+        # the latent DE's first layer runs per stage -- the dense count of SURVEY 8(d) (4 x 13 H^2 + 8 H^2 MACs per RK4 step) is 4x the
+        # arithmetic any implementation of this model has to do, and a fraction of peak priced on it exceeds 1
+        H, xd, zd, vd, idim = w["H"], w["xd"], w["zd"], w["vd"], w["id"]
+        nblk = 4 if zd else 3
+        lat = stages * 2 * H * H + (nblk - 1) * H * H + nblk * H * H             # DE stages, DE per-step constant, AE head (nblk-1 blocks + L2)
+        encdec = sum(d * H + H * H for d in (xd, zd, vd, idim) if d) + 2 * (H * H + H * xd) + 2 * (H * H + H * idim)
+        return 2 * (lat + encdec)
     f = 2 * stages * mlp_macs(p["de"])
     if w["kind"] == "ode02_model":   # + enc x, enc z, 2x dec per grid point (2 880 flop at H=16)
         H, xd, zd, E = w["H"], w["xd"], w["zd"], w.get("E", w["H"])
         f += 2 * ((xd * E + E * H) + (zd * E + E * H) + 2 * (H * E + E * xd))
-    if w["kind"] in ("dae", "dae02_model"):
+    if w["kind"] == "dae":
         f += 2 * mlp_macs(p["ae"])
-    if w["kind"] == "dae02_model":   # + enc z, enc v, enc x, enc i, 2 x dec x, 2 x dec i per grid point (dense count, as SURVEY 8(d) does for ODE_02)
-        H, xd, zd, vd, idim = w["H"], w["xd"], w["zd"], w["vd"], w["id"]
-        f += 2 * (sum(d * H + H * H for d in (xd, zd, vd, idim)) + 2 * (H * H + H * xd) + 2 * (H * H + H * idim))
     return f
 
 
@@ -286,12 +292,32 @@ def traffic_for(workload, method, kname, B, T, H):
 # The other single-GPU configurations of BASELINE.json (configs[2], configs[3]) and the solver the four scripts ship with
 # (Euler: neural_00_ODE_01_no_encode.py:75, neural_01_DAE_01_no_encode.py:92) timed in the default run, after the headline.
 EXTRAS = [("dae01", "rk4"), ("ode02", "rk4"), ("ode01", "euler"), ("dae01", "euler")]
+# Round 4, behind the training lines: the DAE_02 model forward as shipped (hidden 64) on its default route (row kernels + K3c) and in one
+# launch (K3g, opt-in), and the widest --hidden the MFMA integrator carries (256: H->H weights streamed from L2)
+LATE_EXTRAS = [("dae02", "rk4", None, {"PSNODE_DAE02_ONE_LAUNCH": "0"}, "row kernels + K3c (default route)"),
+               ("dae02", "rk4", None, {"PSNODE_DAE02_ONE_LAUNCH": "1"}, "one launch (K3g, opt-in)"),
+               ("ode01", "rk4", 256, {}, "hidden 256: 16 waves per tile, streamed weights")]
 
 
-def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10):
+def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10, hidden=None, env=None, note=None):
     """One more workload on the driver's clock: `steps` passes at B=4096 x 1000 steps, every launch bracketed by HIP events on the
     launch stream; the passes as a whole by synchronize + perf_counter.  Same accounting as the headline line."""
     w = dict(WORKLOADS[workload])
+    if hidden:
+        w["H"] = hidden
+    saved_env = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        return _extra_line(lib, _lib, fused, workload, w, method, dev, steps, warmup, note)
+    finally:
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _extra_line(lib, _lib, fused, workload, w, method, dev, steps, warmup, note):
     B, T = w["B"], w["T"]
     p_cpu = make_problem(w, B, T)
     p = to_dev(p_cpu, dev)
@@ -317,7 +343,7 @@ def extra_line(lib, _lib, fused, workload, method, dev, steps=10, warmup=10):
     kname = kernel_name_for(lib, _lib, fused, w, p, method, "auto", dev)
     ach = flops * ss / (avg * 1e-3) / 1e12
     bound = "valu_fp32" if kname == "valu_dpp" else "mfma"     # K3f issues no MFMA: it is priced against the same fp32 datapath peak
-    return {"workload": f"{workload} {method}: B={B} x {T - 1} steps, H{w['H']}", "kernel": kname, "steps": steps, "warmup": warmup,
+    return {"workload": f"{workload} {method}: B={B} x {T - 1} steps, H{w['H']}" + (f" [{note}]" if note else ""), "kernel": kname, "steps": steps, "warmup": warmup,
             "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
             "outputs_finite": bool(torch.isfinite(outs[0]).all()),
             "roofline": {"bound": bound, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
@@ -689,6 +715,7 @@ def main():
             res["extra"] = [extra_line(lib, _lib, fused, wl, m, dev) for wl, m in EXTRAS]
             if not args.no_train_extras:
                 res["extra"] += [train_extra_line(fused, wl, m, h, dev) for wl, m, h in TRAIN_EXTRAS]
+            res["extra"] += [extra_line(lib, _lib, fused, wl, m, dev, steps=5, warmup=3, hidden=h, env=e, note=n) for wl, m, h, e, n in LATE_EXTRAS]
             outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method, gpu_out=None if args.train else outs[0])

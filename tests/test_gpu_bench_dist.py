@@ -57,11 +57,14 @@ def test_default_bench_line_carries_the_extra_workloads():
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     names = [e["workload"].split(":")[0] for e in d["extra"]]
     train = ["ode01 rk4 TRAIN", "dae01 rk4 TRAIN", "ode01 euler TRAIN", "dae01 euler TRAIN", "ode01 rk4 TRAIN", "dae01 rk4 TRAIN"]
-    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train
+    late = ["dae02 rk4", "dae02 rk4", "ode01 rk4"]       # DAE_02 forward on both routes, hidden 256 (streamed weights)
+    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train + late
     for e in d["extra"]:
         assert e["outputs_finite"] and 0.05 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_median"] > 0
+    assert "H256" in d["extra"][-1]["workload"] and d["extra"][-1]["kernel"] == "mfma" and d["extra"][-1]["roofline"]["frac"] > 0.5
+    assert "K3g" in d["extra"][-2]["workload"] and "default route" in d["extra"][-3]["workload"]
     # round 4: the training steps (row f1) ride on the driver's clock too -- hidden 64 (RK4, Euler) and the scripts' --hidden 128
-    tr = d["extra"][4:]
+    tr = d["extra"][4:10]
     assert [("H64" in e["workload"], "H128" in e["workload"]) for e in tr] == [(True, False)] * 4 + [(False, True)] * 2
     for e in tr:
         fam = e["roofline"]["kernel_ms_by_family"]
