@@ -478,6 +478,10 @@ def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
     res["host_enqueue_ms"] = (time.perf_counter() - th) * 1e3
     torch.cuda.synchronize(dev)
     del tr, p, outs
+    # autograd contexts hold their saved tensors in reference cycles: without a collection HERE the cyclic collector frees this workload's
+    # gigabytes of saved activations (synchronous hipFree calls) in the middle of the NEXT workload's timed loop (a 42 ms step among 8.4 ms ones)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     return res
 

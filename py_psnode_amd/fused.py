@@ -746,14 +746,28 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         a.ev_gi, a.ev_i = ev_gi.data_ptr(), ev_i.data_ptr()
     W1, W2, W3, W4 = (w.detach() for w, _ in de_layers)
     A1, A2, A3, A4 = (w.detach() for w, _ in ae_layers)
-    gW = [torch.zeros_like(w) for w in (W1, W2, W3, W4)]
-    gb = [torch.zeros(w.shape[0], **f32) for w in (W1, W2, W3, W4)]
-    gA = [torch.zeros_like(w) for w in (A1, A2, A3, A4)]
-    gab = [torch.zeros(w.shape[0], **f32) for w in (A1, A2, A3, A4)]
+    # Host-side accumulators of the routes that contract stored rows here (the split form; the AE head's K7h route): made on demand.
+    # The one-launch route at hidden <= 64 (every gradient formed in the kernel) needs none of them -- 18 fills, a [T,B,z+v] copy and 2
+    # small GEMM operands per call that the step's profile showed as glue (profiles/r04o_glue_dae01.txt).
+    gW = gb = S1 = Fe = Ae = zv_all = None
+    gA, gab, Sa1 = [None] * 4, [None] * 4, None
+
+    def host_accumulators(de_too: bool):
+        nonlocal gW, gb, gA, gab, S1, Sa1, Fe, Ae, zv_all
+        if Sa1 is None:
+            gA = [torch.zeros_like(w) for w in (A1, A2, A3, A4)]
+            gab = [torch.zeros(w.shape[0], **f32) for w in (A1, A2, A3, A4)]
+            Sa1 = torch.zeros((B, H), **f32)                    # sum over the heads of the AE's delta_1
+            Ae = _pad_rows(A1[:, n + xd:n + xd + nzv], H)
+            zv_all = torch.cat((z.detach(), v.detach()), -1)    # [T, B, nzv] (one copy of the two input views)
+        if de_too and S1 is None:
+            gW = [torch.zeros_like(w) for w in (W1, W2, W3, W4)]
+            gb = [torch.zeros(w.shape[0], **f32) for w in (W1, W2, W3, W4)]
+            S1 = torch.zeros((B, H), **f32)                     # sum over steps and stages of the DE's delta_1
+            Fe = _pad_rows(W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv], H)       # (Ws + Wd)[:, z|v columns]
+
     gzv = torch.zeros((T, B, nzv), **f32)                       # dL/d(z|v) of the un-jumped inputs
     gjump = torch.zeros((B, n_ev, nzv), **f32) if n_ev else None
-    S1 = torch.zeros((B, H), **f32)                             # sum over steps and stages of the DE's delta_1
-    Sa1 = torch.zeros((B, H), **f32)                            # sum over the heads of the AE's delta_1
     carry_x, carry_i = torch.zeros((B, xd), **f32), torch.zeros((B, 16), **f32)
     a.carry_x, a.carry_i = carry_x.data_ptr(), carry_i.data_ptr()
     if saved is not None and not fuse_de:
@@ -784,9 +798,6 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         a.grad_params_de, a.grad_all_initial_de = gp_de.data_ptr(), ga0_de.data_ptr()
         a.grad_zv = gzv.data_ptr()
         a.grad_jump = gjump.data_ptr() if gjump is not None else None
-    Fe = _pad_rows(W1[:, n + xd:n + xd + nzv] + W1[:, 2 * n + xd:2 * n + xd + nzv], H)       # (Ws + Wd)[:, z|v columns]
-    Ae = _pad_rows(A1[:, n + xd:n + xd + nzv], H)
-    zv_all = torch.cat((z.detach(), v.detach()), -1)            # [T, B, nzv] (one copy of the two input views)
     jump_all = None
     if n_ev:
         parts = ([z_jump.detach()] if zd > 0 else []) + ([v_jump.detach()] if vd > 0 else [])
@@ -909,6 +920,7 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
                 g["de"] = _split_grads(gp_de, de_layers)
                 g["ae"] = [gA[0], gab[0], gA[1], gab[1], gA[2], gab[2], gA[3], gab[3]]
                 return g
+            host_accumulators(False)
             # the AE head's rows -> its parameter gradients and its share of the input gradients (K7h)
             # (the heads at the grid points read the dataset rows under input_true_x; the event heads below always the running state)
             gza = head_grads_hip(arows[:3], B * H, arows[3:], agi, xt_c if x_true is not None else xs_c, zv_all)
@@ -934,6 +946,7 @@ def dae_backward_wide(method: str, de_layers: Layers, ae_layers: Layers, t, z, v
         g["de"] = _split_grads(gp_de, de_layers)
         g["ae"] = [gA[0], gab[0], gA[1], gab[1], gA[2], gab[2], gA[3], gab[3]]
         return g
+    host_accumulators(True)
     if chunk_steps is None:      # ~3 GB of stored rows per chunk
         chunk_steps = max(1, min(T - 1, int(3e9 // ((6 * S + 6) * 4 * B * H))))
     with torch.cuda.device(dev):
