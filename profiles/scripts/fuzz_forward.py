@@ -1,5 +1,6 @@
-"""Random-shape fuzz of the MFMA integrators (K1 / K2: any hidden width <= 128, every slot class, events, teacher forcing) against the
-generic kernel K0.  usage (GPU box, repo root): python profiles/scripts/fuzz_forward.py [seed] [iterations]"""
+"""Random-shape fuzz of the MFMA integrators (K1 / K2: any hidden width <= 128, every slot class, events, teacher forcing; round 4: the
+streamed widths 129..256 within the classes they carry -- ODE x_dim <= 8 up to 256 / any x_dim <= 16 up to 192, DAE up to 192 with
+z+v+i <= 6) against the generic kernel K0.  usage (GPU box, repo root): python profiles/scripts/fuzz_forward.py [seed] [iterations]"""
 import random
 import sys
 
@@ -24,7 +25,7 @@ def close(a, b, what, tag):
 mk = lambda dims: [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     torch.manual_seed(it)
-    H = random.choice([5, 16, 24, 32, 48, 64, 80, 128])
+    H = random.choice([5, 16, 24, 32, 48, 64, 80, 128, 129, 160, 192, 200, 256])
     method = random.choice(["euler", "midpoint", "rk4"])
     B, Tn = random.randint(1, 70), random.randint(1, 14)
     r = lambda *s: 0.1 * torch.randn(*s, device="cuda")
@@ -35,7 +36,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     ev = torch.stack([t[1, :, :], t[Tn - 2, :, :]], dim=1).contiguous() if events else None
     tx, ti = random.random() < 0.3, random.random() < 0.3
     if random.random() < 0.5:
-        xd, zd = random.randint(1, 8), random.randint(0, 8)
+        xd, zd = random.randint(1, 16 if (H <= 192 and random.random() < 0.3) else 8), random.randint(0, 8)
         tag = ("ode", H, method, B, Tn, xd, zd, events, tx)
         de = mk([3 * (xd + zd), H, H, H, xd])
         x, z = r(Tn, B, xd), r(Tn, B, zd)
@@ -48,8 +49,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     else:
         while True:
             xd, zd, vd, idim = random.randint(1, 8), random.randint(0, 4), random.randint(0, 4), random.randint(1, 4)
-            if zd + vd >= 1 and zd + vd + idim <= 8:
+            if zd + vd >= 1 and zd + vd + idim <= (8 if H <= 128 else 6):
                 break
+        H = min(H, 192)                                   # the DAE runs streamed up to 192
         tag = ("dae", H, method, B, Tn, xd, zd, vd, idim, events, tx, ti)
         n = xd + zd + vd + idim
         de, ae = mk([3 * n, H, H, H, xd]), mk([n + xd + zd + vd, H, H, H, idim])

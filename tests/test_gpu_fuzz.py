@@ -49,3 +49,10 @@ def test_forward_shape_fuzz():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     _run("fuzz_forward.py", 5, 150)
+
+
+def test_dae_encoded_shape_fuzz():
+    """K3g (the DAE_02 forward in one launch) against the row kernels + K3c on random shapes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _run("fuzz_dae_encoded.py", 11, 40)
