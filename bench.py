@@ -283,10 +283,10 @@ def traffic_for(workload, method, kname, B, T, H):
     FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) -- counters cannot be read from inside this process; null when that
     configuration was not profiled."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if H is not None or not os.path.exists(tpath):
+    if not os.path.exists(tpath):
         return None
     try:
-        return json.load(open(tpath)).get(f"{workload}:{method}:{kname}:B{B}:T{T}")
+        return json.load(open(tpath)).get(f"{workload}:{method}:{kname}:B{B}:T{T}" + (f":H{H}" if H is not None else ""))
     except Exception:
         return None
 
@@ -349,7 +349,8 @@ def _extra_line(lib, _lib, fused, workload, w, method, dev, steps, warmup, note)
             "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
             "outputs_finite": bool(torch.isfinite(outs[0]).all()),
             "roofline": {"bound": bound, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": traffic_for(workload, method, kname, B, T, None), "traffic_source": "profiles/pmc_traffic.json",
+                         "traffic": traffic_for(workload, method, kname, B, T, w["H"] if w["H"] != WORKLOADS[workload]["H"] else None),
+                         "traffic_source": "profiles/pmc_traffic.json",
                          "kernel_ms": avg, "kernel_ms_median": med,
                          "flop_per_state_step": flops, "bytes_per_state_step": bts,
                          "hbm_achieved_GBs": bts * ss / (avg * 1e-3) / 1e9}}
