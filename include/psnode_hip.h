@@ -31,7 +31,8 @@ extern "C" {
 
 #define PSNODE_ABI_VERSION 6
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
-#define PSNODE_MAX_WIDTH 1024    /* widest layer input/output the kernels accept */
+#define PSNODE_MAX_WIDTH 1024    /* widest layer OUTPUT the kernels accept */
+#define PSNODE_MAX_IN_WIDTH 2048 /* widest first-layer INPUT (the latent DE of DAE_02 at --hidden 128 is 12 x 128 = 1536 wide) */
 
 typedef enum {
     PSNODE_OK = 0,

@@ -26,7 +26,7 @@ size_t transposed_floats(const psnode_mlp_f32* m) {
 int check_mlp(const psnode_mlp_f32& m, int want_in, int want_out) {
     if (m.n_layers < 1 || m.n_layers > kMaxLayers) return PSNODE_ERR_DIMS;
     if (m.in_dim != want_in || m.in_dim < 1) return PSNODE_ERR_DIMS;
-    if (m.in_dim > PSNODE_MAX_WIDTH) return PSNODE_ERR_UNSUPPORTED;       // consistent, but wider than any kernel takes
+    if (m.in_dim > PSNODE_MAX_IN_WIDTH) return PSNODE_ERR_UNSUPPORTED;    // consistent, but wider than any kernel takes
     for (int l = 0; l < m.n_layers; ++l) {
         if (m.out_dim[l] < 1) return PSNODE_ERR_DIMS;
         if (m.out_dim[l] > PSNODE_MAX_WIDTH) return PSNODE_ERR_UNSUPPORTED;

@@ -280,6 +280,11 @@ bool latent64_shape_ok(const IntegrateDev& a, bool dae);
 bool latent64_ptrs_ok(const IntegrateDev& a, bool dae);
 size_t latent64_pack_floats();
 hipError_t launch_latent64(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+// psnode_latent_wide.hip (K3w: the latent shapes at every other hidden_dim <= 128, weights streamed from L2)
+bool latentw_shape_ok(const IntegrateDev& a, bool dae);
+bool latentw_ptrs_ok(const IntegrateDev& a, bool dae);
+size_t latentw_pack_floats();
+hipError_t launch_latent_wide(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 
 // ELU'(pre) from h = ELU(pre): 1 for pre > 0 (h > 0), exp(pre) = h + 1 otherwise -- written min(h, 0) + 1 (identical values; one clamp
 // + one packed add per pair instead of add + compare + select per value: VALU instructions are wall time next to fp32 MFMAs)

@@ -23,6 +23,7 @@ int mfma_hidden_saving(const MlpDev& m, int in_dim, int out_dim) {
 bool mfma_ode_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, false)) return a.a0 == nullptr || latent_ptrs_ok(a, false);   // a0 == NULL: dims-only query
     if (latent64_shape_ok(a, false)) return a.a0 == nullptr || latent64_ptrs_ok(a, false);
+    if (latentw_shape_ok(a, false)) return a.a0 == nullptr || latentw_ptrs_ok(a, false);
     const int h = mfma_hidden(a.de, 3 * (a.xd + a.zd), a.xd);
     if (a.xd < 1 || a.xd > 4 * kNXw || !h) return false;
     if (!streamed_class_ok(h / 16, false, a.xd > 4 * kNXc, nzm_of(a, false))) return false;     // hidden 193..256: x_dim <= 8
@@ -41,6 +42,7 @@ int mfma_ode_save_hidden(const IntegrateDev& a) {
 bool mfma_dae_supported(const IntegrateDev& a) {
     if (latent_shape_ok(a, true)) return a.a0 == nullptr || latent_ptrs_ok(a, true);
     if (latent64_shape_ok(a, true)) return a.a0 == nullptr || latent64_ptrs_ok(a, true);
+    if (latentw_shape_ok(a, true)) return a.a0 == nullptr || latentw_ptrs_ok(a, true);
     const int n = a.xd + a.zd + a.vd + a.id;
     if (a.xd < 1 || a.xd > 4 * kNXc || a.id < 1) return false;
     const int h = mfma_hidden(a.de, 3 * n, a.xd);
@@ -61,7 +63,10 @@ int mfma_dae_save_hidden(const IntegrateDev& a) {
 }
 
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
-    if (de && de->n_layers == 2) return latent_pack_floats() > latent64_pack_floats() ? latent_pack_floats() : latent64_pack_floats();
+    if (de && de->n_layers == 2) {
+        const size_t m = latent_pack_floats() > latent64_pack_floats() ? latent_pack_floats() : latent64_pack_floats();
+        return m > latentw_pack_floats() ? m : latentw_pack_floats();
+    }
     if (!de || de->n_layers != 4) return 0;
     const int n = de->in_dim / 3, nw = (padded_hidden_fwd(de->out_dim[0]) ? padded_hidden_fwd(de->out_dim[0]) : de->out_dim[0] + 15) / 16;
     const size_t one = (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64 + stream_image_floats(nw);
@@ -71,6 +76,7 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
     if (latent_shape_ok(a, dae)) return launch_latent(a, dae, pack, stream);
     if (latent64_shape_ok(a, dae)) return launch_latent64(a, dae, pack, stream);
+    if (latentw_shape_ok(a, dae)) return launch_latent_wide(a, dae, pack, stream);
     switch (padded_hidden_fwd(a.de.out_dim[0])) {
         case 32: return launch_mfma_h32(a, dae, pack, stream);
         case 128: return launch_mfma_h128(a, dae, pack, stream);

@@ -335,7 +335,7 @@ class DAE_Model(nn.Module):
             return None
         if getattr(solver, "kernel", "auto") == "generic":
             return None
-        # Measured (profiles/r04m_dae02_routes.txt, 4096 x 1000 steps): the one launch moves 140 B per state-step instead of ~1.7 KB and needs
+        # Measured (profiles/r04m_dae02_routes.txt, 4096 x 1000 steps): the one launch moves 140 B per state-step instead of 3.4 KB (13.7 GB vs 0.586 GB per batch, measured) and needs
         # none of the six [T,B,64] latent tensors (6.3 GB at that size), but at hidden 64 the encoders / decoders are MFMA work that the
         # row kernels run at full occupancy, and it is 8 % (RK4) / 12 % (Euler) SLOWER than the row kernels + K3c: opt-in
         # (model.one_launch = True or PSNODE_DAE02_ONE_LAUNCH=1), the row-kernel route stays the default.

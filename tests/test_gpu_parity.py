@@ -662,7 +662,7 @@ def test_shapes_beyond_every_kernel_fall_back_to_the_walk():
     from py_psnode_amd import _lib, models
     from py_psnode_amd import neural_dae as nd
     torch.manual_seed(1)
-    de = models.DE_Func(700, (64,), 350).cuda()          # in_features 2100 > PSNODE_MAX_WIDTH
+    de = models.DE_Func(700, (64,), 350).cuda()          # in_features 2100 > PSNODE_MAX_IN_WIDTH
     B, Tn = 3, 3
     t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1).cuda()
     x, z = 0.1 * torch.randn(Tn, B, 350).cuda(), 0.1 * torch.randn(Tn, B, 350).cuda()
