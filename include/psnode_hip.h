@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 6
+#define PSNODE_ABI_VERSION 7
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer OUTPUT the kernels accept */
 #define PSNODE_MAX_IN_WIDTH 2048 /* widest first-layer INPUT (the latent DE of DAE_02 at --hidden 128 is 12 x 128 = 1536 wide) */
@@ -543,6 +543,31 @@ typedef struct {
 int32_t psnode_dae_encoded_supported(const psnode_dae_encoded_args_f32* args);   /* 1 / 0, dims only */
 size_t psnode_dae_encoded_workspace_bytes(const psnode_dae_encoded_args_f32* args);
 int32_t psnode_dae_encoded_integrate_f32(const psnode_dae_encoded_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Adjoint sweep through the latent integrators of the direct_encode models at the hidden widths K9 / K8 do not take (every
+ * hidden_dim <= 128 with hidden_dim % 4 == 0 other than 16 / 64 -- the scripts' argparse default --hidden 128; K9w, ABI 7): the
+ * sequential half of loss.backward() through integrate_ODE / integrate_DAE (my_solvers.py:66-78, 94-129).  Reads what the forward call
+ * saved (psnode_*_integrate_f32 with save_act ...: [T-1,S,B,H] hidden activations, the AE head's [T,B,H] and event [nE,B,H] rows) and
+ * writes the rows every parameter / input gradient is a plain contraction over (library GEMMs on the caller's side,
+ * py_psnode_amd/fused.py: latent_backward_wide):
+ *   gk, d1 [T-1,S,B,H]  adjoint of each stage's RHS value / of its hidden pre-activation        d1s [T-1,B,H]  sum of d1 over the stages
+ *   gi, da1 [T,B,H]     (DAE) adjoint of i_k / of the AE head's hidden pre-activation           gi_ev, da1_ev [nE,B,H]  of the event heads
+ *   grad_x0 [B,H]       dL/dx_0 (x_init of the DAE, x[0] of the ODE)
+ * Every array contiguous and 16-byte aligned; the event rows zero-initialised by the caller (events no step takes stay zero). */
+typedef struct {
+    int32_t method, hidden, z_dim, dae;      /* z_dim = hidden, or 0 for the DAE without z */
+    int64_t T, B;
+    psnode_mlp_f32 de, ae;                   /* the latent MLPs (ae unused for the ODE) */
+    psnode_view_f32 t;
+    const int32_t* event_idx;                /* int32[T-1] or NULL */
+    const float *grad_xs, *grad_is;          /* [T,B,H]; grad_is NULL = zeros (or the ODE) */
+    const float *saved_act, *saved_ae_act, *saved_ev_act;
+    float *gk, *d1, *d1s, *gi, *da1, *gi_ev, *da1_ev, *grad_x0;
+} psnode_latent_bwd_wide_args_f32;
+
+int32_t psnode_latent_backward_wide_supported(int32_t hidden, int32_t z_dim, int32_t dae);
+size_t psnode_latent_backward_wide_workspace_bytes(int32_t hidden);
+int32_t psnode_latent_backward_wide_f32(const psnode_latent_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row width Hp of save_act for these dims (32 / 64 / 128) if an AUTO / MFMA call can save its activations, else 0 (dims only). */
 int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);

@@ -15,12 +15,13 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 6          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 7          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
                          #     psnode_dae_save_hidden;
                          #  5: flags (+ x_true / i_true) in psnode_ode_bwd_args_f32 / psnode_dae_bwd_wide_args_f32: teacher-forced backward;
-                         #  6: psnode_dae_encoded_*: the DAE_02 model forward in one launch)
+                         #  6: psnode_dae_encoded_*: the DAE_02 model forward in one launch;
+                         #  7: psnode_latent_backward_wide_*: the adjoint sweep of the latent integrators at hidden widths other than 16 / 64)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -36,6 +37,7 @@ EXPORTS = (
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
     "psnode_dae_encoded_supported", "psnode_dae_encoded_workspace_bytes", "psnode_dae_encoded_integrate_f32",
+    "psnode_latent_backward_wide_supported", "psnode_latent_backward_wide_workspace_bytes", "psnode_latent_backward_wide_f32",
     "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
     "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
     "psnode_dae_backward_wide_ae_floats",
@@ -124,6 +126,14 @@ class DaeEncodedArgsF32(ctypes.Structure):
                 ("x_pred", c_void_p), ("i_pred", c_void_p),
                 ("x_re", c_void_p), ("xre_stride_t", c_int64), ("xre_stride_b", c_int64),
                 ("i_re", c_void_p), ("ire_stride_t", c_int64), ("ire_stride_b", c_int64)]
+
+
+class LatentBwdWideArgsF32(ctypes.Structure):
+    _fields_ = [("method", c_int32), ("hidden", c_int32), ("z_dim", c_int32), ("dae", c_int32), ("T", c_int64), ("B", c_int64),
+                ("de", MlpF32), ("ae", MlpF32), ("t", ViewF32), ("event_idx", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
+                ("saved_act", c_void_p), ("saved_ae_act", c_void_p), ("saved_ev_act", c_void_p),
+                ("gk", c_void_p), ("d1", c_void_p), ("d1s", c_void_p), ("gi", c_void_p), ("da1", c_void_p), ("gi_ev", c_void_p),
+                ("da1_ev", c_void_p), ("grad_x0", c_void_p)]
 
 
 class OdeBwdWideArgsF32(ctypes.Structure):
@@ -248,6 +258,12 @@ def load():
     lib.psnode_ode_encoded_supported.argtypes = [ctypes.POINTER(OdeEncodedArgsF32)]
     lib.psnode_ode_encoded_integrate_f32.restype = c_int32
     lib.psnode_ode_encoded_integrate_f32.argtypes = [ctypes.POINTER(OdeEncodedArgsF32), c_void_p]
+    lib.psnode_latent_backward_wide_supported.restype = c_int32
+    lib.psnode_latent_backward_wide_supported.argtypes = [c_int32, c_int32, c_int32]
+    lib.psnode_latent_backward_wide_workspace_bytes.restype = c_size_t
+    lib.psnode_latent_backward_wide_workspace_bytes.argtypes = [c_int32]
+    lib.psnode_latent_backward_wide_f32.restype = c_int32
+    lib.psnode_latent_backward_wide_f32.argtypes = [ctypes.POINTER(LatentBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
     lib.psnode_dae_encoded_supported.restype = c_int32
     lib.psnode_dae_encoded_supported.argtypes = [ctypes.POINTER(DaeEncodedArgsF32)]
     lib.psnode_dae_encoded_workspace_bytes.restype = c_size_t

@@ -19,6 +19,8 @@ last_saved_bytes = 0
 
 
 def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
+    if fused.latent_wide_shape(layers, None, x_dim, z_dim):      # K3w saves, K9w reads: the only fused backward at these widths (no recompute form)
+        return True
     if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma"):
         return False
     Hp = fused.ode_save_hidden(method, layers, x_dim, z_dim, kernel)
@@ -36,6 +38,8 @@ def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
 def _want_saved_dae(method, kernel, de, ae, x_dim, z_dim, v_dim, i_dim, T, B):
     """The same policy for the DAE: saved rows are read by the fused-DE backward K7f, i.e. at hidden widths other than 64 (K7, the
     one-launch kernel there, recomputes)."""
+    if fused.latent_wide_shape(de, ae, x_dim, z_dim, v_dim, i_dim):
+        return True
     if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma") or len(de) not in (2, 4):
         return False
     if len(de) == 2:                     # the direct_encode latent shape at hidden 64 (K3c saves, K9 reads); hidden 16 (K3a / K8) recomputes
@@ -72,6 +76,8 @@ class _FusedOde(torch.autograd.Function):
             ctx.method, ctx.has_jump, ctx.has_saved, ctx.event_idx = method, z_jump is not None, False, event_idx
             ctx.save_for_backward(t, z, all_initial, xs, *((z_jump,) if z_jump is not None else ()), *params)
             return xs
+        if kernel == "generic" and fused.latent_wide_shape(layers, None, x0.shape[-1], z.shape[-1]):
+            kernel = "auto"      # training at these widths exists on K3w + K9w only (K0 saves nothing)
         save = _want_saved(method, kernel, layers, x0.shape[-1], z.shape[-1], t.shape[0], t.shape[1])
         res = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
                                   save=save)
@@ -130,6 +136,8 @@ class _FusedDae(torch.autograd.Function):
         ae = [(params[k], params[k + 1]) for k in range(2 * n_de, len(params), 2)]
         T, B = t.shape[0], t.shape[1]
         x_dummy = x_init.new_zeros((1, B, 0))
+        if kernel == "generic" and fused.latent_wide_shape(de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i_shape_like.shape[-1]):
+            kernel = "auto"
         save = _want_saved_dae(method, kernel, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i_shape_like.shape[-1], T, B)
         res = fused.dae_integrate(method, de, ae, x_init, t, x_dummy, z, v, i_shape_like, all_initial, z_jump=z_jump, v_jump=v_jump,
                                   event_idx=event_idx, kernel=kernel, save=save)

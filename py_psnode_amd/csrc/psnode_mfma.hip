@@ -35,6 +35,7 @@ int mfma_ode_save_hidden(const IntegrateDev& a) {
     // alignment requirements hold -- otherwise AUTO would fall back to K0, which writes no saved rows, and return PSNODE_OK all the same
     if (latent64_shape_ok(a, false)) return (a.a0 == nullptr || latent64_ptrs_ok(a, false)) ? 64 : 0;
     if (latent_shape_ok(a, false)) return 0;
+    if (latentw_shape_ok(a, false)) return (a.a0 == nullptr || latentw_ptrs_ok(a, false)) ? a.xd : 0;     // K3w saves rows of the real width
     if ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) || a.xd < 1 || a.xd > 4 * kNXc || nzm_of(a, false) > kMaxNZM) return 0;
     return mfma_hidden_saving(a.de, 3 * (a.xd + a.zd), a.xd);
 }
@@ -58,6 +59,7 @@ bool mfma_dae_supported(const IntegrateDev& a) {
 int mfma_dae_save_hidden(const IntegrateDev& a) {
     if (latent64_shape_ok(a, true)) return (a.a0 == nullptr || latent64_ptrs_ok(a, true)) ? 64 : 0;
     if (latent_shape_ok(a, true)) return 0;
+    if (latentw_shape_ok(a, true)) return (a.a0 == nullptr || latentw_ptrs_ok(a, true)) ? a.xd : 0;
     if ((a.flags & (PSNODE_FLAG_INPUT_TRUE_X | PSNODE_FLAG_INPUT_TRUE_I)) || !mfma_dae_supported(a)) return 0;
     return mfma_hidden_saving(a.de, 3 * (a.xd + a.zd + a.vd + a.id), a.xd);
 }

@@ -115,3 +115,69 @@ def test_models_at_the_argparse_default_hidden_128_run_fused_and_match_the_modul
         ref = m(**kw)
     for o, q in zip(out, ref):
         assert rel_err(o.cpu(), q.cpu(), bdim=0) <= TOL_GPU
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+def _train_case(tag, H, zd, method, events, B, T):
+    """loss.backward() through encoders -> K3w (saving) -> decoders, backward K9w + library GEMMs, vs the fp64 autograd walk on the CPU;
+    solver.fused = 'require': the fused route must take the call."""
+    from py_psnode_amd import models, neural_dae as nd
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+    r = lambda *s: 0.1 * torch.randn(*s, generator=g)
+    t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1)
+    x, z, v, i = r(B, T, 8), r(B, T, zd), r(B, T, 2), r(B, T, 2)
+    ev = t[:, [2, 6], :].contiguous() if (events and T > 7) else -torch.ones(B, 2, 1)
+    zj, vj = r(B, 2, zd), r(B, 2, 2)
+    cls = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]
+    if tag == "ode02":
+        mk = lambda: models.ODE_Model(8, zd, H, direct_encode=True, solver=cls())
+    else:
+        mk = lambda: models.DAE_Model(8, zd, 2, 2, H, direct_encode=True, solver=cls())
+    m32, m64 = mk(), mk().double()
+    m64.load_state_dict({k: v_.double() for k, v_ in m32.state_dict().items()})
+    m64.solver.fused = "off"
+    m32 = m32.cuda()
+    m32.solver.fused = "require"
+
+    def run(model, cast, dev):
+        c = lambda a: cast(a).to(dev)
+        if tag == "ode02":
+            outs = model(t=c(t), x=c(x), z=c(z), event_t=c(ev), z_jump=c(zj))
+        else:
+            outs = model(t=c(t), x=c(x), z=c(z), v=c(v), i=c(i), event_t=c(ev), z_jump=c(zj), v_jump=c(vj))
+        loss = sum(((o - 0.05) ** 2).sum() for o in outs)
+        loss.backward()
+        return [o.detach() for o in outs]
+
+    ref = run(m64, lambda a: a.double(), "cpu")
+    out = run(m32, lambda a: a, "cuda")
+    for a, b in zip(out, ref):
+        _close(a, b, 1e-5, "model output")
+    for (n, p), (_, q) in zip(m32.named_parameters(), m64.named_parameters()):
+        if q.grad is None or p.grad is None:
+            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and (q.grad is None or float(q.grad.abs().max()) == 0.0), n
+            continue
+        _close(p.grad, q.grad, 5e-4, n)
+
+
+@pytest.mark.parametrize("events", [False, True])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("tag,H,zd", [("ode02", 128, 2), ("dae02", 128, 2), ("dae02", 128, 0), ("ode02", 32, 2), ("dae02", 32, 2), ("dae02", 100, 0)])
+def test_direct_encode_training_at_other_hidden_widths_runs_fused_and_matches_fp64(tag, H, zd, method, events):
+    """The scripts' argparse default --hidden 128 (and 32 / 100, zero-padded): every parameter gradient of the direct_encode models --
+    encoders, decoders, Init_Func, the latent DE and AE -- against the fp64 autograd walk."""
+    _train_case(tag, H, zd, method, events, 19, 9)
+
+
+@pytest.mark.parametrize("B,T", [(3, 2), (17, 1), (1, 3), (33, 4)])
+@pytest.mark.parametrize("tag", ["ode02", "dae02"])
+def test_latent_wide_backward_edge_sizes(tag, B, T):
+    """K9w at the edges: single step, no step at all (T = 1), single trajectory, ragged third tile."""
+    _train_case(tag, 128, 2, "rk4", False, B, T)
