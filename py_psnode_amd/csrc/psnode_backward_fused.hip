@@ -22,6 +22,7 @@
 // per-workgroup ring in the workspace that is rewritten every step (24 KB per workgroup: it lives in L2, never in HBM).  Exchange tiles
 // 18 KB + transpose tiles 9 KB of LDS.
 #define PSNODE_ELU_LITERALS
+#include <stdlib.h>
 #include <string.h>
 
 #include "psnode_wide_pack.h"
@@ -36,6 +37,7 @@ __device__ __forceinline__ f4 fm4(float a, float b, f4 c) { return __builtin_amd
 
 struct FusedDev {
     int method, xd, zd, hreal, n_events, NP;
+    int no_roles;                         // PSNODE_K4F_NO_ROLES=1 in the environment: the one-role saved instance (A/B arm, tests)
     int true_x;                           // teacher-forced call: `xs` = the dataset rows, no adjoint carried from step to step (my_solvers.py:72-74)
     long long T, B;
     const float *w1, *w4;                 // raw nn.Linear tensors for the small transposed operands
@@ -69,10 +71,95 @@ struct FusedDev {
 #endif
 constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l's four rows 4g..4g+3 of column j at 4l + 8g
 
+#ifndef PSNODE_K4F_ROLES
+#define PSNODE_K4F_ROLES 1      // <= 4 waves, saved activations: a second set of NWV waves per tile owns the H->H weight gradients (below)
+#endif
+#ifndef PSNODE_K4F_ROLES_PRIO
+#define PSNODE_K4F_ROLES_PRIO 1 // the chain waves run at a higher issue priority than the gradient waves
+#endif
+
+// ROLES (round 4): the two-role form of the saved-activation instances at <= 4 waves per tile.  One wave per SIMD cannot hide an LDS
+// exchange or an MFMA result latency, and half of the backward's MFMAs -- the weight gradients dW2 / dW3 -- are not on the adjoint's
+// critical path at all.  The workgroup gets NWV more waves (one more per SIMD): waves 0..NWV-1 are the CHAIN (the sweep, as before, minus
+// the H->H weight gradients, their accumulators and the two in-wave transposes per stage), waves NWV..2NWV-1 are GRADIENT waves: each
+// loads its own 16 units of the saved h1 / h2 rows straight from the forward's save area (it needs nothing from the chain for that),
+// transposes them in its private tile, and contracts them with the delta tiles the chain's all-gathers publish anyway -- read TRANSPOSED
+// between the barrier that publishes them and the next one (the chain rewrites a parity two exchanges later, so one barrier sequence
+// shared by both roles is all the synchronisation there is).  The gradient waves' MFMAs fill the issue slots the chain leaves empty.
+template <int METHOD, int NZM, int NWV>
+__device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __restrict__ xb, const int l, const int wg) {
+    constexpr int S = rk_stages(METHOD), H = 16 * NWV;
+    const int g = l >> 4, j = l & 15, HR = a.hreal;
+    float* scr = xb + (3 * NWV + wg) * FTILE;                          // private transpose tile (behind the chain waves')
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const long long b = b0 + j < a.B ? b0 + j : a.B - 1;               // padding trajectories: their deltas are zero
+    const int toff = 4 * l + 8 * g, roff = 72 * (j >> 2) + 4 * g + (j & 3);
+    auto tile = [&](const int par, const int wv) -> const float* { return xb + (par * NWV + wv) * FTILE; };
+    auto get_row = [&](const float* t_) -> f4 { const float* s_ = t_ + roff; return f4{s_[0], s_[16], s_[32], s_[48]}; };
+    auto transpose = [&](const f4 v) -> f4 { *reinterpret_cast<f4*>(scr + toff) = v; return get_row(scr); };
+    const unsigned offH = 4u * ((unsigned)(b * H) + 16 * wg + 4 * g);
+    const long long act_layer = a.B * H, nT = a.T;
+    auto load_saved = [&](const long long idx, f4& q1, f4& q2) {
+        const float* rb = a.sact + (size_t)idx * 3 * act_layer;
+        q1 = ldg<f4>(sbase(rb), offH);
+        q2 = ldg<f4>(sbase(rb + act_layer), offH);
+    };
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    f4 accW2[NWV], accW3[NWV];
+#pragma unroll
+    for (int c = 0; c < NWV; ++c) { accW2[c] = zero4; accW3[c] = zero4; }
+    auto contract = [&](const int par, const f4 hT, f4 (&acc)[NWV]) {
+        f4 dT[NWV];
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) dT[c] = get_row(tile(par, (wg + c) & (NWV - 1)));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) acc[c] = fm4(dT[c][kk], hT[kk], acc[c]);      // NWV independent chains
+    };
+    f4 sv1 = zero4, sv2 = zero4;
+    if (nT >= 2) load_saved((nT - 1) * S - 1, sv1, sv2);
+    int p = 0;
+    for (long long k = nT - 2; k >= 0; --k) {
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            const long long idx = k * S + s;
+            const f4 h2T = transpose(sv2), h1T = transpose(sv1);
+            load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2);          // the next stage's rows: a whole stage ahead (nothing here waits on them)
+            lds_barrier();                                         // delta3 of every wave is in parity p
+            contract(p, h2T, accW3);
+            p ^= 1;
+            lds_barrier();                                         // delta2
+            contract(p, h1T, accW2);
+            p ^= 1;
+            lds_barrier();                                         // the stage's all-reduce
+            p ^= 1;
+        }
+        if constexpr (NZM > 0) { lds_barrier(); p ^= 1; }         // dL/dz all-reduce of the step
+    }
+    lds_barrier();                                                 // epilogue: dL/dall_initial all-reduce
+    const int K1 = 3 * (a.xd + a.zd);
+    float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
+    const int oW2 = HR * K1 + HR, oW3 = oW2 + HR * HR + HR;
+    const int v = 16 * wg + j;
+#pragma unroll
+    for (int c = 0; c < NWV; ++c) {
+        const int ub = 16 * ((wg + c) & (NWV - 1)) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (ub + r < HR && v < HR) {
+                wp[oW2 + (size_t)(ub + r) * HR + v] = accW2[c][r];
+                wp[oW3 + (size_t)(ub + r) * HR + v] = accW3[c][r];
+            }
+        }
+    }
+}
+
 // REC = false: the forward call saved the stage activations and stage inputs (psnode_ode_args_f32::save_act / save_xstage): no phase A,
 // the transposed images stay in LDS for the whole launch, the rows of (step, stage) are requested one stage ahead along the sweep.
-template <int METHOD, int NZM, int NWV, bool REC = true>
-__global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const FusedDev a, const float* __restrict__ pack_de,
+// ROLES: 2 NWV waves per tile, see fused_gradient_wave.
+template <int METHOD, int NZM, int NWV, bool REC = true, bool ROLES = false>
+__global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused_kernel(const FusedDev a, const float* __restrict__ pack_de,
                                                                         const f4* __restrict__ pack_t, const f4* __restrict__ pack_f,
                                                                         const int NA) {
     constexpr int NX = kNXc, S = rk_stages(METHOD), H = 16 * NWV;
@@ -82,8 +169,16 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     f4* wT = reinterpret_cast<f4*>(lds);                      // [layer 0: W2^T | 1: W3^T][chunk][wave][lane]
     float* xb = lds + (size_t)2 * NWV * NWV * 64 * 4;         // [2][NWV] exchange tiles (padded)
 
+    static_assert(!ROLES || (!REC && NWV <= 4), "two-role form: saved activations, <= 4 waves per tile");
     const int l = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (ROLES) {
+        if (w >= NWV) {
+            fused_gradient_wave<METHOD, NZM, NWV>(a, xb, l, w - NWV);
+            return;
+        }
+        if constexpr (PSNODE_K4F_ROLES_PRIO) __builtin_amdgcn_s_setprio(2);
+    }
     const int g = l >> 4, j = l & 15, i = j;
     float* scr = xb + 2 * NWV * FTILE + w * FTILE;           // this wave's private transpose tile
     const long long b0 = (long long)blockIdx.x * TBM;
@@ -254,7 +349,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #ifndef PSNODE_K4F_TREAD_AHEAD
 #define PSNODE_K4F_TREAD_AHEAD 1
 #endif
-    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1);
+    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1) && !ROLES;
     f4 pendT[DEFER ? NWV : 1], pend_h = f4{0.f, 0.f, 0.f, 0.f};      // transposed tiles / own activations of the layer whose gradient is still owed
 #ifndef PSNODE_K4F_DEFER8
 #define PSNODE_K4F_DEFER8 1         // 8 waves: the same deferral without holding the transposed tiles: they are re-read from the previous exchange's parity
@@ -304,18 +399,22 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
                                      // its own lgkmcnt(0) (found in the ISA)
 #endif
         if constexpr (PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && !(PSNODE_K4F_ABLATE & 1)) {
-            f4 vq[NWV], wqq[NWV], dTq[NWV];
+            f4 vq[NWV], wqq[NWV], dTq[ROLES ? 1 : NWV];
 #pragma unroll
             for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = wl[c * NWV * 64]; }
+            if constexpr (!ROLES) {
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+                for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 1; c < NWV; ++c) {
                 accA = fm4(wqq[c][0], vq[c][0], accA); accB = fm4(wqq[c][1], vq[c][1], accB);
                 accA = fm4(wqq[c][2], vq[c][2], accA); accB = fm4(wqq[c][3], vq[c][3], accB);
             }
-            if constexpr (DEFER) {
+            if constexpr (ROLES) {
+                (void)dTq; (void)hT; (void)acc;       // the gradient waves' work
+            } else if constexpr (DEFER) {
 #pragma unroll
                 for (int c = 0; c < NWV; ++c) pendT[c] = dTq[c];
                 pend_h = hT;
@@ -596,7 +695,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) accW4 = fm4(gT[kk], hT[kk], accW4);
             }
-            const f4 h2T = transpose(a2);
+            const f4 h2T = ROLES ? zero4 : transpose(a2);
             if constexpr (STREAM) {
                 if (s == S - 1) {    // the transposed images must have landed; the next step's inputs are requested BEHIND that wait
                     dma_wait();
@@ -606,7 +705,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
             const f4 d2 = midT(1, d3, h2T, accW3) * elu_grad_quad(a2);
             S2 += d2;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 1); }     // W3's region: forward image for the next step
-            const f4 h1T = transpose(a1);
+            const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             S1 += d1;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
@@ -718,7 +817,7 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     {
         const int v = 16 * w + j;        // own column
 #pragma unroll
-        for (int c = 0; c < NWV; ++c) {
+        for (int c = 0; c < (ROLES ? 0 : NWV); ++c) {      // (ROLES: written by the gradient waves)
             const int ub = 16 * ((w + c) & (NWV - 1)) + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -758,17 +857,20 @@ __global__ __launch_bounds__(64 * NWV) void ode_backward_fused_kernel(const Fuse
     }
 }
 
-size_t fused_lds_bytes(int nw) { return (wide_t_floats(nw) + (size_t)3 * nw * FTILE) * sizeof(float); }
+size_t fused_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) + (size_t)(roles ? 4 : 3) * nw * FTILE) * sizeof(float); }
 size_t fused_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
 int fused_np(int hr, int xd, int zd) { const int n = xd + zd; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
 
 template <int METHOD, int NWV>
 hipError_t launch_fused(const FusedDev& a, int NZM, const float* pde, const f4* pt, const f4* pf, int NA, hipStream_t s) {
-    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
-    const size_t lds = fused_lds_bytes(NWV);
+    constexpr bool RL = PSNODE_K4F_ROLES && NWV <= 4;
+    const bool roles = RL && a.sact != nullptr && !a.no_roles;
+    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV * (roles ? 2 : 1));
+    const size_t lds = fused_lds_bytes(NWV, roles);
 #define PSNODE_FUSED(NZM_)                                                                                                      \
     {                                                                                                                           \
-        auto kern = a.sact ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false> : &ode_backward_fused_kernel<METHOD, NZM_, NWV, true>; \
+        auto kern = roles ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false, RL>                                            \
+                          : (a.sact ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false> : &ode_backward_fused_kernel<METHOD, NZM_, NWV, true>); \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pt, pf, NA);                                                      \
@@ -851,6 +953,7 @@ int fused_bwd_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStre
     a.wpart = wpart; a.ring = ring;
     a.sact = p->saved_act; a.sxst = p->saved_xstage;
     a.true_x = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0;
+    { const char* e_ = getenv("PSNODE_K4F_NO_ROLES"); a.no_roles = (e_ && e_[0] == '1') ? 1 : 0; }
     if (a.true_x && a.sact) return PSNODE_ERR_UNSUPPORTED;     // a teacher-forced forward saves nothing: recompute form only
     hipError_t e;
     switch (nw) {
