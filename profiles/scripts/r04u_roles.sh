@@ -1,14 +1,19 @@
 #!/bin/bash
 # round 4: K4f two-role form (chain waves + gradient waves) at <= 4 waves per tile, saved activations; PSNODE_K4F_NO_ROLES=1 = the one-role instance
+# usage: r04u_roles.sh "variant names" (build/var_<name>/lib.so, `tree` = the shipped library)
 mkdir -p gpurun_out/r04u; O=gpurun_out/r04u
 timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_grad_goldens.py tests/test_gpu_determinism.py -m gpu -q -x -k "not dae" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 B="python bench.py --no-cpu-baseline --no-extras --train --steps 10 --warmup 3"
-P='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], "ms %.3f" % d["ms_per_step"], d["roofline"].get("kernel_ms_by_family"))'
-for m in rk4 midpoint euler; do
-  $B --workload ode01 --method $m 2>/dev/null | tail -1 | python -c "$P" "ode01 $m h64 roles"
+P='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], "ms %.3f" % d["ms_per_step"])'
+lib() { if [ "$1" = tree ]; then echo py_psnode_amd/libpsnode_hip.so; else echo build/var_$1/lib.so; fi; }
+for m in rk4 euler; do
+  for v in ${1:-tree}; do
+    PSNODE_LIB_PATH=$(lib $v) $B --workload ode01 --method $m 2>/dev/null | tail -1 | python -c "$P" "ode01 $m h64 $v"
+  done
   PSNODE_K4F_NO_ROLES=1 $B --workload ode01 --method $m 2>/dev/null | tail -1 | python -c "$P" "ode01 $m h64 one-role"
 done
-for h in 32 48; do
-  $B --workload ode01 --hidden $h 2>/dev/null | tail -1 | python -c "$P" "ode01 rk4 h$h roles"
-  PSNODE_K4F_NO_ROLES=1 $B --workload ode01 --hidden $h 2>/dev/null | tail -1 | python -c "$P" "ode01 rk4 h$h one-role"
+for h in 32; do
+  for v in ${1:-tree}; do
+    PSNODE_LIB_PATH=$(lib $v) $B --workload ode01 --hidden $h 2>/dev/null | tail -1 | python -c "$P" "ode01 rk4 h$h $v"
+  done
 done

@@ -23,6 +23,7 @@
 // 18 KB + transpose tiles 9 KB of LDS.
 #define PSNODE_ELU_LITERALS
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "psnode_wide_pack.h"
@@ -74,6 +75,14 @@ constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l'
 #ifndef PSNODE_K4F_ROLES
 #define PSNODE_K4F_ROLES 1      // <= 4 waves, saved activations: a second set of NWV waves per tile owns the H->H weight gradients (below)
 #endif
+#ifndef PSNODE_K4F_SAVED_AHEAD
+#define PSNODE_K4F_SAVED_AHEAD 2      // see the comment at its use in the stage loop
+#endif
+#define PSNODE_K4F_SAVED_AHEAD_DEFAULT PSNODE_K4F_SAVED_AHEAD
+#ifndef PSNODE_K4F_ROLES_SMALL
+#define PSNODE_K4F_ROLES_SMALL 1  // the gradient waves also own dW4 and the s columns of dW1 (gk / s / delta1 handed over in LDS tiles): no in-wave
+                                  // transpose is left on the chain
+#endif
 #ifndef PSNODE_K4F_ROLES_PRIO
 #define PSNODE_K4F_ROLES_PRIO 1 // the chain waves run at a higher issue priority than the gradient waves
 #endif
@@ -86,61 +95,109 @@ constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l'
 // transposes them in its private tile, and contracts them with the delta tiles the chain's all-gathers publish anyway -- read TRANSPOSED
 // between the barrier that publishes them and the next one (the chain rewrites a parity two exchanges later, so one barrier sequence
 // shared by both roles is all the synchronisation there is).  The gradient waves' MFMAs fill the issue slots the chain leaves empty.
+// LDS tiles of the two-role form (FTILE floats each, behind the exchange parities): chain-private NWV | gradient-private NWV | delta1 NWV | gk | s
+template <int NWV> __device__ __forceinline__ float* roles_d1_tile(float* xb, const int wv) { return xb + (4 * NWV + wv) * FTILE; }
+template <int NWV> __device__ __forceinline__ float* roles_gk_tile(float* xb) { return xb + 5 * NWV * FTILE; }
+template <int NWV> __device__ __forceinline__ float* roles_s_tile(float* xb) { return xb + (5 * NWV + 1) * FTILE; }
+
 template <int METHOD, int NZM, int NWV>
 __device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __restrict__ xb, const int l, const int wg) {
-    constexpr int S = rk_stages(METHOD), H = 16 * NWV;
-    const int g = l >> 4, j = l & 15, HR = a.hreal;
+    constexpr int S = rk_stages(METHOD), H = 16 * NWV, NX = kNXc;
+    const int g = l >> 4, j = l & 15, i = j, HR = a.hreal, xd = a.xd, zd = a.zd, n = xd + zd;
     float* scr = xb + (3 * NWV + wg) * FTILE;                          // private transpose tile (behind the chain waves')
     const long long b0 = (long long)blockIdx.x * TBM;
     const long long b = b0 + j < a.B ? b0 + j : a.B - 1;               // padding trajectories: their deltas are zero
     const int toff = 4 * l + 8 * g, roff = 72 * (j >> 2) + 4 * g + (j & 3);
+    // row of the s tile that holds column i of the stage input (as the chain's `srow`)
+    const int srow = i < xd ? 4 * (i & 3) + (i >> 2) : (i < n ? 4 * ((i - xd) & 3) + 2 + ((i - xd) >> 2) : -1);
+    const int sroff = srow >= 0 ? 72 * (srow >> 2) + 4 * g + (srow & 3) : 0;
     auto tile = [&](const int par, const int wv) -> const float* { return xb + (par * NWV + wv) * FTILE; };
-    auto get_row = [&](const float* t_) -> f4 { const float* s_ = t_ + roff; return f4{s_[0], s_[16], s_[32], s_[48]}; };
+    auto get_at = [&](const float* t_, const int ro) -> f4 { const float* s_ = t_ + ro; return f4{s_[0], s_[16], s_[32], s_[48]}; };
+    auto get_row = [&](const float* t_) -> f4 { return get_at(t_, roff); };
     auto transpose = [&](const f4 v) -> f4 { *reinterpret_cast<f4*>(scr + toff) = v; return get_row(scr); };
     const unsigned offH = 4u * ((unsigned)(b * H) + 16 * wg + 4 * g);
     const long long act_layer = a.B * H, nT = a.T;
-    auto load_saved = [&](const long long idx, f4& q1, f4& q2) {
+    auto load_saved = [&](const long long idx, f4& q1, f4& q2, f4& q3) {
         const float* rb = a.sact + (size_t)idx * 3 * act_layer;
         q1 = ldg<f4>(sbase(rb), offH);
         q2 = ldg<f4>(sbase(rb + act_layer), offH);
+        if constexpr (PSNODE_K4F_ROLES_SMALL) q3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
     };
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    f4 accW2[NWV], accW3[NWV];
+    f4 accW2[NWV], accW3[NWV], accW4 = zero4, accW1s = zero4;
 #pragma unroll
     for (int c = 0; c < NWV; ++c) { accW2[c] = zero4; accW3[c] = zero4; }
-    auto contract = [&](const int par, const f4 hT, f4 (&acc)[NWV]) {
-        f4 dT[NWV];
+    f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
+    if (nT >= 2) load_saved((nT - 1) * S - 1, sv1, sv2, sv3);
+    int p = 0;
+#ifndef PSNODE_K4F_ROLES_ABLATE
+#define PSNODE_K4F_ROLES_ABLATE 0      // timing experiments only (results WRONG): 1 = the gradient waves only keep the barrier sequence
+#endif
+    if constexpr (PSNODE_K4F_ROLES_ABLATE == 1) {
+        for (long long q = (nT - 1) * (3 * S + (NZM > 0 ? 1 : 0)); q > 0; --q) lds_barrier();
+        lds_barrier();
+        return;
+    }
+#ifndef PSNODE_K4F_ROLES_EARLY
+#define PSNODE_K4F_ROLES_EARLY 1       // chunks (4 MFMAs each) of a contraction issued in the interval its tiles are published in; the rest waits for the
+                                       // interval behind the stage's all-reduce, where the chain is latency-bound and leaves the MFMA pipe idle
+#endif
+    constexpr int E = PSNODE_K4F_ROLES_EARLY < NWV ? PSNODE_K4F_ROLES_EARLY : NWV;
+    auto read_tiles = [&](const int par, f4 (&dT)[NWV]) {
 #pragma unroll
         for (int c = 0; c < NWV; ++c) dT[c] = get_row(tile(par, (wg + c) & (NWV - 1)));
+    };
+    auto chunks = [&](const f4 (&dT)[NWV], const f4 hT, f4 (&acc)[NWV], const int c0, const int c1) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) acc[c] = fm4(dT[c][kk], hT[kk], acc[c]);      // NWV independent chains
+            for (int c = 0; c < NWV; ++c) if (c >= c0 && c < c1) acc[c] = fm4(dT[c][kk], hT[kk], acc[c]);
     };
-    f4 sv1 = zero4, sv2 = zero4;
-    if (nT >= 2) load_saved((nT - 1) * S - 1, sv1, sv2);
-    int p = 0;
     for (long long k = nT - 2; k >= 0; --k) {
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             const long long idx = k * S + s;
+            const f4 h3T = PSNODE_K4F_ROLES_SMALL ? transpose(sv3) : zero4;
             const f4 h2T = transpose(sv2), h1T = transpose(sv1);
-            load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2);          // the next stage's rows: a whole stage ahead (nothing here waits on them)
-            lds_barrier();                                         // delta3 of every wave is in parity p
-            contract(p, h2T, accW3);
+            load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3);     // the next stage's rows: a whole stage ahead (nothing here waits on them)
+            f4 dT3[NWV], dT2[NWV], sT = zero4;
+            lds_barrier();                                         // delta3 of every wave is in parity p; gk and s tiles of the stage
+            read_tiles(p, dT3);
+            if constexpr (PSNODE_K4F_ROLES_SMALL) {
+                const f4 gT = get_row(roles_gk_tile<NWV>(xb));
+                sT = get_at(roles_s_tile<NWV>(xb), sroff);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW4 = fm4(gT[kk], h3T[kk], accW4);
+            }
+            chunks(dT3, h2T, accW3, 0, E);
+            __builtin_amdgcn_sched_barrier(0);
             p ^= 1;
             lds_barrier();                                         // delta2
-            contract(p, h1T, accW2);
+            read_tiles(p, dT2);
+            chunks(dT3, h2T, accW3, E, 2 * E);
+            chunks(dT2, h1T, accW2, 0, E);
+            __builtin_amdgcn_sched_barrier(0);
             p ^= 1;
-            lds_barrier();                                         // the stage's all-reduce
+            lds_barrier();                                         // the stage's all-reduce; delta1 of the chain wave with these units
+            if constexpr (PSNODE_K4F_ROLES_SMALL) {
+                const f4 dT = get_row(roles_d1_tile<NWV>(xb, wg));
+                if (srow < 0) sT = zero4;
+                chunks(dT3, h2T, accW3, 2 * E, NWV);
+                chunks(dT2, h1T, accW2, E, NWV);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accW1s = fm4(dT[kk], sT[kk], accW1s);
+            } else {
+                chunks(dT3, h2T, accW3, 2 * E, NWV);
+                chunks(dT2, h1T, accW2, E, NWV);
+            }
             p ^= 1;
         }
         if constexpr (NZM > 0) { lds_barrier(); p ^= 1; }         // dL/dz all-reduce of the step
     }
-    lds_barrier();                                                 // epilogue: dL/dall_initial all-reduce
-    const int K1 = 3 * (a.xd + a.zd);
+    lds_barrier();                                                 // epilogue: dL/dall_initial all-reduce; sum(delta1) in the chain wave's private tile
+    const int K1 = 3 * n;
     float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
-    const int oW2 = HR * K1 + HR, oW3 = oW2 + HR * HR + HR;
+    const int oW2 = HR * K1 + HR, oW3 = oW2 + HR * HR + HR, oW4 = oW3 + HR * HR + HR;
     const int v = 16 * wg + j;
 #pragma unroll
     for (int c = 0; c < NWV; ++c) {
@@ -150,6 +207,34 @@ __device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __
             if (ub + r < HR && v < HR) {
                 wp[oW2 + (size_t)(ub + r) * HR + v] = accW2[c][r];
                 wp[oW3 + (size_t)(ub + r) * HR + v] = accW3[c][r];
+            }
+        }
+    }
+    if constexpr (PSNODE_K4F_ROLES_SMALL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
+            const int dd = 4 * r + g;
+            if (r < NX && dd < xd && v < HR) wp[oW4 + (size_t)dd * HR + v] = accW4[r];
+        }
+        // dW1: columns [a0 | s-a0 | s]; ca0 = sum(delta1) (x) a0 over the tile's trajectories
+        const f4 s1T = get_row(xb + (2 * NWV + wg) * FTILE);
+        f4 ca0 = zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const long long tb = b0 + 4 * kk + g;
+            const float av = (i < n && tb < a.B) ? a.a0[tb * n + i] : 0.0f;
+            ca0 = fm4(s1T[kk], av, ca0);
+        }
+        if (j < n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = 16 * wg + 4 * g + r;
+                if (u < HR) {
+                    float* row = wp + (size_t)u * K1;
+                    row[j] = ca0[r];
+                    row[n + j] = accW1s[r] - ca0[r];
+                    row[2 * n + j] = accW1s[r];
+                }
             }
         }
     }
@@ -349,6 +434,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
 #ifndef PSNODE_K4F_TREAD_AHEAD
 #define PSNODE_K4F_TREAD_AHEAD 1
 #endif
+    constexpr bool RSM = ROLES && PSNODE_K4F_ROLES_SMALL;
     constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1) && !ROLES;
     f4 pendT[DEFER ? NWV : 1], pend_h = f4{0.f, 0.f, 0.f, 0.f};      // transposed tiles / own activations of the layer whose gradient is still owed
 #ifndef PSNODE_K4F_DEFER8
@@ -558,8 +644,28 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
     };
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
     float svx[NX] = {};
-    if constexpr (!REC) { if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx); }
-    for (long long k = nT - 2; k >= 0; --k) {
+#ifndef PSNODE_K4F_SAVED_AHEAD_ROLES
+#define PSNODE_K4F_SAVED_AHEAD_ROLES 3     // two-role form (registers to spare on the chain): 3 = the rows are requested TWO stages ahead
+#endif
+    constexpr int SAHEAD = ROLES ? PSNODE_K4F_SAVED_AHEAD_ROLES : PSNODE_K4F_SAVED_AHEAD_DEFAULT;
+    // SAHEAD == 3: two register sets; the rows of linear index idx live in set (idx parity) -- a compile-time index: `s & 1` when the
+    // stage count is even, the parity of the step body (KP) at Euler, whose time loop is therefore written out twice per iteration.  (Moving
+    // the second set up with register copies instead would wait for the younger request at the copy.)
+    f4 tv1 = zero4, tv2 = zero4, tv3 = zero4;
+    float tvx[NX] = {};
+    constexpr int QLAST = S == 1 ? 0 : ((S - 1) & 1);      // set of the very first rows consumed
+    if constexpr (!REC) {
+        if (nT >= 2) {
+            const long long last = (nT - 2) * S + (S - 1);
+            if constexpr (SAHEAD == 3) {
+                if constexpr (QLAST == 0) { load_saved(last, sv1, sv2, sv3, svx); load_saved(last > 0 ? last - 1 : 0, tv1, tv2, tv3, tvx); }
+                else { load_saved(last, tv1, tv2, tv3, tvx); load_saved(last > 0 ? last - 1 : 0, sv1, sv2, sv3, svx); }
+            } else load_saved(last, sv1, sv2, sv3, svx);
+        }
+    }
+    auto step = [&](const long long k, auto kp_tag) {
+        constexpr int KP = decltype(kp_tag)::value;
+        (void)KP;
         float x0[NX], gin[NX], ext[NZ];
 #pragma unroll
         for (int r = 0; r < NX; ++r) { x0[r] = x2on(r) ? x0n[r] : 0.0f; gin[r] = x2on(r) ? ginn[r] : 0.0f; }
@@ -656,11 +762,26 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
                                       // Euler, no spills: 9.3 / 10.5 / 9.4: profiles/r03t_ahead.txt)
 #endif
                 const long long idx = k * S + s;
-                if constexpr (PSNODE_K4F_SAVED_AHEAD) {
+                if constexpr (SAHEAD) {
+                    if constexpr (SAHEAD == 3) {      // two stages ahead: this stage's set is consumed and refilled with the rows of idx - 2
+                        const int Q = S == 1 ? KP : (s & 1);      // (compile-time once the stage loop is unrolled)
+                        if (Q == 0) {
+                            a1 = sv1; a2 = sv2; a3 = sv3;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) X[s][r] = x2on(r) ? svx[r] : 0.0f;
+                            load_saved(idx > 1 ? idx - 2 : 0, sv1, sv2, sv3, svx);
+                        } else {
+                            a1 = tv1; a2 = tv2; a3 = tv3;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) X[s][r] = x2on(r) ? tvx[r] : 0.0f;
+                            load_saved(idx > 1 ? idx - 2 : 0, tv1, tv2, tv3, tvx);
+                        }
+                    } else {
                     a1 = sv1; a2 = sv2; a3 = sv3;
 #pragma unroll
                     for (int r = 0; r < NX; ++r) X[s][r] = x2on(r) ? svx[r] : 0.0f;
-                    if constexpr (PSNODE_K4F_SAVED_AHEAD == 1) load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+                    if constexpr (SAHEAD == 1) load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
+                    }
                 } else {
                     load_saved(idx, a1, a2, a3, svx);
 #pragma unroll
@@ -684,12 +805,19 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
             }
             const f2 gk = f2{gks[s][0], NX > 1 ? gks[s][1] : 0.0f};
             db4 += gk;
+            if constexpr (RSM) {      // gk and the stage input for the gradient waves (every chain wave holds the same values)
+                if (w == 0) {
+                    put(roles_gk_tile<NWV>(xb), f4{gk[0], gk[1], 0.f, 0.f});
+                    put(roles_s_tile<NWV>(xb), f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, (NZM > 0 && g < ne) ? ext[0] : 0.0f,
+                                                  (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
+                }
+            }
             f4 g3 = zero4;
 #pragma unroll
             for (int r = 0; r < NX; ++r) g3 = fm4(w4T[r], gks[s][r], g3);
             const f4 d3 = g3 * elu_grad_quad(a3);
             S3 += d3;
-            {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
+            if constexpr (!RSM) {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
                 const f4 gT = transpose(f4{gk[0], gk[1], 0.f, 0.f});
                 const f4 hT = transpose(a3);
 #pragma unroll
@@ -708,6 +836,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
             const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             S1 += d1;
+            if constexpr (RSM) put(roles_d1_tile<NWV>(xb, w), d1);
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
             const f4 ft = own4(fT, d1);           // rows 0..1: gX partial, rows 2..3: gz partial
             gzp += f2{ft[2], ft[3]};
@@ -720,12 +849,12 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
                     na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
                 }
             }
-            if constexpr (!REC && PSNODE_K4F_SAVED_AHEAD == 2) {      // request the next stage's rows late in this one (see SAVED_AHEAD)
+            if constexpr (!REC && SAHEAD == 2) {      // request the next stage's rows late in this one (see SAVED_AHEAD)
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
             }
             const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
-            {   // dW1 (`s` columns) += delta1 (x) s
+            if constexpr (!RSM) {   // dW1 (`s` columns) += delta1 (x) s
                 const f4 dT = transpose(d1);
                 put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, (NZM > 0 && g < ne) ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
                 const f4 sT = srow >= 0 ? get_row(scr, 72 * (srow >> 2) + 4 * g + (srow & 3)) : zero4;
@@ -755,6 +884,13 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
                 }
             }
         }
+    };
+    if constexpr (S == 1 && SAHEAD == 3 && !REC) {
+        long long k = nT - 2;
+        for (; k >= 1; k -= 2) { step(k, std::integral_constant<int, 0>{}); step(k - 1, std::integral_constant<int, 1>{}); }
+        if (k == 0) step(0, std::integral_constant<int, 0>{});
+    } else {
+        for (long long k = nT - 2; k >= 0; --k) step(k, std::integral_constant<int, 0>{});
     }
 
     // ---- epilogue
@@ -769,6 +905,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
         }
     }
     const int K1 = 3 * n;
+    if constexpr (RSM) put(scr, S1);      // for the gradient wave with these units (read behind the barrier below)
     {   // d all_initial[c] = sum_u (Wa - Wd)[u][c] S1[u]: split-K over the waves' own units, 16-byte all-reduce, rows c = 4g + r
         float at[4];
 #pragma unroll
@@ -791,7 +928,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
     // parameter-gradient partials of this workgroup, nn.Linear order with the MLP's real width HR as row stride
     float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
     const int oB1 = HR * K1, oW2 = oB1 + HR, oB2 = oW2 + HR * HR, oW3 = oB2 + HR, oB3 = oW3 + HR * HR, oW4 = oB3 + HR, oB4 = oW4 + xd * HR;
-    {
+    if constexpr (!RSM) {
         // dW1: columns [a0 | s-a0 | s]; ca0 = sum(delta1) (x) a0 over the tile's trajectories
         const f4 sT = transpose(S1);
         f4 ca0 = zero4;
@@ -828,7 +965,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
+        for (int r = 0; r < (RSM ? 0 : 4); ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
             const int dd = 4 * r + g;
             if (r < NX && dd < xd && v < HR) wp[oW4 + (size_t)dd * HR + v] = accW4[r];
         }
@@ -857,7 +994,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
     }
 }
 
-size_t fused_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) + (size_t)(roles ? 4 : 3) * nw * FTILE) * sizeof(float); }
+size_t fused_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) + ((size_t)(roles ? 5 : 3) * nw + (roles ? 2 : 0)) * FTILE) * sizeof(float); }
 size_t fused_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
 int fused_np(int hr, int xd, int zd) { const int n = xd + zd; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
 
