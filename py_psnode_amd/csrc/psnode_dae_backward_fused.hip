@@ -12,7 +12,9 @@
 // (LDS-DMA swap as K4f); the AE's H->H images -- forward and transposed -- are read from the packed tensors (L2) next to the MFMAs
 // that consume them; stage activations through a per-workgroup ring in the workspace.
 #define PSNODE_ELU_LITERALS
+#include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "psnode_wide_pack.h"
 
@@ -35,6 +37,7 @@ struct FusedDaeDev {
     long long zjb, zje, vjb, vje;
     const float *xs, *is, *gxs, *gis;
     const float *xtrue, *itrue;           // teacher forcing (recompute form only; my_solvers.py:111-121): dataset rows [T,B,xd] / [T,B,id]
+    int no_roles;                         // PSNODE_K7F_NO_ROLES=1 in the environment: the one-role saved instances (A/B arm, tests)
     int tx, ti;                           //   tx: DE starts and grid heads read xtrue, no x adjoint from step to step; ti: DE reads itrue, AE -> DE link cut
     float* carry_x;                       // [B, xd]: adjoint of x at grid point 0 (without dL/dxs[0])
     float *gzv, *gjump, *ga0;             // [T, B, nzv] (DE part), [B, n_events, nzv] (DE part), [B, n] (DE part)
@@ -55,10 +58,194 @@ constexpr int FTILE = 64 * 4 + 4 * 8;     // padded 16x16 tile (floats): lane l'
 
 __host__ __device__ constexpr bool aet_in_lds(int nwv) { return nwv <= 4; }
 
+#ifndef PSNODE_K7F_AE_GRADS
+#define PSNODE_K7F_AE_GRADS 1
+#endif
+#define PSNODE_K7F_AE_GRADS_DEFAULT PSNODE_K7F_AE_GRADS
+#ifndef PSNODE_K7F_ROLES
+#define PSNODE_K7F_ROLES 1      // <= 4 waves, saved activations: NWV gradient waves per tile own the four H->H weight gradients (K4f: PSNODE_K4F_ROLES)
+#endif
+#ifndef PSNODE_K7F_ROLES_EARLY
+#define PSNODE_K7F_ROLES_EARLY 1
+#endif
+// Two-role form (round 4; psnode_backward_fused.hip: fused_gradient_wave): waves NWV..2NWV-1 of the workgroup follow the chain's barrier
+// sequence -- per step: the head at grid point k+1 (3 exchanges), 3 per stage, the step's external-input all-reduce, the event's head
+// (3) -- and contract the delta tiles the chain's all-gathers publish with their own 16 units of the SAVED activations (DE stage rows,
+// grid heads, event heads), which they load themselves: dW2 / dW3 of the DE, dAW2 / dAW3 of the AE head.
+// LDS tiles of the two-role form behind the 2 NWV exchange parities (FTILE floats each): chain-private NWV | gradient-private NWV |
+// mailboxes [kind 0: DE stage rows, 1: head rows][wave][3 layers] | x boxes NWV
+template <int NWV> __device__ __forceinline__ float* k7f_roles_mailbox(float* xb, const int kind, const int wv) {
+    return xb + (size_t)(4 * NWV + (kind * NWV + wv) * 3) * FTILE;
+}
+template <int NWV> __device__ __forceinline__ float* k7f_roles_xbox(float* xb, const int wv) { return xb + (size_t)(10 * NWV + wv) * FTILE; }
+
+template <int METHOD, int NZM, int NWV>
+__device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, float* __restrict__ xb, const int l, const int wg) {
+    constexpr int S = rk_stages(METHOD), H = 16 * NWV;
+    const int g = l >> 4, j = l & 15, HR = a.hreal;
+    float* scr = xb + (3 * NWV + wg) * FTILE;                          // private transpose tile (behind the chain waves')
+    const long long b0 = (long long)blockIdx.x * TBM;
+    const long long b = b0 + j < a.B ? b0 + j : a.B - 1;               // padding trajectories: their deltas are zero
+    const int toff = 4 * l + 8 * g, roff = 72 * (j >> 2) + 4 * g + (j & 3);
+    auto tile = [&](const int par, const int wv) -> const float* { return xb + (par * NWV + wv) * FTILE; };
+    auto get_row = [&](const float* t_) -> f4 { const float* s_ = t_ + roff; return f4{s_[0], s_[16], s_[32], s_[48]}; };
+    auto transpose = [&](const f4 v) -> f4 { *reinterpret_cast<f4*>(scr + toff) = v; return get_row(scr); };
+    const unsigned offH = 4u * ((unsigned)(b * H) + 16 * wg + 4 * g);
+    const long long act_layer = a.B * H, nT = a.T;
+    constexpr int NX = kNXc;
+    unsigned offXc[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) offXc[r] = 4u * ((unsigned)(b * a.xd) + (4 * r + g < a.xd ? 4 * r + g : 0));
+    struct Rows { f4 v1, v2, v3; float x[NX]; };
+    auto load_saved = [&](const long long idx, Rows& q) {
+        const float* rb = a.sact + (size_t)idx * 3 * act_layer;
+        q.v1 = ldg<f4>(sbase(rb), offH);
+        q.v2 = ldg<f4>(sbase(rb + act_layer), offH);
+        q.v3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
+        const gptr<const float> xrow = sbase(a.sxst + idx * a.B * a.xd);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) q.x[r] = ldg<float>(xrow, offXc[r]);
+    };
+    auto load_head = [&](const long long kk, Rows& q) {
+        const float* rb = a.saeact + (size_t)kk * act_layer;
+        const size_t lay = (size_t)a.T * act_layer;
+        q.v1 = ldg<f4>(sbase(rb), offH);
+        q.v2 = ldg<f4>(sbase(rb + lay), offH);
+        q.v3 = ldg<f4>(sbase(rb + 2 * lay), offH);
+    };
+    // mailboxes of the chain wave with these units (lane-linear): the chain has no global load of a saved row
+    float* mb_act = k7f_roles_mailbox<NWV>(xb, 0, wg);
+    float* mb_head = k7f_roles_mailbox<NWV>(xb, 1, wg);
+    float* mb_x = k7f_roles_xbox<NWV>(xb, wg);
+    auto publish = [&](float* mb, const Rows& q) {
+        f4* m4 = reinterpret_cast<f4*>(mb) + l;
+        m4[0] = q.v1; m4[64] = q.v2; m4[128] = q.v3;
+    };
+    auto publish_x = [&](const Rows& q) { reinterpret_cast<f2*>(mb_x)[l] = f2{q.x[0], NX > 1 ? q.x[NX > 1 ? 1 : 0] : 0.0f}; };
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    f4 accW2[NWV], accW3[NWV], accA2[NWV], accA3[NWV];
+#pragma unroll
+    for (int c = 0; c < NWV; ++c) { accW2[c] = zero4; accW3[c] = zero4; accA2[c] = zero4; accA3[c] = zero4; }
+    constexpr int E = PSNODE_K7F_ROLES_EARLY < NWV ? PSNODE_K7F_ROLES_EARLY : NWV;
+    auto read_tiles = [&](const int par, f4 (&dT)[NWV]) {
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) dT[c] = get_row(tile(par, (wg + c) & (NWV - 1)));
+    };
+    auto chunks = [&](const f4 (&dT)[NWV], const f4 hT, f4 (&acc)[NWV], const int c0, const int c1) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int c = 0; c < NWV; ++c) if (c >= c0 && c < c1) acc[c] = fm4(dT[c][kk], hT[kk], acc[c]);
+    };
+    int p = 0;
+    // one MLP swept backwards by the chain: two all-gathers (delta3, delta2) and an all-reduce; `mid()` runs between the second
+    // all-gather's barrier and the all-reduce's (where the mailboxes may be rewritten)
+    auto sweep = [&](const f4 h1T, const f4 h2T, f4 (&acc3)[NWV], f4 (&acc2)[NWV], auto&& mid) {
+        f4 dT3[NWV], dT2[NWV];
+        lds_barrier();
+        read_tiles(p, dT3);
+        chunks(dT3, h2T, acc3, 0, E);
+        __builtin_amdgcn_sched_barrier(0);
+        p ^= 1;
+        lds_barrier();
+        read_tiles(p, dT2);
+        mid();
+        chunks(dT3, h2T, acc3, E, 2 * E);
+        chunks(dT2, h1T, acc2, 0, E);
+        __builtin_amdgcn_sched_barrier(0);
+        p ^= 1;
+        lds_barrier();
+        chunks(dT3, h2T, acc3, 2 * E, NWV);
+        chunks(dT2, h1T, acc2, E, NWV);
+        p ^= 1;
+    };
+    auto nothing = [] {};
+    // the DE rows of linear index idx live in set (idx parity): `s & 1` when the stage count is even, the parity KP of the step body at
+    // Euler, whose time loop is written out twice (psnode_backward_fused.hip)
+    Rows r0 = {}, r1 = {}, hn = {};
+    constexpr int QLAST = S == 1 ? 0 : ((S - 1) & 1);
+    if (nT >= 2) {
+        const long long last = (nT - 1) * S - 1;
+        if constexpr (QLAST == 0) { load_saved(last, r0); load_saved(last > 0 ? last - 1 : 0, r1); publish(mb_act, r0); publish_x(r0); }
+        else { load_saved(last, r1); load_saved(last > 0 ? last - 1 : 0, r0); publish(mb_act, r1); publish_x(r1); }
+    }
+    load_head(nT - 1, hn);
+    publish(mb_head, hn);
+    lds_barrier();                                                 // the first rows are in the mailboxes
+    auto step = [&](const long long k, auto kp_tag) {
+        constexpr int KP = decltype(kp_tag)::value;
+        (void)KP;
+        const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
+        {   // the head at grid point k+1
+            const f4 h2T = transpose(hn.v2), h1T = transpose(hn.v1);
+            load_head(k, hn);                                      // the next head: published in front of this step's last exchange
+            sweep(h1T, h2T, accA3, accA2, nothing);
+        }
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            const long long idx = k * S + s;
+            const int Q = S == 1 ? KP : (s & 1);                   // (compile-time once the stage loop is unrolled)
+            if (Q == 0) {
+                const f4 h2T = transpose(r0.v2), h1T = transpose(r0.v1);
+                load_saved(idx > 1 ? idx - 2 : 0, r0);             // two stages ahead
+                sweep(h1T, h2T, accW3, accW2, [&] { publish(mb_act, r1); publish_x(r1); });      // the chain's next stage
+            } else {
+                const f4 h2T = transpose(r1.v2), h1T = transpose(r1.v1);
+                load_saved(idx > 1 ? idx - 2 : 0, r1);
+                sweep(h1T, h2T, accW3, accW2, [&] { publish(mb_act, r0); publish_x(r0); });
+            }
+        }
+        publish(mb_head, hn);
+        lds_barrier();                                             // the step's external-input all-reduce
+        p ^= 1;
+        if (ev >= 0) {                                             // the event's head (rare)
+            f4 e1, e2;
+            const float* rb = a.sevact + (size_t)ev * 3 * act_layer;
+            e1 = ldg<f4>(sbase(rb), offH);
+            e2 = ldg<f4>(sbase(rb + act_layer), offH);
+            const f4 h2T = transpose(e2), h1T = transpose(e1);
+            sweep(h1T, h2T, accA3, accA2, nothing);
+        }
+    };
+    if constexpr (S == 1) {
+        long long k = nT - 2;
+        for (; k >= 1; k -= 2) { step(k, std::integral_constant<int, 0>{}); step(k - 1, std::integral_constant<int, 1>{}); }
+        if (k == 0) step(0, std::integral_constant<int, 0>{});
+    } else {
+        for (long long k = nT - 2; k >= 0; --k) step(k, std::integral_constant<int, 0>{});
+    }
+    {   // the head at grid point 0
+        const f4 h2T = transpose(hn.v2), h1T = transpose(hn.v1);
+        sweep(h1T, h2T, accA3, accA2, nothing);
+    }
+    lds_barrier();                                                 // epilogue: the two all-reduces of dL/dall_initial
+    lds_barrier();
+    const int ne = a.zd + a.vd + a.id, n = a.xd + ne, nzv = a.zd + a.vd, K1 = 3 * n, K1a = n + a.xd + nzv;
+    float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
+    float* wa = a.wpart_ae + (size_t)blockIdx.x * a.NPA;
+    const int oW2 = HR * K1 + HR, oW3 = oW2 + HR * HR + HR;
+    const int aW2 = HR * K1a + HR, aW3 = aW2 + HR * HR + HR;
+    const int v = 16 * wg + j;
+#pragma unroll
+    for (int c = 0; c < NWV; ++c) {
+        const int ub = 16 * ((wg + c) & (NWV - 1)) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (ub + r < HR && v < HR) {
+                wp[oW2 + (size_t)(ub + r) * HR + v] = accW2[c][r];
+                wp[oW3 + (size_t)(ub + r) * HR + v] = accW3[c][r];
+                wa[aW2 + (size_t)(ub + r) * HR + v] = accA2[c][r];
+                wa[aW3 + (size_t)(ub + r) * HR + v] = accA3[c][r];
+            }
+        }
+    }
+}
+
 // REC = false: the forward call saved every ELU output and stage input: no forward evaluation in here at all (no phase A, no head
 // recompute), the DE's transposed images stay in LDS for the whole launch, rows of (step, stage) are requested late in the previous stage.
-template <int METHOD, int NZM, int NZA, int NWV, bool REC = true>
-__global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const FusedDaeDev a, const float* __restrict__ pack_de,
+// ROLES: 2 NWV waves per tile, see dae_fused_gradient_wave.
+template <int METHOD, int NZM, int NZA, int NWV, bool REC = true, bool ROLES = false>
+__global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused_kernel(const FusedDaeDev a, const float* __restrict__ pack_de,
                                                                         const float* __restrict__ pack_ae, const f4* __restrict__ pack_t,
                                                                         const f4* __restrict__ pack_f, const f4* __restrict__ pack_ta,
                                                                         const f4* __restrict__ pack_fa, const int NA) {
@@ -78,8 +265,15 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     f4* wT = reinterpret_cast<f4*>(lds);                                  // DE: [layer 0: W2 | 1: W3][chunk][wave][lane]; AET_LDS: the AE's transposes behind it
     float* xb = lds + (size_t)TSZ * 4 * (AET_LDS ? 2 : 1);               // [2][NWV] exchange tiles (padded)
 
+    static_assert(!ROLES || (!REC && NWV <= 4), "two-role form: saved activations, <= 4 waves per tile");
     const int l = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (ROLES) {
+        if (w >= NWV) {
+            dae_fused_gradient_wave<METHOD, NZM, NWV>(a, xb, l, w - NWV);
+            return;
+        }
+    }
     const int g = l >> 4, j = l & 15, i = j;
     float* scr = xb + 2 * NWV * FTILE + w * FTILE;                       // this wave's private transpose tile
     const long long b0 = (long long)blockIdx.x * TBM;
@@ -301,7 +495,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #ifndef PSNODE_K7F_DEFER_DW
 #define PSNODE_K7F_DEFER_DW 1        // <= 4 waves: a layer's weight-gradient MFMAs run behind the NEXT exchange's LDS write (K4f: PSNODE_K4F_DEFER_DW)
 #endif
-    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD && PSNODE_K7F_DEFER_DW;
+    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD && PSNODE_K7F_DEFER_DW && !ROLES;
     f4 pendT[DEFER ? NWV : 1], pend_h = zero4;
 #ifndef PSNODE_K7F_DEFER8
 #define PSNODE_K7F_DEFER8 1         // 8 waves: the same deferral without holding the transposed tiles: they are re-read from the previous exchange's parity
@@ -344,18 +538,22 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
         if constexpr (PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD) {
-            f4 vq[NWV], wqq[NWV], dTq[NWV];
+            f4 vq[NWV], wqq[NWV], dTq[ROLES ? 1 : NWV];
 #pragma unroll
             for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = wl[c * NWV * 64]; }
+            if constexpr (!ROLES) {
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+                for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 1; c < NWV; ++c) {
                 accA = fm4(wqq[c][0], vq[c][0], accA); accB = fm4(wqq[c][1], vq[c][1], accB);
                 accA = fm4(wqq[c][2], vq[c][2], accA); accB = fm4(wqq[c][3], vq[c][3], accB);
             }
-            if constexpr (DEFER) {
+            if constexpr (ROLES) {
+                (void)dTq; (void)hT; (void)acc;       // the gradient waves' work
+            } else if constexpr (DEFER) {
 #pragma unroll
                 for (int c = 0; c < NWV; ++c) pendT[c] = dTq[c];
                 pend_h = hT;
@@ -526,10 +724,10 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) accAP3 = fm4(gT[kk], hT[kk], accAP3);
             }
-            const f4 h2T = transpose(a2);
+            const f4 h2T = ROLES ? zero4 : transpose(a2);
             const f4 d2 = midT(3, d3, h2T, accA3) * elu_grad_quad(a2);           // the AE's W3^T (layer 3 of wT), dAW3 from the published tiles
             SA2 += d2;
-            const f4 h1T = transpose(a1);
+            const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(2, d2, h1T, accA2, &accA3) * elu_grad_quad(a1);
             SA1 += d1;
             const f4 ft = own4(afT, d1), fz = own4(afZ, d1);
@@ -640,12 +838,18 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #endif
     // (<= 4 waves only: hidden-64 training step 20.9 -> 20.6 ms; at 8 waves the twelve registers cost more in spills than the latency they
     //  hide -- RK4 49.9 -> 56.3 ms, profiles/r03y_head_ahead_ab.txt)
-    constexpr bool HEAD_AHEAD = !REC && NWV <= 4 && PSNODE_K7F_HEAD_AHEAD;
+    constexpr bool HEAD_AHEAD = !REC && NWV <= 4 && PSNODE_K7F_HEAD_AHEAD && !ROLES;
     f4 hn1 = zero4, hn2 = zero4, hn3 = zero4;
-    if constexpr (!REC) {
+    if constexpr (!REC && !ROLES) {
         if (nT >= 2) load_saved((nT - 2) * S + (S - 1), sv1, sv2, sv3, svx);
         if constexpr (HEAD_AHEAD) load_head(nT - 1, hn1, hn2, hn3);
     }
+    // ROLES: the saved rows arrive through the mailboxes the gradient wave with the same units fills (it requests them two stages / a
+    // whole step ahead): this wave issues no global load for them, and holds no register set of rows in flight
+    auto mailbox = [&](const int kind, f4& q1, f4& q2, f4& q3) {
+        const f4* m4 = reinterpret_cast<const f4*>(k7f_roles_mailbox<NWV>(xb, kind, w)) + l;
+        q1 = m4[0]; q2 = m4[64]; q3 = m4[128];
+    };
 #ifndef PSNODE_K7F_INPUTS_AHEAD
 #define PSNODE_K7F_INPUTS_AHEAD 1
 #endif
@@ -742,6 +946,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             if constexpr (REC) load_x2(a.tx ? a.xtrue : a.xs, nT - 1, x1_c);
         }
     }
+    if constexpr (ROLES) lds_barrier();      // the first rows are in the mailboxes
     for (long long k = nT - 2; k >= 0; --k) {
         int ev;
         float gq[NZM], gin[NX], ext[NZM], x0[NX] = {}, x1[NX] = {}, xh[NX], zvh[NZA], h_;
@@ -765,6 +970,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             f4 a1, a2, a3;
             if constexpr (REC) {
                 ae_hidden(x1, k + 1, -1, a1, a2, a3);
+            } else if constexpr (ROLES) {
+                mailbox(1, a1, a2, a3);
             } else if constexpr (HEAD_AHEAD) {
                 a1 = hn1; a2 = hn2; a3 = hn3;
             } else {
@@ -887,7 +1094,12 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             f4 a1, a2, a3;
-            if constexpr (!REC) {
+            if constexpr (ROLES) {
+                mailbox(0, a1, a2, a3);
+                const f2 xq = reinterpret_cast<const f2*>(k7f_roles_xbox<NWV>(xb, w))[l];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) X[s][r] = (4 * r + g < xd) ? xq[r & 1] : 0.0f;
+            } else if constexpr (!REC) {
                 a1 = sv1; a2 = sv2; a3 = sv3;
 #pragma unroll
                 for (int r = 0; r < NX; ++r) X[s][r] = (4 * r + g < xd) ? svx[r] : 0.0f;
@@ -906,12 +1118,12 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) accW4 = fm4(gT[kk], hT[kk], accW4);
             }
-            const f4 h2T = transpose(a2);
+            const f4 h2T = ROLES ? zero4 : transpose(a2);
             if constexpr (STREAM) { if (s == S - 1) dma_wait(); }     // the transposed images must have landed
             const f4 d2 = midT(1, d3, h2T, accW3) * elu_grad_quad(a2);
             S2 += d2;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 1); }     // W3's region: forward image for the next step
-            const f4 h1T = transpose(a1);
+            const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             D1 += d1;
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
@@ -924,7 +1136,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
                     na3 = ldg<f4>(sbase(a.ring + rb + 2 * nrow * H), offH);
                 }
             }
-            if constexpr (!REC) {      // the next stage's rows, requested late in this one (K4f: PSNODE_K4F_SAVED_AHEAD)
+            if constexpr (!REC && !ROLES) {      // the next stage's rows, requested late in this one (K4f: PSNODE_K4F_SAVED_AHEAD)
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
                 if constexpr (HEAD_AHEAD) { if (s == 0) load_head(k, hn1, hn2, hn3); }      // grid point k: the head of the next iteration (or the one behind the loop)
@@ -996,6 +1208,8 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
             float x1[NX];
             load_x2(a.tx ? a.xtrue : a.xs, 0, x1);
             ae_hidden(x1, 0, -1, a1, a2, a3);
+        } else if constexpr (ROLES) {
+            mailbox(1, a1, a2, a3);
         } else if constexpr (HEAD_AHEAD) {
             if (nT >= 2) { a1 = hn1; a2 = hn2; a3 = hn3; }
             else load_head(0, a1, a2, a3);
@@ -1069,7 +1283,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     {
         const int v = 16 * w + j;        // own column
 #pragma unroll
-        for (int c = 0; c < NWV; ++c) {
+        for (int c = 0; c < (ROLES ? 0 : NWV); ++c) {      // (ROLES: written by the gradient waves)
             const int ub = 16 * ((w + c) & (NWV - 1)) + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1135,7 +1349,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
         {
             const int v = 16 * w + j;        // own column
 #pragma unroll
-            for (int c = 0; c < NWV; ++c) {
+            for (int c = 0; c < (ROLES ? 0 : NWV); ++c) {
                 const int ub = 16 * ((w + c) & (NWV - 1)) + 4 * g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1168,7 +1382,7 @@ __global__ __launch_bounds__(64 * NWV) void dae_backward_fused_kernel(const Fuse
     }
 }
 
-size_t k7f_lds_bytes(int nw) { return (wide_t_floats(nw) * (aet_in_lds(nw) ? 2 : 1) + (size_t)3 * nw * FTILE) * sizeof(float); }
+size_t k7f_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) * (aet_in_lds(nw) ? 2 : 1) + (size_t)(roles ? 11 : 3) * nw * FTILE) * sizeof(float); }
 size_t k7f_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
 int k7f_np(int hr, int xd, int ne) { const int n = xd + ne; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
 // <= 4 waves: the AE head's partials [dAW1 | db1 | dAW2 | db2 | dAW3 | db3 | P3 (16 x h) | sum gi (16)]
@@ -1180,11 +1394,14 @@ size_t k7f_fwd_floats(int nw, int n) { return ((wide_fwd_floats(nw, n) + 63) / 6
 template <int METHOD, int NWV>
 hipError_t launch_k7f(const FusedDaeDev& a, int NZM, int NZA, const float* pde, const float* pae, const f4* pt, const f4* pf, const f4* pta,
                       const f4* pfa, int NA, hipStream_t s) {
-    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
-    const size_t lds = k7f_lds_bytes(NWV);
+    constexpr bool RL = PSNODE_K7F_ROLES && PSNODE_K7F_AE_GRADS_DEFAULT && NWV <= 4;
+    const bool roles = RL && a.sact != nullptr && !a.no_roles;
+    const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV * (roles ? 2 : 1));
+    const size_t lds = k7f_lds_bytes(NWV, roles);
 #define PSNODE_K7F(NZM_, NZA_)                                                                                                  \
     {                                                                                                                           \
-        auto kern = a.sact ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false> : &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, true>; \
+        auto kern = roles ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false, RL>                                      \
+                          : (a.sact ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false> : &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, true>); \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, pt, pf, pta, pfa, NA);                                       \
@@ -1281,6 +1498,7 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     a.xs = p->xs; a.is = p->is; a.gxs = p->grad_xs; a.gis = p->grad_is;
     a.tx = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0; a.ti = (p->flags & PSNODE_FLAG_INPUT_TRUE_I) ? 1 : 0;
     a.xtrue = p->x_true; a.itrue = p->i_true;
+    { const char* e_ = getenv("PSNODE_K7F_NO_ROLES"); a.no_roles = (e_ && e_[0] == '1') ? 1 : 0; }
     if ((a.tx || a.ti) && p->saved_act) return PSNODE_ERR_UNSUPPORTED;      // a teacher-forced forward saves nothing: recompute form only
     if ((a.tx && !a.xtrue) || (a.ti && !a.itrue)) return PSNODE_ERR_NULL;
     a.carry_x = p->carry_x;
