@@ -78,6 +78,13 @@ template <int NWV> __device__ __forceinline__ float* k7f_roles_mailbox(float* xb
     return xb + (size_t)(4 * NWV + (kind * NWV + wv) * 3) * FTILE;
 }
 template <int NWV> __device__ __forceinline__ float* k7f_roles_xbox(float* xb, const int wv) { return xb + (size_t)(10 * NWV + wv) * FTILE; }
+// ... | delta1 NWV | g (output adjoint of the MLP being swept) | u (its first-layer input rows): handed to the gradient waves (padded tiles)
+template <int NWV> __device__ __forceinline__ float* k7f_roles_d1_tile(float* xb, const int wv) { return xb + (size_t)(11 * NWV + wv) * FTILE; }
+template <int NWV> __device__ __forceinline__ float* k7f_roles_g_tile(float* xb) { return xb + (size_t)(12 * NWV) * FTILE; }
+template <int NWV> __device__ __forceinline__ float* k7f_roles_u_tile(float* xb) { return xb + (size_t)(12 * NWV + 1) * FTILE; }
+#ifndef PSNODE_K7F_ROLES_SMALL
+#define PSNODE_K7F_ROLES_SMALL 1  // the gradient waves also own dW4 / dW1 (s columns) / dAW4 (P3) / dAW1 (u columns): no in-wave transpose left on the chain
+#endif
 
 template <int METHOD, int NZM, int NWV>
 __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, float* __restrict__ xb, const int l, const int wg) {
@@ -123,9 +130,16 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
     };
     auto publish_x = [&](const Rows& q) { reinterpret_cast<f2*>(mb_x)[l] = f2{q.x[0], NX > 1 ? q.x[NX > 1 ? 1 : 0] : 0.0f}; };
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    f4 accW2[NWV], accW3[NWV], accA2[NWV], accA3[NWV];
+    f4 accW2[NWV], accW3[NWV], accA2[NWV], accA3[NWV], accW4 = zero4, accW1s = zero4, accAP3 = zero4, accA1u = zero4;
 #pragma unroll
     for (int c = 0; c < NWV; ++c) { accW2[c] = zero4; accW3[c] = zero4; accA2[c] = zero4; accA3[c] = zero4; }
+    constexpr bool RSM = PSNODE_K7F_ROLES_SMALL;
+    // rows of the u tile that hold column i of the first-layer input: the DE's stage input s = (x | ext), the head's u = (x | z | v)
+    const int xd_ = a.xd, nzv_ = a.zd + a.vd, n_ = a.xd + nzv_ + a.id, i = j;
+    const int rowx_ = 4 * (i & 3) + (i >> 2), rowe_ = 4 * ((i - xd_) & 3) + 2 + ((i - xd_) >> 2);
+    const int srow = i < xd_ ? rowx_ : (i < n_ ? rowe_ : -1), arow = i < xd_ ? rowx_ : (i < xd_ + nzv_ ? rowe_ : -1);
+    const int sroff = srow >= 0 ? 72 * (srow >> 2) + 4 * g + (srow & 3) : 0, aroff = arow >= 0 ? 72 * (arow >> 2) + 4 * g + (arow & 3) : 0;
+    auto get_at = [&](const float* t_, const int ro) -> f4 { const float* s_ = t_ + ro; return f4{s_[0], s_[16], s_[32], s_[48]}; };
     constexpr int E = PSNODE_K7F_ROLES_EARLY < NWV ? PSNODE_K7F_ROLES_EARLY : NWV;
     auto read_tiles = [&](const int par, f4 (&dT)[NWV]) {
 #pragma unroll
@@ -140,10 +154,18 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
     int p = 0;
     // one MLP swept backwards by the chain: two all-gathers (delta3, delta2) and an all-reduce; `mid()` runs between the second
     // all-gather's barrier and the all-reduce's (where the mailboxes may be rewritten)
-    auto sweep = [&](const f4 h1T, const f4 h2T, f4 (&acc3)[NWV], f4 (&acc2)[NWV], auto&& mid) {
-        f4 dT3[NWV], dT2[NWV];
+    // (RSM: h3T = the MLP's third ELU output, own units, operand layout; acc4 += g (x) h3, acc1 += delta1 (x) u; uoff / uon: this lane's row of the u tile)
+    auto sweep = [&](const f4 h1T, const f4 h2T, const f4 h3T, f4 (&acc3)[NWV], f4 (&acc2)[NWV], f4& acc4, f4& acc1, const int uoff, const bool uon,
+                     auto&& mid) {
+        f4 dT3[NWV], dT2[NWV], uT = zero4;
         lds_barrier();
         read_tiles(p, dT3);
+        if constexpr (RSM) {
+            const f4 gT = get_row(k7f_roles_g_tile<NWV>(xb));
+            uT = get_at(k7f_roles_u_tile<NWV>(xb), uoff);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc4 = fm4(gT[kk], h3T[kk], acc4);
+        }
         chunks(dT3, h2T, acc3, 0, E);
         __builtin_amdgcn_sched_barrier(0);
         p ^= 1;
@@ -155,11 +177,21 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
         __builtin_amdgcn_sched_barrier(0);
         p ^= 1;
         lds_barrier();
-        chunks(dT3, h2T, acc3, 2 * E, NWV);
-        chunks(dT2, h1T, acc2, E, NWV);
+        if constexpr (RSM) {
+            const f4 dT = get_row(k7f_roles_d1_tile<NWV>(xb, wg));
+            if (!uon) uT = zero4;
+            chunks(dT3, h2T, acc3, 2 * E, NWV);
+            chunks(dT2, h1T, acc2, E, NWV);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc1 = fm4(dT[kk], uT[kk], acc1);
+        } else {
+            chunks(dT3, h2T, acc3, 2 * E, NWV);
+            chunks(dT2, h1T, acc2, E, NWV);
+        }
         p ^= 1;
     };
     auto nothing = [] {};
+    auto tr3 = [&](const f4 v3) -> f4 { return RSM ? transpose(v3) : zero4; };
     // the DE rows of linear index idx live in set (idx parity): `s & 1` when the stage count is even, the parity KP of the step body at
     // Euler, whose time loop is written out twice (psnode_backward_fused.hip)
     Rows r0 = {}, r1 = {}, hn = {};
@@ -177,34 +209,35 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
         (void)KP;
         const int ev = a.ev ? __builtin_amdgcn_readfirstlane(a.ev[k]) : -1;
         {   // the head at grid point k+1
-            const f4 h2T = transpose(hn.v2), h1T = transpose(hn.v1);
+            const f4 h3T = tr3(hn.v3), h2T = transpose(hn.v2), h1T = transpose(hn.v1);
             load_head(k, hn);                                      // the next head: published in front of this step's last exchange
-            sweep(h1T, h2T, accA3, accA2, nothing);
+            sweep(h1T, h2T, h3T, accA3, accA2, accAP3, accA1u, aroff, arow >= 0, nothing);
         }
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
             const long long idx = k * S + s;
             const int Q = S == 1 ? KP : (s & 1);                   // (compile-time once the stage loop is unrolled)
             if (Q == 0) {
-                const f4 h2T = transpose(r0.v2), h1T = transpose(r0.v1);
+                const f4 h3T = tr3(r0.v3), h2T = transpose(r0.v2), h1T = transpose(r0.v1);
                 load_saved(idx > 1 ? idx - 2 : 0, r0);             // two stages ahead
-                sweep(h1T, h2T, accW3, accW2, [&] { publish(mb_act, r1); publish_x(r1); });      // the chain's next stage
+                sweep(h1T, h2T, h3T, accW3, accW2, accW4, accW1s, sroff, srow >= 0, [&] { publish(mb_act, r1); publish_x(r1); });      // the chain's next stage
             } else {
-                const f4 h2T = transpose(r1.v2), h1T = transpose(r1.v1);
+                const f4 h3T = tr3(r1.v3), h2T = transpose(r1.v2), h1T = transpose(r1.v1);
                 load_saved(idx > 1 ? idx - 2 : 0, r1);
-                sweep(h1T, h2T, accW3, accW2, [&] { publish(mb_act, r0); publish_x(r0); });
+                sweep(h1T, h2T, h3T, accW3, accW2, accW4, accW1s, sroff, srow >= 0, [&] { publish(mb_act, r0); publish_x(r0); });
             }
         }
         publish(mb_head, hn);
         lds_barrier();                                             // the step's external-input all-reduce
         p ^= 1;
         if (ev >= 0) {                                             // the event's head (rare)
-            f4 e1, e2;
+            f4 e1, e2, e3 = zero4;
             const float* rb = a.sevact + (size_t)ev * 3 * act_layer;
             e1 = ldg<f4>(sbase(rb), offH);
             e2 = ldg<f4>(sbase(rb + act_layer), offH);
-            const f4 h2T = transpose(e2), h1T = transpose(e1);
-            sweep(h1T, h2T, accA3, accA2, nothing);
+            if constexpr (RSM) e3 = ldg<f4>(sbase(rb + 2 * act_layer), offH);
+            const f4 h3T = tr3(e3), h2T = transpose(e2), h1T = transpose(e1);
+            sweep(h1T, h2T, h3T, accA3, accA2, accAP3, accA1u, aroff, arow >= 0, nothing);
         }
     };
     if constexpr (S == 1) {
@@ -215,8 +248,8 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
         for (long long k = nT - 2; k >= 0; --k) step(k, std::integral_constant<int, 0>{});
     }
     {   // the head at grid point 0
-        const f4 h2T = transpose(hn.v2), h1T = transpose(hn.v1);
-        sweep(h1T, h2T, accA3, accA2, nothing);
+        const f4 h3T = tr3(hn.v3), h2T = transpose(hn.v2), h1T = transpose(hn.v1);
+        sweep(h1T, h2T, h3T, accA3, accA2, accAP3, accA1u, aroff, arow >= 0, nothing);
     }
     lds_barrier();                                                 // epilogue: the two all-reduces of dL/dall_initial
     lds_barrier();
@@ -236,6 +269,37 @@ __device__ __forceinline__ void dae_fused_gradient_wave(const FusedDaeDev& a, fl
                 wp[oW3 + (size_t)(ub + r) * HR + v] = accW3[c][r];
                 wa[aW2 + (size_t)(ub + r) * HR + v] = accA2[c][r];
                 wa[aW3 + (size_t)(ub + r) * HR + v] = accA3[c][r];
+            }
+        }
+    }
+    if constexpr (RSM) {
+        const int oW4 = oW3 + HR * HR + HR, aP3 = aW3 + HR * HR + HR;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units; P3 rows (g, r) <-> slot 4r+g
+            const int dd = 4 * r + g;
+            if (r < NX && dd < a.xd && v < HR) wp[oW4 + (size_t)dd * HR + v] = accW4[r];
+            if (v < HR) wa[aP3 + (size_t)(4 * r + g) * HR + v] = accAP3[r];
+        }
+        // first layers: ca0 = sum(delta1) (x) a0 over the tile's trajectories; the chain waves left sum(delta1) of the DE in their private
+        // tiles and of the AE head in their stage-row mailboxes (padded layout)
+        const f4 s1T = get_row(xb + (2 * NWV + wg) * FTILE), sa1T = get_row(k7f_roles_mailbox<NWV>(xb, 0, wg));
+        f4 ca0 = zero4, caa = zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const long long tb = b0 + 4 * kk + g;
+            const float av = (i < n_ && tb < a.B) ? a.a0[tb * n_ + i] : 0.0f;
+            ca0 = fm4(s1T[kk], av, ca0);
+            caa = fm4(sa1T[kk], av, caa);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = 16 * wg + 4 * g + r;
+            if (u < HR) {
+                float* row = wp + (size_t)u * K1;
+                if (j < n_) { row[j] = ca0[r]; row[n_ + j] = accW1s[r] - ca0[r]; row[2 * n_ + j] = accW1s[r]; }
+                float* rowa = wa + (size_t)u * K1a;
+                if (j < n_) rowa[j] = caa[r];
+                if (j < xd_ + nzv_) rowa[n_ + j] = accA1u[r];
             }
         }
     }
@@ -495,6 +559,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
 #ifndef PSNODE_K7F_DEFER_DW
 #define PSNODE_K7F_DEFER_DW 1        // <= 4 waves: a layer's weight-gradient MFMAs run behind the NEXT exchange's LDS write (K4f: PSNODE_K4F_DEFER_DW)
 #endif
+    constexpr bool RSM = ROLES && PSNODE_K7F_ROLES_SMALL;
     constexpr bool DEFER = PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD && PSNODE_K7F_DEFER_DW && !ROLES;
     f4 pendT[DEFER ? NWV : 1], pend_h = zero4;
 #ifndef PSNODE_K7F_DEFER8
@@ -718,7 +783,12 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             SA3 += d3;
             const f4 gs4 = f4{gs[0], NZM > 1 ? gs[NZM > 1 ? 1 : 0] : 0.0f, NZM > 2 ? gs[NZM > 2 ? 2 : 0] : 0.0f, NZM > 3 ? gs[NZM > 3 ? 3 : 0] : 0.0f};
             SGi += gs4;
-            {   // dAW4[slot of row][own unit] += gs (x) h3, contracted over the tile's trajectories (rows (g, r) <-> slot 4r+g)
+            if constexpr (RSM) {      // the head's output adjoint and first-layer input rows for the gradient waves (the same in every chain wave)
+                if (w == 0) {
+                    put(k7f_roles_g_tile<NWV>(xb), gs4);
+                    put(k7f_roles_u_tile<NWV>(xb), f4{xa[0], NX > 1 ? xa[NX > 1 ? 1 : 0] : 0.0f, zva[0], NZA > 1 ? zva[NZA > 1 ? 1 : 0] : 0.0f});
+                }
+            } else {   // dAW4[slot of row][own unit] += gs (x) h3, contracted over the tile's trajectories (rows (g, r) <-> slot 4r+g)
                 const f4 gT = transpose(gs4);
                 const f4 hT = transpose(a3);
 #pragma unroll
@@ -730,9 +800,10 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(2, d2, h1T, accA2, &accA3) * elu_grad_quad(a1);
             SA1 += d1;
+            if constexpr (RSM) put(k7f_roles_d1_tile<NWV>(xb, w), d1);
             const f4 ft = own4(afT, d1), fz = own4(afZ, d1);
             const f4 red = allreduce4(f4{ft[0], ft[1], fz[0], fz[1]}, zero4, &accA2);
-            {   // dAW1 (u columns) += delta1 (x) u, u = (x | z | v) of the head
+            if constexpr (!RSM) {   // dAW1 (u columns) += delta1 (x) u, u = (x | z | v) of the head
                 const f4 dT = transpose(d1);
                 put(scr, f4{xa[0], NX > 1 ? xa[NX > 1 ? 1 : 0] : 0.0f, zva[0], NZA > 1 ? zva[NZA > 1 ? 1 : 0] : 0.0f});
                 const f4 sT = arow >= 0 ? get_row(scr, 72 * (arow >> 2) + 4 * g + (arow & 3)) : zero4;
@@ -1112,7 +1183,12 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             for (int r = 0; r < NX; ++r) g3 = fm4(w4T[r], gks[s][r], g3);
             const f4 d3 = g3 * elu_grad_quad(a3);
             S3 += d3;
-            {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
+            if constexpr (RSM) {      // gk and the stage input for the gradient waves (every chain wave holds the same values)
+                if (w == 0) {
+                    put(k7f_roles_g_tile<NWV>(xb), f4{gk[0], gk[1], 0.f, 0.f});
+                    put(k7f_roles_u_tile<NWV>(xb), f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, g < ne ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
+                }
+            } else {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
                 const f4 gT = transpose(f4{gk[0], gk[1], 0.f, 0.f});
                 const f4 hT = transpose(a3);
 #pragma unroll
@@ -1126,6 +1202,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             const f4 h1T = ROLES ? zero4 : transpose(a1);
             const f4 d1 = midT(0, d2, h1T, accW2, &accW3) * elu_grad_quad(a1);
             D1 += d1;
+            if constexpr (RSM) put(k7f_roles_d1_tile<NWV>(xb, w), d1);
             if constexpr (STREAM) { if (s == 0 && k > 0) dma_layer(pack_f, 0); }
             const f4 ft = own4(fT, d1);
             if constexpr (STREAM) {
@@ -1142,7 +1219,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
                 if constexpr (HEAD_AHEAD) { if (s == 0) load_head(k, hn1, hn2, hn3); }      // grid point k: the head of the next iteration (or the one behind the loop)
             }
             const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
-            {   // dW1 (`s` columns) += delta1 (x) s, s = (X_s | ext)
+            if constexpr (!RSM) {   // dW1 (`s` columns) += delta1 (x) s, s = (X_s | ext)
                 const f4 dT = transpose(d1);
                 put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, g < ne ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
                 const f4 sT = srow >= 0 ? get_row(scr, 72 * (srow >> 2) + 4 * g + (srow & 3)) : zero4;
@@ -1231,6 +1308,10 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
         for (int r = 0; r < NX; ++r) if (4 * r + g < xd) stg<float>(sbase(a.carry_x), offX + 16u * r, gcar[r]);
     }
     const int K1 = 3 * n;
+    if constexpr (RSM) {      // for the gradient wave with these units (read behind the barriers below): padded layout
+        put(scr, S1);
+        put(k7f_roles_mailbox<NWV>(xb, 0, w), SA1);
+    }
     {   // DE part of d all_initial[c] = sum_u (Wa - Wd)[u][c] S1[u]: split-K over the waves' own units, all-reduce, rows c = 4g + r
         float at[4];
 #pragma unroll
@@ -1257,7 +1338,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
     // parameter-gradient partials of this workgroup, nn.Linear order with the MLP's real width HR as row stride
     float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
     const int oB1 = HR * K1, oW2 = oB1 + HR, oB2 = oW2 + HR * HR, oW3 = oB2 + HR, oB3 = oW3 + HR * HR, oW4 = oB3 + HR, oB4 = oW4 + xd * HR;
-    {
+    if constexpr (!RSM) {
         // dW1: columns [a0 | s-a0 | s]; ca0 = sum(delta1) (x) a0 over the tile's trajectories
         const f4 sT = transpose(S1);
         f4 ca0 = zero4;
@@ -1294,7 +1375,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
+        for (int r = 0; r < (RSM ? 0 : 4); ++r) {   // dW4 rows (g, r) <-> x-dim 4r+g, columns = own units
             const int dd = 4 * r + g;
             if (r < NX && dd < xd && v < HR) wp[oW4 + (size_t)dd * HR + v] = accW4[r];
         }
@@ -1327,7 +1408,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
         float* wa = a.wpart_ae + (size_t)blockIdx.x * a.NPA;
         const int K1a = n + xd + nzv;
         const int aB1 = HR * K1a, aW2 = aB1 + HR, aB2 = aW2 + HR * HR, aW3 = aB2 + HR, aB3 = aW3 + HR * HR, aP3 = aB3 + HR, aSG = aP3 + 16 * HR;
-        {
+        if constexpr (!RSM) {
             const f4 sT = transpose(SA1);
             f4 ca0 = zero4;
 #pragma unroll
@@ -1360,7 +1441,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (v < HR) wa[aP3 + (size_t)(4 * r + g) * HR + v] = accAP3[r];      // rows (g, r) <-> slot 4r+g
+            for (int r = 0; r < (RSM ? 0 : 4); ++r) if (v < HR) wa[aP3 + (size_t)(4 * r + g) * HR + v] = accAP3[r];      // rows (g, r) <-> slot 4r+g
         }
         f4 s1 = SA1, s2 = SA2, s3 = SA3, sg = SGi;
 #pragma unroll
@@ -1382,7 +1463,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
     }
 }
 
-size_t k7f_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) * (aet_in_lds(nw) ? 2 : 1) + (size_t)(roles ? 11 : 3) * nw * FTILE) * sizeof(float); }
+size_t k7f_lds_bytes(int nw, bool roles = false) { return (wide_t_floats(nw) * (aet_in_lds(nw) ? 2 : 1) + ((size_t)(roles ? 12 : 3) * nw + (roles ? 2 : 0)) * FTILE) * sizeof(float); }
 size_t k7f_ring_floats(int nw, int method, long long B) { return nw >= 8 ? (size_t)rk_stages(method) * 3 * (size_t)B * 16 * nw : 0; }
 int k7f_np(int hr, int xd, int ne) { const int n = xd + ne; return hr * 3 * n + hr + 2 * (hr * hr + hr) + xd * hr + xd; }
 // <= 4 waves: the AE head's partials [dAW1 | db1 | dAW2 | db2 | dAW3 | db3 | P3 (16 x h) | sum gi (16)]
