@@ -860,3 +860,42 @@ def test_saved_activations_of_another_call_are_refused():
     _, saved_e = fused.ode_integrate("euler", layers, t, x, z, a0, save=True)
     with pytest.raises(ValueError, match="saved activations do not belong"):
         fused.ode_backward("rk4", layers, t, z, a0, xs, G, saved=saved_e)                               # other method (S = 1 vs 4)
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("H", [32, 64])
+@pytest.mark.parametrize("kind", ["ode", "dae"])
+def test_two_role_and_one_role_saved_backward_agree(kind, H, method, monkeypatch):
+    """Round 4: at <= 4 waves per tile the saved-activation backward kernels run in the two-role form (chain waves + gradient waves that
+    own the weight-gradient contractions; K7f: the gradient waves also load the saved rows for the chain).  Same arithmetic in the same
+    order as the one-role instances (PSNODE_K4F_NO_ROLES / PSNODE_K7F_NO_ROLES = 1): every output must be bit-equal, on a ragged tile,
+    with events and per-trajectory clocks, odd and even step counts (the Euler loop is written out twice per iteration)."""
+    from py_psnode_amd import fused
+    for Tn in (8, 9, 2):
+        B = 21
+        if kind == "ode":
+            lin, t, x, z, ev, zj, G = _case(B, Tn, 8, 2, seed=7 + Tn, events=Tn > 4)
+            lin = [nn.Linear(d0, d1) for d0, d1 in zip([30, H, H, H], [H, H, H, 8])]
+            c = lambda a: None if a is None else a.cuda()
+            layers = [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in lin]
+            a0 = torch.cat((x[0], z[0]), -1).cuda()
+            xs, saved = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj), save=True)
+            tab = fused.event_table(c(t), c(ev)) if ev is not None else None
+            run = lambda: fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), saved=saved, kernel="wide")
+            flat = lambda o: [q for q in o[:4] if q is not None] + list(o[4])
+        else:
+            de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(B, Tn, 8, 2, 2, 2, 11 + Tn, Tn > 4, H=H)
+            xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, 2, device="cuda")
+            xs, is_, saved = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj, save=True)
+            tab = fused.event_table(t, ev) if ev is not None else None
+            run = lambda: fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, Gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="wide", saved=saved)
+            flat = lambda o: [o[k_] for k_ in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial") if o[k_] is not None] + list(o["de"]) + list(o["ae"])
+        two = flat(run())
+        monkeypatch.setenv("PSNODE_K4F_NO_ROLES", "1")
+        monkeypatch.setenv("PSNODE_K7F_NO_ROLES", "1")
+        one = flat(run())
+        monkeypatch.delenv("PSNODE_K4F_NO_ROLES")
+        monkeypatch.delenv("PSNODE_K7F_NO_ROLES")
+        assert len(two) == len(one)
+        for k_, (p, q) in enumerate(zip(two, one)):
+            assert torch.equal(p, q), f"{kind} H{H} {method} T{Tn}: output {k_} differs between the two-role and the one-role kernel: {(p - q).abs().max().item():.3e}"
