@@ -21,24 +21,18 @@
 // in LDS, each lane reading back the A-operand values it wrote; W2 of the AE (event steps only) and the a0 blocks (epilogue
 // only) are streamed from the packed image.
 #define PSNODE_ELU_LITERALS   // register-bound kernels: ELU coefficients as literals, not as 8 resident VGPRs (psnode_common.h)
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
 
-#include "psnode_common.h"
+#include "psnode_latent64_bwd.h"
 
 namespace psnode {
 namespace {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int H9 = 64, NW9 = 4, SCR9 = 64 * 4 + 4 * 8;
 
-__device__ __forceinline__ f4 m9(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f4 elu9(f4 v) { return elu_quad(v); }
-__device__ __forceinline__ f4 dact9(f4 h) {
-    return elu_grad_quad(h);
-}
-__device__ __forceinline__ f4 z9() { return f4{0.f, 0.f, 0.f, 0.f}; }
 
 // pack[wave][reg][lane]; forward section identical to K3c's image, then the transposed section:
 //   fwd:  F[nfront] (16 each) | B1 (4) | W2 (16) | B2 (4) | A0[nblk] (16 each)
@@ -82,15 +76,7 @@ __global__ void pack9_kernel(const Pack9 p) {
     }
 }
 
-struct Bwd9Dev {
-    IntegrateDev a;          // t, z, v, a0, ev, zj, vj (+strides), T, B, zd, method
-    const float *xs, *is_, *gxs, *gis;
-    float *gx0, *gz, *gv, *gzj, *gvj, *ga0, *wpart;
-    int n_events, NP_de, NP_ae;
-};
-
 struct V9 { f4 v[4]; };      // a 64-wide vector in chunk layout: v[c] = dims 16((w+c)&3) + 4g + (0..3) of trajectory j
-struct A9 { f4 c[4]; };      // gradient of one 64x64 block, own 16 rows: c[chunk] rows 16w+4g+r, columns 16((w+chunk)&3) + j
 
 // REC = false: the training forward (K3c SAVE instances) saved the hidden ELU outputs and stage inputs of every DE stage, the AE head's
 // hidden layer per grid point and per event taken, and the event-time i0 (IntegrateDev::sact / sxst / saeact / sevact / sevi): nothing is
@@ -626,6 +612,7 @@ __global__ __launch_bounds__(256) void latent64_backward_kernel(const Bwd9Dev d,
     }
 }
 
+
 int np9(int k1) { return H9 * k1 + H9 + H9 * H9 + H9; }
 bool two9(const psnode_mlp_f32& m, int in_dim) { return m.n_layers == 2 && m.in_dim == in_dim && m.out_dim[0] == H9 && m.out_dim[1] == H9; }
 bool mis9(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
@@ -635,8 +622,15 @@ bool fits9(long long B, long long stride_b) { return stride_b >= 0 && (unsigned 
 size_t pack9_floats(int nblk) { return (size_t)2 * NW9 * p9_regs(nblk, nblk) * 64; }
 size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 + 4 * NW9 * 64 + nlb * 4 * NW9 * 64) * sizeof(f4) + (size_t)NW9 * SCR9 * sizeof(float); }
 
+#ifndef PSNODE_K9_ROLES
+#define PSNODE_K9_ROLES 1
+#endif
 template <int METHOD, int NBE, bool DAE>
 hipError_t launch9(const Bwd9Dev& d, const float* pde, const float* pae, hipStream_t s) {
+    if constexpr (DAE && PSNODE_K9_ROLES) {
+        const char* e_ = getenv("PSNODE_K9_NO_ROLES");
+        if (d.a.sact && !(e_ && e_[0] == '1')) return launch9_roles(METHOD, NBE, d, pde, pae, s);      // saved activations: the two-role form (psnode_latent64_bwd_roles.hip)
+    }
     auto kern = d.a.sact ? &latent64_backward_kernel<METHOD, NBE, DAE, false> : &latent64_backward_kernel<METHOD, NBE, DAE, true>;
     const size_t lds = lds9_bytes((DAE && !d.a.sact) ? 2 * NBE : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
