@@ -489,6 +489,74 @@ def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
     return res
 
 
+MODEL_TRAIN_EXTRAS = [("dae02", "rk4"), ("dae02", "euler"), ("ode02", "rk4")]
+
+
+def model_train_extra_line(workload, method, dev, steps=8, warmup=3):
+    """Training step of a direct_encode MODEL as the script runs it (neural_01_DAE_02_direct_encode.py:359-370 / neural_00_ODE_02_direct_encode.py:267-275):
+    encoders -> fused latent integrator -> decoders -> the script's loss (K6) -> backward through all of it (row-MLP backward kernels, K9 / K8f),
+    B=4096 x 1000 steps at the hidden width the script ships with.  roofline.frac on the 3x-forward executed-flop convention."""
+    from py_psnode_amd import loss as L, models
+    from py_psnode_amd import neural_dae as nd
+    w = dict(WORKLOADS[workload])
+    B, T, H = w["B"], w["T"], w["H"]
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: (0.1 * torch.randn(*s, generator=g)).to(dev)
+    t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1).to(dev)
+    x, z, v, i = r(B, T, 8), r(B, T, 2), r(B, T, 2), r(B, T, 2)
+    ev, zj, vj = -torch.ones(B, 2, 1, device=dev), torch.zeros(B, 2, 2, device=dev), torch.zeros(B, 2, 2, device=dev)
+    mask8, mask1 = torch.ones(B, T, 8, device=dev), torch.ones(B, T, 1, device=dev)
+    solver = {"rk4": nd.RK4, "euler": nd.Euler, "midpoint": nd.Midpoint}[method]()
+    torch.manual_seed(0)
+    if workload == "ode02":
+        m = models.ODE_Model(8, 2, H, direct_encode=True, solver=solver).to(dev)
+    else:
+        m = models.DAE_Model(8, 2, 2, 2, H, direct_encode=True, solver=solver).to(dev)
+    m.solver.fused = "require"
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        if workload == "ode02":
+            o = m(t=t, x=x, z=z, event_t=ev, z_jump=zj)
+            loss = L.ode02_loss(o[0], o[1], x, mask8)[0]
+        else:
+            o = m(t=t, x=x, z=z, v=v, i=i, event_t=ev, z_jump=zj, v_jump=vj)
+            loss = L.dae02_loss(o[0], o[1], o[2], o[3], x, i, mask1)[0]
+        loss.backward()
+        return o
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    E = lambda: torch.cuda.Event(enable_timing=True)
+    evs = [(E(), E()) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        evs[k][0].record()
+        outs = step()
+        evs[k][1].record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    each = sorted(a.elapsed_time(b) for a, b in evs)
+    avg, med = sum(each) / steps, each[steps // 2]
+    ss = B * (T - 1)
+    p_cpu = make_problem(w, 16, 3)
+    flops = 3 * flops_per_state_step(w, p_cpu, method)
+    ach = flops * ss / (avg * 1e-3) / 1e12
+    grads_ok = all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in m.parameters())
+    res = {"workload": f"{workload} {method} MODEL TRAIN (encoders + latent integrator + decoders + the script's loss + backward): B={B} x {T - 1} steps, H{H}",
+           "steps": steps, "warmup": warmup, "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
+           "outputs_finite": bool(torch.isfinite(outs[0]).all()), "grads_finite": grads_ok,
+           "roofline": {"bound": "mfma" if H >= 64 else "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                        "flop_convention": "3 x forward executed flops per state-step", "flop_per_state_step": flops,
+                        "kernel_ms": avg, "kernel_ms_median": med, "kernel_ms_each": [round(a.elapsed_time(b), 3) for a, b in evs]}}
+    del m, outs
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run on this
     node (one process per GPU, RCCL; rendezvous on 127.0.0.1 at a free port) and return its exit code.  The children see
@@ -722,6 +790,7 @@ def main():
             res["extra"] = [extra_line(lib, _lib, fused, wl, m, dev) for wl, m in EXTRAS]
             if not args.no_train_extras:
                 res["extra"] += [train_extra_line(fused, wl, m, h, dev) for wl, m, h in TRAIN_EXTRAS]
+                res["extra"] += [model_train_extra_line(wl, m, dev) for wl, m in MODEL_TRAIN_EXTRAS]
             res["extra"] += [extra_line(lib, _lib, fused, wl, m, dev, steps=5, warmup=3, hidden=h, env=e, note=n) for wl, m, h, e, n in LATE_EXTRAS]
             outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:

@@ -57,8 +57,11 @@ def test_default_bench_line_carries_the_extra_workloads():
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     names = [e["workload"].split(":")[0] for e in d["extra"]]
     train = ["ode01 rk4 TRAIN", "dae01 rk4 TRAIN", "ode01 euler TRAIN", "dae01 euler TRAIN", "ode01 rk4 TRAIN", "dae01 rk4 TRAIN"]
+    model_train = ["dae02 rk4 MODEL TRAIN", "dae02 euler MODEL TRAIN", "ode02 rk4 MODEL TRAIN"]      # whole direct_encode training steps (round 4)
     late = ["dae02 rk4", "dae02 rk4", "ode01 rk4"]       # DAE_02 forward on both routes, hidden 256 (streamed weights)
-    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train + late
+    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train + model_train + late
+    for e in d["extra"][10:13]:
+        assert e["grads_finite"] and e["roofline"]["flop_convention"].startswith("3 x forward")
     for e in d["extra"]:
         assert e["outputs_finite"] and 0.05 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_median"] > 0
     assert "H256" in d["extra"][-1]["workload"] and d["extra"][-1]["kernel"] == "mfma" and d["extra"][-1]["roofline"]["frac"] > 0.5
