@@ -134,7 +134,7 @@ __device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __
 #define PSNODE_K4F_ROLES_ABLATE 0      // timing experiments only (results WRONG): 1 = the gradient waves only keep the barrier sequence
 #endif
     if constexpr (PSNODE_K4F_ROLES_ABLATE == 1) {
-        for (long long q = (nT - 1) * (3 * S + (NZM > 0 ? 1 : 0)); q > 0; --q) lds_barrier();
+        for (long long q = (nT - 1) * (3 * S); q > 0; --q) lds_barrier();
         lds_barrier();
         return;
     }
@@ -192,8 +192,7 @@ __device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __
             }
             p ^= 1;
         }
-        if constexpr (NZM > 0) { lds_barrier(); p ^= 1; }         // dL/dz all-reduce of the step
-    }
+    }                                                              // (the step's dL/dz rides on the last stage's all-reduce)
     lds_barrier();                                                 // epilogue: dL/dall_initial all-reduce; sum(delta1) in the chain wave's private tile
     const int K1 = 3 * n;
     float* wp = a.wpart + (size_t)blockIdx.x * a.NP;
@@ -572,6 +571,17 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
         p ^= 1;
         return out;
     };
+    // 16-byte form: the last stage's dL/dx rides with the step's dL/dz (one exchange less per step: a quarter of them at Euler)
+    auto allreduce4 = [&](const f4 part, f4 (*pacc)[NWV] = nullptr) -> f4 {
+        put(tile(p, w), part);
+        if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
+        lds_barrier();
+        f4 out = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NWV; ++c) out += getl(tile(p, c));
+        p ^= 1;
+        return out;
+    };
     // split-K over the waves' own units (4 MFMAs)
     auto own4 = [&](const float (&wq)[4], const f4 h) -> f4 {
         f4 accA = fm4(wq[0], h[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
@@ -750,6 +760,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
             for (int s = 0; s < S; ++s) gks[s][r] = (h_ * rk_b(METHOD, s)) * g1;
         }
         f2 gzp = f2{0.f, 0.f};                    // z rows of F^T delta1: this wave's partial, summed over the stages (z is frozen over them)
+        f2 gzr = f2{0.f, 0.f};                    // ... all-reduced with the last stage's dL/dx
         f4 na1 = la1, na2 = la2, na3 = la3;       // STREAM: activations of the stage handled next, requested one stage ahead
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
@@ -853,7 +864,12 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
                 const long long idx = k * S + s;
                 load_saved(idx > 0 ? idx - 1 : 0, sv1, sv2, sv3, svx);
             }
-            const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
+            f2 gx;
+            if (NZM > 0 && s == 0) {      // (compile-time once the stage loop is unrolled)
+                const f4 r4 = allreduce4(f4{ft[0], ft[1], gzp[0], gzp[1]}, &accW2);
+                gx = f2{r4[0], r4[1]};
+                gzr = f2{r4[2], r4[3]};
+            } else gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f}, &accW2);
             if constexpr (!RSM) {   // dW1 (`s` columns) += delta1 (x) s
                 const f4 dT = transpose(d1);
                 put(scr, f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, (NZM > 0 && g < ne) ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
 #pragma unroll
         for (int r = 0; r < NX; ++r) gcar[r] = gx0[r];
         if constexpr (NZM > 0) {     // gradient of this step's external input: row 0 -> z-dim g, row 1 -> z-dim 4+g
-            const f2 gzr = allreduce2(gzp, f2{0.f, 0.f});
+
             if (w == 0 && valid) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
