@@ -472,6 +472,16 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
         put(tile(p, w), d);
         const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
         f4 wq = wl[0];
+#ifndef PSNODE_K4F_W_AHEAD
+#define PSNODE_K4F_W_AHEAD 1      // two-role chain: the layer's weight chunks are read from LDS BEFORE the exchange's barrier (they do not depend on it): behind it
+                                  // only the three tiles of the other waves are left to read -- half of the LDS traffic on the critical path
+#endif
+        constexpr bool WAH = ROLES && PSNODE_K4F_W_AHEAD;
+        f4 wah[WAH ? NWV : 1];
+        if constexpr (WAH) {
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) wah[c] = wl[c * NWV * 64];
+        }
         f4 accA = fm4(wq[0], d[0], f4{0.f, 0.f, 0.f, 0.f}), accB = fm4(wq[1], d[1], f4{0.f, 0.f, 0.f, 0.f});
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
         if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
         if constexpr (PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && !(PSNODE_K4F_ABLATE & 1)) {
             f4 vq[NWV], wqq[NWV], dTq[ROLES ? 1 : NWV];
 #pragma unroll
-            for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = wl[c * NWV * 64]; }
+            for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = WAH ? wah[WAH ? c : 0] : wl[c * NWV * 64]; }
             if constexpr (!ROLES) {
 #pragma unroll
                 for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);

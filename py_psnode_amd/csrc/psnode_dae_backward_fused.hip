@@ -597,6 +597,16 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
         put(tile(p, w), d);
         const f4* wl = wT + ((size_t)layer * NWV * NWV + w) * 64 + l;
         f4 wq = wl[0];
+#ifndef PSNODE_K7F_W_AHEAD
+#define PSNODE_K7F_W_AHEAD 1      // two-role chain: the layer's weight chunks are read from LDS BEFORE the exchange's barrier (they do not depend on it): behind it
+                                  // only the three tiles of the other waves are left to read -- half of the LDS traffic on the critical path
+#endif
+        constexpr bool WAH = ROLES && PSNODE_K7F_W_AHEAD;
+        f4 wah[WAH ? NWV : 1];
+        if constexpr (WAH) {
+#pragma unroll
+            for (int c = 1; c < NWV; ++c) wah[c] = wl[c * NWV * 64];
+        }
         f4 accA = fm4(wq[0], d[0], zero4), accB = fm4(wq[1], d[1], zero4);
         accA = fm4(wq[2], d[2], accA); accB = fm4(wq[3], d[3], accB);
         if constexpr (DEFER || DEFER8) { if (pacc) flush(*pacc); }
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
         if constexpr (PREFETCH_ALL && PSNODE_K7F_TREAD_AHEAD) {
             f4 vq[NWV], wqq[NWV], dTq[ROLES ? 1 : NWV];
 #pragma unroll
-            for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = wl[c * NWV * 64]; }
+            for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = WAH ? wah[WAH ? c : 0] : wl[c * NWV * 64]; }
             if constexpr (!ROLES) {
 #pragma unroll
                 for (int c = 0; c < NWV; ++c) dTq[c] = get_row(tile(p, (w + c) & (NWV - 1)), roff);
@@ -775,6 +785,13 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
     struct HeadOut { f2 gx, gz; };
     auto ae_adjoint = [&](const f4 a1, const f4 a2, const f4 a3, const float (&gs)[NZM], const HeadRows hr, const size_t row,
                           const float (&xa)[NX], const float (&zva)[NZA]) -> HeadOut {
+        if constexpr (RSM) {      // the head's output adjoint and first-layer input rows for the gradient waves (the same in every chain wave);
+                                  // in FRONT of the MFMAs: a uniform branch behind them puts a VALU write on their destination across its taken edge (ISA lint B)
+            if (w == 0) {
+                put(k7f_roles_g_tile<NWV>(xb), f4{gs[0], NZM > 1 ? gs[NZM > 1 ? 1 : 0] : 0.0f, NZM > 2 ? gs[NZM > 2 ? 2 : 0] : 0.0f, NZM > 3 ? gs[NZM > 3 ? 3 : 0] : 0.0f});
+                put(k7f_roles_u_tile<NWV>(xb), f4{xa[0], NX > 1 ? xa[NX > 1 ? 1 : 0] : 0.0f, zva[0], NZA > 1 ? zva[NZA > 1 ? 1 : 0] : 0.0f});
+            }
+        }
         f4 g3 = zero4;
 #pragma unroll
         for (int m = 0; m < NZM; ++m) g3 = fm4(aw4T[m], gs[m], g3);
@@ -783,12 +800,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             SA3 += d3;
             const f4 gs4 = f4{gs[0], NZM > 1 ? gs[NZM > 1 ? 1 : 0] : 0.0f, NZM > 2 ? gs[NZM > 2 ? 2 : 0] : 0.0f, NZM > 3 ? gs[NZM > 3 ? 3 : 0] : 0.0f};
             SGi += gs4;
-            if constexpr (RSM) {      // the head's output adjoint and first-layer input rows for the gradient waves (the same in every chain wave)
-                if (w == 0) {
-                    put(k7f_roles_g_tile<NWV>(xb), gs4);
-                    put(k7f_roles_u_tile<NWV>(xb), f4{xa[0], NX > 1 ? xa[NX > 1 ? 1 : 0] : 0.0f, zva[0], NZA > 1 ? zva[NZA > 1 ? 1 : 0] : 0.0f});
-                }
-            } else {   // dAW4[slot of row][own unit] += gs (x) h3, contracted over the tile's trajectories (rows (g, r) <-> slot 4r+g)
+            if constexpr (!RSM) {   // dAW4[slot of row][own unit] += gs (x) h3, contracted over the tile's trajectories (rows (g, r) <-> slot 4r+g)
                 const f4 gT = transpose(gs4);
                 const f4 hT = transpose(a3);
 #pragma unroll
@@ -1178,17 +1190,18 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             else { a1 = h1[s]; a2 = h2[s]; a3 = h3[s]; }
             const f2 gk = f2{gks[s][0], NX > 1 ? gks[s][1] : 0.0f};
             db4 += gk;
+            if constexpr (RSM) {      // gk and the stage input for the gradient waves (every chain wave holds the same values); in front of the MFMAs
+                if (w == 0) {
+                    put(k7f_roles_g_tile<NWV>(xb), f4{gk[0], gk[1], 0.f, 0.f});
+                    put(k7f_roles_u_tile<NWV>(xb), f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, g < ne ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
+                }
+            }
             f4 g3 = zero4;
 #pragma unroll
             for (int r = 0; r < NX; ++r) g3 = fm4(w4T[r], gks[s][r], g3);
             const f4 d3 = g3 * elu_grad_quad(a3);
             S3 += d3;
-            if constexpr (RSM) {      // gk and the stage input for the gradient waves (every chain wave holds the same values)
-                if (w == 0) {
-                    put(k7f_roles_g_tile<NWV>(xb), f4{gk[0], gk[1], 0.f, 0.f});
-                    put(k7f_roles_u_tile<NWV>(xb), f4{X[s][0], NX > 1 ? X[s][1] : 0.0f, g < ne ? ext[0] : 0.0f, (NZM > 1 && 4 + g < ne) ? ext[NZM > 1 ? 1 : 0] : 0.0f});
-                }
-            } else {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
+            if constexpr (!RSM) {   // dW4[x-dim of row][own unit] += gk (x) h3, contracted over the tile's trajectories
                 const f4 gT = transpose(f4{gk[0], gk[1], 0.f, 0.f});
                 const f4 hT = transpose(a3);
 #pragma unroll
