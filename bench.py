@@ -327,17 +327,24 @@ def _extra_line(lib, _lib, fused, workload, w, method, dev, steps, warmup, note)
         from py_psnode_amd import neural_dae as nd
         p["model"].solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
         p["model"].solver.fused, p["model"].solver.kernel = "require", "auto"
+    import gc
+    gc.collect()                    # the previous workload's cyclic garbage (autograd contexts, modules) goes NOW, not inside the timed loop:
+    torch.cuda.empty_cache()        # a collection that frees gigabytes of device memory is a run of synchronous hipFree calls (a 38 ms pass among 0.9 ms ones)
     for _ in range(warmup):
         outs = run_fused(fused, w, p, method, "auto")
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for k in range(steps):
-        ev[k][0].record()
-        outs = run_fused(fused, w, p, method, "auto")
-        ev[k][1].record()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            outs = run_fused(fused, w, p, method, "auto")
+            ev[k][1].record()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     kern = sorted(a.elapsed_time(b) for a, b in ev)
     avg, med = sum(kern) / len(kern), kern[len(kern) // 2]
     ss = B * (T - 1)
