@@ -133,12 +133,21 @@ struct RowsBwdArgs {
 
 constexpr int RSCR = 64 * 4 + 4 * 8;   // padded transpose tile (floats)
 
+// WLDS (round 4; the decoders at hidden 64: in = hidden = 64): the two 64 x 64 operand sets of the first layer -- W1 for the recomputed hidden
+// layer, W1^T for d in -- live in LDS (8 KB per workgroup, every wave reads the values its lanes would have held: lane-linear, conflict-free)
+// instead of 128 registers per lane.  373 registers meant ONE wave per SIMD for a kernel whose tile is 224 MFMAs behind 13 in-wave
+// transposes and 64 ELUs; with 245 two waves share a SIMD (__launch_bounds__(256, 2)).
 template <int NM, int HT, int OT>
-__global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
+__global__ __launch_bounds__(256, ((NM == 16 && HT == 4 && OT == 1) || (NM <= 4 && HT == 4 && OT == 4)) ? 2 : 1) void rows_bwd_kernel(const RowsBwdArgs a) {
     constexpr int HID = 16 * HT;
     constexpr int IT = NM > 4 ? NM / 4 : 1;      // input column tiles
     constexpr int NC = NM > 4 ? 4 : NM;          // columns per lane per tile
+    constexpr bool WLDS = NM == 16 && HT == 4 && OT == 1;
     __shared__ __attribute__((aligned(16))) float scr_all[4][2][RSCR];
+    __shared__ __attribute__((aligned(16))) f4 lw1[WLDS ? HT * (NM / 4) * 64 : 1], lw1t[WLDS ? IT * HT * 64 : 1];
+    // ... and the encoders at hidden 64 (in <= 16, out = hidden = 64): W2^T (64 registers of 313) in LDS, 249 registers, two waves per SIMD
+    constexpr bool W2LDS = NM <= 4 && HT == 4 && OT == 4;
+    __shared__ __attribute__((aligned(16))) f4 lw2t[W2LDS ? HT * OT * 64 : 1];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, g = l >> 4, j = l & 15, i = l & 15;
     float* scrA = scr_all[wv][0];
     float* scrB = scr_all[wv][1];
@@ -148,30 +157,61 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
         return (c >= 0 && c < a.in_dim) ? c : -1;
     };
     // ---- weights -> registers
-    float w1[HT][NM], w2t[HT][OT * 4], w1t[IT][HT * 4];
+    float w1[WLDS ? 1 : HT][WLDS ? 1 : NM], w2t[W2LDS ? 1 : HT][W2LDS ? 1 : OT * 4], w1t[WLDS ? 1 : IT][WLDS ? 1 : HT * 4];
     f4 b1r[HT];
 #pragma unroll
     for (int ht = 0; ht < HT; ++ht) {
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int m4 = 0; m4 < NM / 4; ++m4) {      // (every wave writes the same values: the weights depend on the lane only)
+                f4 q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int c = NM * g + 4 * m4 + r; q[r] = c < a.in_dim ? a.w1[(16 * ht + i) * a.in_dim + c] : 0.0f; }
+                lw1[(ht * (NM / 4) + m4) * 64 + l] = q;
+            }
+        } else {
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int c = NM * g + m;
             w1[ht][m] = c < a.in_dim ? a.w1[(16 * ht + i) * a.in_dim + c] : 0.0f;
         }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) b1r[ht][r] = a.b1[16 * ht + 4 * g + r];
+        if constexpr (W2LDS) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                f4 q_;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int o = 16 * ot + 4 * g + r; q_[r] = o < a.out_dim ? a.w2[o * HID + 16 * ht + i] : 0.0f; }
+                lw2t[(ht * OT + ot) * 64 + l] = q_;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < OT * 4; ++q) {            // delta = W2^T g: rows = units of tile ht, k-slot g <-> out dim 16*ot + 4g + r
             const int o = 16 * (q >> 2) + 4 * g + (q & 3);
             w2t[ht][q] = o < a.out_dim ? a.w2[o * HID + 16 * ht + i] : 0.0f;
         }
+        }
     }
 #pragma unroll
     for (int q = 0; q < IT; ++q) {
         const int c = col_of(i >> 2, i & 3, q);
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) {
+                f4 t_;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t_[r] = c >= 0 ? a.w1[(16 * ht + 4 * g + r) * a.in_dim + c] : 0.0f;
+                lw1t[(q * HT + ht) * 64 + l] = t_;
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < HT * 4; ++k)               // d in = W1^T delta1: rows = input columns, k-slot g <-> unit 16*ht + 4g + r
             w1t[q][k] = c >= 0 ? a.w1[(16 * (k >> 2) + 4 * g + (k & 3)) * a.in_dim + c] : 0.0f;
+        }
     }
+    if constexpr (WLDS || W2LDS) __syncthreads();
     f4 accW1[HT][IT], accW2[OT][HT], sb1[HT], sb2[OT];
 #pragma unroll
     for (int ht = 0; ht < HT; ++ht) {
@@ -237,14 +277,29 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) {
             f4 acc = b1r[ht];
+            if constexpr (WLDS) {
+#pragma unroll
+                for (int m4 = 0; m4 < NM / 4; ++m4) {
+                    const f4 wq = lw1[(ht * (NM / 4) + m4) * 64 + l];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = rmfma(wq[r], v[4 * m4 + r], acc);
+                }
+            } else {
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc = rmfma(w1[ht][m], v[m], acc);
+            }
             h[ht] = elu_quad(acc);
             f4 tA = {0.f, 0.f, 0.f, 0.f}, tB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
+                if constexpr (W2LDS) {
+                    const f4 wq = lw2t[(ht * OT + ot) * 64 + l];
+                    tA = rmfma(wq[0], go[ot][0], tA); tB = rmfma(wq[1], go[ot][1], tB);
+                    tA = rmfma(wq[2], go[ot][2], tA); tB = rmfma(wq[3], go[ot][3], tB);
+                } else {
                 tA = rmfma(w2t[ht][4 * ot + 0], go[ot][0], tA); tB = rmfma(w2t[ht][4 * ot + 1], go[ot][1], tB);
                 tA = rmfma(w2t[ht][4 * ot + 2], go[ot][2], tA); tB = rmfma(w2t[ht][4 * ot + 3], go[ot][3], tB);
+                }
             }
             const f4 tt = tA + tB;
 #pragma unroll
@@ -258,8 +313,14 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(const RowsBwdArgs a) {
                 f4 gA = {0.f, 0.f, 0.f, 0.f}, gB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ht = 0; ht < HT; ++ht) {
+                    if constexpr (WLDS) {
+                        const f4 wt = lw1t[(q * HT + ht) * 64 + l];
+                        gA = rmfma(wt[0], d1[ht][0], gA); gB = rmfma(wt[1], d1[ht][1], gB);
+                        gA = rmfma(wt[2], d1[ht][2], gA); gB = rmfma(wt[3], d1[ht][3], gB);
+                    } else {
                     gA = rmfma(w1t[q][4 * ht + 0], d1[ht][0], gA); gB = rmfma(w1t[q][4 * ht + 1], d1[ht][1], gB);
                     gA = rmfma(w1t[q][4 * ht + 2], d1[ht][2], gA); gB = rmfma(w1t[q][4 * ht + 3], d1[ht][3], gB);
+                    }
                 }
                 const f4 gi = gA + gB;                      // lane (g, j): columns NM*g + 4q + r of row j
                 if (valid) {
