@@ -56,3 +56,13 @@ def test_dae_encoded_shape_fuzz():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     _run("fuzz_dae_encoded.py", 11, 40)
+
+
+@pytest.mark.parametrize("seed", [4321, 4322])
+def test_two_role_kernels_are_bit_equal_to_the_one_role_ones_on_random_shapes(seed):
+    """Round 4: K4f / K7f on saved activations at hidden <= 64 run as chain waves + gradient waves; on random shapes (every slot class,
+    events, ragged tiles, grad_is = None) every output must equal the one-role instance's bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = _run("fuzz_roles.py", seed, 60)
+    assert out.count("skipped") <= 6, out[-2000:]
