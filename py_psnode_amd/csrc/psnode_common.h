@@ -102,9 +102,13 @@ __device__ __forceinline__ elu_f2 elu_pair(const elu_f2 x, const float knee, con
 #ifndef PSNODE_ELU_EXPM1
     // = max(x, exp2(min(x,0) log2e) - 1): e^x - 1 >= x everywhere, so the max picks x for x > 0 (where the other side is exactly 0)
     // and the exponential side for x <= 0 -- one packed add less than max(x,0) + (..)
-    const elu_f2 xn = elu_f2{fminf(x[0], 0.0f), fminf(x[1], 0.0f)};
-    const elu_f2 yq = xn * kLog2e;
-    const elu_f2 tq = elu_f2{__builtin_amdgcn_exp2f(yq[0]), __builtin_amdgcn_exp2f(yq[1])};
+    // Round 5: exp2(min(x, 0) log2e) == clamp(exp2(x log2e), 0, 1) bit for bit (for x <= 0 the same product goes through the same
+    // v_exp_f32; for x > 0 both are exactly 1), and the clamp is the VOP3 OUTPUT MODIFIER of v_exp_f32 (`v_exp_f32_e64 v, v clamp`:
+    // the compiler folds fmed3(e, 0, 1) into it under the default DX10_CLAMP mode) -- the two v_min_f32 per pair are gone: 3 issue
+    // slots per value instead of 4 (profiles/r05_ubench_4x4.txt checks the two forms bitwise over 3 x 2^24 inputs).
+    const elu_f2 yq = x * kLog2e;
+    const elu_f2 tq = elu_f2{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(yq[0]), 0.0f, 1.0f),
+                             __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(yq[1]), 0.0f, 1.0f)};
     const elu_f2 uq = tq - 1.0f;
     return elu_f2{fmaxf(x[0], uq[0]), fmaxf(x[1], uq[1])};
 #endif
@@ -131,6 +135,18 @@ __device__ __forceinline__ elu_f4 elu_quad(const elu_f4 v) {
     const elu_f2 a = elu_pair(elu_f2{v[0], v[1]}, knee, neg_t0, c4, c3, c2, c1);
     const elu_f2 b = elu_pair(elu_f2{v[2], v[3]}, knee, neg_t0, c4, c3, c2, c1);
     return elu_f4{a[0], a[1], b[0], b[1]};
+}
+// Round 5, the inference forwards K1 / K2: ELU in the log2(e)-scaled domain.  With p' = log2e * p delivered by the MFMAs themselves
+// (PackMfma::scaled), g = log2e * ELU(p) = max(p', log2e * clamp(exp2(p')) - log2e): v_exp (clamp) -> v_pk_fma -> v_max, a dependent
+// chain of THREE instructions and 2.5 issue slots per value; the unscaled form's leading v_pk_mul is gone (at one wave per SIMD every
+// instruction of this chain is exposed latency: removing the v_min alone took K1 from 3.89 to 3.68 ms).  p' > 0: the fma is exactly 0,
+// g = p' bit for bit; p' <= 0: fma(log2e, e, -log2e) rounds the exact log2e (e - 1) once.
+__device__ __forceinline__ elu_f4 elu_quad_scaled(const elu_f4 v) {
+    const elu_f2 c = elu_f2{kLog2e, kLog2e}, nc = elu_f2{-kLog2e, -kLog2e};
+    const elu_f2 ea = elu_f2{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(v[0]), 0.0f, 1.0f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(v[1]), 0.0f, 1.0f)};
+    const elu_f2 eb = elu_f2{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(v[2]), 0.0f, 1.0f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(v[3]), 0.0f, 1.0f)};
+    const elu_f2 ua = __builtin_elementwise_fma(c, ea, nc), ub = __builtin_elementwise_fma(c, eb, nc);
+    return elu_f4{fmaxf(v[0], ua[0]), fmaxf(v[1], ua[1]), fmaxf(v[2], ub[0]), fmaxf(v[3], ub[1])};
 }
 __device__ __forceinline__ float elu_fast(const float x) {   // scalar form of the same function (bit-identical to elu_quad)
     PSNODE_ELU_CONSTS

@@ -63,7 +63,13 @@ __host__ __device__ constexpr size_t stream_image_floats(int nwv) { return nwv >
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ f4 elu4(f4 v) { return elu_quad(v); }
+// SC: the log2e-scaled domain of the inference forwards (PackMfma::scaled); the training forwards (SAVE) store ELU outputs for the
+// backward kernels and stay in the plain domain
+#ifndef PSNODE_SCALED_ELU
+#define PSNODE_SCALED_ELU 1
+#endif
+template <bool SC>
+__device__ __forceinline__ f4 elu4(f4 v) { if constexpr (SC && PSNODE_SCALED_ELU) return elu_quad_scaled(v); else return elu_quad(v); }
 
 // layers 2..4 of one MLP, in registers (NWV = waves per tile = hidden / 16)
 template <int NWV>
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             accB = mfma4(wm[4 * c + 3], v[3], accB);
         }
         p ^= 1;
-        return elu4(accA + accB);
+        return elu4<!SAVE>(accA + accB);
     };
     // the same layer with the weights of `layer` (0: L2, 1: L3) read from aew
     auto mid_lds = [&](const int layer, const f4 bias, const f4 h) -> f4 {
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             accB = mfma4(wq[3], v[3], accB);
         }
         p ^= 1;
-        return elu4(accA + accB);
+        return elu4<!SAVE>(accA + accB);
     };
     // the same layer with the A operands streamed from the stream image (`wl` = this lane's f4 of chunk 0 of the layer): all NWV chunk
     // loads are requested first -- they travel while the tile publishes / gathers the activations
@@ -397,14 +403,14 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             __builtin_amdgcn_sched_barrier(0);
         }
         p ^= 1;
-        return elu4(accA + accB);
+        return elu4<!SAVE>(accA + accB);
     };
     // layers 2..4 from the L1 pre-activation; every wave returns the identical output rows.
     // ROWS2: only rows r < 2 of the output carry data (the DE with x_dim <= 8): all-reduce 8 bytes per lane instead of 16.
     // `wmode`: where the H->H weights are -- 0 registers, 1 LDS (the AE at 8 waves), 2 the stream image (more than 8 waves)
     auto tail = [&](const f4 pre1, const Tail<NWV>& t, auto rows2, auto wmode, auto&& keep) -> f4 {
         constexpr bool ROWS2 = decltype(rows2)::value;
-        f4 h = elu4(pre1);
+        f4 h = elu4<!SAVE>(pre1);
         keep(0, h);
         if constexpr (decltype(wmode)::value == 1) {
             h = mid_lds(0, t.b2, h);
@@ -816,6 +822,7 @@ hipError_t launch_mfma_nw(const IntegrateDev& a, bool dae, float* pack, hipStrea
     p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
     p.out_dim = a.xd;
     p.out = pack;
+    p.scaled = (a.sact || !PSNODE_SCALED_ELU) ? 0 : 1;        // the inference instances (SAVE = false) run the hidden layers in the log2e-scaled domain
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(16), dim3(256), 0, stream, p);
     const size_t one = (size_t)NWV * (max_regs(NWV) + NA) * 64 + stream_image_floats(NWV);
     if constexpr (weights_streamed(NWV))     // the stream image sits right behind the register image of its MLP (Tail::gw)

@@ -51,6 +51,10 @@ struct PackMfma {
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
     int out_dim;            // x_dim (DE) or i_dim (AE)
     float* out;
+    int scaled = 0;         // forward image of the inference kernels (round 5): the hidden layers run in the log2(e)-SCALED domain --
+                            // every L1 register and the biases b1, b2, b3 carry a factor log2e, the L4 slice a factor 1/log2e, the
+                            // H->H matrices are untouched (their input g = log2e * ELU(p) and their output log2e * p carry the same
+                            // factor) -- so that the ELU's exp2 argument IS the pre-activation (psnode_common.h: elu_quad_scaled)
 };
 
 // the hidden width the MFMA kernels run a width-h MLP at (0: none)
@@ -124,6 +128,12 @@ __device__ inline float pack_fwd_value(const PackMfma& p, int w, int reg, int la
             v = p.w1[u * K1 + q];
             if (p.fold && q < p.xd) v -= p.w1[u * K1 + p.n + q];
         }
+    }
+    if (p.scaled) {
+        const bool mid = (reg >= W2 && reg < B2) || (reg >= W3 && reg < B3);   // H->H matrices: scale-free
+        const bool out = reg >= W4 && reg < COUNT;                                // L4 slice (/ log2e) and b4 (unscaled output)
+        if (out) { if (reg < B4) v = v / kLog2e; }
+        else if (!mid) v = v * kLog2e;
     }
     return v;
 }
