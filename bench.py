@@ -582,6 +582,32 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7      # MI355X: 7 xGMI links per GPU, ~153 GB/s each direction (MI355X_MICROARCH.md)
+
+
+def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, pipelined, chunk_model):
+    """What a reader needs to interpret an N > 1 line without a second run: the shard each rank contributes, what the all-gather should
+    cost on xGMI (every rank receives (N-1) shards; a direct all-gather spreads them over N-1 of the 7 links, a ring pushes them all through
+    one), what the two legs cost alone, and how much of the shorter one the pipeline hid."""
+    widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
+    shard = sum(T * B * d * 4 for d in widths)
+    recv = (world - 1) * shard
+    direct = shard / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0
+    ring = recv / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0
+    rep = {"shard_bytes": shard, "received_bytes_per_rank": recv,
+           "predicted_gather_ms": {"direct_one_link_per_peer": direct, "ring_one_link": ring,
+                                   "assumption": f"{XGMI_LINKS} xGMI links x {XGMI_LINK_GBS} GB/s per GPU, point to point"},
+           "integrate_only_ms": integrate_ms, "gather_only_ms": gather_ms, "step_ms": step_ms, "chunks": chunks, "pipelined": bool(pipelined),
+           "chunk_model": chunk_model}
+    if gather_ms is not None:
+        serial = integrate_ms + gather_ms
+        rep["serial_ms"] = serial
+        rep["hidden_ms"] = serial - step_ms                      # > 0: the pipeline overlapped that much of the two legs
+        rep["hidden_frac_of_shorter_leg"] = (serial - step_ms) / max(min(integrate_ms, gather_ms), 1e-9)
+        rep["gather_achieved_GBs_per_rank"] = recv / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,7 +615,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ode01", choices=sorted(WORKLOADS))
     ap.add_argument("--method", default="rk4", choices=["euler", "midpoint", "rk4"])
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma", "tile", "wave"], help="tile / wave: K1 (4-wave tile) / K1x (one wave per 4 trajectories) for the ODE forward")
     ap.add_argument("--batch", type=int, default=None, help="override trajectories per GPU")
     ap.add_argument("--grid", type=int, default=None, help="override grid points T")
     ap.add_argument("--hidden", type=int, default=None, help="override the MLPs' hidden width (the scripts' --hidden)")
@@ -606,15 +632,20 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
     ap.add_argument("--gather-layout", default="chunks", choices=["chunks", "batch"],
                     help="N>1, pipelined: per-chunk rank-major buffers (zero-copy) or every chunk gathered INTO one [T, N*B, D] tensor")
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap)")
+    ap.add_argument("--chunks", default="auto", help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap; 'auto' = chosen from "
+                    "the measured integrate-only and gather-only times of the warm-up)")
     args = ap.parse_args()
+    requested_gpus = args.gpus
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist):
         sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world             # the launcher's world size is authoritative
+    if world != requested_gpus and not args.force_dist:
+        # a line that says n_gpus = 8 must have run on 8 ranks: a launcher / --gpus mismatch is an error, not a silently smaller job
+        sys.exit(f"bench.py: --gpus {requested_gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the fused integrator has no CPU path)")
     if local_rank >= torch.cuda.device_count():
@@ -649,6 +680,8 @@ def main():
     n_out = 1 if w["kind"] == "ode" else (4 if w["kind"] == "dae02_model" else 2)
     from py_psnode_amd import sharded
     do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train   # training never gathers (sharded loss)
+    auto_chunks = str(args.chunks) == "auto"
+    args.chunks = 4 if auto_chunks else int(args.chunks)
     pipelined = do_gather and w["kind"] in ("ode", "dae") and args.chunks > 1
     gathered = None
     if do_gather and not pipelined:
@@ -701,6 +734,40 @@ def main():
 
     if do_gather:
         sharded.require_equal_shards(B, dev)     # once, outside the timed region: every rank holds B trajectories (weak scaling)
+    chunk_model = None
+    if do_gather and w["kind"] in ("ode", "dae") and auto_chunks:
+        # --chunks auto: measure the two legs alone (untimed region), then pick the chunk count of the pipeline from them.  Model: with c
+        # chunks the shorter leg hides behind the longer one except for its first / last chunk, and every chunk costs one more launch +
+        # collective start (~0.05 ms): total(c) = max(I, G) + min(I, G) / c + 0.05 c  ->  c* = sqrt(min(I, G) / 0.05), clamped to 1..16
+        outs0 = run_fused(fused, w, p, args.method, args.kernel)
+        fence()
+        t_i = time.perf_counter()
+        for _ in range(2):
+            outs0 = run_fused(fused, w, p, args.method, args.kernel)
+        fence()
+        i_ms = (time.perf_counter() - t_i) / 2 * 1e3
+        bufs = [torch.empty((world * T, B, o.shape[-1]), dtype=torch.float32, device=dev) for o in outs0]
+        for f_, o in zip(bufs, outs0):
+            dist.all_gather_into_tensor(f_, o.contiguous())
+        fence()
+        t_g = time.perf_counter()
+        for _ in range(2):
+            for f_, o in zip(bufs, outs0):
+                dist.all_gather_into_tensor(f_, o.contiguous())
+        fence()
+        g_ms = (time.perf_counter() - t_g) / 2 * 1e3
+        tt = torch.tensor([i_ms, g_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # every rank must pick the SAME count
+        i_ms, g_ms = float(tt[0]), float(tt[1])
+        c_star = int(round((min(i_ms, g_ms) / 0.05) ** 0.5))
+        args.chunks = max(1, min(16, c_star))
+        pipelined = args.chunks > 1
+        chunk_model = {"integrate_only_ms": i_ms, "gather_only_ms": g_ms, "per_chunk_overhead_ms": 0.05, "chunks": args.chunks,
+                       "predicted_total_ms": max(i_ms, g_ms) + min(i_ms, g_ms) / args.chunks + 0.05 * args.chunks}
+        if not pipelined:
+            widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
+            gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
+        del bufs, outs0
     for _ in range(args.warmup):
         one_step()
     fence()
@@ -761,6 +828,8 @@ def main():
                        "collective": ((f"rccl all_gather of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration"
                                        if pipelined else "rccl all_gather of the output shards [T,B,D]") if do_gather else "none"),
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
+            "multi_gpu": multi_gpu_report(w, world, B, T, elapsed / args.steps * 1e3, kern_avg_ms, gather_only_ms, args.chunks if do_gather else None,
+                                          pipelined, chunk_model) if dist is not None else None,
             "roofline": {"bound": "valu_fp32" if kname == "valu_dpp" else "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic is not None else None,
                          "kernel_ms": kern_avg_ms, "kernel_ms_median": kern_med_ms,
@@ -807,6 +876,8 @@ def main():
                 acc = res["cpu_baseline"]["gpu_vs_oracle"]
                 res["config"]["rel_err_vs_oracle"] = {"per_trajectory": acc["per_trajectory_rel_err"], "elementwise": acc["elementwise_rel_err"],
                                                       "sample": acc["sample"]}
+        if dist is not None and world > 1 and not res["config"]["rccl_version"]:
+            sys.exit("bench.py: N > 1 without an RCCL version -- the collective did not run on RCCL")
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line on stdout
         import ctypes
         sys.stdout.flush()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 7
+#define PSNODE_ABI_VERSION 8
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer OUTPUT the kernels accept */
 #define PSNODE_MAX_IN_WIDTH 2048 /* widest first-layer INPUT (the latent DE of DAE_02 at --hidden 128 is 12 x 128 = 1536 wide) */
@@ -50,8 +50,10 @@ typedef enum { PSNODE_EULER = 0, PSNODE_MIDPOINT = 1, PSNODE_RK4_38 = 2 } psnode
 /* kernel selection: AUTO picks the MFMA kernel when the shape has one, else the generic kernel */
 typedef enum {
     PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2,
-    PSNODE_KERNEL_MFMA_WIDE = 3      /* backward calls only: the width-generic one-launch MFMA backward (hidden <= 128 zero-padded to 32 / 64 / 128) even
-                                        where AUTO / MFMA would take the hidden-64 specialisation */
+    PSNODE_KERNEL_MFMA_TILE = 4,     /* forward ODE calls only: K1, the 4-waves-per-16-trajectory-tile MFMA integrator, where AUTO / MFMA would pick K1x */
+    PSNODE_KERNEL_MFMA_WAVE = 5,     /* forward ODE calls only: K1x, the one-wave-per-4-trajectories (exchange-free) MFMA integrator; UNSUPPORTED outside its shapes */
+    PSNODE_KERNEL_MFMA_WIDE = 3      /* backward calls only: the one-launch MFMA backward K4f (hidden <= 128 zero-padded to 32 / 64 / 128); since ABI 8
+                                        (K4 removed) the same kernel AUTO / MFMA pick for these shapes */
 } psnode_kernel;
 
 /* flags: teacher forcing of my_solvers.py:52 (input_true_x) and :82 (input_true_x, input_true_i) */
@@ -241,48 +243,6 @@ int64_t psnode_ode_backward_param_count(const psnode_ode_bwd_args_f32* args);
 size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_f32* args);
 int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Stage adjoints of the ODE integrator for hidden widths the one-launch backward does not cover (hidden 32 and 128: the scripts'
- * argparse default is --hidden 128, neural_00_ODE_01_no_encode.py:245-246).  At those widths the weights, their transposes and the
- * parameter-gradient accumulators do not fit the register file + LDS of a CU together, so the backward is split where the algebra
- * splits: THIS call runs the sequential part of loss.backward() through integrate_ODE (my_solvers.py:66-78) -- the recomputed stage
- * evaluations and the adjoint recursion through the stages and steps k1-1 .. k0 (MFMA, weights in registers, transposed weights in
- * LDS) -- and writes, per (step, stage, trajectory), what the parameter gradients contract over:
- *     act[l]   = h_l      (ELU outputs of hidden layer l = 1..3)            [k1-k0, S, B, H]
- *     delta[l] = dL/dpre_l (adjoint of the pre-activation of layer l)       [k1-k0, S, B, H]
- *     gk       = dL/dk_s  (adjoint of the stage derivative = delta of the output layer)   [k1-k0, S, B, x_dim]
- *     xstage   = X_s      (the stage's state input)                          [k1-k0, S, B, x_dim]
- *     dsum[l]  = sum over the stages of delta[l]                              [k1-k0, B, H]
- * The parameter gradients are then PLAIN GEMMs over those rows (dW_l = delta_l^T . act_{l-1}, library GEMMs on the host side:
- * py_psnode_amd/fused.py:ode_backward_wide), as are dL/dz = D1 . (Ws+Wd)[:, z] and dL/dall_initial = sum_t D1 . (Wa-Wd), D1 = sum_s delta_1.
- * `carry` [B, x_dim] holds the adjoint of x[k1] WITHOUT dL/dxs[k1] on entry (zeros for the last chunk) and of x[k0] likewise on exit, so
- * the sweep can be cut into time chunks to bound the size of the stored rows.  Shape class: de = 3n -> h -> h -> h -> x_dim,
- * h <= 128, x_dim <= 8, z_dim <= 8.  H in the row shapes above is h rounded up to the kernels' 32 / 64 / 128 (the integrators do the
- * same, psnode_ode_integrate_f32): columns h..H-1 of the rows are exact zeros (zero-padded units: zero weights, ELU(0) = 0). */
-typedef struct {
-    int32_t method;
-    int32_t x_dim, z_dim;
-    int64_t T, B;                    /* grid points / trajectories of the whole call */
-    int64_t k0, k1;                  /* steps k0 <= k < k1 of this chunk (0 <= k0 < k1 <= T-1) */
-    psnode_mlp_f32 de;
-    psnode_view_f32 t, z;
-    const float* all_initial;        /* [B, x+z] */
-    const int32_t* event_idx;        /* int32[T-1] or NULL */
-    const float* z_jump;
-    int64_t zj_stride_b, zj_stride_e;
-    const float* xs;                 /* forward result [T,B,x_dim] contiguous */
-    const float* grad_xs;            /* dL/dxs [T,B,x_dim] contiguous */
-    float* carry;                    /* [B,x_dim] in/out */
-    float* act[3];                   /* [k1-k0, S, B, H] each, S = stages of the method */
-    float* delta[3];
-    float* gk;                       /* [k1-k0, S, B, x_dim] */
-    float* xstage;                   /* [k1-k0, S, B, x_dim] */
-    float* dsum[3];                  /* [k1-k0, B, H]: sum over the stages of delta[l] (bias gradients, dL/dz, dL/dall_initial) */
-} psnode_ode_bwd_wide_args_f32;
-
-int32_t psnode_ode_backward_wide_supported(const psnode_ode_bwd_wide_args_f32* args);   /* dims only */
-size_t psnode_ode_backward_wide_workspace_bytes(const psnode_ode_bwd_wide_args_f32* args);
-int32_t psnode_ode_backward_wide_f32(const psnode_ode_bwd_wide_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
-
 /* Backward pass through psnode_dae_integrate_f32 (no teacher forcing): loss.backward() through integrate_DAE
  * (neural_01_DAE_01_no_encode.py:422-424 over my_solvers.py:94-129), including the AE head, the feedback of the
  * algebraic variable into the DE input and the event-time recomputation i0 = g(x0; jumps).
@@ -326,37 +286,31 @@ int32_t psnode_dae_backward_supported(const psnode_dae_bwd_args_f32* args);
 size_t psnode_dae_backward_workspace_bytes(const psnode_dae_bwd_args_f32* args);
 int32_t psnode_dae_backward_f32(const psnode_dae_bwd_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The DAE counterpart of psnode_ode_backward_wide_f32 (hidden 32 / 64 / 128): the sequential part of loss.backward() through
- * integrate_DAE (my_solvers.py:94-129) for steps k1-1 .. k0 -- per grid point the AE head's recompute + adjoint (its output adjoint
- * = dL/dis of that grid point + what the DE of the step starting there returned through its algebraic inputs), per step the DE stages as
- * in the ODE call, at event steps the recompute i0 = g(x0; jumps) and its adjoint -- writing the rows the parameter gradients contract
- * over.  "Slot" layout of an algebraic-variable row [.., 16]: slot q < 2(z+v+i) is the DE's external input q of the `s - a0` block
- * (q < z+v+i) or of the `s` block; the adjoint / value of i-dim d sits in slots z+v+d and (z+v+i)+z+v+d (values: equal; adjoints: to be
- * summed by the caller).  Rows:
- *     act / delta / gk / xstage : the DE's, as in psnode_ode_bwd_wide_args_f32
- *     ae_act[l], ae_delta[l]    : [k1-k0+1, B, H]  AE head at grid point k0+r (row 0 is written only when k0 == 0)
- *     ae_gi                     : [k1-k0+1, B, 16] adjoint of the head's output, slot layout
- *     ev_act[l], ev_delta[l]    : [n_events, B, H] the event-time recompute of event e (written for events taken in [k0,k1))
- *     ev_gi, ev_i               : [n_events, B, 16] its output adjoint and its value i0, slot layout
- * carry_x [B,x_dim] / carry_i [B,16] (slot layout): adjoint of x[k1] without dL/dxs[k1] / of is[k1] without dL/dis[k1] on entry (zeros for
- * the last chunk), of x[k0] / is[k0] likewise on exit -- except that the chunk with k0 == 0 also runs the head at grid point 0, so its
- * carry_x is dL/dx_init without dL/dxs[0] and its carry_i is zero.  Parameter and input gradients: py_psnode_amd/fused.py:dae_backward_wide.
- * Shape class: de = 3n -> h -> h -> h -> x_dim, ae = n+x+z+v -> h -> h -> h -> i_dim (the same h <= 128), x_dim <= 8, z+v+i <= 8;
- * H = h rounded up to 32 / 64 / 128 as above.
- *
- * grad_params_de != NULL selects the FUSED-DE form (K7f, csrc/psnode_dae_backward_fused.hip): one launch over the whole grid
- * (k0 = 0, k1 = T-1 required; carry_x is output only), the DE's parameter gradients accumulated in the kernel (flat, nn.Linear order
- * W1,b1,..,W4,b4), and the DE's share of the input gradients written in their final layout:
+/* The DAE backward at hidden <= 128 (K7f, csrc/psnode_dae_backward_fused.hip): loss.backward() through integrate_DAE
+ * (my_solvers.py:94-129) in ONE launch over the whole grid -- per grid point the AE head's adjoint (its output adjoint = dL/dis of that
+ * grid point + what the DE of the step starting there returned through its algebraic inputs), per step the DE stages, at event steps the
+ * recompute i0 = g(x0; jumps) and its adjoint.  The DE's parameter gradients are accumulated in the kernel (grad_params_de: flat,
+ * nn.Linear order W1,b1,..,W4,b4) and the DE's share of the input gradients is written in its final layout:
  *     grad_zv             [T, B, z+v]          dL/d(z | v) through the DE (zero at event steps and at grid point T-1); every entry written
  *     grad_jump           [B, n_events, z+v]   the same for the jump values of the events taken; zero-initialised by the caller
  *     grad_all_initial_de [B, x+z+v+i]         the DE's share of dL/dall_initial
- * act / delta / gk / xstage / dsum / carry_i are not touched (may be NULL); the AE head rows (ae_*, ev_*) are written as above, with
- * row r = grid point r, and are what the caller still contracts (AE parameter gradients, the AE's share of the input gradients). */
+ * carry_x [B,x_dim] (output) = dL/dx_init without dL/dxs[0].
+ * "Slot" layout of an algebraic-variable row [.., 16]: slot q < 2(z+v+i) is the DE's external input q of the `s - a0` block (q < z+v+i) or of
+ * the `s` block; the adjoint / value of i-dim d sits in slots z+v+d and (z+v+i)+z+v+d (values: equal; adjoints: to be summed by the caller).
+ * Unless psnode_dae_backward_wide_ae_floats(args) > 0 (below) the AE head's rows are written for the caller to contract (K7h,
+ * psnode_dae_head_grads_f32: AE parameter gradients, the AE's share of the input gradients), row r = grid point r:
+ *     ae_act[l], ae_delta[l]    : [T, B, H]  AE head at grid point r (ELU outputs / pre-activation adjoints of hidden layer l = 1..3)
+ *     ae_gi                     : [T, B, 16] adjoint of the head's output, slot layout
+ *     ev_act[l], ev_delta[l]    : [n_events, B, H] the event-time recompute of event e (written for the events taken)
+ *     ev_gi, ev_i               : [n_events, B, 16] its output adjoint and its value i0, slot layout
+ * Shape class: de = 3n -> h -> h -> h -> x_dim, ae = n+x+z+v -> h -> h -> h -> i_dim (the same h <= 128), x_dim <= 8, z+v+i <= 8;
+ * H = h rounded up to the kernels' 32 / 64 / 128 (columns h..H-1 of the rows are exact zeros: zero-padded units).
+ * (ABI <= 7 also had a split form behind this entry point -- adjoint sweep in time chunks + library GEMMs on the host side -- and its
+ * ODE counterpart psnode_ode_backward_wide_f32; removed in ABI 8, K4f / K7f cover their shapes.) */
 typedef struct {
     int32_t method;
     int32_t x_dim, z_dim, v_dim, i_dim;
     int64_t T, B;
-    int64_t k0, k1;
     psnode_mlp_f32 de, ae;
     psnode_view_f32 t, z, v;
     const float* all_initial;        /* [B, x+z+v+i] */
@@ -368,13 +322,7 @@ typedef struct {
     const float* is;
     const float* grad_xs;            /* dL/dxs [T,B,x_dim] */
     const float* grad_is;            /* dL/dis [T,B,i_dim] or NULL (= zeros) */
-    float* carry_x;                  /* [B,x_dim] in/out */
-    float* carry_i;                  /* [B,16] in/out */
-    float* act[3];
-    float* delta[3];
-    float* gk;
-    float* xstage;
-    float* dsum[3];                  /* [k1-k0, B, H]: sum over the stages of delta[l] */
+    float* carry_x;                  /* [B,x_dim] out */
     float* ae_act[3];
     float* ae_delta[3];
     float* ae_gi;
@@ -382,11 +330,11 @@ typedef struct {
     float* ev_delta[3];
     float* ev_gi;
     float* ev_i;
-    float* grad_params_de;           /* NULL = the split form above */
+    float* grad_params_de;           /* required */
     float* grad_zv;
     float* grad_jump;
     float* grad_all_initial_de;
-    /* Fused-DE form only, optional, all of them or none: what the forward call wrote to psnode_dae_args_f32::save_* (same method, T, B,
+    /* Optional, all of them or none: what the forward call wrote to psnode_dae_args_f32::save_* (same method, T, B,
      * MLPs; the two event buffers with event_idx).  The kernel then evaluates nothing forwards; ae_act / ev_act / ev_i are NOT written
      * (contract over saved_ae_act / saved_ev_act instead). */
     const float* saved_act;
@@ -394,7 +342,7 @@ typedef struct {
     const float* saved_ae_act;
     const float* saved_ev_act;
     const float* saved_ev_i;
-    /* ABI 5, fused-DE recompute form only (saved_* NULL): backward of a teacher-forced integrate_DAE (my_solvers.py:111-121).
+    /* ABI 5, recompute form only (saved_* NULL): backward of a teacher-forced integrate_DAE (my_solvers.py:111-121).
      * PSNODE_FLAG_INPUT_TRUE_X: the DE of step k starts from x_true[k] and the head at grid point j reads x_true[j] (dataset rows
      * [T,B,x_dim] contiguous) -- no adjoint flows from step to step through x except through an event's recomputed i0, whose head reads
      * the RUNNING state xs[k]; PSNODE_FLAG_INPUT_TRUE_I: the DE reads i_true[k] ([T,B,i_dim] contiguous) instead of the head's value --
@@ -402,7 +350,7 @@ typedef struct {
     uint32_t flags;
     const float* x_true;
     const float* i_true;
-    /* ABI 5, fused-DE form at hidden <= 64 WITH saved activations (psnode_dae_backward_wide_ae_floats(args) > 0; then REQUIRED): the AE head's gradients are
+    /* ABI 5, at hidden <= 64 WITH saved activations (psnode_dae_backward_wide_ae_floats(args) > 0; then REQUIRED): the AE head's gradients are
      * formed in the kernel as well -- nothing is left to contract, no head row is written (ae_act / ae_delta / ae_gi / ev_delta / ev_gi may
      * be NULL; ev_act / ev_i are still scratch of the recompute form).  Flat output, h = the MLPs' hidden width, K1a = n + x + z + v:
      *     [ dAW1 (h x K1a) | db1 (h) | dAW2 (h x h) | db2 | dAW3 (h x h) | db3 | P3 (16 x h) | sg (16) ]

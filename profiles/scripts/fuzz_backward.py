@@ -50,8 +50,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         if VERBOSE: torch.cuda.synchronize(); print("    fwd ok", flush=True)
         b = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="generic")
         if VERBOSE: torch.cuda.synchronize(); print("    generic ok", flush=True)
-        runs = [("split", lambda: fused.ode_backward_wide(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, chunk_steps=chunk)),
-                ("K4f", lambda: fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="wide")),
+        runs = [("K4f", lambda: fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="wide")),
                 ("K4f saved", lambda: fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="wide", saved=saved))]
         for name, fn in runs:
             if VERBOSE: print("   ", name, flush=True)
@@ -76,7 +75,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         gi = Gi if use_gi else None
         b = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="generic")
         kw = dict(event_idx=tab, z_jump=zj, v_jump=vj)
-        runs = [("split", lambda: fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, chunk_steps=chunk, fuse_de=False, **kw)),
+        runs = [("K7f sliced", lambda: fused._dae_backward_wide_sliced(16, method, de, ae, t, z, v, a0, xs, is_, Gx, gi, tab, zj, vj, None, None)),
                 ("K7f", lambda: fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, **kw)),
                 ("K7f saved", lambda: fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, saved=saved, **kw))]
         for name, fn in runs:

@@ -13,6 +13,7 @@
 //   3  as 2 with FOUR accumulator chains (3 packed adds more)
 //   4  as 2 with the round-5 ELU (the clamp of the negative side rides on v_exp_f32's output modifier: 3 instead of 4 issue slots per value)
 //   5  64 MFMA without the A broadcast (CBSZ = 0): is the 10-cycle issue interval a property of the broadcast?
+//   6  the whole layer with the scaled-domain ELU;  7 / 8  64 MFMA with one / two SALU instructions behind each: are they free?
 // It also checks, bit for bit over 2^24 inputs, that the round-5 ELU form equals round 3's.
 // Grid: 1024 single-wave workgroups (= B 4096: one wave per SIMD), and 2048 (two per SIMD) for reference.
 #include <hip/hip_runtime.h>
@@ -100,10 +101,12 @@ __device__ __forceinline__ f4 quad_transpose(f4 v, const int) {
     return f4{o0, o1, o2, o3};
 }
 
-template <int C, int B0, int NACC, bool BC = true>
-__device__ __forceinline__ void quarter(const float (&wreg)[64], const float hc, f4 (&acc)[4]) {
+template <int C, int B0, int NACC, bool BC = true, int FILL = 0>
+__device__ __forceinline__ void quarter(const float (&wreg)[64], const float hc, f4 (&acc)[4], unsigned& g_sfill) {
     // the 16 k's that register c of the A operand carries: k = 4b + c, ABID = b
-#define STEP(B) acc[(B) % NACC] = mf<B, BC>(hc, wreg[4 * (B) + C], acc[(B) % NACC]);
+#define STEP(B) acc[(B) % NACC] = mf<B, BC>(hc, wreg[4 * (B) + C], acc[(B) % NACC]); \
+    if constexpr (FILL == 1) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(g_sfill)); } \
+    if constexpr (FILL == 2) { asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 3" : "+s"(g_sfill)); }
     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
 #undef STEP
 }
@@ -116,27 +119,29 @@ __global__ __launch_bounds__(64) void bench(float* out, long long* cyc, int nite
     for (int i = 0; i < 64; ++i) wreg[i] = wsrc[i * 64 + l];
     f4 h = f4{0.1f + 0.001f * l, 0.2f, 0.3f, 0.4f};
     constexpr int NACC = MODE == 3 ? 4 : 2;
+    unsigned sfill = 0;
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < niter; ++it) {
         f4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-        quarter<0, 0, NACC, MODE != 5>(wreg, h[0], acc);
-        quarter<1, 0, NACC, MODE != 5>(wreg, h[1], acc);
-        quarter<2, 0, NACC, MODE != 5>(wreg, h[2], acc);
-        quarter<3, 0, NACC, MODE != 5>(wreg, h[3], acc);
+        constexpr int FILL = MODE == 7 ? 1 : (MODE == 8 ? 2 : 0);      // modes 7 / 8: one / two SALU instructions behind every MFMA
+        quarter<0, 0, NACC, MODE != 5, FILL>(wreg, h[0], acc, sfill);
+        quarter<1, 0, NACC, MODE != 5, FILL>(wreg, h[1], acc, sfill);
+        quarter<2, 0, NACC, MODE != 5, FILL>(wreg, h[2], acc, sfill);
+        quarter<3, 0, NACC, MODE != 5, FILL>(wreg, h[3], acc, sfill);
         __builtin_amdgcn_sched_barrier(0);
         f4 s = acc[0] + acc[1];
         if constexpr (NACC == 4) s += acc[2] + acc[3];
         if constexpr (MODE == 6) s = elu_quad_scaled(s);
         else if constexpr (MODE == 4) s = elu_quad_clamp(s);
         else if constexpr (MODE >= 2 && MODE < 5) s = elu_quad(s);
-        if constexpr (MODE >= 1 && MODE != 5) s = quad_transpose(s, l);
+        if constexpr (MODE >= 1 && MODE != 5 && MODE < 7) s = quad_transpose(s, l);
         h = s * 1e-3f;      // keep the chain finite (one packed multiply pair; K1 has the accumulator sum in its place)
         __builtin_amdgcn_sched_barrier(0);
     }
     const long long t1 = __builtin_readcyclecounter();
-    out[blockIdx.x * 64 + l] = h[0] + h[1] + h[2] + h[3];
+    out[blockIdx.x * 64 + l] = h[0] + h[1] + h[2] + h[3] + (float)sfill;
     if (blockIdx.x == 0 && l == 0) *cyc = t1 - t0;
 }
 
@@ -214,10 +219,11 @@ __global__ void check(const float* __restrict__ W, const float* __restrict__ act
     f4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    quarter<0, 0, 2>(wreg, h[0], acc);
-    quarter<1, 0, 2>(wreg, h[1], acc);
-    quarter<2, 0, 2>(wreg, h[2], acc);
-    quarter<3, 0, 2>(wreg, h[3], acc);
+    unsigned sf = 0;
+    quarter<0, 0, 2>(wreg, h[0], acc, sf);
+    quarter<1, 0, 2>(wreg, h[1], acc, sf);
+    quarter<2, 0, 2>(wreg, h[2], acc, sf);
+    quarter<3, 0, 2>(wreg, h[3], acc, sf);
     f4 s = acc[0] + acc[1];                                               // D: lane (b,c) register r = out[unit 4b+c][traj r]
     s = quad_transpose(s, l);                                             // A layout again: lane (b,t) register c = out[unit 4b+c][traj t]
 #pragma unroll
@@ -267,6 +273,8 @@ int main() {
     run<4>("the whole layer with the round-5 ELU (v_exp clamp)", 1024, out, cyc, w);
     run<6>("the whole layer with the scaled-domain ELU", 1024, out, cyc, w);
     run<5>("64 x 4x4x1 without the A broadcast (CBSZ = 0)", 1024, out, cyc, w);
+    run<7>("64 x (4x4x1 + 1 SALU instruction), nothing else", 1024, out, cyc, w);
+    run<8>("64 x (4x4x1 + 2 SALU instructions), nothing else", 1024, out, cyc, w);
     run<0>("64 x 4x4x1 (2 chains), nothing else", 2048, out, cyc, w);
     run<2>("64 x 4x4x1 + ELU + transpose (the whole layer)", 2048, out, cyc, w);
     run16<0, true>("16x16x4 layer as K1 runs it, round-3 ELU", out, cyc, w);

@@ -12,16 +12,18 @@ MAX_WIDTH = 1024
 
 OK = 0
 EULER, MIDPOINT, RK4_38 = 0, 1, 2
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE, KERNEL_MFMA_TILE, KERNEL_MFMA_WAVE = 0, 1, 2, 3, 4, 5
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 7          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 8          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
                          #     psnode_dae_save_hidden;
                          #  5: flags (+ x_true / i_true) in psnode_ode_bwd_args_f32 / psnode_dae_bwd_wide_args_f32: teacher-forced backward;
                          #  6: psnode_dae_encoded_*: the DAE_02 model forward in one launch;
-                         #  7: psnode_latent_backward_wide_*: the adjoint sweep of the latent integrators at hidden widths other than 16 / 64)
+                         #  7: psnode_latent_backward_wide_*: the adjoint sweep of the latent integrators at hidden widths other than 16 / 64;
+                         #  8: the split backward forms are gone -- no psnode_ode_backward_wide_*, no k0 / k1 / stored DE rows in
+                         #     psnode_dae_bwd_wide_args_f32 -- and PSNODE_KERNEL_MFMA_TILE / _WAVE select K1 / K1x for forward ODE calls)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -38,7 +40,6 @@ EXPORTS = (
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
     "psnode_dae_encoded_supported", "psnode_dae_encoded_workspace_bytes", "psnode_dae_encoded_integrate_f32",
     "psnode_latent_backward_wide_supported", "psnode_latent_backward_wide_workspace_bytes", "psnode_latent_backward_wide_f32",
-    "psnode_ode_backward_wide_supported", "psnode_ode_backward_wide_workspace_bytes", "psnode_ode_backward_wide_f32",
     "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
     "psnode_dae_backward_wide_ae_floats",
 )
@@ -136,22 +137,14 @@ class LatentBwdWideArgsF32(ctypes.Structure):
                 ("da1_ev", c_void_p), ("grad_x0", c_void_p)]
 
 
-class OdeBwdWideArgsF32(ctypes.Structure):
-    _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("T", c_int64), ("B", c_int64), ("k0", c_int64), ("k1", c_int64),
-                ("de", MlpF32), ("t", ViewF32), ("z", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p), ("z_jump", c_void_p),
-                ("zj_stride_b", c_int64), ("zj_stride_e", c_int64), ("xs", c_void_p), ("grad_xs", c_void_p), ("carry", c_void_p),
-                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p), ("dsum", c_void_p * 3)]
-
-
 class DaeBwdWideArgsF32(ctypes.Structure):
     _fields_ = [("method", c_int32), ("x_dim", c_int32), ("z_dim", c_int32), ("v_dim", c_int32), ("i_dim", c_int32),
-                ("T", c_int64), ("B", c_int64), ("k0", c_int64), ("k1", c_int64), ("de", MlpF32), ("ae", MlpF32),
+                ("T", c_int64), ("B", c_int64), ("de", MlpF32), ("ae", MlpF32),
                 ("t", ViewF32), ("z", ViewF32), ("v", ViewF32), ("all_initial", c_void_p), ("event_idx", c_void_p),
                 ("z_jump", c_void_p), ("zj_stride_b", c_int64), ("zj_stride_e", c_int64),
                 ("v_jump", c_void_p), ("vj_stride_b", c_int64), ("vj_stride_e", c_int64), ("n_events", c_int32),
                 ("xs", c_void_p), ("is_", c_void_p), ("grad_xs", c_void_p), ("grad_is", c_void_p),
-                ("carry_x", c_void_p), ("carry_i", c_void_p),
-                ("act", c_void_p * 3), ("delta", c_void_p * 3), ("gk", c_void_p), ("xstage", c_void_p), ("dsum", c_void_p * 3),
+                ("carry_x", c_void_p),
                 ("ae_act", c_void_p * 3), ("ae_delta", c_void_p * 3), ("ae_gi", c_void_p),
                 ("ev_act", c_void_p * 3), ("ev_delta", c_void_p * 3), ("ev_gi", c_void_p), ("ev_i", c_void_p),
                 ("grad_params_de", c_void_p), ("grad_zv", c_void_p), ("grad_jump", c_void_p), ("grad_all_initial_de", c_void_p),
@@ -270,12 +263,6 @@ def load():
     lib.psnode_dae_encoded_workspace_bytes.argtypes = [ctypes.POINTER(DaeEncodedArgsF32)]
     lib.psnode_dae_encoded_integrate_f32.restype = c_int32
     lib.psnode_dae_encoded_integrate_f32.argtypes = [ctypes.POINTER(DaeEncodedArgsF32), c_void_p, c_size_t, c_void_p]
-    lib.psnode_ode_backward_wide_supported.restype = c_int32
-    lib.psnode_ode_backward_wide_supported.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
-    lib.psnode_ode_backward_wide_workspace_bytes.restype = c_size_t
-    lib.psnode_ode_backward_wide_workspace_bytes.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32)]
-    lib.psnode_ode_backward_wide_f32.restype = c_int32
-    lib.psnode_ode_backward_wide_f32.argtypes = [ctypes.POINTER(OdeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
     lib.psnode_dae_backward_wide_supported.restype = c_int32
     lib.psnode_dae_backward_wide_supported.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
     lib.psnode_dae_backward_wide_workspace_bytes.restype = c_size_t

@@ -4,6 +4,7 @@ This is what lets the reference's training loops (`loss.backward()` through the 
 neural_00_ODE_01_no_encode.py:358-360) run on the fused HIP path instead of an unrolled T-step autograd graph.
 """
 import os
+import warnings
 
 import torch
 
@@ -16,11 +17,41 @@ from . import fused
 SAVE_ACTIVATIONS = os.environ.get("PSNODE_SAVE_ACTIVATIONS", "auto")
 # bytes of stage activations the most recent training forward kept for its backward (0: the backward recomputes) -- bench.py reports it
 last_saved_bytes = 0
+_warned_generic_override = False
+
+
+def latent_wide_training_fits(method, de, ae, hidden, T, B, dev) -> bool:
+    """Training at the latent-wide hidden widths exists in ONE form: K3w saves its rows, K9w writes as many adjoint rows again and the
+    host contracts them (fused.latent_backward_wide) -- there is no recompute form to fall back to.  True if all of that fits half of the
+    free HBM and PSNODE_SAVE_ACTIVATIONS is not "0"; otherwise the solver takes the walk through the user's callables (with its warning)."""
+    if SAVE_ACTIVATIONS == "0" or T < 2:
+        return False
+    if SAVE_ACTIVATIONS == "1":
+        return True
+    S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    rows = (T - 1) * S * B * hidden * 4              # one [T-1,S,B,H] tensor
+    grid = T * B * hidden * 4                        # one [T,B,H] tensor
+    need = 4 * rows + (6 if ae is None else 12) * grid       # saved act + xst, gk + d1; d1s, the where / contiguous copies of the external blocks, (DAE) gi, da1, s_ae
+    free, _ = torch.cuda.mem_get_info(dev)
+    return need <= free // 2
+
+
+def ode_training_supported(method, layers, x_dim, z_dim, T, B, kernel="auto") -> bool:
+    """What the solver asks before it routes a call that needs autograd to the fused forward + backward pair."""
+    if kernel in ("auto", "mfma") and fused.latent_wide_shape(layers, None, x_dim, z_dim):
+        return latent_wide_training_fits(method, layers, None, x_dim, T, B, layers[0][0].device)
+    return fused.ode_backward_supported(method, layers, x_dim, z_dim, kernel)
+
+
+def dae_training_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim, T, B) -> bool:
+    if fused.latent_wide_shape(de, ae, x_dim, z_dim, v_dim, i_dim):
+        return latent_wide_training_fits(method, de, ae, x_dim, T, B, de[0][0].device)
+    return fused.dae_backward_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim)
 
 
 def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
-    if fused.latent_wide_shape(layers, None, x_dim, z_dim):      # K3w saves, K9w reads: the only fused backward at these widths (no recompute form)
-        return True
+    if fused.latent_wide_shape(layers, None, x_dim, z_dim):      # K3w saves, K9w reads: the only fused backward at these widths (the solver
+        return True                                              # asked latent_wide_training_fits before it came here)
     if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma"):
         return False
     Hp = fused.ode_save_hidden(method, layers, x_dim, z_dim, kernel)
@@ -69,20 +100,30 @@ class _FusedOde(torch.autograd.Function):
     def forward(ctx, method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params):
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
         ctx.x_true = None
+        global last_saved_bytes
+        ctx.x_true = False
         if x0.dim() == 3:        # teacher forcing (my_solvers.py:72-74): x0 is the whole dataset x [T,B,xd]; nothing is saved, K4f recomputes
-            ctx.x_true = x0.detach().contiguous()
-            xs = fused.ode_integrate(method, layers, t, ctx.x_true, z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
+            x_true = x0.detach().contiguous()
+            xs = fused.ode_integrate(method, layers, t, x_true, z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
                                      input_true_x=True)
+            last_saved_bytes = 0
+            ctx.x_true = True
             ctx.method, ctx.has_jump, ctx.has_saved, ctx.event_idx = method, z_jump is not None, False, event_idx
-            ctx.save_for_backward(t, z, all_initial, xs, *((z_jump,) if z_jump is not None else ()), *params)
+            # (the dataset rows go through save_for_backward like everything else the backward reads: autograd's version counter then
+            #  catches an in-place edit of x between forward and backward)
+            ctx.save_for_backward(t, z, all_initial, xs, *((z_jump,) if z_jump is not None else ()), x_true, *params)
             return xs
         if kernel == "generic" and fused.latent_wide_shape(layers, None, x0.shape[-1], z.shape[-1]):
+            global _warned_generic_override
+            if not _warned_generic_override:
+                _warned_generic_override = True
+                warnings.warn("kernel='generic' is ignored for training at the latent hidden widths other than 16 / 64: the only backward "
+                              "there reads the rows K3w saves (K0 saves nothing)", RuntimeWarning, stacklevel=3)
             kernel = "auto"      # training at these widths exists on K3w + K9w only (K0 saves nothing)
         save = _want_saved(method, kernel, layers, x0.shape[-1], z.shape[-1], t.shape[0], t.shape[1])
         res = fused.ode_integrate(method, layers, t, x0.unsqueeze(0), z, all_initial, z_jump=z_jump, event_idx=event_idx, kernel=kernel,
                                   save=save)
         xs, saved = res if save else (res, None)
-        global last_saved_bytes
         last_saved_bytes = sum(q.numel() * q.element_size() for q in saved) if saved is not None else 0
         ctx.method = method
         ctx.has_jump = z_jump is not None
@@ -101,11 +142,13 @@ class _FusedOde(torch.autograd.Function):
         pos += 1 if ctx.has_jump else 0
         acts = (saved[pos], saved[pos + 1]) if ctx.has_saved else None
         pos += 2 if ctx.has_saved else 0
+        x_true = saved[pos] if ctx.x_true else None
+        pos += 1 if ctx.x_true else 0
         params = saved[pos:]
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
         need_z = ctx.needs_input_grad[5]
-        if ctx.x_true is not None:   # teacher forcing: every step started from a dataset row -- K4f with the dataset as `xs`, no carried adjoint
-            gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, ctx.x_true, grad_xs, event_idx=ctx.event_idx,
+        if x_true is not None:   # teacher forcing: every step started from a dataset row -- K4f with the dataset as `xs`, no carried adjoint
+            gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, x_true, grad_xs, event_idx=ctx.event_idx,
                                                          z_jump=z_jump, need_grad_z=need_z, kernel="wide", input_true_x=True)
             if gz is None and need_z:
                 gz = torch.zeros_like(z)

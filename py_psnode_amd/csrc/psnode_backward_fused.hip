@@ -38,7 +38,6 @@ __device__ __forceinline__ f4 fm4(float a, float b, f4 c) { return __builtin_amd
 
 struct FusedDev {
     int method, xd, zd, hreal, n_events, NP;
-    int no_roles;                         // PSNODE_K4F_NO_ROLES=1 in the environment: the one-role saved instance (A/B arm, tests)
     int true_x;                           // teacher-forced call: `xs` = the dataset rows, no adjoint carried from step to step (my_solvers.py:72-74)
     long long T, B;
     const float *w1, *w4;                 // raw nn.Linear tensors for the small transposed operands
@@ -60,9 +59,6 @@ struct FusedDev {
 #endif
 #ifndef PSNODE_K4F_BOUND_SAVED
 #define PSNODE_K4F_BOUND_SAVED 3      // the same knob for the instances that read saved activations (REC = false)
-#endif
-#ifndef PSNODE_K4F_ABLATE
-#define PSNODE_K4F_ABLATE 0     // timing experiments only (results WRONG): 1 = no weight-gradient MFMAs in the H->H layers, 2 = no in-wave transposes
 #endif
 #ifndef PSNODE_K4F_EVERY_SAVED
 #define PSNODE_K4F_EVERY_SAVED 2
@@ -130,14 +126,6 @@ __device__ __forceinline__ void fused_gradient_wave(const FusedDev& a, float* __
     f4 sv1 = zero4, sv2 = zero4, sv3 = zero4;
     if (nT >= 2) load_saved((nT - 1) * S - 1, sv1, sv2, sv3);
     int p = 0;
-#ifndef PSNODE_K4F_ROLES_ABLATE
-#define PSNODE_K4F_ROLES_ABLATE 0      // timing experiments only (results WRONG): 1 = the gradient waves only keep the barrier sequence
-#endif
-    if constexpr (PSNODE_K4F_ROLES_ABLATE == 1) {
-        for (long long q = (nT - 1) * (3 * S); q > 0; --q) lds_barrier();
-        lds_barrier();
-        return;
-    }
 #ifndef PSNODE_K4F_ROLES_EARLY
 #define PSNODE_K4F_ROLES_EARLY 1       // chunks (4 MFMAs each) of a contraction issued in the interval its tiles are published in; the rest waits for the
                                        // interval behind the stage's all-reduce, where the chain is latency-bound and leaves the MFMA pipe idle
@@ -374,7 +362,6 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
     auto getl = [&](const float* t_) -> f4 { return *reinterpret_cast<const f4*>(t_ + toff); };
     auto get_row = [&](const float* t_, const int ro) -> f4 { const float* s_ = t_ + ro; return f4{s_[0], s_[16], s_[32], s_[48]}; };
     auto transpose = [&](const f4 v) -> f4 {
-        if constexpr (PSNODE_K4F_ABLATE & 2) return v;
         put(scr, v); return get_row(scr, roff);
     };   // own D tile -> operand layout (trajectory g + 4kk)
 
@@ -434,7 +421,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
 #define PSNODE_K4F_TREAD_AHEAD 1
 #endif
     constexpr bool RSM = ROLES && PSNODE_K4F_ROLES_SMALL;
-    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !(PSNODE_K4F_ABLATE & 1) && !ROLES;
+    constexpr bool DEFER = PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && PSNODE_K4F_DEFER_DW && !ROLES;
     f4 pendT[DEFER ? NWV : 1], pend_h = f4{0.f, 0.f, 0.f, 0.f};      // transposed tiles / own activations of the layer whose gradient is still owed
 #ifndef PSNODE_K4F_DEFER8
 #define PSNODE_K4F_DEFER8 1         // 8 waves: the same deferral without holding the transposed tiles: they are re-read from the previous exchange's parity
@@ -493,7 +480,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
                                      // needs one.  Left to the scheduler the transposed reads recycled two registers, each pair of MFMAs behind
                                      // its own lgkmcnt(0) (found in the ISA)
 #endif
-        if constexpr (PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD && !(PSNODE_K4F_ABLATE & 1)) {
+        if constexpr (PREFETCH_ALL && PSNODE_K4F_TREAD_AHEAD) {
             f4 vq[NWV], wqq[NWV], dTq[ROLES ? 1 : NWV];
 #pragma unroll
             for (int c = 1; c < NWV; ++c) { vq[c] = getl(tile(p, (w + c) & (NWV - 1))); wqq[c] = WAH ? wah[WAH ? c : 0] : wl[c * NWV * 64]; }
@@ -552,7 +539,7 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void ode_backward_fused
 #ifndef PSNODE_K4F_DW_PAIR
 #define PSNODE_K4F_DW_PAIR 4     // 8 waves: the weight-gradient MFMAs of two chunks interleaved (two accumulator chains, both transposed tiles read first)
 #endif
-        if constexpr (!(PSNODE_K4F_ABLATE & 1)) {
+        {
         if constexpr (PSNODE_K4F_DW_PAIR && NWV >= 8 && !REC) {      // (recompute instance at RK4: 48.2 -> 50.3 ms with it, profiles/r03y_dw_pair_ab.txt)
             if constexpr (DEFER8) { pend_par = p; pend_h = hT; }      // (the tiles of this parity stay intact until the exchange after next)
             else dw_groups(p, hT, acc);
@@ -1027,13 +1014,12 @@ int fused_np(int hr, int xd, int zd) { const int n = xd + zd; return hr * 3 * n 
 template <int METHOD, int NWV>
 hipError_t launch_fused(const FusedDev& a, int NZM, const float* pde, const f4* pt, const f4* pf, int NA, hipStream_t s) {
     constexpr bool RL = PSNODE_K4F_ROLES && NWV <= 4;
-    const bool roles = RL && a.sact != nullptr && !a.no_roles;
+    const bool roles = RL && a.sact != nullptr;
     const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV * (roles ? 2 : 1));
     const size_t lds = fused_lds_bytes(NWV, roles);
 #define PSNODE_FUSED(NZM_)                                                                                                      \
     {                                                                                                                           \
-        auto kern = roles ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false, RL>                                            \
-                          : (a.sact ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false> : &ode_backward_fused_kernel<METHOD, NZM_, NWV, true>); \
+        auto kern = a.sact ? &ode_backward_fused_kernel<METHOD, NZM_, NWV, false, RL> : &ode_backward_fused_kernel<METHOD, NZM_, NWV, true>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pt, pf, NA);                                                      \
@@ -1116,7 +1102,6 @@ int fused_bwd_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hipStre
     a.wpart = wpart; a.ring = ring;
     a.sact = p->saved_act; a.sxst = p->saved_xstage;
     a.true_x = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0;
-    { const char* e_ = getenv("PSNODE_K4F_NO_ROLES"); a.no_roles = (e_ && e_[0] == '1') ? 1 : 0; }
     if (a.true_x && a.sact) return PSNODE_ERR_UNSUPPORTED;     // a teacher-forced forward saves nothing: recompute form only
     hipError_t e;
     switch (nw) {

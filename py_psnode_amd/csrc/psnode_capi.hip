@@ -90,7 +90,10 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
     if (dae) for (int l = 0; l < ae->n_layers; ++l) d.maxo = ae->out_dim[l] > d.maxo ? ae->out_dim[l] : d.maxo;
 
     const bool has_mfma = dae ? mfma_dae_supported(d) : mfma_ode_supported(d);
-    if (kernel == PSNODE_KERNEL_MFMA && !has_mfma) return PSNODE_ERR_UNSUPPORTED;
+    const bool want_mfma = kernel == PSNODE_KERNEL_MFMA || kernel == PSNODE_KERNEL_MFMA_TILE || kernel == PSNODE_KERNEL_MFMA_WAVE;
+    if (want_mfma && !has_mfma) return PSNODE_ERR_UNSUPPORTED;
+    if (kernel == PSNODE_KERNEL_MFMA_WAVE && (dae || !mfma_x_ode_supported(d))) return PSNODE_ERR_UNSUPPORTED;
+    d.kern = kernel;
     const bool use_mfma = has_mfma && kernel != PSNODE_KERNEL_GENERIC;
     if (d.T < 1 || d.B < 1) return PSNODE_ERR_DIMS;
 

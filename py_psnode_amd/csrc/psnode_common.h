@@ -49,6 +49,7 @@ struct IntegrateDev {
     float* sevi;
     int maxw;              // widest activation vector incl. the MLP inputs (generic kernel buffer A)
     int maxo;              // widest layer OUTPUT (generic kernel buffer B: it only ever holds layer outputs)
+    int kern;              // the caller's psnode_*_args_f32::kernel (PSNODE_KERNEL_MFMA_TILE / _WAVE pick between K1 and K1x)
 };
 
 // ELU(alpha=1) with the negative branch at expm1 quality: ATen's CPU kernel (what the reference runs) returns
@@ -234,6 +235,10 @@ bool mfma_dae_supported(const IntegrateDev& a);
 int mfma_dae_save_hidden(const IntegrateDev& a);     // likewise for K2 proper
 size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
+// psnode_mfma_x.hip (K1x: one wave per 4 trajectories, no LDS exchange; ODE inference at hidden <= 64)
+bool mfma_x_ode_supported(const IntegrateDev& a);
+size_t mfma_x_pack_floats();
+hipError_t launch_mfma_x(const IntegrateDev& a, float* pack, hipStream_t stream);
 // psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
 hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
 // K4f (psnode_backward_fused.hip): one-launch MFMA backward of the ODE integrator at hidden <= 128 (zero-padded to 32 / 64 / 128), x_dim <= 8, z_dim <= 8
@@ -262,10 +267,6 @@ bool latent64_dae_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
 bool latent64_dae_bwd_ptrs_ok(const psnode_dae_bwd_args_f32* a);
 size_t latent64_dae_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
 int latent64_dae_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
-// K7 (psnode_dae_backward.hip): MFMA backward of the DAE integrator at hidden 64
-bool dae_mfma_bwd_shape_ok(const psnode_dae_bwd_args_f32* a);
-size_t dae_mfma_bwd_workspace_floats(const psnode_dae_bwd_args_f32* a);
-int dae_mfma_bwd_launch(const psnode_dae_bwd_args_f32* a, float* workspace, hipStream_t s);
 hipError_t launch_mfma_h32(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);    // psnode_mfma_h32.hip
 hipError_t launch_mfma_h128(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h128.hip
 hipError_t launch_mfma_h192(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);   // psnode_mfma_h192.hip (forward only)

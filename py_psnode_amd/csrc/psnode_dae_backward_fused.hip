@@ -37,7 +37,6 @@ struct FusedDaeDev {
     long long zjb, zje, vjb, vje;
     const float *xs, *is, *gxs, *gis;
     const float *xtrue, *itrue;           // teacher forcing (recompute form only; my_solvers.py:111-121): dataset rows [T,B,xd] / [T,B,id]
-    int no_roles;                         // PSNODE_K7F_NO_ROLES=1 in the environment: the one-role saved instances (A/B arm, tests)
     int tx, ti;                           //   tx: DE starts and grid heads read xtrue, no x adjoint from step to step; ti: DE reads itrue, AE -> DE link cut
     float* carry_x;                       // [B, xd]: adjoint of x at grid point 0 (without dL/dxs[0])
     float *gzv, *gjump, *ga0;             // [T, B, nzv] (DE part), [B, n_events, nzv] (DE part), [B, n] (DE part)
@@ -829,21 +828,12 @@ __global__ __launch_bounds__(64 * NWV * (ROLES ? 2 : 1)) void dae_backward_fused
             d2 = mid_lds(TSZ + NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
             d1 = mid_lds(TSZ, zero4, d2) * elu_grad_quad(a1);
         } else {
-#ifndef PSNODE_K7F_ABLATE_HEAD
-#define PSNODE_K7F_ABLATE_HEAD 0     // timing experiments only (results WRONG): 1 = the head's two transposed layers skipped, 2 = its row stores skipped, 4 = layers on the DE's LDS images
-#endif
-            if constexpr (PSNODE_K7F_ABLATE_HEAD & 1) { d2 = d3 * elu_grad_quad(a2); d1 = d2 * elu_grad_quad(a1); }
-            else if constexpr (PSNODE_K7F_ABLATE_HEAD & 4) {
-                d2 = mid_lds(NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
-                d1 = mid_lds(0, zero4, d2) * elu_grad_quad(a1);
-            } else {
             d2 = mid_g(pack_ta + NWV * NWV * 64, zero4, d3) * elu_grad_quad(a2);
             d1 = mid_g(pack_ta, zero4, d2) * elu_grad_quad(a1);
-            }
         }
         const f4 ft = own4(afT, d1);
         const f2 gx = allreduce2(f2{ft[0], ft[1]}, f2{0.f, 0.f});
-        if (valid && !(PSNODE_K7F_ABLATE_HEAD & 2)) {
+        if (valid) {
             const size_t rb = row * a.B * H;
             if constexpr (REC) {      // (saved activations: the caller contracts over the forward call's buffers)
                 stg<f4>(sbase(hr.a1 + rb), offH, a1);
@@ -1489,13 +1479,12 @@ template <int METHOD, int NWV>
 hipError_t launch_k7f(const FusedDaeDev& a, int NZM, int NZA, const float* pde, const float* pae, const f4* pt, const f4* pf, const f4* pta,
                       const f4* pfa, int NA, hipStream_t s) {
     constexpr bool RL = PSNODE_K7F_ROLES && PSNODE_K7F_AE_GRADS_DEFAULT && NWV <= 4;
-    const bool roles = RL && a.sact != nullptr && !a.no_roles;
+    const bool roles = RL && a.sact != nullptr;
     const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV * (roles ? 2 : 1));
     const size_t lds = k7f_lds_bytes(NWV, roles);
 #define PSNODE_K7F(NZM_, NZA_)                                                                                                  \
     {                                                                                                                           \
-        auto kern = roles ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false, RL>                                      \
-                          : (a.sact ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false> : &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, true>); \
+        auto kern = a.sact ? &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, false, RL> : &dae_backward_fused_kernel<METHOD, NZM_, NZA_, NWV, true>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, pt, pf, pta, pfa, NA);                                       \
@@ -1592,7 +1581,6 @@ int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* p, float* workspace
     a.xs = p->xs; a.is = p->is; a.gxs = p->grad_xs; a.gis = p->grad_is;
     a.tx = (p->flags & PSNODE_FLAG_INPUT_TRUE_X) ? 1 : 0; a.ti = (p->flags & PSNODE_FLAG_INPUT_TRUE_I) ? 1 : 0;
     a.xtrue = p->x_true; a.itrue = p->i_true;
-    { const char* e_ = getenv("PSNODE_K7F_NO_ROLES"); a.no_roles = (e_ && e_[0] == '1') ? 1 : 0; }
     if ((a.tx || a.ti) && p->saved_act) return PSNODE_ERR_UNSUPPORTED;      // a teacher-forced forward saves nothing: recompute form only
     if ((a.tx && !a.xtrue) || (a.ti && !a.itrue)) return PSNODE_ERR_NULL;
     a.carry_x = p->carry_x;

@@ -371,360 +371,6 @@ struct ModelDev {
     float* ire; long long ire_st, ire_sb;
 };
 
-template <int METHOD, bool HASZ>
-__global__ __launch_bounds__(256) void latent64_model_kernel(const ModelDev md, const float* __restrict__ pack_de,
-                                                              const float* __restrict__ pack_ae, const float* __restrict__ pack_ed) {
-    constexpr int NBE = HASZ ? 3 : 2, NBLK = 1 + NBE, NZV = NBE - 1;
-    constexpr int RDE = 16 * NBLK + 24 + 16 * NBLK, RAE = 16 * NBE + 24 + 16 * NBLK;
-    const IntegrateDev& a = md.a;
-    __shared__ f4 xbuf[2][NW64][64];
-    __shared__ f4 gbuf[2][4][NW64][64];
-    const int l = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = l >> 4, j = l & 15;
-    const long long b0 = (long long)blockIdx.x * 16;
-    const bool valid = b0 + j < a.B;
-    const long long b = valid ? b0 + j : a.B - 1;
-    const bool recon = md.xre != nullptr;
-
-    // ---- weights -> registers (latent DE / AE as K3c; encoders / decoders from the enc/dec image)
-    const float* pw = pack_de + (size_t)w * RDE * 64 + l;
-    float wf[NBLK][16], w2[16];
-    f4 b1r, b2r;
-#pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wf[blk][k] = pw[(16 * blk + k) * 64];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) w2[k] = pw[(16 * NBLK + 4 + k) * 64];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { b1r[r] = pw[(16 * NBLK + r) * 64]; b2r[r] = pw[(16 * NBLK + 20 + r) * 64]; }
-    const float* pwa = pack_ae + (size_t)w * RAE * 64 + l;
-    float af[NBE][16], aw2[16];
-    f4 ab1r, ab2r;
-#pragma unroll
-    for (int blk = 0; blk < NBE; ++blk)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) af[blk][k] = pwa[(16 * blk + k) * 64];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) aw2[k] = pwa[(16 * NBE + 4 + k) * 64];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ab1r[r] = pwa[(16 * NBE + r) * 64]; ab2r[r] = pwa[(16 * NBE + 20 + r) * 64]; }
-    const float* pe = pack_ed + (size_t)w * kEncDecRegs * 64 + l;
-    auto load_enc = [&](const int m, EncW& e) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e.w1[q] = pe[(28 * m + q) * 64]; e.b1[q] = pe[(28 * m + 4 + q) * 64]; e.b2[q] = pe[(28 * m + 24 + q) * 64]; }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) e.w2[q] = pe[(28 * m + 8 + q) * 64];
-    };
-    auto load_dec = [&](const int m, DecW& d) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) d.w1[q] = pe[(28 * m + q) * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { d.b1[q] = pe[(28 * m + 16 + q) * 64]; d.w2s[q] = pe[(28 * m + 20 + q) * 64]; d.b2[q] = pe[(28 * m + 24 + q) * 64]; }
-    };
-    EncW ex, ez, evv, ei;
-    DecW dx, di;
-    load_enc(0, ex); load_enc(1, ez); load_enc(2, evv); load_enc(3, ei);
-    load_dec(4, dx); load_dec(5, di);
-
-    // 16 MFMAs of one 64x64 block against a chunk-layout vector, two accumulator chains
-    auto mm = [&](const float (&wr)[16], const V4& x, f4& accA, f4& accB) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            accA = mf(wr[4 * c + 0], x.v[c][0], accA); accB = mf(wr[4 * c + 1], x.v[c][1], accB);
-            accA = mf(wr[4 * c + 2], x.v[c][2], accA); accB = mf(wr[4 * c + 3], x.v[c][3], accB);
-        }
-    };
-    int p = 0, q2 = 0;
-    auto gather = [&](const f4 own) -> V4 {
-        xbuf[p][w][l] = own;
-        lds_barrier();
-        V4 o;
-        o.v[0] = own;
-#pragma unroll
-        for (int c = 1; c < 4; ++c) o.v[c] = xbuf[p][(w + c) & 3][l];
-        __builtin_amdgcn_sched_barrier(0);
-        p ^= 1;
-        return o;
-    };
-    // N vectors in one exchange (one barrier)
-    auto gather4 = [&](const f4 (&own)[4], V4 (&o)[4], const int n) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) if (s < n) gbuf[q2][s][w][l] = own[s];
-        lds_barrier();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < n) {
-                o[s].v[0] = own[s];
-#pragma unroll
-                for (int c = 1; c < 4; ++c) o[s].v[c] = gbuf[q2][s][(w + c) & 3][l];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        q2 ^= 1;
-    };
-    auto layer = [&](const float (&wr)[16], const f4 init, const f4 own) -> f4 {
-        xbuf[p][w][l] = own;
-        f4 accA = init, accB = {0.f, 0.f, 0.f, 0.f};
-        accA = mf(wr[0], own[0], accA); accB = mf(wr[1], own[1], accB);
-        accA = mf(wr[2], own[2], accA); accB = mf(wr[3], own[3], accB);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
-        f4 vq[4];
-#pragma unroll
-        for (int c = 1; c < 4; ++c) vq[c] = xbuf[p][(w + c) & 3][l];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 1; c < 4; ++c) {
-            const f4 v = vq[c];
-            accA = mf(wr[4 * c + 0], v[0], accA); accB = mf(wr[4 * c + 1], v[1], accB);
-            accA = mf(wr[4 * c + 2], v[2], accA); accB = mf(wr[4 * c + 3], v[3], accB);
-        }
-        p ^= 1;
-        return accA + accB;
-    };
-
-    // ---- raw rows: lane (g, j) holds column 4m + g of trajectory j's row (the B operand of encoder L1's MFMA m), 0 beyond the width
-    struct Raw { float x[4], z[2], v[2], i[2]; };
-    const int xd = a.xd, zd = a.zd, vd = a.vd, idm = a.id;
-    const float* tp = a.t.p + b * a.t.sb;
-    const float* xp = a.x.p ? a.x.p + b * a.x.sb : tp;
-    const float* zp = HASZ ? a.z.p + b * a.z.sb : tp;
-    const float* vp = a.v.p + b * a.v.sb;
-    const float* ip = a.i.p ? a.i.p + b * a.i.sb : tp;
-    const long long xst = a.x.p ? a.x.st : 0, zst = HASZ ? a.z.st : 0, vst = a.v.st, ist = a.i.p ? a.i.st : 0;
-    auto colv = [&](const float* row, const int m, const int width) -> float {       // branch-free: clamped load, value select
-        const int c = 4 * m + g;
-        const float v = row[c < width ? c : 0];
-        return c < width ? v : 0.0f;
-    };
-    auto load_raw = [&](const long long k, Raw& r) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) r.x[m] = recon ? colv(xp + k * xst, m, xd) : 0.0f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            r.z[m] = HASZ ? colv(zp + k * zst, m, zd) : 0.0f;
-            r.v[m] = colv(vp + k * vst, m, vd);
-            r.i[m] = recon ? colv(ip + k * ist, m, idm) : 0.0f;
-        }
-    };
-    auto enc_l1 = [&](const EncW& e, const float* raw, const int nm) -> f4 {      // ELU(b1 + W1 . raw)
-        f4 acc = e.b1;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) if (m < nm) acc = mf(e.w1[m], raw[m], acc);
-        return elu4l(acc);
-    };
-    auto enc_l2 = [&](const EncW& e, const V4& h) -> f4 {
-        f4 accA = e.b2, accB = {0.f, 0.f, 0.f, 0.f};
-        mm(e.w2, h, accA, accB);
-        return accA + accB;
-    };
-    const int nmx = (xd + 3) >> 2, nmz = (zd + 3) >> 2, nmv = (vd + 3) >> 2, nmi = (idm + 3) >> 2;
-    // the four encoders on one grid point's raw rows: out[0] = Xh (reconstruction), [1] = Zh, [2] = Vh, [3] = Ih (reconstruction), gathered
-    auto encode_rows = [&](const Raw& r, V4 (&out)[4]) {
-        f4 h[4];
-        h[0] = recon ? enc_l1(ex, r.x, nmx) : f4{0.f, 0.f, 0.f, 0.f};
-        h[1] = HASZ ? enc_l1(ez, r.z, nmz) : f4{0.f, 0.f, 0.f, 0.f};
-        h[2] = enc_l1(evv, r.v, nmv);
-        h[3] = recon ? enc_l1(ei, r.i, nmi) : f4{0.f, 0.f, 0.f, 0.f};
-        V4 hg[4];
-        gather4(h, hg, 4);
-        f4 o[4];
-        o[0] = recon ? enc_l2(ex, hg[0]) : h[0];
-        o[1] = HASZ ? enc_l2(ez, hg[1]) : h[1];
-        o[2] = enc_l2(evv, hg[2]);
-        o[3] = recon ? enc_l2(ei, hg[3]) : h[3];
-        gather4(o, out, 4);
-    };
-    // the z | v encoders alone (event steps: the RAW jump rows)
-    auto encode_zv = [&](const float (&rz)[2], const float (&rv)[2], V4 (&out)[4]) {
-        f4 h[4] = {};
-        h[0] = HASZ ? enc_l1(ez, rz, nmz) : f4{0.f, 0.f, 0.f, 0.f};
-        h[1] = enc_l1(evv, rv, nmv);
-        V4 hg[4];
-        gather4(h, hg, 2);
-        f4 o[4] = {};
-        o[0] = HASZ ? enc_l2(ez, hg[0]) : h[0];
-        o[1] = enc_l2(evv, hg[1]);
-        gather4(o, out, 2);
-    };
-    // ---- decoders: four vectors in, wave d stores output d (0: x_pred, 1: i_pred, 2: x_re, 3: i_re)
-    const bool is_i = (w & 1) != 0, is_re = w >= 2;
-    float* const obase = is_re ? (is_i ? md.ire : md.xre) : (is_i ? a.io : a.xo);
-    const int odim = is_i ? idm : xd;
-    const long long ost = is_re ? (is_i ? md.ire_st : md.xre_st) : a.B * odim, osb = is_re ? (is_i ? md.ire_sb : md.xre_sb) : odim;
-    const f4 ob2 = is_i ? di.b2 : dx.b2;
-    auto dec_part = [&](const DecW& d, const V4& vin) -> f4 {
-        f4 accA = d.b1, accB = {0.f, 0.f, 0.f, 0.f};
-        mm(d.w1, vin, accA, accB);
-        const f4 h = elu4l(accA + accB);
-        f4 pa = mf(d.w2s[0], h[0], f4{0.f, 0.f, 0.f, 0.f}), pb = mf(d.w2s[1], h[1], f4{0.f, 0.f, 0.f, 0.f});
-        pa = mf(d.w2s[2], h[2], pa); pb = mf(d.w2s[3], h[3], pb);
-        return pa + pb;
-    };
-    // first (grid point 0): wave 0's row is the raw x0 instead of the decoded one (neural_01_DAE_02_direct_encode.py:150).
-    // Returns this wave's output row (lane (g, j): dims 4g..4g+3 of trajectory j); the caller stores it at the top of the NEXT step, behind
-    // the loop-top s_waitcnt vmcnt(0) -- stores count in vmcnt on gfx9, and issued at the end of their own step the whole tile waited out
-    // their round trip every step (first build: 10.8 ms per 4096 x 1000 RK4 batch, slower than the five launches it replaces)
-    auto decode_rows = [&](const V4& xs, const V4& is_, const V4& xr, const V4& ir, const bool first) -> f4 {
-        gbuf[q2][0][w][l] = dec_part(dx, xs);
-        gbuf[q2][1][w][l] = dec_part(di, is_);
-        if (recon) { gbuf[q2][2][w][l] = dec_part(dx, xr); gbuf[q2][3][w][l] = dec_part(di, ir); }
-        lds_barrier();
-        f4 o = ob2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o += gbuf[q2][w][c][l];
-        q2 ^= 1;
-        if (first && w == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int d = 4 * g + r; o[r] = md.x0[b * xd + (d < xd ? d : 0)]; }
-        }
-        return o;
-    };
-    const bool storing = valid && (recon || !is_re);
-    float* orow = obase + b * osb + 4 * g;          // running output row pointer (this lane's first dim)
-    auto store_row = [&](const f4 o) {
-        if (storing) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (4 * g + r < odim) orow[r] = o[r];
-        }
-        orow += ost;
-    };
-
-    // ---- grid point 0: encoders, all_initial, the constants c0 (DE) / c0a (AE), i_0
-    Raw r0;
-    load_raw(0, r0);
-    float x0raw[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) x0raw[m] = colv(md.x0 + b * xd, m, xd);
-    V4 enc0[4];
-    encode_rows(r0, enc0);                         // Xh[0] (reconstruction), Zh[0], Vh[0], Ih[0]
-    V4 ih0g = enc0[3];
-    // Xh0 = x_encoder(x0): own dims + gathered
-    f4 x;
-    V4 xg;
-    {
-        const f4 h = enc_l1(ex, x0raw, nmx);
-        const V4 hg = gather(h);
-        x = enc_l2(ex, hg);
-        xg = gather(x);
-    }
-    if (!recon) {       // i_encoder(i[0]) for all_initial (the raw i row is read only here)
-        float ri[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) ri[m] = colv(a.i.p + b * a.i.sb, m, idm);
-        const f4 h = enc_l1(ei, ri, nmi);
-        const V4 hg = gather(h);
-        ih0g = gather(enc_l2(ei, hg));
-    }
-    f4 c0A = b1r, c0B = {0.f, 0.f, 0.f, 0.f}, caA = ab1r, caB = c0B;
-    auto a0_block = [&](const int blk, const V4& a0v) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 4 * c + r;
-                if (q & 1) { c0B = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0B); caB = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caB); }
-                else { c0A = mf(pw[(16 * NBLK + 24 + 16 * blk + q) * 64], a0v.v[c][r], c0A); caA = mf(pwa[(16 * NBE + 24 + 16 * blk + q) * 64], a0v.v[c][r], caA); }
-            }
-    };
-    a0_block(0, xg);
-    if constexpr (HASZ) a0_block(1, enc0[1]);
-    a0_block(NBLK - 2, enc0[2]);
-    a0_block(NBLK - 1, ih0g);
-    const f4 c0 = c0A + c0B, c0a = caA + caB;
-
-    struct Ext { V4 b[2]; };       // Zh | Vh gathered (b[0] unused without z)
-    auto ae_eval = [&](const V4& xgv, const Ext& zv) -> f4 {
-        f4 accA = c0a, accB = {0.f, 0.f, 0.f, 0.f};
-        mm(af[0], xgv, accA, accB);
-        if constexpr (HASZ) mm(af[1], zv.b[0], accA, accB);
-        mm(af[NBE - 1], zv.b[1], accA, accB);
-        const f4 h1 = elu4l(accA + accB);
-        return layer(aw2, ab2r, h1);
-    };
-    Ext ext_cur;
-    ext_cur.b[0] = enc0[1]; ext_cur.b[1] = enc0[2];
-    V4 ig = gather(ae_eval(xg, ext_cur));          // i_0 = g(x_0; z[0], v[0])  (my_solvers.py:95)
-    f4 o_prev = decode_rows(xg, ig, enc0[0], ih0g, true);
-    const long long nT = a.T, tst = a.t.st;
-    if (nT < 2) { store_row(o_prev); return; }
-
-    auto rhs_from_gathered = [&](const V4& xgv, const f4 cz) -> f4 {
-        f4 accA = cz, accB = {0.f, 0.f, 0.f, 0.f};
-        mm(wf[0], xgv, accA, accB);
-        return layer(w2, b2r, elu4l(accA + accB));
-    };
-    auto rhs = [&](const f4 xs_own, const f4 cz) -> f4 { return layer(w2, b2r, elu4l(layer(wf[0], cz, xs_own))); };
-
-    float t_cur = tp[0], t_nxt = tp[tst];
-    int lane_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const bool has_ev = a.ev != nullptr;
-    const int* evp = (has_ev ? a.ev : reinterpret_cast<const int*>(a.t.p)) + lane_zero;
-    int ev_cur = has_ev ? a.ev[0] : -1;
-    int ev_raw = evp[nT > 2 ? 1 : 0];
-    Raw rn;                                         // raw rows of grid point k+1, requested a step ahead
-    load_raw(1, rn);
-
-    for (long long k = 0; k + 1 < nT; ++k) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): everything in flight was requested a step ago
-        const float h_ = t_nxt - t_cur;
-        t_cur = t_nxt;
-        const Raw rk1 = rn;
-        const int ev_now = ev_cur;
-        const bool more = k + 2 < nT;
-        store_row(o_prev);                          // grid point k's outputs: a whole step to drain
-        {
-            const long long kn = more ? k + 2 : k + 1;          // the last step re-reads its own rows (unused)
-            t_nxt = tp[kn * tst];
-            ev_cur = (has_ev && more) ? ev_raw : -1;
-            load_raw(kn, rn);
-            ev_raw = evp[k + 3 < nT ? k + 2 : 0];
-        }
-        Ext ext_step = ext_cur;
-        if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {      // jump: encode the RAW jump rows, i0 = g(x0; jumped z, v)  (my_solvers.py:108-110)
-            float rz[2], rv[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                rz[m] = HASZ ? colv(a.zj + b * a.zjb + (long long)ev_now * a.zje, m, zd) : 0.0f;
-                rv[m] = colv(a.vj + b * a.vjb + (long long)ev_now * a.vje, m, vd);
-            }
-            V4 ej[4];
-            encode_zv(rz, rv, ej);
-            ext_step.b[0] = ej[0]; ext_step.b[1] = ej[1];
-            ig = gather(ae_eval(xg, ext_step));
-        }
-        // per-step constant: c0 + F_z . Zh + F_v . Vh + F_i . Ih
-        f4 czA = c0, czB = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (HASZ) mm(wf[1], ext_step.b[0], czA, czB);
-        mm(wf[NBLK - 2], ext_step.b[1], czA, czB);
-        mm(wf[NBLK - 1], ig, czA, czB);
-        const f4 cz = czA + czB;
-
-        const f4 k1 = rhs_from_gathered(xg, cz);
-        if constexpr (METHOD == PSNODE_EULER) {
-            x = x + h_ * k1;
-        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
-            const f4 k2 = rhs(x + k1 * (0.5f * h_), cz);
-            x = x + h_ * k2;
-        } else {
-            const f4 k2 = rhs(x + h_ * k1 * kOneThird, cz);
-            const f4 k3 = rhs(x + h_ * (k2 - k1 * kOneThird), cz);
-            const f4 k4 = rhs(x + h_ * (k1 - k2 + k3), cz);
-            x = x + (k1 + 3.0f * (k2 + k3) + k4) * h_ * 0.125f;
-        }
-        xg = gather(x);
-        V4 en[4];
-        encode_rows(rk1, en);                       // grid point k+1: Xh (reconstruction), Zh, Vh, Ih (reconstruction)
-        ext_cur.b[0] = en[1]; ext_cur.b[1] = en[2];
-        ig = gather(ae_eval(xg, ext_cur));          // i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]) with the un-jumped rows  (my_solvers.py:121)
-        o_prev = decode_rows(xg, ig, en[0], en[3], false);
-    }
-    store_row(o_prev);
-}
-
 constexpr size_t kModel2Lds = 18 * sizeof(f4) * NW64 * 64;       // xbuf[2] + slotA[4] + slotB[4] + slotC[4] + slotJ[2] vectors of 4 KB
 // K3g, two-role form (the default): 8 waves per 16-trajectory tile, 2 per SIMD, ONE barrier sequence.
 //   waves 0..3  "chain":  exactly K3c's work -- per-step constant, RK stages, AE head -- 240 MFMAs and 10 exchanges per RK4 step;
@@ -1197,12 +843,6 @@ namespace {
 template <int METHOD>
 hipError_t launch_model_method(const ModelDev& md, const float* pde, const float* pae, const float* ped, hipStream_t s) {
     const dim3 grid((unsigned)((md.a.B + 15) / 16));
-    static const bool one_role = [] { const char* e = getenv("PSNODE_K3G_ONE_ROLE"); return e && e[0] == '1'; }();      // the straight fusion (A/B arm)
-    if (one_role) {
-        if (md.a.zd) hipLaunchKernelGGL((latent64_model_kernel<METHOD, true>), grid, dim3(256), 0, s, md, pde, pae, ped);
-        else hipLaunchKernelGGL((latent64_model_kernel<METHOD, false>), grid, dim3(256), 0, s, md, pde, pae, ped);
-        return hipGetLastError();
-    }
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kModel2Lds);
         if (e != hipSuccess) return e;

@@ -622,16 +622,14 @@ bool fits9(long long B, long long stride_b) { return stride_b >= 0 && (unsigned 
 size_t pack9_floats(int nblk) { return (size_t)2 * NW9 * p9_regs(nblk, nblk) * 64; }
 size_t lds9_bytes(int nlb) { return (size_t)(2 * NW9 * 64 + 2 * NW9 * NW9 * 64 + 4 * NW9 * 64 + nlb * 4 * NW9 * 64) * sizeof(f4) + (size_t)NW9 * SCR9 * sizeof(float); }
 
-#ifndef PSNODE_K9_ROLES
-#define PSNODE_K9_ROLES 1
-#endif
 template <int METHOD, int NBE, bool DAE>
 hipError_t launch9(const Bwd9Dev& d, const float* pde, const float* pae, hipStream_t s) {
-    if constexpr (DAE && PSNODE_K9_ROLES) {
-        const char* e_ = getenv("PSNODE_K9_NO_ROLES");
-        if (d.a.sact && !(e_ && e_[0] == '1')) return launch9_roles(METHOD, NBE, d, pde, pae, s);      // saved activations: the two-role form (psnode_latent64_bwd_roles.hip)
+    if constexpr (DAE) {
+        if (d.a.sact) return launch9_roles(METHOD, NBE, d, pde, pae, s);      // saved activations: the two-role form (psnode_latent64_bwd_roles.hip)
     }
-    auto kern = d.a.sact ? &latent64_backward_kernel<METHOD, NBE, DAE, false> : &latent64_backward_kernel<METHOD, NBE, DAE, true>;
+    // (the DAE's saved-activation instance IS the two-role kernel: its one-role twin is not instantiated)
+    constexpr bool REC_SAVED = DAE;      // 4th parameter of the saved-activation instance: false (reads the saved rows) for the ODE only
+    auto kern = (!DAE && d.a.sact) ? &latent64_backward_kernel<METHOD, NBE, DAE, REC_SAVED> : &latent64_backward_kernel<METHOD, NBE, DAE, true>;
     const size_t lds = lds9_bytes((DAE && !d.a.sact) ? 2 * NBE : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

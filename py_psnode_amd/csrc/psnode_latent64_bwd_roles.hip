@@ -77,11 +77,7 @@ __global__ __launch_bounds__(512) void latent64_backward_roles_kernel(const Bwd9
         float* scr = gscr + w * SCR9;
         auto transpose = [&](const f4 v) -> f4 { *reinterpret_cast<f4*>(scr + 4 * l + 8 * g) = v; return get_t(scr); };
         auto tr_pub = [&](const int par, const int slot, const f4 v) { pub[((par * 4 + slot) * NW9 + w) * 64 + l] = transpose(v); };
-#ifndef PSNODE_K9_ROLES_ABLATE
-#define PSNODE_K9_ROLES_ABLATE 0      // timing experiments only (results WRONG): 1 = no outer products on the gradient waves (chain-only time)
-#endif
         auto outer = [&](A9& acc, const f4 dT, const int par, const int slot) {
-            if constexpr (PSNODE_K9_ROLES_ABLATE & 1) return;
 #pragma unroll
             for (int c2 = 0; c2 < 4; c2 += 2) {      // two tiles at a time (registers: this wave holds 144 accumulators)
                 f4 vT[2];

@@ -72,13 +72,16 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
     if (!de || de->n_layers != 4) return 0;
     const int n = de->in_dim / 3, nw = (padded_hidden_fwd(de->out_dim[0]) ? padded_hidden_fwd(de->out_dim[0]) : de->out_dim[0] + 15) / 16;
     const size_t one = (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64 + stream_image_floats(nw);
-    return ae ? 2 * one : one;
+    const size_t both = ae ? 2 * one : one;
+    return both > mfma_x_pack_floats() ? both : mfma_x_pack_floats();
 }
 
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
     if (latent_shape_ok(a, dae)) return launch_latent(a, dae, pack, stream);
     if (latent64_shape_ok(a, dae)) return launch_latent64(a, dae, pack, stream);
     if (latentw_shape_ok(a, dae)) return launch_latent_wide(a, dae, pack, stream);
+    // K1x (one wave per 4 trajectories, no LDS exchange) where it takes the shape, unless the caller asks for the 4-wave tile
+    if (!dae && a.kern != PSNODE_KERNEL_MFMA_TILE && mfma_x_ode_supported(a)) return launch_mfma_x(a, pack, stream);
     switch (padded_hidden_fwd(a.de.out_dim[0])) {
         case 32: return launch_mfma_h32(a, dae, pack, stream);
         case 128: return launch_mfma_h128(a, dae, pack, stream);

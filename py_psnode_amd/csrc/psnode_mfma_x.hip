@@ -1,0 +1,401 @@
+// K1x -- the exchange-free form of the fused ODE integrator (round 5; DESIGN.md "K1x"): ONE WAVE owns 4 trajectories and ALL hidden
+// units of `3n -> H -> H -> H -> x_dim` (H <= 64, x_dim <= 8, z_dim <= 8), so nothing crosses waves: no LDS, no barrier.  At the headline
+// batch (4096 trajectories = 1024 waves = one per SIMD) K1's 4-wave tile spends ~23 % of a stage in its three LDS exchanges
+// (ds_write -> s_barrier -> ds_read with nothing else to issue); here the layer-to-layer re-layout is a 4 x 4 transpose inside every lane
+// quad (8 v_cndmask_b32_dpp) and the L4 reduction a 4-stage lane butterfly (profiles/r05_ubench_4x4.txt: 325 vs 402 ns per H -> H layer).
+//
+// Arithmetic on v_mfma_f32_4x4x1_16B_f32 (16 blocks of D_b(4x4) += A_b(4x1) B_b(1x4); exact fp32, the same 64 flop/clk/SIMD peak as
+// 16x16x4 -- it issues every 10 cycles instead of 8).  Lane l = (block b = l >> 2, c = l & 3).
+//   hidden layers   A = activations, B = weights:   D[traj r][unit 4b'+c'] += act[k][traj r] * W[unit 4b'+c'][k]
+//       A layout: four registers hA[cc], lane (b, t) holds act[k = 4b + cc][trajectory t]; CBSZ = 4 / ABID = b hands block b's rows to all
+//       16 blocks, so ONE MFMA adds one k for all 64 units and 4 trajectories; B = one VGPR per k (64 per H -> H matrix, resident).
+//       D layout: register r = trajectory, lane (b', c') = unit 4b' + c'.  ELU runs on D; the in-quad transpose turns D into the next A.
+//   L4 (64 -> x_dim <= 8), split K over the BLOCKS, roles swapped (A = weights, B = activations, no broadcast):
+//       P_j[dim 4j + r][traj c] (block b) += W4[4j + r][4b + cc] * act[4b + cc][c]      8 MFMAs, then the sum over the 16 blocks:
+//       v_permlane32_swap (lane bit 5), v_permlane16_swap (bit 4) -- each folds TWO registers into one -- and two DPP row rotations
+//       (bits 3, 2).  Result = the state layout below, so the RK update is 2 registers wide and feeds L1 without any data movement.
+//   State layout: X01 / X23, lane in row rho = l >> 4, trajectory t = l & 3:  X01 = x[4 (rho >> 1) + 2 (rho & 1)][t],  X23 = the NEXT dim
+//       (adjacent dims: a row's two state values are one 8-byte store).  L1 reads dim d with ABID = 4 rho(d) from X01 or X23 (8 MFMAs per
+//       stage, folded image as K1).
+// External inputs: slot q (K1's order: q < ne -> ext[q] - a0, ne <= q < 2 ne -> ext[q - ne]) lives in block q of ONE register (lane (q, t));
+// the per-step constant of L1 is 4 NZM MFMAs with ABID = q.  Hidden layers run in the log2e-scaled domain (psnode_common.h:
+// elu_quad_scaled).  Inference only (no saved activations); teacher forcing (input_true_x) is a uniform runtime branch.
+#include <string.h>
+
+#include <type_traits>
+
+#include "psnode_pack.h"
+
+namespace psnode {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// register image: pack[reg][lane] (64 lanes)
+struct XRegs {
+    static constexpr int W2 = 0, W3 = 64, W1X = 128, W1E = 136, W1A = 152, B1 = 168, B2 = 169, B3 = 170, W4A = 171, B4C = 179, COUNT = 187;
+};
+struct PackX {
+    int xd, zd, n, hreal;
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+    float* out;
+};
+// dim that MFMA m of L1 multiplies: register X01 (m < 4) or X23, ABID = 4 (m & 3)
+__host__ __device__ constexpr int l1_dim(int m) { return 4 * ((m & 3) >> 1) + 2 * ((m & 3) & 1) + (m >= 4 ? 1 : 0); }
+
+__global__ void pack_x_kernel(const PackX p) {
+    const int H = p.hreal, n = p.n, xd = p.xd, ne = p.zd, K1 = 3 * n;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < XRegs::COUNT * 64; idx += gridDim.x * blockDim.x) {
+        const int reg = idx >> 6, l = idx & 63, b = l >> 2, c = l & 3, u = l;      // B operands: lane (b', c') = unit 4b' + c' = l
+        float v = 0.0f;
+        if (reg < XRegs::W1X) {                         // H -> H matrices, k in MFMA order: k = 4 bb + cc  (scale-free)
+            const int k = reg & 63;
+            const float* W = reg < XRegs::W3 ? p.w2 : p.w3;
+            if (u < H && k < H) v = W[u * H + k];
+        } else if (reg < XRegs::W1E) {                  // x columns of L1, folded: Ws + Wd
+            const int d = l1_dim(reg - XRegs::W1X);
+            if (u < H && d < xd) v = (p.w1[u * K1 + 2 * n + d] + p.w1[u * K1 + n + d]) * kLog2e;
+        } else if (reg < XRegs::W1A) {                  // ext slots
+            const int q = reg - XRegs::W1E;
+            if (u < H && q < ne) v = p.w1[u * K1 + n + xd + q] * kLog2e;
+            else if (u < H && q < 2 * ne) v = p.w1[u * K1 + 2 * n + xd + (q - ne)] * kLog2e;
+        } else if (reg < XRegs::B1) {                   // a0 columns (folded: Wa - Wd on the x dims)
+            const int q = reg - XRegs::W1A;
+            if (u < H && q < n) {
+                v = p.w1[u * K1 + q];
+                if (q < xd) v -= p.w1[u * K1 + n + q];
+                v *= kLog2e;
+            }
+        } else if (reg == XRegs::B1) { if (u < H) v = p.b1[u] * kLog2e;
+        } else if (reg == XRegs::B2) { if (u < H) v = p.b2[u] * kLog2e;
+        } else if (reg == XRegs::B3) { if (u < H) v = p.b3[u] * kLog2e;
+        } else if (reg < XRegs::B4C) {                  // L4 as A operand: lane (b, r = c) = W4[dim 4j + r][k = 4b + cc] / log2e
+            const int j = (reg - XRegs::W4A) >> 2, cc = (reg - XRegs::W4A) & 3, d = 4 * j + c, k = 4 * b + cc;
+            if (d < xd && k < H) v = p.w4[d * H + k] / kLog2e;
+        } else {                                        // C init of L4: D lane (b, c), register r -> dim 4j + r: the bias enters in block 0 only
+            const int j = (reg - XRegs::B4C) >> 2, r = (reg - XRegs::B4C) & 3, d = 4 * j + r;
+            if (b == 0 && d < xd) v = p.b4[d];
+        }
+        p.out[idx] = v;
+    }
+}
+
+template <int ABID>
+__device__ __forceinline__ f4 mfx(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+__device__ __forceinline__ f4 mfn(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// 4 x 4 transpose of registers (r0..r3) x lanes (4q..4q+3): two butterfly stages of four v_cndmask_b32_dpp (D = vcc ? src1 : dpp(src0)).
+// One asm block (the hazard recognizer does not look inside): s_nop 1 covers VALU write -> DPP read (2 wait states); inside, every DPP
+// source was written at least two instructions earlier.
+__device__ __forceinline__ f4 quad_transpose(const f4 v) {
+    float a0, a1, a2, a3, o0, o1, o2, o3;
+    const unsigned long long EVEN = 0x5555555555555555ull, LO = 0x3333333333333333ull;
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_mov_b64 vcc, %12\n\t"
+        "v_cndmask_b32_dpp %0, %9, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %11, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %1, %8, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %10, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %13\n\t"
+        "v_cndmask_b32_dpp %4, %2, %0, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %5, %3, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %6, %0, %2, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %7, %1, %3, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(EVEN), "s"(LO)
+        : "vcc", "scc");
+    return f4{o0, o1, o2, o3};
+}
+
+// (a, b) -> sums over the four blocks of each row of 16 lanes, in every lane: x += row_ror:8 (x); x += row_ror:4 (x) as v_add_f32_dpp.
+// One asm block (left to the compiler the rotation is a v_mov_b32_dpp into a zeroed register in front of a packed add: 4 instructions
+// per rotation); it carries its own wait states (VALU write -> DPP read: 2).
+__device__ __forceinline__ void row_sum2(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b));
+}
+// (a, b) -> one register: lanes 0..31 hold a[l] + a[l + 32], lanes 32..63 hold b[l - 32] + b[l]
+__device__ __forceinline__ float fold32(const float a, const float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// (a, b) -> one register: even rows hold a[row] + a[row + 1], odd rows hold b[row - 1] + b[row]
+__device__ __forceinline__ float fold16(const float a, const float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// all 64 k of one H -> H layer: k = 4 bb + cc <-> A register cc, ABID bb
+template <int BB>
+__device__ __forceinline__ void hh_block(const float (&wk)[64], const f4 hA, f4& accA, f4& accB) {
+    accA = mfx<BB>(hA[0], wk[4 * BB + 0], accA);
+    accB = mfx<BB>(hA[1], wk[4 * BB + 1], accB);
+    accA = mfx<BB>(hA[2], wk[4 * BB + 2], accA);
+    accB = mfx<BB>(hA[3], wk[4 * BB + 3], accB);
+}
+__device__ __forceinline__ f4 hh_layer(const float (&wk)[64], const float bias, const f4 hA) {
+    f4 accA = f4{bias, bias, bias, bias}, accB = f4{0.f, 0.f, 0.f, 0.f};
+    hh_block<0>(wk, hA, accA, accB); hh_block<1>(wk, hA, accA, accB); hh_block<2>(wk, hA, accA, accB); hh_block<3>(wk, hA, accA, accB);
+    hh_block<4>(wk, hA, accA, accB); hh_block<5>(wk, hA, accA, accB); hh_block<6>(wk, hA, accA, accB); hh_block<7>(wk, hA, accA, accB);
+    hh_block<8>(wk, hA, accA, accB); hh_block<9>(wk, hA, accA, accB); hh_block<10>(wk, hA, accA, accB); hh_block<11>(wk, hA, accA, accB);
+    hh_block<12>(wk, hA, accA, accB); hh_block<13>(wk, hA, accA, accB); hh_block<14>(wk, hA, accA, accB); hh_block<15>(wk, hA, accA, accB);
+    return quad_transpose(elu_quad_scaled(accA + accB));
+}
+
+template <int Q0, int NQ>
+__device__ __forceinline__ f4 ext_mfmas(const float (&we)[16], const float eA, f4 acc) {
+    if constexpr (NQ > 0) {
+        acc = mfx<Q0>(eA, we[Q0], acc);
+        return ext_mfmas<Q0 + 1, NQ - 1>(we, eA, acc);
+    } else {
+        return acc;
+    }
+}
+
+constexpr int kXWaves = 4;      // independent waves per workgroup (one per SIMD; they share nothing)
+
+// FAST: no event table, no teacher forcing, even x_dim -- the plain inference call.  With one wave per SIMD every scalar instruction and
+// every branch of the per-step bookkeeping is wall time (~4 / ~8 cycles each, nothing else to issue: 72 SALU + 19 branches were ~200 ns of
+// a 1.05 us Euler step), so the common call gets a loop without the event / teacher-forcing / odd-width code, and BOTH forms peel the last
+// step (which prefetches nothing) instead of clamping every row pointer every step.
+template <int METHOD, int NZM, bool FAST>
+__global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
+    const int l = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = l >> 2, c = l & 3, rho = l >> 4;
+    const long long tile = (long long)blockIdx.x * kXWaves + wv;
+    if (tile * 4 >= a.B) return;                                   // (nothing is shared between the waves: a surplus wave just leaves)
+    const bool valid = tile * 4 + c < a.B;
+    const long long tr = valid ? tile * 4 + c : a.B - 1;
+    const int xd = a.xd, zd = a.zd, ne = zd, n = xd + zd;
+    const bool true_x = (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
+
+    // ---- weights -> registers (once per launch)
+    const float* pw = pack + l;
+    float w2[64], w3[64], w1x[8], w1e[16], w4a[8];
+    f4 b4c[2];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { w2[k] = pw[(XRegs::W2 + k) * 64]; w3[k] = pw[(XRegs::W3 + k) * 64]; }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { w1x[m] = pw[(XRegs::W1X + m) * 64]; w4a[m] = pw[(XRegs::W4A + m) * 64]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w1e[q] = q < 4 * NZM ? pw[(XRegs::W1E + q) * 64] : 0.0f;
+    const float b1 = pw[XRegs::B1 * 64], b2 = pw[XRegs::B2 * 64], b3 = pw[XRegs::B3 * 64];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4c[j][r] = pw[(XRegs::B4C + 4 * j + r) * 64];
+
+    // ---- per-trajectory constants
+    const int d01 = 4 * (rho >> 1) + 2 * (rho & 1), d23 = d01 + 1;  // the dims this lane's row carries in X01 / X23 (adjacent)
+    const float* a0p = a.a0 + tr * n;
+    f4 c0 = f4{b1, b1, b1, b1};                                     // bias + W1[:, a0 columns] . a0: constant for the whole launch
+    {
+        const float a0A = b < n ? a0p[b] : 0.0f;                    // block q = a0 column q
+        float wa[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wa[q] = pw[(XRegs::W1A + q) * 64];
+        c0 = ext_mfmas<0, 16>(wa, a0A, c0);
+    }
+    const int ecol = b < ne ? b : (b < 2 * ne ? b - ne : 0);        // z column of this lane's ext slot (slot q = block b)
+    const float a0e = b < ne ? a0p[xd + b] : 0.0f;
+    const bool eon = b < 2 * ne;
+    float X01 = 0.0f, X23 = 0.0f;
+    {
+        const float* x0 = a.x.p + tr * a.x.sb;
+        if (d01 < xd) X01 = x0[d01];
+        if (d23 < xd) X23 = x0[d23];
+    }
+    const bool storer = (b & 3) == 0 && valid;                      // the first block of each row writes the row's two dims
+    if (a.T < 2 && storer) {                                         // (T >= 2: row 0 is stored by the first pass of the time loop)
+        float* row = a.xo + tr * xd;
+        if (d01 < xd) row[d01] = X01;
+        if (d23 < xd) row[d23] = X23;
+    }
+    const int nT = (int)a.T;                                         // (32-bit loop counters: there is no 64-bit scalar compare, a `long long` k puts
+    if (nT < 2) return;                                              //  every end-of-grid test on the VALU; the launcher refuses T >= 2^31)
+
+    // Addressing of the time loop (psnode_common.h: sbase / ldg): <uniform row base in SGPRs> + <32-bit per-lane byte offset>.  With one wave
+    // per SIMD every instruction of the per-step bookkeeping is wall time (~5 cycles each, nothing else to issue): the row bases advance by
+    // scalar adds, a lane owns ONE clock entry, ONE external-input column and two state dims.
+    const long long tst = a.t.st, xst = a.x.st;
+    const bool has_z = zd > 0, has_zj = has_z && a.zj != nullptr;
+    const long long zst = has_z ? a.z.st : 0, zje = has_zj ? a.zje : 0;
+    const unsigned toff = (unsigned)(tr * a.t.sb) * 4u;
+    const unsigned zoff = has_z ? (unsigned)(tr * a.z.sb + ecol) * 4u : toff;          // absent source: the trajectory's clock (meets a zero weight)
+    const unsigned zjoff = has_zj ? (unsigned)(tr * a.zjb + ecol) * 4u : toff;
+    const float* zbase = has_z ? a.z.p : a.t.p;
+    const float* zjbase = has_zj ? a.zj : a.t.p;
+    const int d01c = d01 < xd ? d01 : 0, d23c = d23 < xd ? d23 : 0;
+    const unsigned xtoff01 = (unsigned)(tr * a.x.sb + d01c) * 4u, xtoff23 = (unsigned)(tr * a.x.sb + d23c) * 4u;
+    const unsigned xooff = (unsigned)(tr * xd + d01) * 4u;
+    auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };      // uniform row base (SGPR pair) as a global pointer
+    auto load_evb = [&](const int blk) -> int {                       // event indices travel 64 steps at a time (lane i: step 64 blk + i)
+        const int i = blk * 64 + l;
+        const int v = (a.ev && i + 1 < nT) ? a.ev[i] : -1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        return v;
+    };
+    int evb = FAST ? -1 : load_evb(0);
+    int ev_cur = FAST ? -1 : __builtin_amdgcn_readlane(evb, 0);
+    float t_cur = ldg<float>(as_g(a.t.p), toff), t_nxt = ldg<float>(as_g(a.t.p + tst), toff);
+    float e_nxt = (!FAST && ev_cur >= 0) ? ldg<float>(as_g(zjbase + (long long)ev_cur * zje), zjoff) : ldg<float>(as_g(zbase), zoff);
+    const float* trun = a.t.p + 2 * tst;                              // uniform running row bases: the clock entry / z row the next prefetch reads
+    const float* zrun = zbase + zst;
+    float* xo_run = a.xo;                                             // step k stores row k (the previous step's result; step 0: the start row)
+    const long long xo_step = a.B * xd;
+    const float* xt_run = a.x.p;                                      // teacher forcing: the dataset row of grid point k
+    const bool st01 = storer && d01 < xd, st23 = storer && d23 < xd;
+    const bool pair_ok = FAST || (xd & 1) == 0;                       // even x_dim: both dims exist together and the pair is 8-byte aligned
+    auto store_row = [&](float* row) {
+        if (pair_ok) {
+            if (st01) stg<f2>((gptr<float>)(uintptr_t)row, xooff, f2{X01, X23});
+        } else {
+            if (st01) stg<float>((gptr<float>)(uintptr_t)row, xooff, X01);
+            if (st23) stg<float>((gptr<float>)(uintptr_t)row, xooff + 4u, X23);
+        }
+    };
+
+    // DE right-hand side in the state layout: k(X01, X23)
+    auto rhs = [&](const float s01, const float s23, const f4 cz, float& k01, float& k23) {
+        f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
+        accA = mfx<0>(s01, w1x[0], accA);  accB = mfx<4>(s01, w1x[1], accB);
+        accA = mfx<8>(s01, w1x[2], accA);  accB = mfx<12>(s01, w1x[3], accB);
+        accA = mfx<0>(s23, w1x[4], accA);  accB = mfx<4>(s23, w1x[5], accB);
+        accA = mfx<8>(s23, w1x[6], accA);  accB = mfx<12>(s23, w1x[7], accB);
+        f4 hA = quad_transpose(elu_quad_scaled(accA + accB));
+        hA = hh_layer(w2, b2, hA);
+        hA = hh_layer(w3, b3, hA);
+        f4 p0 = b4c[0], p1 = b4c[1];
+        p0 = mfn(w4a[0], hA[0], p0); p1 = mfn(w4a[4], hA[0], p1);
+        p0 = mfn(w4a[1], hA[1], p0); p1 = mfn(w4a[5], hA[1], p1);
+        p0 = mfn(w4a[2], hA[2], p0); p1 = mfn(w4a[6], hA[2], p1);
+        p0 = mfn(w4a[3], hA[3], p0); p1 = mfn(w4a[7], hA[3], p1);
+        // sum over the 16 blocks: lane bits 5, 4 fold two registers into one each; bits 3, 2 are row rotations
+        const float q0 = fold32(p0[0], p1[0]), q1 = fold32(p0[1], p1[1]), q2 = fold32(p0[2], p1[2]), q3 = fold32(p0[3], p1[3]);
+        k01 = fold16(q0, q2); k23 = fold16(q1, q3);          // (pairs (0,2) / (1,3): a row ends up with two ADJACENT dims)
+        row_sum2(k01, k23);
+    };
+
+    // One step.  LAST (the peeled final step) prefetches nothing.
+    auto step = [&](const int k, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // What is in flight here was issued a whole step ago: this step's inputs and, LAST in program order, the previous row's store.
+        // vmcnt counts in order: vmcnt(1) waits for the inputs and leaves the store (exactly one instruction at even x_dim) a second
+        // step to be acknowledged.
+        if (pair_ok) __builtin_amdgcn_s_waitcnt(0x0F71);   // vmcnt(1)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+        const float h_ = t_nxt - t_cur;
+        t_cur = t_nxt;
+        const float eA = eon ? (b < ne ? e_nxt - a0e : e_nxt) : 0.0f;
+        float s01 = X01, s23 = X23;
+        if constexpr (!FAST) {
+            if (true_x) {                                            // teacher forcing: the step starts from the dataset's x[k] (uniform branch)
+                const float v01 = ldg<float>(as_g(xt_run), xtoff01), v23 = ldg<float>(as_g(xt_run), xtoff23);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                s01 = d01 < xd ? v01 : 0.0f;
+                s23 = d23 < xd ? v23 : 0.0f;
+            }
+            xt_run += xst;
+        }
+        if constexpr (!LAST) {   // prefetch the next step's inputs: t[k + 2] and the external row of step k + 1 (both exist: k + 2 <= T - 1)
+            t_nxt = ldg<float>(as_g(trun), toff);
+            if constexpr (FAST) {
+                e_nxt = ldg<float>(as_g(zrun), zoff);
+            } else {
+                if (((k + 1) & 63) == 0) evb = load_evb((k + 1) >> 6);
+                ev_cur = __builtin_amdgcn_readlane(evb, (k + 1) & 63);
+                const bool jump = __builtin_amdgcn_readfirstlane(ev_cur) >= 0;
+                const float* zr = jump ? zjbase + (long long)ev_cur * zje : zrun;      // an event step takes the jump row (uniform select)
+                e_nxt = ldg<float>(as_g(zr), jump ? zjoff : zoff);
+            }
+            trun += tst;
+            zrun += zst;
+        }
+        store_row(xo_run);                                           // deferred store of the previous step's result, BEHIND the prefetch (above)
+        xo_run += xo_step;
+        const f4 cz = ext_mfmas<0, 4 * NZM>(w1e, eA, c0);            // per-step constant of L1
+        float k1a, k1b;
+        rhs(s01, s23, cz, k1a, k1b);
+        if constexpr (METHOD == PSNODE_EULER) {
+            X01 = s01 + h_ * k1a; X23 = s23 + h_ * k1b;
+        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+            const float hh = 0.5f * h_;
+            float k2a, k2b;
+            rhs(s01 + k1a * hh, s23 + k1b * hh, cz, k2a, k2b);
+            X01 = s01 + h_ * k2a; X23 = s23 + h_ * k2b;
+        } else {
+            float k2a, k2b, k3a, k3b, k4a, k4b;
+            rhs(s01 + h_ * k1a * kOneThird, s23 + h_ * k1b * kOneThird, cz, k2a, k2b);
+            rhs(s01 + h_ * (k2a - k1a * kOneThird), s23 + h_ * (k2b - k1b * kOneThird), cz, k3a, k3b);
+            rhs(s01 + h_ * (k1a - k2a + k3a), s23 + h_ * (k1b - k2b + k3b), cz, k4a, k4b);
+            X01 = s01 + (k1a + 3.0f * (k2a + k3a) + k4a) * h_ * 0.125f;
+            X23 = s23 + (k1b + 3.0f * (k2b + k3b) + k4b) * h_ * 0.125f;
+        }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step's inputs (no store is in flight yet for the loop's vmcnt(1) to skip)
+    for (int k = 0; k + 2 < nT; ++k) step(k, std::false_type{});
+    step(nT - 2, std::true_type{});
+    store_row(xo_run);
+}
+
+template <int METHOD>
+hipError_t launch_x_method(const IntegrateDev& a, const float* pack, hipStream_t s) {
+    const long long tiles = (a.B + 3) / 4;
+    const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves);
+    const bool fast = a.ev == nullptr && !(a.flags & PSNODE_FLAG_INPUT_TRUE_X) && (a.xd & 1) == 0;
+#define PSNODE_X(NZM_)                                                                                          \
+    if (fast) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, true>), grid, block, 0, s, a, pack);         \
+    else hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, false>), grid, block, 0, s, a, pack);             \
+    break;
+    switch ((2 * a.zd + 3) / 4) {
+        case 0: PSNODE_X(0)
+        case 1: PSNODE_X(1)
+        case 2: PSNODE_X(2)
+        case 3: PSNODE_X(3)
+        case 4: PSNODE_X(4)
+        default: return hipErrorNotSupported;
+    }
+#undef PSNODE_X
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// shapes K1x takes: the ODE's `3n -> h -> h -> h -> x_dim` with h <= 64 (zero-padded to 64), x_dim <= 8, z_dim <= 8, no saved activations
+bool mfma_x_ode_supported(const IntegrateDev& a) {
+    const MlpDev& m = a.de;
+    if (a.sact || a.xd < 1 || a.xd > 8 || a.zd < 0 || a.zd > 8 || a.T >= (1ll << 31)) return false;
+    if (m.n_layers != 4 || m.in_dim != 3 * (a.xd + a.zd) || m.out_dim[3] != a.xd) return false;
+    const int h = m.out_dim[0];
+    return h >= 1 && h <= 64 && m.out_dim[1] == h && m.out_dim[2] == h;
+}
+size_t mfma_x_pack_floats() { return (size_t)XRegs::COUNT * 64; }
+
+hipError_t launch_mfma_x(const IntegrateDev& a, float* pack, hipStream_t stream) {
+    PackX p;
+    p.xd = a.xd; p.zd = a.zd; p.n = a.xd + a.zd; p.hreal = a.de.out_dim[0];
+    p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
+    p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
+    p.out = pack;
+    hipLaunchKernelGGL(pack_x_kernel, dim3(16), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    switch (a.method) {
+        case PSNODE_EULER: return launch_x_method<PSNODE_EULER>(a, pack, stream);
+        case PSNODE_MIDPOINT: return launch_x_method<PSNODE_MIDPOINT>(a, pack, stream);
+        default: return launch_x_method<PSNODE_RK4_38>(a, pack, stream);
+    }
+}
+
+}  // namespace psnode

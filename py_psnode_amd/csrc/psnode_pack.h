@@ -59,6 +59,13 @@ struct PackMfma {
 
 // the hidden width the MFMA kernels run a width-h MLP at (0: none)
 __host__ __device__ inline int padded_hidden(int h) { return h < 1 ? 0 : (h <= 32 ? 32 : (h <= 64 ? 64 : (h <= 128 ? 128 : 0))); }
+// the width class a backward kernel runs the 4-layer MLP `in -> h -> h -> h -> out` at (zero-padded units beyond h); 0: another shape
+inline int wide_hidden(const psnode_mlp_f32& m) {
+    if (m.n_layers != 4) return 0;
+    const int h = m.out_dim[0];
+    if (m.out_dim[1] != h || m.out_dim[2] != h) return 0;
+    return padded_hidden(h);
+}
 // ... and the FORWARD kernels K1 / K2 alone (round 4): 129..192 -> 12 waves, 193..256 -> 16 waves per tile, the H->H weights of these
 // two classes streamed from the L2-resident image every layer (no CU holds them: two 256 x 256 fp32 matrices are the whole register file)
 __host__ __device__ inline int padded_hidden_fwd(int h) { return h <= 128 ? padded_hidden(h) : (h <= 192 ? 192 : (h <= 256 ? 256 : 0)); }

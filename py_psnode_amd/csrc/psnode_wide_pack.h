@@ -49,12 +49,6 @@ __global__ void pack_wide_f_kernel(const PackWideT p) {
     }
 }
 
-int wide_hidden(const psnode_mlp_f32& m) {
-    if (m.n_layers != 4) return 0;
-    const int h = m.out_dim[0];
-    if (m.out_dim[1] != h || m.out_dim[2] != h) return 0;
-    return padded_hidden(h);      // the width class the kernel runs at (zero-padded units beyond h)
-}
 size_t wide_fwd_floats(int nw, int n) { return (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64; }
 size_t wide_t_floats(int nw) { return (size_t)2 * nw * nw * 64 * 4; }
 

@@ -1,0 +1,72 @@
+"""Recognition for the solver classes of py_psnode_amd.neural_dae: is this `integrate_ODE` / `integrate_DAE` call fusable, and with which
+layers / event tensors."""
+
+import torch
+
+from ._common import _recipe_ok, ae_layers_of, de_layers_of
+
+# ----------------------------------------------------------------------------- planning for the solver classes
+def _event_tensors(event_fn, jump_change_fn, want_v: bool):
+    """(ok, event_t, z_jump, v_jump).  Events can be fused when both callbacks are the bound methods of one
+    ODE_Event / DAE_Event-like object (attributes event_t, z_jump[, v_jump]) -- neural_base.py:43-65,169-196."""
+    if event_fn is None:
+        return True, None, None, None       # my_solvers.py:70: `event_fn is not None and ...`
+    ev = getattr(event_fn, "__self__", None)
+    if ev is None or getattr(jump_change_fn, "__self__", None) is not ev:
+        return False, None, None, None
+    if getattr(event_fn, "__name__", "") != "event_fn" or getattr(jump_change_fn, "__name__", "") != "jump_change_fn":
+        return False, None, None, None
+    if not getattr(type(ev), "_psnode_event", False):
+        return False, None, None, None
+    if ev.event_t is None:
+        return True, None, None, None       # neural_base.py:53
+    return True, ev.event_t, ev.z_jump, (getattr(ev, "v_jump", None) if want_v else None)
+
+
+def _needs_autograd(tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _all_f32_on(dev, *tensors) -> bool:
+    return all(a is None or (torch.is_tensor(a) and a.dtype == torch.float32 and a.device == dev) for a in tensors)
+
+
+def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=None):
+    """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump, needs_autograd)."""
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 3 or z.dim() != 3:
+        return None
+    if not _all_f32_on(x.device, z, all_initial, t):      # mixed dtypes / devices: 'auto' promises the walk, not a TypeError
+        return None
+    xd, zd = x.shape[-1], z.shape[-1]
+    if all_initial.dim() != 2 or all_initial.shape[-1] != xd + zd:
+        return None
+    layers = de_layers_of(x_func, xd + zd, xd)
+    if layers is None or not _recipe_ok(x_func, layers, "de_ode", (xd, zd)):
+        return None
+    ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
+    if not ok or not _all_f32_on(x.device, event_t, z_jump):
+        return None
+    needs_grad = _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb])
+    return layers, event_t, z_jump, needs_grad
+
+
+def plan_dae(x_init, x_func, i_func, z, v, i, all_initial, event_fn, jump_change_fn, t=None):
+    if x_init.device.type != "cuda" or x_init.dtype != torch.float32 or z.dim() != 3:
+        return None
+    if not _all_f32_on(x_init.device, z, v, all_initial, t):
+        return None
+    xd, zd, vd, idim = x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]
+    n = xd + zd + vd + idim
+    if all_initial.dim() != 2 or all_initial.shape[-1] != n:
+        return None
+    de = de_layers_of(x_func, n, xd)
+    ae = ae_layers_of(i_func, n, xd + zd + vd, idim)
+    if de is None or ae is None:
+        return None
+    if not _recipe_ok(x_func, de, "de_dae", (xd, zd, vd, idim)) or not _recipe_ok(i_func, ae, "ae", (xd, zd, vd, n)):
+        return None
+    ok, event_t, z_jump, v_jump = _event_tensors(event_fn, jump_change_fn, True)
+    if not ok or not _all_f32_on(x_init.device, event_t, z_jump, v_jump):
+        return None
+    needs_grad = _needs_autograd([x_init, z, v, all_initial, z_jump, v_jump] + [p for wb in list(de) + list(ae) for p in wb])
+    return de, ae, event_t, z_jump, v_jump, needs_grad

@@ -1,0 +1,101 @@
+"""Encoder / decoder row MLPs of the direct_encode models (`nn.Sequential(Linear, ELU, Linear)` over the last dim) on the HIP row
+kernels K3b, forward and backward, with an autograd bridge."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ._common import Layers, _aligned_ptr, _empty, _f32_dev, _mlp, _split_grads, sequential_layers
+from .plan import _needs_autograd
+
+def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
+    """Fused `nn.Sequential(Linear, ELU, Linear)` over the last dim of `inp` (any leading shape) on the HIP row kernel:
+    the encoders / decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:64-69)."""
+    lib = _lib.load()
+    dev = inp.device
+    keep: list = []
+    m = _mlp(layers, dev, "mlp", keep)
+    if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
+        raise ValueError("mlp_rows: needs Linear(in, H) ELU Linear(H, out) with H in {16, 64}, in <= 16 (or in = H = 64), out <= 16 (or out = H)")
+    x = _f32_dev(inp, dev, "input")
+    if x.shape[-1] != m.in_dim:
+        raise ValueError(f"mlp_rows: input width {x.shape[-1]}, expected {m.in_dim}")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    out = _empty((*x.shape[:-1], layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.psnode_mlp_rows_f32(ctypes.byref(m), x2.shape[0], x2.data_ptr(), x2.stride(0), out.data_ptr(), out.shape[-1],
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_mlp_rows_f32")
+    return out
+
+
+def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor, need_grad_in: bool = True):
+    """Backward of `mlp_rows`: returns (grad_in or None, [dW1, db1, dW2, db2]) from the saved input and grad_out (row kernel)."""
+    lib = _lib.load()
+    dev = inp.device
+    keep: list = []
+    m = _mlp(layers, dev, "mlp", keep)
+    if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
+        raise ValueError("mlp_rows_backward: unsupported MLP shape")
+    x2 = _f32_dev(inp, dev, "input").reshape(-1, inp.shape[-1])
+    g2 = _f32_dev(grad_out, dev, "grad_out").reshape(-1, grad_out.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    if g2.stride(-1) != 1:
+        g2 = g2.contiguous()
+    if g2.shape[0] != x2.shape[0] or g2.shape[1] != layers[-1][0].shape[0]:
+        raise ValueError(f"mlp_rows_backward: grad_out {tuple(grad_out.shape)} does not match input {tuple(inp.shape)}")
+    rows = x2.shape[0]
+    with torch.cuda.device(dev):
+        gin = _empty((*inp.shape[:-1], inp.shape[-1]), dtype=torch.float32, device=dev) if need_grad_in else None
+        npar = sum(w.numel() + b.numel() for w, b in layers)
+        gp = _empty(npar, dtype=torch.float32, device=dev)
+        nbytes = lib.psnode_mlp_rows_backward_workspace_bytes(ctypes.byref(m), rows)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        rc = lib.psnode_mlp_rows_backward_f32(ctypes.byref(m), rows, x2.data_ptr(), x2.stride(0), g2.data_ptr(), g2.stride(0),
+                                              gin.data_ptr() if gin is not None else None, inp.shape[-1], gp.data_ptr(), wp, wn,
+                                              torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psnode_mlp_rows_backward_f32")
+    return gin, _split_grads(gp, layers)
+
+
+class _RowsMlp(torch.autograd.Function):
+    """mlp_rows with a fused backward: forward saves only the input rows (h is recomputed in the backward kernel)."""
+
+    @staticmethod
+    def forward(ctx, inp, w1, b1, w2, b2):
+        ctx.save_for_backward(inp, w1, b1, w2, b2)
+        return mlp_rows([(w1, b1), (w2, b2)], inp)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inp, w1, b1, w2, b2 = ctx.saved_tensors
+        gin, gp = mlp_rows_backward([(w1.detach(), b1.detach()), (w2.detach(), b2.detach())], inp.detach(), grad_out,
+                                    need_grad_in=ctx.needs_input_grad[0])
+        return (gin, *gp)
+
+
+def mlp_rows_autograd(seq, inp: torch.Tensor) -> torch.Tensor:
+    """`seq(inp)` for a recognised Linear-ELU-Linear on the row kernels, differentiable w.r.t. the input and the parameters."""
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    return _RowsMlp.apply(inp, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
+
+
+def rows_layers_of(seq, inp: torch.Tensor, allow_grad: bool = False):
+    """Layers if `seq(inp)` can run on the row kernel (2-layer ELU-MLP, hidden 16 / 64, fp32 HIP tensor); with autograd in play
+    only when `allow_grad` (the caller then goes through mlp_rows_autograd)."""
+    if inp.device.type != "cuda" or inp.dtype != torch.float32 or inp.numel() == 0:
+        return None
+    layers = sequential_layers(seq)
+    if layers is None or len(layers) != 2:
+        return None
+    H, din, dout = layers[0][0].shape[0], layers[0][0].shape[1], layers[1][0].shape[0]
+    if H not in (16, 64) or not (din <= 16 or (din == 64 and H == 64)) or not (dout <= 16 or dout == H):
+        return None
+    if not allow_grad and _needs_autograd([inp] + [p for wb in layers for p in wb]):
+        return None
+    return layers

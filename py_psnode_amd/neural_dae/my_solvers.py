@@ -27,6 +27,11 @@ class NotFusableError(RuntimeError):
     pass
 
 
+def _autograd():
+    from .. import autograd       # (imported on first use: autograd imports fused, which this module imports too)
+    return autograd
+
+
 class FixedGridODESolver(metaclass=abc.ABCMeta):
     order: int
     method: str = ""
@@ -99,7 +104,8 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                         if self.fused == "require":
                             raise
                 # training: fused forward + fused backward when the backward kernel covers the shape
-                elif not input_true_x and _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1]):
+                elif not input_true_x and _autograd().ode_training_supported(self.method, layers, x.shape[-1], z.shape[-1], t.shape[0],
+                                                                             t.shape[1]):
                     from ..autograd import fused_ode_integrate
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
                                                check_events=self._check_events_now(event_t))
@@ -145,8 +151,8 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                     except UnsupportedShapeError:
                         if self.fused == "require":
                             raise
-                elif not (input_true_x or input_true_i) and _fused.dae_backward_supported(
-                        self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1]):
+                elif not (input_true_x or input_true_i) and _autograd().dae_training_supported(
+                        self.method, de, ae, x_init.shape[-1], z.shape[-1], v.shape[-1], i.shape[-1], t.shape[0], t.shape[1]):
                     from ..autograd import fused_dae_integrate
                     return fused_dae_integrate(self.method, self.kernel, de, ae, x_init, t, z, v, i, all_initial, event_t, z_jump, v_jump,
                                                check_events=self._check_events_now(event_t))

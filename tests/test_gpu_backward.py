@@ -125,8 +125,8 @@ def _param_grads(seq):
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
 @pytest.mark.parametrize("xd,zd,H", [(8, 2, 128), (8, 2, 32), (8, 2, 64), (5, 3, 128), (3, 0, 32), (8, 4, 128), (8, 6, 64), (5, 8, 128), (8, 7, 48)])
 def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
-    """K4w (psnode_ode_backward_wide_f32: MFMA adjoint sweep in time chunks + library GEMMs for the parameter gradients) at hidden
-    128 / 32 / 64 vs the fp64 autograd walk: ragged tile, per-trajectory clocks, two events, three time chunks, every NZM class."""
+    """K4f (the one-launch MFMA backward, recompute and saved-activation forms) at hidden 128 / 32 / 64 / 48 vs the fp64 autograd walk:
+    ragged tile, per-trajectory clocks, two events, every NZM class."""
     from py_psnode_amd import fused
     B, Tn = 21, 12
     g = torch.Generator().manual_seed(500 + H + xd)
@@ -163,30 +163,22 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
     c = lambda a: None if a is None else a.cuda()
     xs = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj))
     tab = fused.event_table(c(t), c(ev)) if ev is not None else None
-    gx0, gz, gzj, ga0, gp = fused.ode_backward_wide(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), chunk_steps=4)
     _close(xs, xs_ref.detach(), "xs")
-    _close(gx0 + ga0[:, :xd], xq.grad[0], "grad x0")
-    if zd:
-        gz_tot = gz.clone(); gz_tot[0] += ga0[:, xd:]
-        _close(gz_tot, zq.grad, "grad z")
-        _close(gzj, zjq.grad, "grad z_jump")
-    for k, (a_, p_) in enumerate(zip(gp, de.x_dot.parameters())):
-        _close(a_, p_.grad, f"grad param {k}")
-    # K4f, the width-generic ONE-launch backward (weight gradients accumulated in the kernel; `auto` at every width but 64): the same
-    # fp64 truth, every output
+    # K4f, the width-generic ONE-launch backward (weight gradients accumulated in the kernel): every output against the fp64 truth
     fx0, fz, fzj, fa0, fp = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), kernel="wide")
     _close(fx0 + fa0[:, :xd], xq.grad[0], "K4f grad x0")
     if zd:
         fz_tot = fz.clone(); fz_tot[0] += fa0[:, xd:]
         _close(fz_tot, zq.grad, "K4f grad z")
         _close(fzj, zjq.grad, "K4f grad z_jump")
-    _close(fa0, ga0.double().cpu(), "K4f grad all_initial vs split")
     for k, (a_, p_) in enumerate(zip(fp, de.x_dot.parameters())):
         _close(a_, p_.grad, f"K4f grad param {k}")
     # the same backward fed with the activations the FORWARD saved (ode_integrate(save=True): no recompute in K4f): the forward result must
     # not depend on saving, the gradients must meet the same truth
     xs_s, saved = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj), save=True)
-    assert torch.equal(xs_s, xs), "saving the activations changed the forward result"
+    # (round 5: the inference forward runs its hidden layers in the log2e-scaled domain -- K1x / K1 -- the saving one in the plain domain:
+    #  the same function, different roundings)
+    _close(xs_s, xs.double().cpu(), "training forward (saving) vs inference forward")
     S_ = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     assert saved[0].shape == (Tn - 1, S_, 3, B, 32 if H <= 32 else (64 if H <= 64 else 128)) and saved[1].shape == (Tn - 1, S_, B, xd)
     sx0, sz, szj, sa0, sp = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), saved=saved)
@@ -197,10 +189,10 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
         _close(szj, zjq.grad, "K4f(saved) grad z_jump")
     for k, (a_, p_) in enumerate(zip(sp, de.x_dot.parameters())):
         _close(a_, p_.grad, f"K4f(saved) grad param {k}")
-    # the auto route picks K4f at hidden 32 / 128 / 48 and the one-launch K4 at 64: same numbers either way
+    # the auto route is the same kernel at every width (K4 at hidden 64 is gone since round 5): bit-identical
     auto = fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj))
-    for k, (a_, b_) in enumerate(zip(gp, auto[4])):
-        _close(a_, b_.double().cpu(), f"auto vs split param {k}")
+    for k, (a_, b_) in enumerate(zip(fp, auto[4])):
+        assert torch.equal(a_, b_), f"auto vs wide param {k}"
 
 
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
@@ -232,7 +224,7 @@ def test_wide_backward_without_external_inputs_at_hidden_128(method, H, xd):
 
 def test_hidden128_training_takes_the_one_launch_backward():
     """ODE_Model at --hidden 128 (the scripts' argparse default) under autograd with fused='require': forward K1, backward K4f in ONE
-    launch -- not round 2's split (adjoint sweep + library GEMMs over stored rows)."""
+    launch."""
     from py_psnode_amd import fused, models
     from py_psnode_amd import neural_dae as nd
     torch.manual_seed(1)
@@ -241,15 +233,8 @@ def test_hidden128_training_takes_the_one_launch_backward():
     B, Tn = 40, 30
     t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(1, Tn, 1).repeat(B, 1, 1).cuda()
     x, z = (0.1 * torch.randn(B, Tn, 8)).cuda(), (0.1 * torch.randn(B, Tn, 2)).cuda()
-    calls = []
-    orig = fused.ode_backward_wide
-    try:
-        fused.ode_backward_wide = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-        pred = m(t=t, x=x, z=z, event_t=torch.full((B, 1, 1), -1.0).cuda(), z_jump=torch.zeros(B, 1, 2).cuda())
-        nn.functional.mse_loss(pred, x).backward()
-    finally:
-        fused.ode_backward_wide = orig
-    assert calls == [], "hidden 128 must not take the split backward any more"
+    pred = m(t=t, x=x, z=z, event_t=torch.full((B, 1, 1), -1.0).cuda(), z_jump=torch.zeros(B, 1, 2).cuda())
+    nn.functional.mse_loss(pred, x).backward()
     # ... and by default (PSNODE_SAVE_ACTIVATIONS=auto) the training forward at this width saves its activations for the backward
     from py_psnode_amd import autograd as pag
     layers_ = fused.de_layers_of(m.de_func, 10, 8)
@@ -262,8 +247,8 @@ def test_hidden128_training_takes_the_one_launch_backward():
 
 def test_dae_hidden128_training_takes_the_fused_backward_without_library_gemms():
     """DAE_Model at --hidden 128 (the scripts' argparse default, neural_01_DAE_01_no_encode.py) under autograd with fused='require':
-    forward K2 saving its activations, backward K7f (DE gradients in the kernel) + K7h (AE head contractions): neither round 2's
-    split nor a torch matmul / bmm over stored rows; two runs are bit-identical."""
+    forward K2 saving its activations, backward K7f (DE gradients in the kernel) + K7h (AE head contractions): no torch matmul / bmm
+    over stored rows; two runs are bit-identical."""
     from py_psnode_amd import fused, models
     from py_psnode_amd import autograd as pag
     from py_psnode_amd import neural_dae as nd
@@ -278,26 +263,25 @@ def test_dae_hidden128_training_takes_the_fused_backward_without_library_gemms()
     zj, vj = r(B, 2, 2), r(B, 2, 2)
     de, ae = fused.de_layers_of(m.de_func, 14, 8), fused.ae_layers_of(m.ae_func, 14, 12, 2)
     assert pag._want_saved_dae("rk4", "auto", de, ae, 8, 2, 2, 2, Tn, B) is True
-    seen = {"split": 0, "head": 0, "mm": 0}
-    orig_wide, orig_gemm = fused.dae_backward_wide, fused._gemm_tn
+    seen = {"head": 0, "mm": 0}
+    orig_wide, orig_gemm = fused.backward_dae.dae_backward_wide, fused.latent._gemm_tn
 
     def wide(*a, **k):
-        seen["split"] += int(k.get("fuse_de", True) is False)
         assert k.get("saved") is not None, "the training forward must have saved its activations"
         return orig_wide(*a, **k)
 
     grads = []
     try:
-        fused.dae_backward_wide = wide
-        fused._gemm_tn = lambda *a, **k: (seen.__setitem__("mm", seen["mm"] + 1), orig_gemm(*a, **k))[1]
+        fused.backward_dae.dae_backward_wide = wide       # (the module-level name dae_backward resolves)
+        fused.latent._gemm_tn = lambda *a, **k: (seen.__setitem__("mm", seen["mm"] + 1), orig_gemm(*a, **k))[1]
         for _ in range(2):
             m.zero_grad()
             xp, ip = m(t=t, x=x, z=z, v=v, i=i, event_t=ev, z_jump=zj, v_jump=vj)
             (nn.functional.mse_loss(xp, x) + nn.functional.mse_loss(ip, i)).backward()
             grads.append([p.grad.clone() for p in m.parameters()])
     finally:
-        fused.dae_backward_wide, fused._gemm_tn = orig_wide, orig_gemm
-    assert seen["split"] == 0 and seen["mm"] == 0
+        fused.backward_dae.dae_backward_wide, fused.latent._gemm_tn = orig_wide, orig_gemm
+    assert seen["mm"] == 0
     assert all(torch.isfinite(g_).all() and float(g_.abs().max()) > 0 for g_ in grads[0])
     assert all(torch.equal(p_, q_) for p_, q_ in zip(*grads)), "training step not bit-reproducible"
 
@@ -557,7 +541,7 @@ def test_dae_mfma_backward_matches_generic_every_shape_class(xd, zd, vd, idim, m
     _dae_both_kernels(method, 21, 9, xd, zd, vd, idim, seed=40 + xd + zd, events=True)
 
 
-def _dae_wide_vs_generic(method, H, B, Tn, xd, zd, vd, idim, seed, events, with_gi=True, chunk_steps=None):
+def _dae_wide_vs_generic(method, H, B, Tn, xd, zd, vd, idim, seed, events, with_gi=True, slice_step=None):
     from py_psnode_amd import fused
     de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(B, Tn, xd, zd, vd, idim, seed, events, H=H)
     xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, idim, device="cuda")
@@ -565,18 +549,17 @@ def _dae_wide_vs_generic(method, H, B, Tn, xd, zd, vd, idim, seed, events, with_
     tab = fused.event_table(t, ev) if ev is not None else None
     gi = Gi if with_gi else None
     b = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="generic")
-    if chunk_steps is None:
-        a = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj,
-                               kernel="wide" if H == 64 else "auto")
-    else:
-        a = fused.dae_backward_wide(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, chunk_steps=chunk_steps,
-                                    fuse_de=False)      # round 2's split (K7w in time chunks + library GEMMs)
-    runs = [("K7f" if chunk_steps is None else "K7w", a)]
-    if chunk_steps is None:
+    if slice_step is None:
+        a = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="auto")
+    else:      # the low-memory route: K7f over batch slices of `slice_step` trajectories
+        a = fused._dae_backward_wide_sliced(slice_step, method, de, ae, t, z, v, a0, xs, is_, Gx, gi, tab, zj, vj, None, None)
+    runs = [("K7f" if slice_step is None else "K7f in batch slices", a)]
+    if slice_step is None:
         # the same backward fed with what the FORWARD saved (dae_integrate(save=True): K7f evaluates nothing forwards); the forward's
         # results must not depend on saving
         xs_s, is_s, saved = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj, save=True)
-        assert torch.equal(xs_s, xs) and torch.equal(is_s, is_)
+        _close(xs_s, xs.double().cpu(), "xs: training forward (saving) vs inference forward")      # (scaled vs plain ELU domain: roundings differ)
+        _close(is_s, is_.double().cpu(), "is: training forward (saving) vs inference forward")
         Hp = 32 if H <= 32 else (64 if H <= 64 else 128)
         assert saved[2].shape == (3, Tn, B, Hp)
         runs.append(("K7f(saved)", fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, gi, event_idx=tab, z_jump=zj, v_jump=vj,
@@ -609,7 +592,7 @@ def test_wide_backwards_at_zero_padded_hidden_widths(method, H):
     back to the real width on the host side) against the generic backward K5, ODE and DAE, with events and two time chunks."""
     from py_psnode_amd import fused
     _dae_wide_vs_generic(method, H, 21, 9, 8, 2, 2, 2, seed=340 + H, events=True)
-    _dae_wide_vs_generic(method, H, 19, 9, 5, 1, 1, 1, seed=343 + H, events=True, chunk_steps=5)
+    _dae_wide_vs_generic(method, H, 19, 9, 5, 1, 1, 1, seed=343 + H, events=True, slice_step=16)
     g = torch.Generator().manual_seed(250 + H)
     torch.manual_seed(250 + H)
     B, Tn, xd, zd = 21, 9, 8, 2
@@ -628,7 +611,7 @@ def test_wide_backwards_at_zero_padded_hidden_widths(method, H):
     xs = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj, kernel="mfma")
     xs_g = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj, kernel="generic")
     _close(xs, xs_g.double().cpu(), "xs (padded MFMA vs generic)")
-    a = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj)           # auto: the split backward
+    a = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj)           # auto: K4f
     b = fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel="generic")
     for nme, p_, q_ in zip(["grad x0", "grad z", "grad z_jump", "grad all_initial"], a[:4], b[:4]):
         _close(p_, q_.double().cpu(), nme)
@@ -638,13 +621,12 @@ def test_wide_backwards_at_zero_padded_hidden_widths(method, H):
 
 
 @pytest.mark.parametrize("H", [32, 128])
-@pytest.mark.parametrize("B,Tn,chunk", [(1, 2, None), (17, 2, None), (33, 3, 1), (16, 12, 4), (37, 12, 5)])
+@pytest.mark.parametrize("B,Tn,chunk", [(1, 2, None), (17, 2, None), (33, 3, 16), (16, 12, None), (37, 12, 16)])
 def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):
-    """single trajectory, T = 2, ragged tiles, time chunks (carried x / algebraic adjoints, events inside and at chunk borders),
-    grad_is = None"""
-    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True, chunk_steps=chunk)
-    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False, chunk_steps=chunk)
-    if chunk is not None:      # the same cases on the one-launch form (K7f)
+    """single trajectory, T = 2, ragged tiles, batch slices of the low-memory route (events, ragged last slice), grad_is = None"""
+    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True, slice_step=chunk)
+    _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False, slice_step=chunk)
+    if chunk is not None:      # the same cases in one launch
         _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=170 + B, events=True)
         _dae_wide_vs_generic("rk4", H, B, Tn, 8, 2, 2, 2, seed=171 + B, events=False, with_gi=False)
 
@@ -652,10 +634,10 @@ def test_dae_wide_backward_edge_sizes_and_chunks(B, Tn, chunk, H):
 @pytest.mark.parametrize("xd,zd,vd,idim", [(4, 0, 1, 3), (4, 1, 1, 2), (3, 2, 0, 2)])
 def test_dae_wide_backward_without_grad_is_on_the_four_slot_classes(xd, zd, vd, idim):
     """grad_is = None on the shapes with z + v + i = 4 (found by profiles/scripts/fuzz_backward.py: round 2's split kernel K7w got the AE
-    gradients wrong there; the host now always hands it an explicit zero tensor): K7f, K7f(saved) and the split form against K5."""
+    gradients wrong there -- a uniform `if (grad_is)` branch scheduled inside an MFMA's result latency): K7f and
+    K7f(saved) against K5."""
     for H, method in ((64, "euler"), (64, "rk4"), (32, "midpoint"), (128, "rk4")):
         _dae_wide_vs_generic(method, H, 24, 5, xd, zd, vd, idim, seed=900 + xd, events=False, with_gi=False)
-        _dae_wide_vs_generic(method, H, 9, 3, xd, zd, vd, idim, seed=901 + xd, events=False, with_gi=False, chunk_steps=2)
     # ... and the one-launch kernel K7 (hidden 64) on the same shapes
     from py_psnode_amd import fused
     for method in ("euler", "rk4"):
@@ -803,18 +785,17 @@ def test_full_size_backward_two_implementations_agree(kind):
 
 
 @pytest.mark.parametrize("events", [False, True])
-def test_dae_wide_low_memory_fallback_takes_the_split_route(monkeypatch, events):
-    """dae_backward_wide falls back from the one-launch K7f to the time-chunked split route when the AE head's rows of the whole grid
-    would not fit half of the free HBM.  Round 3 cleared the flag AFTER filling the fused-only fields of the argument struct (the C side
-    picks K7f on grad_params_de != NULL): every chunk but the first failed with PSNODE_ERR_DIMS, and a single chunk ran K7f while the host
-    contracted buffers K7f never writes.  Forced here through torch.cuda.mem_get_info; gradients equal K7f's."""
+def test_dae_wide_low_memory_fallback_runs_in_batch_slices(monkeypatch, events):
+    """dae_backward_wide (recompute form) falls back from ONE K7f launch to K7f over batch slices when the AE head's rows of the whole grid
+    would not fit half of the free HBM (trajectories are independent: parameter gradients add, per-trajectory gradients concatenate).
+    Forced here through torch.cuda.mem_get_info; gradients equal the single launch's."""
     from py_psnode_amd import fused
     de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(37, 9, 8, 2, 2, 2, 4242, events, H=128)
     xe, ie = torch.zeros(9, 37, 0, device="cuda"), torch.zeros(9, 37, 2, device="cuda")
     xs, is_ = fused.dae_integrate("rk4", de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj)
     tab = fused.event_table(t, ev) if ev is not None else None
     kw = dict(event_idx=tab, z_jump=zj, v_jump=vj)
-    ref = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, **kw)                   # K7f
+    ref = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, **kw)                   # one launch
     calls = []
     real = fused._lib.load().psnode_dae_backward_wide_f32
 
@@ -826,10 +807,10 @@ def test_dae_wide_low_memory_fallback_takes_the_split_route(monkeypatch, events)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a_, **k_: (1 << 16, 1 << 40))
     monkeypatch.setattr(lib, "psnode_dae_backward_wide_f32", Spy(), raising=False)
     try:
-        got = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, chunk_steps=3, **kw)
+        got = fused.dae_backward_wide("rk4", de, ae, t, z, v, a0, xs, is_, Gx, Gi, **kw)
     finally:
         monkeypatch.undo()
-    assert len(calls) == 3, "8 steps in chunks of 3 on the split route"
+    assert len(calls) == 3, "37 trajectories in slices of 16"
     for key in ("x_init", "all_initial", "z", "v", "z_jump", "v_jump"):
         if ref[key] is not None:
             _close(got[key], ref[key].double().cpu(), f"fallback {key}")
@@ -862,40 +843,3 @@ def test_saved_activations_of_another_call_are_refused():
         fused.ode_backward("rk4", layers, t, z, a0, xs, G, saved=saved_e)                               # other method (S = 1 vs 4)
 
 
-@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-@pytest.mark.parametrize("H", [32, 64])
-@pytest.mark.parametrize("kind", ["ode", "dae"])
-def test_two_role_and_one_role_saved_backward_agree(kind, H, method, monkeypatch):
-    """Round 4: at <= 4 waves per tile the saved-activation backward kernels run in the two-role form (chain waves + gradient waves that
-    own the weight-gradient contractions; K7f: the gradient waves also load the saved rows for the chain).  Same arithmetic in the same
-    order as the one-role instances (PSNODE_K4F_NO_ROLES / PSNODE_K7F_NO_ROLES = 1): every output must be bit-equal, on a ragged tile,
-    with events and per-trajectory clocks, odd and even step counts (the Euler loop is written out twice per iteration)."""
-    from py_psnode_amd import fused
-    for Tn in (8, 9, 2):
-        B = 21
-        if kind == "ode":
-            lin, t, x, z, ev, zj, G = _case(B, Tn, 8, 2, seed=7 + Tn, events=Tn > 4)
-            lin = [nn.Linear(d0, d1) for d0, d1 in zip([30, H, H, H], [H, H, H, 8])]
-            c = lambda a: None if a is None else a.cuda()
-            layers = [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in lin]
-            a0 = torch.cat((x[0], z[0]), -1).cuda()
-            xs, saved = fused.ode_integrate(method, layers, c(t), c(x), c(z), a0, event_t=c(ev), z_jump=c(zj), save=True)
-            tab = fused.event_table(c(t), c(ev)) if ev is not None else None
-            run = lambda: fused.ode_backward(method, layers, c(t), c(z), a0, xs, c(G), event_idx=tab, z_jump=c(zj), saved=saved, kernel="wide")
-            flat = lambda o: [q for q in o[:4] if q is not None] + list(o[4])
-        else:
-            de, ae, t, z, v, xi, a0, ev, zj, vj, Gx, Gi = _dae_raw_case(B, Tn, 8, 2, 2, 2, 11 + Tn, Tn > 4, H=H)
-            xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, 2, device="cuda")
-            xs, is_, saved = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj, save=True)
-            tab = fused.event_table(t, ev) if ev is not None else None
-            run = lambda: fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, Gi, event_idx=tab, z_jump=zj, v_jump=vj, kernel="wide", saved=saved)
-            flat = lambda o: [o[k_] for k_ in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial") if o[k_] is not None] + list(o["de"]) + list(o["ae"])
-        two = flat(run())
-        monkeypatch.setenv("PSNODE_K4F_NO_ROLES", "1")
-        monkeypatch.setenv("PSNODE_K7F_NO_ROLES", "1")
-        one = flat(run())
-        monkeypatch.delenv("PSNODE_K4F_NO_ROLES")
-        monkeypatch.delenv("PSNODE_K7F_NO_ROLES")
-        assert len(two) == len(one)
-        for k_, (p, q) in enumerate(zip(two, one)):
-            assert torch.equal(p, q), f"{kind} H{H} {method} T{Tn}: output {k_} differs between the two-role and the one-role kernel: {(p - q).abs().max().item():.3e}"

@@ -30,9 +30,17 @@ def test_bench_force_dist_runs_the_rccl_path(workload):
     cfg = d["config"]
     assert d["n_gpus"] == 1 and cfg["outputs_finite"] is True
     assert cfg["world_size_seen"] == 1 and cfg["device_count"] >= 1 and cfg["rccl_version"]
-    assert "time chunks overlapped" in cfg["collective"]
+    assert "rccl all_gather" in cfg["collective"]
     assert cfg["integrate_only_ms"] > 0 and cfg["gather_only_ms"] is not None and cfg["gather_only_ms"] > 0
     assert d["roofline"]["frac"] > 0
+    # round 5: the block that makes an N > 1 line self-explaining -- shard bytes, the xGMI prediction, both legs alone, what the pipeline
+    # hid, the chunk count --chunks auto picked from the measured legs
+    mg = d["multi_gpu"]
+    assert mg["shard_bytes"] == 301 * 512 * (8 if workload == "ode01" else 10) * 4 and mg["received_bytes_per_rank"] == 0
+    assert set(mg["predicted_gather_ms"]) >= {"direct_one_link_per_peer", "ring_one_link"}
+    assert mg["integrate_only_ms"] > 0 and mg["gather_only_ms"] > 0 and mg["step_ms"] > 0 and "hidden_ms" in mg
+    cm = mg["chunk_model"]
+    assert cm is not None and 1 <= cm["chunks"] <= 16 and cm["chunks"] == mg["chunks"] and cm["integrate_only_ms"] > 0 and cm["gather_only_ms"] > 0
 
 
 def test_bench_under_an_external_launcher():

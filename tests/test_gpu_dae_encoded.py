@@ -225,19 +225,3 @@ def test_default_route_is_the_row_kernels_and_the_env_knob_selects_k3g(monkeypat
         assert calls == [1]
     finally:
         fused().dae_encoded_integrate = orig
-
-
-def test_straight_fusion_arm_matches_the_oracle_in_its_own_process():
-    """PSNODE_K3G_ONE_ROLE=1 (read once per process): the 4-wave straight fusion, kept as the A/B arm of the two-role kernel."""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys; sys.path.insert(0, 'tests'); import test_gpu_dae_encoded as t\n"
-            "for m in ('euler', 'rk4'):\n"
-            "    t.test_dae_encoded_forward_matches_oracle(m, 37, 23, 8, 2, 2, 2)\n"
-            "    t.test_dae_encoded_forward_matches_oracle(m, 16, 9, 5, 0, 3, 1)\n"
-            "print('one-role ok')\n")
-    env = dict(os.environ, PSNODE_K3G_ONE_ROLE="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert res.returncode == 0 and "one-role ok" in res.stdout, res.stderr[-1500:]

@@ -127,40 +127,3 @@ def _direct_encode_case(tag, H, zd, method, events, B, T):
             assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and (q.grad is None or float(q.grad.abs().max()) == 0.0), n
             continue
         _close(p.grad, q.grad, 5e-4, n)
-
-
-@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-@pytest.mark.parametrize("zd", [2, 0])
-def test_latent64_two_role_and_one_role_backward_agree(method, zd, monkeypatch):
-    """Round 4: K9 on saved activations runs in the two-role form (4 chain waves + 4 gradient waves that load the saved rows, publish
-    their transposed tiles and own the block gradients).  Same arithmetic in the same order as the one-role kernel
-    (PSNODE_K9_NO_ROLES = 1): every parameter and input gradient of the DAE_02 model at hidden 64 must be bit-equal -- ragged tile,
-    events, odd and even step counts (the Euler iteration is written out twice)."""
-    from py_psnode_amd import models, neural_dae as nd
-    cls = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]
-    for T in (9, 8, 2):
-        B = 21
-        torch.manual_seed(5)
-        g = torch.Generator().manual_seed(6 + T)
-        r = lambda *s: (0.1 * torch.randn(*s, generator=g)).cuda()
-        t = (torch.arange(T, dtype=torch.float32) * 0.01).view(1, T, 1).repeat(B, 1, 1).cuda()
-        x, z, v, i = r(B, T, 8), r(B, T, zd), r(B, T, 2), r(B, T, 2)
-        ev = t[:, [2, 6], :].contiguous() if T > 7 else -torch.ones(B, 2, 1, device="cuda")
-        zj, vj = r(B, 2, zd), r(B, 2, 2)
-        m = models.DAE_Model(8, zd, 2, 2, 64, direct_encode=True, solver=cls()).cuda()
-        m.solver.fused = "require"
-
-        def grads():
-            m.zero_grad()
-            xin = x.clone().requires_grad_(True)
-            outs = m(t=t, x=xin, z=z, v=v, i=i, event_t=ev, z_jump=zj, v_jump=vj)
-            sum(((o - 0.05) ** 2).sum() for o in outs).backward()
-            return [xin.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
-
-        two = grads()
-        monkeypatch.setenv("PSNODE_K9_NO_ROLES", "1")
-        one = grads()
-        monkeypatch.delenv("PSNODE_K9_NO_ROLES")
-        assert len(two) == len(one)
-        for k_, (p, q) in enumerate(zip(two, one)):
-            assert torch.equal(p, q), f"{method} zd={zd} T={T}: gradient {k_} differs between the two-role and the one-role K9: {(p - q).abs().max().item():.3e}"

@@ -125,11 +125,11 @@ def test_latent_models_save_their_activations_by_default(tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel,tag", [("generic", "ode01"), ("mfma", "ode01"), ("wide", "ode01"), ("wide", "ode01_h128"), ("wide", "ode01_h32"),
-                                        ("generic", "ode01_h128"), ("split", "ode01_h128"),
+                                        ("generic", "ode01_h128"),
                                         ("saved", "ode01"), ("saved", "ode01_h128"), ("saved", "ode01_h32")])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
 def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel, tag):
-    """K5 (generic), K4 (mfma, hidden 64), K4f (wide: the one-launch backward at hidden 32 / 64 / 128) and round 2's split route through
+    """K5 (generic) and K4f (mfma / wide: the one-launch backward at hidden 32 / 64 / 128, recompute and saved forms) through
     the raw-tensor API against the reference's ODE_01 gradients at the matching --hidden."""
     from py_psnode_amd import fused
     d = load(f"g7_grad_{tag}.npz")
@@ -144,7 +144,7 @@ def test_ode_backward_kernels_raw_api_vs_reference_gradients(method, kernel, tag
     saved = None
     if kernel == "saved":       # K4f fed with the activations the forward saved (no recompute)
         xs2, saved = fused.ode_integrate(method, de, t, x, z, a0, event_t=ev, z_jump=zj, save=True)
-        assert torch.equal(xs2, xs)
+        _close(xs2, xs.cpu(), "training forward (saving) vs inference forward", TOL_GPU)      # (plain vs log2e-scaled ELU domain: roundings differ)
     gx0, gz, gzj, ga0, gp = fused.ode_backward(method, de, t, z, a0, xs, G, event_idx=tab, z_jump=zj,
                                                kernel="auto" if kernel == "saved" else kernel, saved=saved)
     gx_ref = T(d[f"{method}_g_x"])                       # [B,T,xd]: only x[:,0] carries gradient (directly + via all_initial)
