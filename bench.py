@@ -270,7 +270,8 @@ def kernel_name_for(lib, _lib, fused, w, p, method, kernel, dev):
         a.de = fused._mlp(p["de"], dev, "de", [])
         a.ae = fused._mlp(p["ae"], dev, "ae", [])
         auto_kernel = lib.psnode_dae_kernel_for(a)
-    kname = kernel if kernel != "auto" else {1: "generic", 2: "mfma"}[auto_kernel]
+    kname = kernel if kernel != "auto" else {1: "generic", 2: "mfma", 5: "mfma_wave"}[auto_kernel]      # mfma_wave: K1x
+    kname = {"wave": "mfma_wave", "tile": "mfma"}.get(kname, kname)
     if w["kind"] == "dae02_model":    # the two routes of the DAE_02 model forward (py_psnode_amd/models.py: DAE_Model._forward_encoded)
         kname = "k3g" if getattr(p.get("model"), "one_launch", False) else "rows+k3c"
     if kname == "mfma" and w["H"] == 16 and w["kind"] in ("ode", "ode02_model"):

@@ -521,7 +521,8 @@ int32_t psnode_latent_backward_wide_f32(const psnode_latent_bwd_wide_args_f32* a
 int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);
 int32_t psnode_dae_save_hidden(const psnode_dae_args_f32* args);
 
-/* Which kernel an AUTO call with these dims would run: returns PSNODE_KERNEL_GENERIC or PSNODE_KERNEL_MFMA. */
+/* Which kernel an AUTO call with these dims (and batch size B) would run: PSNODE_KERNEL_GENERIC, PSNODE_KERNEL_MFMA or -- the ODE's
+ * one-wave-per-4-trajectories integrator K1x, hidden <= 64 at up to one wave per SIMD -- PSNODE_KERNEL_MFMA_WAVE. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);
 

@@ -43,9 +43,11 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         a0 = torch.cat((x[0], z[0]), -1)
         zj = r(B, 2, zd) if events else None
         kw = dict(event_t=ev, z_jump=zj, input_true_x=tx)
-        a = fused.ode_integrate(method, de, t, x, z, a0, kernel="mfma", **kw)
         b = fused.ode_integrate(method, de, t, x, z, a0, kernel="generic", **kw)
-        close(a, b, "xs", tag)
+        # hidden <= 64 with x_dim <= 8: both MFMA integrators (round 5: K1 "tile", K1x "wave"); otherwise the one "mfma" picks
+        for kern in (("tile", "wave") if (H <= 64 and xd <= 8) else ("mfma",)):
+            a = fused.ode_integrate(method, de, t, x, z, a0, kernel=kern, **kw)
+            close(a, b, "xs " + kern, tag)
     else:
         while True:
             xd, zd, vd, idim = random.randint(1, 8), random.randint(0, 4), random.randint(0, 4), random.randint(1, 4)

@@ -59,7 +59,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     o0, g0 = run("0")
     info = (tag, H, zd, method, B, T, events)
     for k, (a, b) in enumerate(zip(o1, o0)):
-        if not torch.equal(a, b):
+        # (round 5: a training forward that saves runs its ELUs in the plain domain, one that does not -- like inference -- in the log2e-scaled
+        #  domain of K1 / K1x / K2: the same function, different roundings)
+        if not float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6):
             bad += 1; print("OUTPUT DIFFERS", info, k, float((a - b).abs().max()))
     for (n, _), a, b in zip(m.named_parameters(), g1, g0):
         if (a is None) != (b is None):

@@ -24,9 +24,9 @@ def latent_wide_training_fits(method, de, ae, hidden, T, B, dev) -> bool:
     """Training at the latent-wide hidden widths exists in ONE form: K3w saves its rows, K9w writes as many adjoint rows again and the
     host contracts them (fused.latent_backward_wide) -- there is no recompute form to fall back to.  True if all of that fits half of the
     free HBM and PSNODE_SAVE_ACTIVATIONS is not "0"; otherwise the solver takes the walk through the user's callables (with its warning)."""
-    if SAVE_ACTIVATIONS == "0" or T < 2:
+    if SAVE_ACTIVATIONS == "0":
         return False
-    if SAVE_ACTIVATIONS == "1":
+    if SAVE_ACTIVATIONS == "1" or T < 2:         # (T = 1: no step, nothing to save)
         return True
     S = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
     rows = (T - 1) * S * B * hidden * 4              # one [T-1,S,B,H] tensor

@@ -290,7 +290,9 @@ int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* a) {
     memset(&d, 0, sizeof(d));
     d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.T = a->T; d.B = a->B;
     bind_dims(a->de, d.de);
-    return mfma_ode_supported(d) ? PSNODE_KERNEL_MFMA : PSNODE_KERNEL_GENERIC;
+    if (!mfma_ode_supported(d)) return PSNODE_KERNEL_GENERIC;
+    d.sact = a->save_act;
+    return mfma_x_ode_preferred(d) ? PSNODE_KERNEL_MFMA_WAVE : PSNODE_KERNEL_MFMA;      // (_WAVE: K1x -- the one-wave-per-4-trajectories integrator)
 }
 
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {

@@ -237,6 +237,7 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae);
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream);
 // psnode_mfma_x.hip (K1x: one wave per 4 trajectories, no LDS exchange; ODE inference at hidden <= 64)
 bool mfma_x_ode_supported(const IntegrateDev& a);
+bool mfma_x_ode_preferred(const IntegrateDev& a);       // ... and AUTO / MFMA (or the forced _WAVE) would run it on this call (batch size)
 size_t mfma_x_pack_floats();
 hipError_t launch_mfma_x(const IntegrateDev& a, float* pack, hipStream_t stream);
 // psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)

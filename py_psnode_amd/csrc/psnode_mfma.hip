@@ -80,8 +80,10 @@ hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t
     if (latent_shape_ok(a, dae)) return launch_latent(a, dae, pack, stream);
     if (latent64_shape_ok(a, dae)) return launch_latent64(a, dae, pack, stream);
     if (latentw_shape_ok(a, dae)) return launch_latent_wide(a, dae, pack, stream);
-    // K1x (one wave per 4 trajectories, no LDS exchange) where it takes the shape, unless the caller asks for the 4-wave tile
-    if (!dae && a.kern != PSNODE_KERNEL_MFMA_TILE && mfma_x_ode_supported(a)) return launch_mfma_x(a, pack, stream);
+    // K1x (one wave per 4 trajectories, no LDS exchange) where it takes the shape, up to ONE wave per SIMD (1024 SIMDs x 4 trajectories, + 1/8
+    // of slack): beyond, two or more tiles per CU hide K1's exchanges and K1 is the faster one (profiles/r05f_tile_vs_wave.txt: B = 8192
+    // 0.752 vs 0.750, 12288 0.779 vs 0.757).  PSNODE_KERNEL_MFMA_TILE / _WAVE force either.
+    if (!dae && mfma_x_ode_preferred(a)) return launch_mfma_x(a, pack, stream);
     switch (padded_hidden_fwd(a.de.out_dim[0])) {
         case 32: return launch_mfma_h32(a, dae, pack, stream);
         case 128: return launch_mfma_h128(a, dae, pack, stream);

@@ -108,7 +108,7 @@ __device__ __forceinline__ void load_tail(const float* pw, Tail<NWV>& t) {
 
 template <int N> struct Arr { float v[N > 0 ? N : 1]; };
 
-template <int METHOD, int NX, int NZM, int NZA, bool TRUE_X, bool DAE, int NWV, bool SAVE = false>
+template <int METHOD, int NX, int NZM, int NZA, bool DAE, int NWV, bool SAVE = false>
 __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const IntegrateDev a, const float* __restrict__ pack_de,
                                                                   const float* __restrict__ pack_ae, const int NA) {
     using RD = Regs<NX, 0, NZM, NWV>;     // folded DE image: no `s - a0` registers for the x dims (psnode_pack.h)
@@ -154,6 +154,9 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     const int xd = a.xd, zd = a.zd, vd = DAE ? a.vd : 0, idim = DAE ? a.id : 0;
     const int nzv = zd + vd, ne = nzv + idim, n = xd + ne;
     const bool true_i = DAE && (a.flags & PSNODE_FLAG_INPUT_TRUE_I) != 0;
+    // teacher forcing of x is a RUNTIME flag since round 5 (it was a template parameter: a second instance of every inference kernel,
+    // ~190 of the library's 1100): a uniform branch around two loads that are waited for inside it, as the teacher-forced i always was
+    const bool true_x = !SAVE && (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
 
     // ---- weights -> registers (once per launch)
     const float* pw = pack_de + (size_t)w * (RD::COUNT + NA) * 64 + l;
@@ -508,7 +511,11 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
     auto sae_rows = [&](const long long kk) -> float* { return (SAVE && DAE) ? sae_lane + (size_t)kk * a.B * (16 * NWV) : nullptr; };
     auto load_x = [&](long long k, float (&dst)[NX]) {
 #pragma unroll
-        for (int r = 0; r < NX; ++r) dst[r] = 4 * r + g < xd ? a.x.p[k * a.x.st + b * a.x.sb + 4 * r + g] : 0.0f;
+        for (int r = 0; r < NX; ++r) {      // branch-free: a clamped column, the predicate only selects the value (no divergent region)
+            const int d = 4 * r + g;
+            const float v = a.x.p[k * a.x.st + b * a.x.sb + (d < xd ? d : 0)];
+            dst[r] = d < xd ? v : 0.0f;
+        }
     };
     auto store_x_at = [&](float* o) {        // o = this trajectory's output row
         if (w == 0 && valid) {
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         float xa[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) xa[r] = x[r];
-        if constexpr (TRUE_X) load_x(0, xa);
+        if (true_x) load_x(0, xa);
         icur = ae_eval(xa, pick_ae(rz, rv), sae_rows(0), sae_layer);
         store_i(0, icur);
         if (nT > 1) load_ae_raw(1, -1, zaz_nxt, zav_nxt);
@@ -597,7 +604,10 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
         float xsrc[NX];
 #pragma unroll
         for (int r = 0; r < NX; ++r) xsrc[r] = x[r];
-        if constexpr (TRUE_X) load_x(k, xsrc);   // teacher forcing: the step starts from the dataset's x[k]
+        if (true_x) {                            // teacher forcing: the step starts from the dataset's x[k]; read HERE, in front of the
+            load_x(k, xsrc);                     // prefetch, and waited for inside the branch (cf. the teacher-forced i below)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        }
         // teacher-forced algebraic input i[k]: read HERE, in front of the prefetch, and waited for inside the branch -- what is still
         // in flight at this point are the inputs of this very step.  Read where it is consumed (behind the prefetch) the join of this
         // branch put an s_waitcnt vmcnt(0) on the prefetch of EVERY step, teacher forcing or not.
@@ -693,7 +703,10 @@ __global__ __launch_bounds__(64 * NWV) void integrate_mfma_kernel(const Integrat
             float xa[NX];
 #pragma unroll
             for (int r = 0; r < NX; ++r) xa[r] = x[r];
-            if constexpr (TRUE_X) load_x(k + 1, xa);
+            if (true_x) {
+                load_x(k + 1, xa);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (the step's prefetch is a whole step old here)
+            }
             icur = ae_eval(xa, zva, sae_rows(k + 1), sae_layer);
         }
     }
@@ -705,13 +718,13 @@ inline int nzm_of(const IntegrateDev& a, bool dae) { return (2 * (a.zd + (dae ? 
 inline int nza_of(const IntegrateDev& a) { return (a.zd + a.vd + 3) / 4; }
 inline int na_of(const IntegrateDev& a, bool dae) { return (a.xd + a.zd + (dae ? a.vd + a.id : 0) + 3) / 4; }
 
-template <int NWV, int METHOD, bool TRUE_X, int NXR = kNXc>
+template <int NWV, int METHOD, int NXR = kNXc>
 hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
     const dim3 grid((unsigned)((a.B + TBM - 1) / TBM)), block(64 * NWV);
     const int NZM = nzm_of(a, dae), NZA = dae ? nza_of(a) : 0;
 #define PSNODE_LAUNCH(NZM_, NZA_, DAE_)                                                                                    \
     {                                                                                                                      \
-        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, TRUE_X, DAE_, NWV>;                                   \
+        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, DAE_, NWV>;                                           \
         const size_t lds = ae_weights_in_lds(DAE_, NWV) ? ae_lds_bytes(NWV) : 0;                                           \
         if (lds) {                                                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
@@ -721,11 +734,12 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, pde, pae, NA);                                                    \
         return hipGetLastError();                                                                                          \
     }
-    if constexpr (!TRUE_X && NXR == kNXc && !weights_streamed(NWV)) {      // the training forwards exist where a fused backward does (hidden <= 128)
+    if constexpr (NXR == kNXc && !weights_streamed(NWV)) {      // the training forwards exist where a fused backward does (hidden <= 128)
         if (!dae && a.sact) {
+            if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return hipErrorNotSupported;
 #define PSNODE_LAUNCH_SAVE(NZM_)                                                                                           \
     {                                                                                                                      \
-        hipLaunchKernelGGL((integrate_mfma_kernel<METHOD, NXR, NZM_, 0, false, false, NWV, true>), grid, block, 0, s, a, pde, pae, NA); \
+        hipLaunchKernelGGL((integrate_mfma_kernel<METHOD, NXR, NZM_, 0, false, NWV, true>), grid, block, 0, s, a, pde, pae, NA); \
         return hipGetLastError();                                                                                          \
     }
             switch (NZM) {
@@ -739,12 +753,12 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
 #undef PSNODE_LAUNCH_SAVE
         }
     }
-    if constexpr (!TRUE_X && NXR == kNXc && !weights_streamed(NWV)) {
+    if constexpr (NXR == kNXc && !weights_streamed(NWV)) {
         if (dae && a.sact) {
-            if (a.flags & PSNODE_FLAG_INPUT_TRUE_I) return hipErrorNotSupported;
+            if (a.flags & (PSNODE_FLAG_INPUT_TRUE_I | PSNODE_FLAG_INPUT_TRUE_X)) return hipErrorNotSupported;
 #define PSNODE_LAUNCH_SAVE(NZM_, NZA_)                                                                                     \
     {                                                                                                                      \
-        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, false, true, NWV, true>;                              \
+        auto kern = &integrate_mfma_kernel<METHOD, NXR, NZM_, NZA_, true, NWV, true>;                              \
         const size_t lds = ae_weights_in_lds(true, NWV) ? ae_lds_bytes(NWV) : 0;                                           \
         if (lds) {                                                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
@@ -802,12 +816,8 @@ hipError_t launch_shape(const IntegrateDev& a, bool dae, const float* pde, const
 
 template <int NWV, int METHOD>
 hipError_t launch_method(const IntegrateDev& a, bool dae, const float* pde, const float* pae, int NA, hipStream_t s) {
-    if (a.xd > 4 * kNXc) {     // x_dim 9..16: four x registers per lane (ODE only), 16-byte L4 all-reduce
-        if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_shape<NWV, METHOD, true, kNXw>(a, dae, pde, pae, NA, s);
-        return launch_shape<NWV, METHOD, false, kNXw>(a, dae, pde, pae, NA, s);
-    }
-    if (a.flags & PSNODE_FLAG_INPUT_TRUE_X) return launch_shape<NWV, METHOD, true>(a, dae, pde, pae, NA, s);
-    return launch_shape<NWV, METHOD, false>(a, dae, pde, pae, NA, s);
+    if (a.xd > 4 * kNXc) return launch_shape<NWV, METHOD, kNXw>(a, dae, pde, pae, NA, s);     // x_dim 9..16: four x registers per lane (ODE only), 16-byte L4 all-reduce
+    return launch_shape<NWV, METHOD>(a, dae, pde, pae, NA, s);
 }
 
 // pack the weights into the register images, then run the integrator (both on `stream`)

@@ -164,11 +164,11 @@ __device__ __forceinline__ f4 ext_mfmas(const float (&we)[16], const float eA, f
 
 constexpr int kXWaves = 4;      // independent waves per workgroup (one per SIMD; they share nothing)
 
-// FAST: no event table, no teacher forcing, even x_dim -- the plain inference call.  With one wave per SIMD every scalar instruction and
+// FAST (a loop variant inside the kernel): no event in the table, no teacher forcing, even x_dim -- the plain inference call.  With one wave per SIMD every scalar instruction and
 // every branch of the per-step bookkeeping is wall time (~4 / ~8 cycles each, nothing else to issue: 72 SALU + 19 branches were ~200 ns of
 // a 1.05 us Euler step), so the common call gets a loop without the event / teacher-forcing / odd-width code, and BOTH forms peel the last
 // step (which prefetches nothing) instead of clamping every row pointer every step.
-template <int METHOD, int NZM, bool FAST>
+template <int METHOD, int NZM>
 __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,6 +239,17 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     const int d01c = d01 < xd ? d01 : 0, d23c = d23 < xd ? d23 : 0;
     const unsigned xtoff01 = (unsigned)(tr * a.x.sb + d01c) * 4u, xtoff23 = (unsigned)(tr * a.x.sb + d23c) * 4u;
     const unsigned xooff = (unsigned)(tr * xd + d01) * 4u;
+    // FAST is decided per launch, on the device: no teacher forcing, even x_dim, and an event table that is absent or holds no event -- the
+    // scripts always pass an event list ("no events" = the time -1, neural_00_ODE_01_no_encode.py), so the table is scanned once (T / 64 loads
+    // per lane, before the time loop) instead of trusting the pointer.
+    bool fast_rt = !true_x && (xd & 1) == 0;
+    if (fast_rt && a.ev) {
+        int any = -1;
+        for (int i = l; i + 1 < nT; i += 64) any = max(any, a.ev[i]);
+        fast_rt = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
+    }
+    auto time_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };      // uniform row base (SGPR pair) as a global pointer
     auto load_evb = [&](const int blk) -> int {                       // event indices travel 64 steps at a time (lane i: step 64 blk + i)
         const int i = blk * 64 + l;
@@ -287,17 +298,22 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         row_sum2(k01, k23);
     };
 
-    // One step.  LAST (the peeled final step) prefetches nothing.
-    auto step = [&](const int k, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        // What is in flight here was issued a whole step ago: this step's inputs and, LAST in program order, the previous row's store.
-        // vmcnt counts in order: vmcnt(1) waits for the inputs and leaves the store (exactly one instruction at even x_dim) a second
-        // step to be acknowledged.
-        if (pair_ok) __builtin_amdgcn_s_waitcnt(0x0F71);   // vmcnt(1)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
-        const float h_ = t_nxt - t_cur;
-        t_cur = t_nxt;
-        const float eA = eon ? (b < ne ? e_nxt - a0e : e_nxt) : 0.0f;
+    // One step.  `tuse` / `euse`: the registers that hold t[k + 1] and the external value of step k; with PF the step re-issues loads INTO
+    // them (the clock entry / z row `trun` / `zrun` point at).  WAITN = the vmcnt the step may start at: what was issued, in program order,
+    // BEHIND the loads of tuse / euse -- per step two loads and, last, one store (even x_dim; otherwise the count is 0: wait for everything).
+    //   one step of look-ahead (general form):  store(k-1)                                  -> vmcnt(1)
+    //   two steps (FAST, Euler / Midpoint):     store(k-2), load t, load e, store(k-1)     -> vmcnt(4)
+    // A 1 us Euler step does not cover a clock / z row that misses the caches (SQ_WAIT_ANY 28 % of the wave's cycles with one step of
+    // look-ahead, profiles/r05g_k1x_euler_pmc_sq.txt); RK4's 3 us step does.
+    auto step = [&](const int k, float& tuse, float& euse, auto pf_tag, auto wait_tag) {
+        constexpr bool PF = decltype(pf_tag)::value;
+        constexpr int WAITN = decltype(wait_tag)::value;
+        if (pair_ok && WAITN == 4) __builtin_amdgcn_s_waitcnt(0x0F74);        // vmcnt(4)
+        else if (pair_ok && WAITN == 1) __builtin_amdgcn_s_waitcnt(0x0F71);   // vmcnt(1)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+        const float h_ = tuse - t_cur;
+        t_cur = tuse;
+        const float eA = eon ? (b < ne ? euse - a0e : euse) : 0.0f;
         float s01 = X01, s23 = X23;
         if constexpr (!FAST) {
             if (true_x) {                                            // teacher forcing: the step starts from the dataset's x[k] (uniform branch)
@@ -308,16 +324,16 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
             }
             xt_run += xst;
         }
-        if constexpr (!LAST) {   // prefetch the next step's inputs: t[k + 2] and the external row of step k + 1 (both exist: k + 2 <= T - 1)
-            t_nxt = ldg<float>(as_g(trun), toff);
+        if constexpr (PF) {   // prefetch: the clock entry and the external row the running bases point at (the caller keeps them inside the grid)
+            tuse = ldg<float>(as_g(trun), toff);
             if constexpr (FAST) {
-                e_nxt = ldg<float>(as_g(zrun), zoff);
+                euse = ldg<float>(as_g(zrun), zoff);
             } else {
                 if (((k + 1) & 63) == 0) evb = load_evb((k + 1) >> 6);
                 ev_cur = __builtin_amdgcn_readlane(evb, (k + 1) & 63);
                 const bool jump = __builtin_amdgcn_readfirstlane(ev_cur) >= 0;
                 const float* zr = jump ? zjbase + (long long)ev_cur * zje : zrun;      // an event step takes the jump row (uniform select)
-                e_nxt = ldg<float>(as_g(zr), jump ? zjoff : zoff);
+                euse = ldg<float>(as_g(zr), jump ? zjoff : zoff);
             }
             trun += tst;
             zrun += zst;
@@ -343,21 +359,47 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
             X23 = s23 + (k1b + 3.0f * (k2b + k3b) + k4b) * h_ * 0.125f;
         }
     };
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step's inputs (no store is in flight yet for the loop's vmcnt(1) to skip)
-    for (int k = 0; k + 2 < nT; ++k) step(k, std::false_type{});
-    step(nT - 2, std::true_type{});
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W4 = std::integral_constant<int, 4>;
+    constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38;
+    if constexpr (TWO_AHEAD) {
+        // ring of two register pairs: (t_nxt, e_nxt) serve the even steps, (t_n2, e_n2) the odd ones; a step reloads the pair it used
+        float t_n2 = ldg<float>(as_g(a.t.p + (nT > 2 ? 2 : 1) * tst), toff);            // t[2]
+        float e_n2 = ldg<float>(as_g(zbase + zst), zoff);                                 // external row of step 1 (row 1 exists: T >= 2)
+        trun = a.t.p + 3 * tst;                                                           // next: t[3], row 2 -- loaded by step 0
+        zrun = zbase + 2 * zst;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        int k = 0;
+        for (; k + 5 <= nT; k += 2) {         // steps k and k + 1 both prefetch: k + 1 <= T - 4
+            step(k, t_nxt, e_nxt, std::true_type{}, W4{});
+            step(k + 1, t_n2, e_n2, std::true_type{}, W4{});
+        }
+        if (k + 4 <= nT) {                    // one more step that can still prefetch (t[k + 3] exists); k is even here
+            step(k, t_nxt, e_nxt, std::true_type{}, W4{});
+            ++k;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // the last (up to two) steps: everything has arrived, nothing more is requested
+        for (; k + 1 < nT; ++k) {
+            if (k & 1) step(k, t_n2, e_n2, std::false_type{}, W0{});
+            else step(k, t_nxt, e_nxt, std::false_type{}, W0{});
+        }
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first step's inputs (no store is in flight yet for the loop's vmcnt(1) to skip)
+        for (int k = 0; k + 2 < nT; ++k) step(k, t_nxt, e_nxt, std::true_type{}, W1{});
+        step(nT - 2, t_nxt, e_nxt, std::false_type{}, W0{});
+    }
     store_row(xo_run);
+    };      // time_loop
+    if (fast_rt) time_loop(std::true_type{});
+    else time_loop(std::false_type{});
 }
 
 template <int METHOD>
 hipError_t launch_x_method(const IntegrateDev& a, const float* pack, hipStream_t s) {
     const long long tiles = (a.B + 3) / 4;
     const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves);
-    const bool fast = a.ev == nullptr && !(a.flags & PSNODE_FLAG_INPUT_TRUE_X) && (a.xd & 1) == 0;
-#define PSNODE_X(NZM_)                                                                                          \
-    if (fast) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, true>), grid, block, 0, s, a, pack);         \
-    else hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, false>), grid, block, 0, s, a, pack);             \
-    break;
+#define PSNODE_X(NZM_) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_>), grid, block, 0, s, a, pack); break;
     switch ((2 * a.zd + 3) / 4) {
         case 0: PSNODE_X(0)
         case 1: PSNODE_X(1)
@@ -379,6 +421,11 @@ bool mfma_x_ode_supported(const IntegrateDev& a) {
     if (m.n_layers != 4 || m.in_dim != 3 * (a.xd + a.zd) || m.out_dim[3] != a.xd) return false;
     const int h = m.out_dim[0];
     return h >= 1 && h <= 64 && m.out_dim[1] == h && m.out_dim[2] == h;
+}
+// ... and the calls it takes them for: forced (PSNODE_KERNEL_MFMA_WAVE), or up to one wave per SIMD unless the 4-wave tile is forced
+bool mfma_x_ode_preferred(const IntegrateDev& a) {
+    if (a.kern == PSNODE_KERNEL_MFMA_TILE || a.kern == PSNODE_KERNEL_GENERIC || !mfma_x_ode_supported(a)) return false;
+    return a.kern == PSNODE_KERNEL_MFMA_WAVE || a.B <= 4608;
 }
 size_t mfma_x_pack_floats() { return (size_t)XRegs::COUNT * 64; }
 

@@ -234,8 +234,9 @@ def test_accelerate_puts_script_style_encoders_on_the_row_kernels(method):
         return m, out
 
     try:
-        f.mlp_rows = lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), of(*a, **k))[1]
-        f.mlp_rows_backward = lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), ob(*a, **k))[1]
+        # (both names: models.py calls fused.mlp_rows through the package, the autograd bridge in fused/rows.py its module-level names)
+        f.mlp_rows = f.rows.mlp_rows = lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), of(*a, **k))[1]
+        f.mlp_rows_backward = f.rows.mlp_rows_backward = lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), ob(*a, **k))[1]
         m, out = run(d, grad=False)
         assert calls["fwd"] == 5                        # enc x, enc z, enc z_jump, dec solution, dec reconstruction
         for k, o in enumerate(out):
@@ -243,7 +244,8 @@ def test_accelerate_puts_script_style_encoders_on_the_row_kernels(method):
         m, out = run(dg, grad=True)
         assert calls["bwd"] == 5
     finally:
-        f.mlp_rows, f.mlp_rows_backward = of, ob
+        f.mlp_rows = f.rows.mlp_rows = of
+        f.mlp_rows_backward = f.rows.mlp_rows_backward = ob
     for name, p in m.named_parameters():
         ref = torch.as_tensor(dg[f"{method}_gp__" + name.replace(".", "__")], dtype=torch.float64)
         err = float((p.grad.double().cpu() - ref).abs().max())

@@ -65,6 +65,51 @@ def test_g3_integrate_dae(method, kernel):
     assert rel_err(is_.cpu(), d[f"{method}_xdim0_i"]) <= TOL_GPU
 
 
+@pytest.mark.parametrize("kernel", ("tile", "wave"))
+@pytest.mark.parametrize("method", METHODS)
+def test_g2_g5_on_both_mfma_integrators(method, kernel):
+    """The reference's goldens G2 (events, teacher forcing, ragged clocks) and G5 (1000 steps) on K1 ("tile") and K1x ("wave") explicitly:
+    AUTO picks one of them by batch size, both must hold the goldens."""
+    d = load("g2_ode.npz")
+    de = dl(layers(d, "de__x_dot"))
+    t, tr, x, z = (T(d[k]).cuda().permute(1, 0, 2) for k in ("t", "t_ragged", "x", "z"))
+    a0, ev, zj = T(d["all_initial"]).cuda(), T(d["event_t"]).cuda(), T(d["z_jump"]).cuda()
+    f = fused()
+    run = lambda **kw: f.ode_integrate(method, de, kw.pop("t", t), x, z, a0, kernel=kernel, **kw).cpu()
+    assert rel_err(run(), d[f"{method}_noevfn"]) <= TOL_GPU
+    assert rel_err(run(event_t=ev, z_jump=zj), d[f"{method}_events"]) <= TOL_GPU
+    assert rel_err(run(event_t=ev, z_jump=zj, input_true_x=True), d[f"{method}_events_truex"]) <= TOL_GPU
+    assert rel_err(run(t=tr, event_t=ev, z_jump=zj), d[f"{method}_ragged"]) <= TOL_GPU
+    if method != "midpoint":
+        d = load("g5_long.npz")
+        de = dl(layers(d, "de__x_dot"))
+        t, z = (T(d[k]).cuda().permute(1, 0, 2) for k in ("t", "z"))
+        x = torch.zeros(t.shape[0], t.shape[1], 8, device="cuda")
+        x[0] = T(d["x0"])[:, 0].cuda()
+        assert rel_err(f.ode_integrate(method, de, t, x, z, T(d["all_initial"]).cuda(), kernel=kernel).cpu(), d[method]) <= TOL_GPU
+
+
+@pytest.mark.parametrize("B,Tn", [(4096, 40), (4609, 12), (5, 300), (1, 2), (130, 3), (64, 66), (7, 130)])
+def test_k1_and_k1x_agree_and_auto_picks_by_batch(B, Tn):
+    """K1 and K1x on the same call (even and odd x_dim, events crossing the 64-step blocks of the event table, T = 2, T = 3, ragged last
+    wave): equal to rounding (plain vs log2e-scaled ELU domain, different summation orders).  AUTO = K1x up to one wave per SIMD
+    (B <= 4608), K1 beyond: bit-equal to the forced kernel."""
+    for xd, zd, method in ((8, 2, "rk4"), (5, 3, "euler"), (8, 0, "midpoint")):
+        ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=3 + B, H=64)
+        g = torch.Generator().manual_seed(4)
+        ev = zj = None
+        if zd and Tn > 4:
+            ev = torch.stack([t[1, :, :], t[min(Tn - 2, 65), :, :]], dim=1).contiguous().cuda()
+            zj = (0.1 * torch.randn(B, 2, zd, generator=g)).cuda()
+        kw = dict(event_t=ev, z_jump=zj)
+        f = fused()
+        tile = f.ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="tile", **kw)
+        wave = f.ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="wave", **kw)
+        auto = f.ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="auto", **kw)
+        assert rel_err(wave.cpu(), tile.cpu()) <= TOL_GPU
+        assert torch.equal(auto, wave if B <= 4608 else tile)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_g5_long_run(kernel):
     d = load("g5_long.npz")
@@ -243,14 +288,18 @@ def _check_mfma_ode(xd, zd, method, H):
     t[:, 0] = torch.arange(Tn, dtype=torch.float32).view(Tn, 1) * 0.01      # trajectory 0 = the event clock
     ev = torch.stack([t[4, :, :], t[9, :, :]], dim=1).contiguous()           # [B,2,1]
     zj = 0.1 * torch.randn(B, 2, zd, generator=g)
+    # hidden <= 64 with x_dim <= 8 has TWO MFMA integrators (round 5): K1 (4-wave tile, "tile") and K1x (one wave per 4 trajectories,
+    # "wave"; what "mfma" / "auto" pick at this batch) -- both are checked against the oracle
+    kernels = ("tile", "wave") if (H <= 64 and xd <= 8) else ("mfma",)
     ref = O.integrate_ode(method, ls, t, x, z, a0, ev, zj)
-    out = fused().ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel="mfma")
-    assert rel_err(out.cpu(), ref) <= TOL_GPU
     xt = 0.1 * torch.randn(Tn, B, xd, generator=g)
     xt[0] = x[0]
-    ref = O.integrate_ode(method, ls, t, xt, z, a0, ev, zj, input_true_x=True)
-    out = fused().ode_integrate(method, dl(ls), t.cuda(), xt.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), input_true_x=True, kernel="mfma")
-    assert rel_err(out.cpu(), ref) <= TOL_GPU
+    ref_tf = O.integrate_ode(method, ls, t, xt, z, a0, ev, zj, input_true_x=True)
+    for kern in kernels:
+        out = fused().ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), kernel=kern)
+        assert rel_err(out.cpu(), ref) <= TOL_GPU, kern
+        out = fused().ode_integrate(method, dl(ls), t.cuda(), xt.cuda(), z.cuda(), a0.cuda(), event_t=ev.cuda(), z_jump=zj.cuda(), input_true_x=True, kernel=kern)
+        assert rel_err(out.cpu(), ref_tf) <= TOL_GPU, kern
 
 
 def _synthetic_dae(B, Tn, xd, zd, vd, idim, seed=0, H=64):
@@ -439,23 +488,26 @@ def test_auto_picks_mfma_for_reference_shape():
     a.de.n_layers, a.de.in_dim = 4, 30
     for k, o in enumerate((64, 64, 64, 8)):
         a.de.out_dim[k] = o
-    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA_WAVE      # K1x: hidden <= 64 at up to one wave per SIMD (B <= 4608)
+    a.B = 32768
+    assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA           # the node-size batch: K1 (two and more tiles per CU)
+    a.B = 4096
     a.de.out_dim[1] = 32                       # mixed widths: no MFMA kernel
     assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_GENERIC
-    for H in (32, 128):                        # --hidden 32 / 128: the 2- and 8-wave instantiations
+    for H, want in ((32, _lib.KERNEL_MFMA_WAVE), (128, _lib.KERNEL_MFMA)):      # --hidden 32 runs zero-padded on K1x, 128 on K1's 8-wave instance
         for k in range(3):
             a.de.out_dim[k] = H
-        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == want
     d = _lib.DaeArgsF32()
     d.method, d.x_dim, d.z_dim, d.v_dim, d.i_dim, d.T, d.B = _lib.RK4_38, 8, 2, 2, 2, 1001, 4096
     d.de.n_layers, d.de.in_dim, d.ae.n_layers, d.ae.in_dim = 4, 42, 4, 26
     for k, (o1, o2) in enumerate(zip((64, 64, 64, 8), (64, 64, 64, 2))):
         d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
     assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA
-    for H in (48, 100):                        # in-between widths run zero-padded on the next instantiation up
+    for H, want in ((48, _lib.KERNEL_MFMA_WAVE), (100, _lib.KERNEL_MFMA)):      # in-between widths run zero-padded on the next instantiation up
         for k in range(3):
             a.de.out_dim[k] = H
-        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
+        assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == want
     for xd_ in (9, 12, 16):                    # x_dim 9..16 (data-defined upstream): four x registers per lane, still MFMA
         a.x_dim, a.de.in_dim, a.de.out_dim[3] = xd_, 3 * (xd_ + 2), xd_
         assert lib.psnode_ode_kernel_for(ctypes.byref(a)) == _lib.KERNEL_MFMA
@@ -483,8 +535,10 @@ def test_full_size_subset_vs_oracle():
 def test_config5_node_batch_on_one_gpu():
     """BASELINE config 5's GLOBAL batch (32 768 trajectories = 8 tiles per CU: the regime where two waves share a SIMD) on one GPU,
     1000 RK4 steps: 40 trajectories spread over the batch against the oracle run on just those, and -- trajectories being independent --
-    rank r's 4096-trajectory shard integrated on its own must reproduce its slice of the full run BIT FOR BIT (what the 8-GPU run
-    relies on; the gloo test checks the gather, this checks that a shard does not depend on who shares the launch)."""
+    rank r's 4096-trajectory shard integrated on its own BY THE SAME KERNEL must reproduce its slice of the full run BIT FOR BIT (the gloo
+    test checks the gather, this checks that a shard does not depend on who shares the launch).  Round 5: AUTO picks the integrator by the
+    launch's batch (K1x up to one wave per SIMD = the 4096-trajectory shard, K1 for the node-size launch): the shard as the 8-GPU run
+    integrates it agrees with the node-size launch to rounding, and is itself checked against the oracle."""
     B, Tn = 32768, 1001
     ls, t, x, z, a0 = _synthetic_ode(B, Tn, seed=5)
     lay = dl(ls)
@@ -496,8 +550,12 @@ def test_config5_node_batch_on_one_gpu():
     assert rel_err(out[:, idx.cuda()].cpu(), ref) <= TOL_GPU
     for r in (0, 3, 7):
         lo, hi = 4096 * r, 4096 * (r + 1)
-        shard = fused().ode_integrate("rk4", lay, tc[:, lo:hi], xc[:, lo:hi], zc[:, lo:hi], ac[lo:hi])
+        shard = fused().ode_integrate("rk4", lay, tc[:, lo:hi], xc[:, lo:hi], zc[:, lo:hi], ac[lo:hi], kernel="tile")
         assert torch.equal(shard, out[:, lo:hi]), f"shard {r} differs from its slice of the node-size launch"
+        auto = fused().ode_integrate("rk4", lay, tc[:, lo:hi], xc[:, lo:hi], zc[:, lo:hi], ac[lo:hi])      # K1x, as on the 8-GPU node
+        assert rel_err(auto.cpu(), out[:, lo:hi].cpu()) <= TOL_GPU
+        sel = idx[(idx >= lo) & (idx < hi)]
+        assert rel_err(auto[:, (sel - lo).cuda()].cpu(), O.integrate_ode("rk4", ls, t[:, sel], x[:, sel], z[:, sel], a0[sel])) <= TOL_GPU
 
 
 def test_accuracy_equivalent_to_reference_vs_fp64():
@@ -624,7 +682,8 @@ def test_order_of_accuracy_full_batch():
     ratios = {}
     for method in ("euler", "rk4"):
         errs = []
-        for steps in (4, 8, 16):
+        # (RK4 on 2 / 4 / 8 steps: at 16 its truncation error, 1e-6, is the fp32 roundoff of the integration itself)
+        for steps in ((4, 8, 16) if method == "euler" else (2, 4, 8)):
             t, x, z = grid(steps, torch.float32)
             out = fused().ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda())
             errs.append(float((out[-1][idx.cuda()].double().cpu() - truth).abs().max()))

@@ -4,8 +4,8 @@ every parameter .grad and the input gradients, golden set G7).
 
   CPU  (not gpu): this package's callback walk under fp32 autograd reproduces them (pins the host mirror's training path).
   GPU  (-m gpu) : the fused route -- K1/K2/K3a/K3c forward, K4/K7/K8/K9 (+ row-MLP backward) -- and, through the raw-tensor
-                  API, the generic backward K5, against the same arrays.  Tolerance: 2e-4 of each tensor's max magnitude
-                  (fp32 accumulation over steps x stages x trajectories in a different summation order).
+                  API, the generic backward K5, against the same arrays.  Tolerance: 1e-5 of each tensor's max magnitude
+                  (round 5: ~6 x the worst achieved error, profiles/r05_grad_accuracy_report.txt).
 """
 import pytest
 import torch
@@ -19,7 +19,8 @@ TAGS = ["ode01", "dae01", "ode02", "ode02_h64", "dae02", "dae02_h64", "dae02_z0"
         # round 3 (make_goldens_r3.py): the scripts' argparse default --hidden 128 and --hidden 32 -- K4f (ODE) / K7w (DAE) on the GPU
         "ode01_h128", "ode01_h32", "dae01_h128", "dae01_h32"]
 TOL_CPU = 2e-5      # same ATen ops in (almost) the same order as the reference
-TOL_GPU = 2e-4
+TOL_GPU = 1e-5      # ~6 x the worst achieved error over every model x method x tensor (1.63e-6: profiles/r05_grad_accuracy_report.txt; the reference's
+                    # own fp32 gradients sit 1.2e-6 from an fp64 walk)
 
 
 def _build(tag):
