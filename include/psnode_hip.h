@@ -50,8 +50,8 @@ typedef enum { PSNODE_EULER = 0, PSNODE_MIDPOINT = 1, PSNODE_RK4_38 = 2 } psnode
 /* kernel selection: AUTO picks the MFMA kernel when the shape has one, else the generic kernel */
 typedef enum {
     PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2,
-    PSNODE_KERNEL_MFMA_TILE = 4,     /* forward ODE calls only: K1, the 4-waves-per-16-trajectory-tile MFMA integrator, where AUTO / MFMA would pick K1x */
-    PSNODE_KERNEL_MFMA_WAVE = 5,     /* forward ODE calls only: K1x, the one-wave-per-4-trajectories (exchange-free) MFMA integrator; UNSUPPORTED outside its shapes */
+    PSNODE_KERNEL_MFMA_TILE = 4,     /* forward calls only: K1 / K2, the 4-waves-per-16-trajectory-tile MFMA integrators, where AUTO / MFMA would pick K1x / K2x */
+    PSNODE_KERNEL_MFMA_WAVE = 5,     /* forward calls only: K1x / K2x, the one-wave-per-4-trajectories (exchange-free) MFMA integrators; UNSUPPORTED outside their shapes */
     PSNODE_KERNEL_MFMA_WIDE = 3      /* backward calls only: the one-launch MFMA backward K4f (hidden <= 128 zero-padded to 32 / 64 / 128); since ABI 8
                                         (K4 removed) the same kernel AUTO / MFMA pick for these shapes */
 } psnode_kernel;
@@ -521,8 +521,8 @@ int32_t psnode_latent_backward_wide_f32(const psnode_latent_bwd_wide_args_f32* a
 int32_t psnode_ode_save_hidden(const psnode_ode_args_f32* args);
 int32_t psnode_dae_save_hidden(const psnode_dae_args_f32* args);
 
-/* Which kernel an AUTO call with these dims (and batch size B) would run: PSNODE_KERNEL_GENERIC, PSNODE_KERNEL_MFMA or -- the ODE's
- * one-wave-per-4-trajectories integrator K1x, hidden <= 64 at up to one wave per SIMD -- PSNODE_KERNEL_MFMA_WAVE. */
+/* Which kernel an AUTO call with these dims (and batch size B) would run: PSNODE_KERNEL_GENERIC, PSNODE_KERNEL_MFMA or -- the
+ * one-wave-per-4-trajectories integrators K1x / K2x, hidden <= 64 at up to one wave per SIMD -- PSNODE_KERNEL_MFMA_WAVE. */
 int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* args);
 int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* args);
 

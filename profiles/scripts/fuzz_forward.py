@@ -60,7 +60,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         x, z, v, i, xi = r(Tn, B, xd), r(Tn, B, zd), r(Tn, B, vd), r(Tn, B, idim), r(B, xd)
         a0 = torch.cat((xi, z[0], v[0], i[0]), -1)
         kw = dict(event_t=ev, z_jump=r(B, 2, zd) if events else None, v_jump=r(B, 2, vd) if events else None, input_true_x=tx, input_true_i=ti)
-        a = fused.dae_integrate(method, de, ae, xi, t, x, z, v, i, a0, kernel="mfma", **kw)
         b = fused.dae_integrate(method, de, ae, xi, t, x, z, v, i, a0, kernel="generic", **kw)
-        close(a[0], b[0], "xs", tag); close(a[1], b[1], "is", tag)
+        for kern in (("tile", "wave") if (H <= 64 and not tx and not ti) else ("mfma",)):      # K2 and K2x where both take the call
+            a = fused.dae_integrate(method, de, ae, xi, t, x, z, v, i, a0, kernel=kern, **kw)
+            close(a[0], b[0], "xs " + kern, tag); close(a[1], b[1], "is " + kern, tag)
 print("fuzz done, mismatches:", bad)

@@ -92,7 +92,7 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
     const bool has_mfma = dae ? mfma_dae_supported(d) : mfma_ode_supported(d);
     const bool want_mfma = kernel == PSNODE_KERNEL_MFMA || kernel == PSNODE_KERNEL_MFMA_TILE || kernel == PSNODE_KERNEL_MFMA_WAVE;
     if (want_mfma && !has_mfma) return PSNODE_ERR_UNSUPPORTED;
-    if (kernel == PSNODE_KERNEL_MFMA_WAVE && (dae || !mfma_x_ode_supported(d))) return PSNODE_ERR_UNSUPPORTED;
+    if (kernel == PSNODE_KERNEL_MFMA_WAVE && !(dae ? mfma_x_dae_supported(d) : mfma_x_ode_supported(d))) return PSNODE_ERR_UNSUPPORTED;
     d.kern = kernel;
     const bool use_mfma = has_mfma && kernel != PSNODE_KERNEL_GENERIC;
     if (d.T < 1 || d.B < 1) return PSNODE_ERR_DIMS;
@@ -303,7 +303,9 @@ int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {
     d.T = a->T; d.B = a->B;
     bind_dims(a->de, d.de);
     bind_dims(a->ae, d.ae);
-    return mfma_dae_supported(d) ? PSNODE_KERNEL_MFMA : PSNODE_KERNEL_GENERIC;
+    if (!mfma_dae_supported(d)) return PSNODE_KERNEL_GENERIC;
+    d.sact = a->save_act;
+    return mfma_x_dae_preferred(d) ? PSNODE_KERNEL_MFMA_WAVE : PSNODE_KERNEL_MFMA;      // (_WAVE: K2x)
 }
 
 }  // extern "C"

@@ -240,6 +240,11 @@ bool mfma_x_ode_supported(const IntegrateDev& a);
 bool mfma_x_ode_preferred(const IntegrateDev& a);       // ... and AUTO / MFMA (or the forced _WAVE) would run it on this call (batch size)
 size_t mfma_x_pack_floats();
 hipError_t launch_mfma_x(const IntegrateDev& a, float* pack, hipStream_t stream);
+// psnode_mfma_xd.hip (K2x: the same decomposition for the DAE; inference at hidden <= 64, i_dim <= 4, no teacher forcing)
+bool mfma_x_dae_supported(const IntegrateDev& a);
+bool mfma_x_dae_preferred(const IntegrateDev& a);
+size_t mfma_xd_pack_floats();
+hipError_t launch_mfma_xd(const IntegrateDev& a, float* pack, hipStream_t stream);
 // psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
 hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
 // K4f (psnode_backward_fused.hip): one-launch MFMA backward of the ODE integrator at hidden <= 128 (zero-padded to 32 / 64 / 128), x_dim <= 8, z_dim <= 8

@@ -73,7 +73,8 @@ size_t mfma_pack_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
     const int n = de->in_dim / 3, nw = (padded_hidden_fwd(de->out_dim[0]) ? padded_hidden_fwd(de->out_dim[0]) : de->out_dim[0] + 15) / 16;
     const size_t one = (size_t)nw * (max_regs(nw) + (n + 3) / 4) * 64 + stream_image_floats(nw);
     const size_t both = ae ? 2 * one : one;
-    return both > mfma_x_pack_floats() ? both : mfma_x_pack_floats();
+    const size_t wave = ae ? mfma_xd_pack_floats() : mfma_x_pack_floats();
+    return both > wave ? both : wave;
 }
 
 hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t stream) {
@@ -84,6 +85,7 @@ hipError_t launch_mfma(const IntegrateDev& a, bool dae, float* pack, hipStream_t
     // of slack): beyond, two or more tiles per CU hide K1's exchanges and K1 is the faster one (profiles/r05f_tile_vs_wave.txt: B = 8192
     // 0.752 vs 0.750, 12288 0.779 vs 0.757).  PSNODE_KERNEL_MFMA_TILE / _WAVE force either.
     if (!dae && mfma_x_ode_preferred(a)) return launch_mfma_x(a, pack, stream);
+    if (dae && mfma_x_dae_preferred(a)) return launch_mfma_xd(a, pack, stream);
     switch (padded_hidden_fwd(a.de.out_dim[0])) {
         case 32: return launch_mfma_h32(a, dae, pack, stream);
         case 128: return launch_mfma_h128(a, dae, pack, stream);

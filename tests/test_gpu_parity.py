@@ -110,6 +110,26 @@ def test_k1_and_k1x_agree_and_auto_picks_by_batch(B, Tn):
         assert torch.equal(auto, wave if B <= 4608 else tile)
 
 
+@pytest.mark.parametrize("kernel", ("tile", "wave"))
+@pytest.mark.parametrize("method", METHODS)
+def test_g3_on_both_mfma_dae_integrators(method, kernel):
+    """The reference's golden G3 (events, x_dim == 0 dataset rows) on K2 ("tile") and K2x ("wave") explicitly."""
+    d = load("g3_dae.npz")
+    de, ae = dl(layers(d, "de__x_dot")), dl(layers(d, "ae__i_calculator"))
+    t, x, z, v, i = (T(d[k]).cuda().permute(1, 0, 2) for k in ("t", "x", "z", "v", "i"))
+    xi, a0 = T(d["x_init"]).cuda(), T(d["all_initial"]).cuda()
+    ev, zj, vj = T(d["event_t"]).cuda(), T(d["z_jump"]).cuda(), T(d["v_jump"]).cuda()
+    f = fused()
+    for evk, kw in (("ev0", {}), ("ev1", dict(event_t=ev, z_jump=zj, v_jump=vj))):
+        xs, is_ = f.dae_integrate(method, de, ae, xi, t, x, z, v, i, a0, kernel=kernel, **kw)
+        assert rel_err(xs.cpu(), d[f"{method}_tx0_ti0_{evk}_x"]) <= TOL_GPU
+        assert rel_err(is_.cpu(), d[f"{method}_tx0_ti0_{evk}_i"]) <= TOL_GPU
+    xe = torch.zeros(t.shape[0], t.shape[1], 0, device="cuda")
+    xs, is_ = f.dae_integrate(method, de, ae, xi, t, xe, z, v, i, a0, kernel=kernel)
+    assert rel_err(xs.cpu(), d[f"{method}_xdim0_x"]) <= TOL_GPU
+    assert rel_err(is_.cpu(), d[f"{method}_xdim0_i"]) <= TOL_GPU
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_g5_long_run(kernel):
     d = load("g5_long.npz")
@@ -341,10 +361,14 @@ def _check_mfma_dae(xd, zd, vd, idim, method, H):
     for tx in (False, True):
         for ti in (False, True):
             ref_x, ref_i = O.integrate_dae(method, de, ae, xi, t, x, z, v, i, a0, ev, zj, vj, input_true_x=tx, input_true_i=ti)
-            xs, is_ = fused().dae_integrate(method, dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), event_t=c(ev),
-                                            z_jump=c(zj), v_jump=c(vj), input_true_x=tx, input_true_i=ti, kernel="mfma")
-            assert rel_err(xs.cpu(), ref_x) <= TOL_GPU, (tx, ti)
-            assert rel_err(is_.cpu(), ref_i) <= TOL_GPU, (tx, ti)
+            # hidden <= 64, i_dim <= 4, no teacher forcing has TWO MFMA integrators (round 5): K2 ("tile") and K2x ("wave", what "mfma" /
+            # "auto" pick at this batch); every other call has K2 alone
+            kernels = ("tile", "wave") if (H <= 64 and idim <= 4 and not tx and not ti) else ("mfma",)
+            for kern in kernels:
+                xs, is_ = fused().dae_integrate(method, dl(de), dl(ae), c(xi), c(t), c(x), c(z), c(v), c(i), c(a0), event_t=c(ev),
+                                                z_jump=c(zj), v_jump=c(vj), input_true_x=tx, input_true_i=ti, kernel=kern)
+                assert rel_err(xs.cpu(), ref_x) <= TOL_GPU, (tx, ti, kern)
+                assert rel_err(is_.cpu(), ref_i) <= TOL_GPU, (tx, ti, kern)
 
 
 def test_dae_full_size_subset_vs_oracle():
