@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 8
+#define PSNODE_ABI_VERSION 9
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer OUTPUT the kernels accept */
 #define PSNODE_MAX_IN_WIDTH 2048 /* widest first-layer INPUT (the latent DE of DAE_02 at --hidden 128 is 12 x 128 = 1536 wide) */
@@ -189,8 +189,12 @@ int32_t psnode_dae_integrate_f32(const psnode_dae_args_f32* args, void* workspac
  * Supported: hidden width 16 (the scripts' default hidden_dim) or 64 (their debug override), in/out width up to the
  * hidden width -- see psnode_mlp_rows_supported. */
 int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* mlp);
-int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, float* out,
-                            int64_t out_row_stride, void* stream);
+/* Input row r sits at in + r * in_row_stride (in_inner_rows == 0), or -- two-level -- at
+ *   in + (r / in_inner_rows) * in_outer_stride + (r % in_inner_rows) * in_row_stride      (rows, in_inner_rows < 2^32):
+ * the DataLoader's [B,T,D] batch read as the time-major rows r = t * B + b the latent tensors are laid out in (in_inner_rows = B,
+ * in_row_stride = T * D, in_outer_stride = D) -- the x.permute(1, 0, 2) of neural_00_ODE_02_direct_encode.py:76 without a copy. */
+int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride, int64_t in_inner_rows,
+                            int64_t in_outer_stride, float* out, int64_t out_row_stride, void* stream);
 
 /* Backward of psnode_mlp_rows_f32: grad_in[r,:] (optional) and the parameter gradients as ONE flat vector in nn.Linear order
  * [W1 (H x in), b1 (H), W2 (out x H), b2 (out)], from the saved input rows and grad_out.  What loss.backward() does for the
@@ -198,7 +202,7 @@ int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float
  * Deterministic (per-wave partials in `workspace`, summed in a fixed order). */
 size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32* mlp, int64_t rows);
 int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride,
-                                     const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
+                                     int64_t in_inner_rows, int64_t in_outer_stride, const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
                                      float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward (discretise-then-optimise) pass through psnode_ode_integrate_f32: what loss.backward() computes when it

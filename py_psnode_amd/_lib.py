@@ -15,7 +15,7 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE, KERNEL_MFMA_TILE, KERNEL_MFMA_WAVE = 0, 1, 2, 3, 4, 5
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 8          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 9          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
                          #     psnode_dae_save_hidden;
@@ -223,7 +223,7 @@ def load():
     lib.psnode_mlp_rows_supported.restype = c_int32
     lib.psnode_mlp_rows_supported.argtypes = [ctypes.POINTER(MlpF32)]
     lib.psnode_mlp_rows_f32.restype = c_int32
-    lib.psnode_mlp_rows_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.psnode_mlp_rows_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
     lib.psnode_ode_backward_supported.restype = c_int32
     lib.psnode_ode_backward_supported.argtypes = [ctypes.POINTER(OdeBwdArgsF32)]
     lib.psnode_ode_backward_param_count.restype = c_int64
@@ -241,7 +241,7 @@ def load():
     lib.psnode_mlp_rows_backward_workspace_bytes.restype = c_size_t
     lib.psnode_mlp_rows_backward_workspace_bytes.argtypes = [ctypes.POINTER(MlpF32), c_int64]
     lib.psnode_mlp_rows_backward_f32.restype = c_int32
-    lib.psnode_mlp_rows_backward_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+    lib.psnode_mlp_rows_backward_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                                  c_void_p, c_void_p, c_size_t, c_void_p]
     lib.psnode_masked_mse_workspace_bytes.restype = c_size_t
     lib.psnode_masked_mse_workspace_bytes.argtypes = [ctypes.POINTER(LossArgsF32)]

@@ -160,7 +160,8 @@ class _FusedOde(torch.autograd.Function):
         return (None, None, None, None, gx0, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)
 
 
-def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None, check_events=False, input_true_x=False):
+def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=None, z_jump=None, check_events=False, input_true_x=False,
+                        x_init=None):
     """Differentiable fused integrate_ODE: gradients flow to x[0], z, all_initial, z_jump and the MLP.  input_true_x (teacher forcing,
     my_solvers.py:72-74): every step starts from the dataset row x[k]; gradients flow to z, all_initial, z_jump and the MLP (the dataset
     x gets none: callers whose x requires grad take the callback walk)."""
@@ -169,7 +170,8 @@ def fused_ode_integrate(method, kernel, layers, t, x, z, all_initial, event_t=No
     if event_idx is None:
         z_jump = None
     params = [p for wb in layers for p in wb]
-    return _FusedOde.apply(method, kernel, event_idx, t, x.detach() if input_true_x else x[0], z, all_initial, z_jump, *params)
+    x0 = x.detach() if input_true_x else (x[0] if x_init is None else x_init)     # (x_init: integrate_ODE's extension -- no SelectBackward)
+    return _FusedOde.apply(method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params)
 
 
 class _FusedDae(torch.autograd.Function):

@@ -85,6 +85,33 @@ __device__ __forceinline__ f4 hh_layer(const float (&wk)[64], const float bias, 
     return quad_transpose(elu_quad_scaled(accA + accB));
 }
 
+// The same layer with the weights in AccVGPRs (K2x's AE head: 128 B operands that do not fit the 256 architectural VGPRs next to the DE's).
+// Left to the register allocator the AGPR-resident weights come back through v_accvgpr_read in front of every MFMA and the scheduler
+// serialises the two accumulator chains; here the B operand is READ from the AGPR (`a` constraint) and the order is fixed.  One asm block
+// per 4 k; wait states inside (the hazard recognizer does not look): a dependent SrcC needs 2 (the other chain's MFMA + s_nop 0).
+template <int BB>
+__device__ __forceinline__ void hh_block_acc(const float (&wk)[64], const f4 hA, f4& accA, f4& accB) {
+    asm volatile(
+        "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0"
+        : "+v"(accA), "+v"(accB)
+        : "v"(hA[0]), "v"(hA[1]), "v"(hA[2]), "v"(hA[3]), "a"(wk[4 * BB + 0]), "a"(wk[4 * BB + 1]), "a"(wk[4 * BB + 2]), "a"(wk[4 * BB + 3]), "n"(BB));
+}
+__device__ __forceinline__ f4 hh_layer_acc(const float (&wk)[64], const float bias, const f4 hA) {
+    f4 accA = f4{bias, bias, bias, bias}, accB = f4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 1" : "+v"(accA), "+v"(accB));           // VALU write -> MFMA SrcC read
+    hh_block_acc<0>(wk, hA, accA, accB); hh_block_acc<1>(wk, hA, accA, accB); hh_block_acc<2>(wk, hA, accA, accB); hh_block_acc<3>(wk, hA, accA, accB);
+    hh_block_acc<4>(wk, hA, accA, accB); hh_block_acc<5>(wk, hA, accA, accB); hh_block_acc<6>(wk, hA, accA, accB); hh_block_acc<7>(wk, hA, accA, accB);
+    hh_block_acc<8>(wk, hA, accA, accB); hh_block_acc<9>(wk, hA, accA, accB); hh_block_acc<10>(wk, hA, accA, accB); hh_block_acc<11>(wk, hA, accA, accB);
+    hh_block_acc<12>(wk, hA, accA, accB); hh_block_acc<13>(wk, hA, accA, accB); hh_block_acc<14>(wk, hA, accA, accB); hh_block_acc<15>(wk, hA, accA, accB);
+    asm volatile("s_nop 3" : "+v"(accA), "+v"(accB));           // MFMA write (2 passes) -> VALU read
+    return quad_transpose(elu_quad_scaled(accA + accB));
+}
+
 template <int Q0, int NQ>
 __device__ __forceinline__ f4 ext_mfmas(const float (&we)[16], const float eA, f4 acc) {
     if constexpr (NQ > 0) {

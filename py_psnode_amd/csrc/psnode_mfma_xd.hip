@@ -3,9 +3,10 @@
 //   DE  3n -> h -> h -> h -> x_dim,   AE  n + x + z + v -> h -> h -> h -> i_dim,   h <= 64, x_dim <= 8, z + v + i <= 8, i_dim <= 4,
 // inference without teacher forcing (everything else stays on K2, psnode_mfma_impl.h).
 // What is new against K1x:
-//   * the DE's H -> H weights stay in VGPRs (128); the AE's live in LDS, ONE 32 KB copy per workgroup ([layer][k / 4][lane] f4: every
-//     wave's lane l reads the same 16 bytes -- the B operand of a 4x4x1 MFMA is per LANE, not per wave), read a 4-k chunk ahead of its
-//     four MFMAs; nothing is ever written after the prologue's barrier, so the waves still share no barrier in the time loop;
+//   * the DE's H -> H weights stay in VGPRs (128); the AE's live in the wave's AccVGPRs (128 more: one wave per SIMD owns all 512
+//     registers) and are READ from there as the MFMA's B operand (psnode_mfma_x.h: hh_layer_acc -- inline asm, because left to the register
+//     allocator they come back through a v_accvgpr_read per MFMA).  A first version kept them in LDS (one 32 KB image per workgroup, a
+//     ds_read_b128 per 4 MFMAs): 5.16 ms at dae01 / RK4 against K2's 4.66; from AccVGPRs 4.41 (profiles/r05n_dae_tile_vs_wave.txt).
 //   * the AE's output layer (64 -> i_dim <= 4) is K1x's split-K layer with ONE accumulator; its lane folds (v_permlane32_swap,
 //     v_permlane16_swap, row rotations: 8 VALU instructions) leave algebraic variable d in every lane of ROW drow^-1(d), drow = {0,2,1,3};
 //   * the DE's external slots (z | v | i, K2's order: slot q < ne carries ext[q] - a0, ne <= q < 2 ne carries ext[q - ne]) are PLACED for that:
@@ -32,10 +33,10 @@ __host__ __device__ inline int xd_slot_of_block(int b, int nzv, int id) {
     return idx < nzv ? idx : ne + (idx - nzv);
 }
 
-struct XDRegs {      // register image pack[reg][lane]; the AE's H -> H matrices follow as the LDS image [2][16][64] f4
+struct XDRegs {      // register image pack[reg][lane]; the AE's H -> H matrices follow as [layer][k / 4][lane][k % 4]
     static constexpr int W2 = 0, W3 = 64, W1X = 128, W1E = 136, W1A = 152, B1 = 168, B2 = 169, B3 = 170, W4A = 171, B4C = 179,
                          AW1X = 187, AW1E = 195, AW1A = 203, AB1 = 219, AB2 = 220, AB3 = 221, AW4A = 222, AB4C = 226, COUNT = 230;
-    static constexpr int LDS_F4 = 2 * 16 * 64;
+    static constexpr int HH_F4 = 2 * 16 * 64;
 };
 struct PackXD {
     int xd, zd, vd, id, hreal;
@@ -46,7 +47,7 @@ struct PackXD {
 
 __global__ void pack_xd_kernel(const PackXD p) {
     const int H = p.hreal, xd = p.xd, nzv = p.zd + p.vd, id = p.id, ne = nzv + id, n = xd + ne, K1 = 3 * n, K1a = n + xd + nzv;
-    const int total = XDRegs::COUNT * 64 + XDRegs::LDS_F4 * 4;
+    const int total = XDRegs::COUNT * 64 + XDRegs::HH_F4 * 4;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         float v = 0.0f;
         if (idx >= XDRegs::COUNT * 64) {          // AE H -> H image: [layer][kq][lane] f4, component cc = W[unit = lane][k = 4 kq + cc]
@@ -106,23 +107,6 @@ __global__ void pack_xd_kernel(const PackXD p) {
     }
 }
 
-// one H -> H layer with the B operands read from the workgroup's LDS image (a 4-k chunk per ds_read_b128)
-template <int KQ>
-__device__ __forceinline__ void hh_block_lds(const f4* __restrict__ wl, const f4 hA, f4& accA, f4& accB) {
-    const f4 wq = wl[KQ * 64];
-    accA = mfx<KQ>(hA[0], wq[0], accA);
-    accB = mfx<KQ>(hA[1], wq[1], accB);
-    accA = mfx<KQ>(hA[2], wq[2], accA);
-    accB = mfx<KQ>(hA[3], wq[3], accB);
-}
-__device__ __forceinline__ f4 hh_layer_lds(const f4* __restrict__ wl, const float bias, const f4 hA) {
-    f4 accA = f4{bias, bias, bias, bias}, accB = f4{0.f, 0.f, 0.f, 0.f};
-    hh_block_lds<0>(wl, hA, accA, accB); hh_block_lds<1>(wl, hA, accA, accB); hh_block_lds<2>(wl, hA, accA, accB); hh_block_lds<3>(wl, hA, accA, accB);
-    hh_block_lds<4>(wl, hA, accA, accB); hh_block_lds<5>(wl, hA, accA, accB); hh_block_lds<6>(wl, hA, accA, accB); hh_block_lds<7>(wl, hA, accA, accB);
-    hh_block_lds<8>(wl, hA, accA, accB); hh_block_lds<9>(wl, hA, accA, accB); hh_block_lds<10>(wl, hA, accA, accB); hh_block_lds<11>(wl, hA, accA, accB);
-    hh_block_lds<12>(wl, hA, accA, accB); hh_block_lds<13>(wl, hA, accA, accB); hh_block_lds<14>(wl, hA, accA, accB); hh_block_lds<15>(wl, hA, accA, accB);
-    return quad_transpose(elu_quad_scaled(accA + accB));
-}
 // x += row_ror:8 (x); x += row_ror:4 (x): the sum over the four blocks of a row, in every lane
 __device__ __forceinline__ void row_sum1(float& a) {
     asm volatile(
@@ -135,12 +119,6 @@ __device__ __forceinline__ void row_sum1(float& a) {
 
 template <int METHOD>
 __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const IntegrateDev a, const float* __restrict__ pack) {
-    __shared__ f4 aew[XDRegs::LDS_F4];
-    {   // the AE's H -> H image: one copy per workgroup (before any wave may leave: the only barrier of the kernel)
-        const f4* src = reinterpret_cast<const f4*>(pack + XDRegs::COUNT * 64);
-        for (int i = threadIdx.x; i < XDRegs::LDS_F4; i += 64 * kXWaves) aew[i] = src[i];
-        __syncthreads();
-    }
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = l >> 2, c = l & 3, rho = l >> 4;
@@ -170,8 +148,12 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         b4c[0][r] = pw[(XDRegs::B4C + r) * 64]; b4c[1][r] = pw[(XDRegs::B4C + 4 + r) * 64];
         aw4a[r] = pw[(XDRegs::AW4A + r) * 64]; ab4c[r] = pw[(XDRegs::AB4C + r) * 64];
     }
-    const f4* aew2 = aew + l;
-    const f4* aew3 = aew + 16 * 64 + l;
+    float aw2[64], aw3[64];                                    // the AE's H -> H weights: AccVGPRs (hh_layer_acc)
+    {
+        const float* pa = pack + XDRegs::COUNT * 64 + 4 * l;   // [layer][kq][lane][cc]
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { aw2[k] = pa[(k >> 2) * 256 + (k & 3)]; aw3[k] = pa[4096 + (k >> 2) * 256 + (k & 3)]; }
+    }
 
     // ---- per-trajectory constants
     const int d01 = 4 * (rho >> 1) + 2 * (rho & 1), d23 = d01 + 1;
@@ -216,10 +198,9 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
     // 0 of a row that exists (z's, else v's, else the clock) -- the value is never selected.
     const bool de_v = kind_de == 1 || (kind_de >= 2 && !has_z && has_v), ae_v = kind_ae == 1 || (kind_ae >= 2 && !has_z && has_v);
     auto lane_off = [&](const bool isv, const int kind, const int col, const bool jump) -> unsigned {
-        const int cc = kind <= 1 ? col : 0;
-        if (isv) return (unsigned)(tr * (jump ? a.vjb : a.v.sb) + cc) * 4u;
-        if (has_z) return (unsigned)(tr * (jump ? a.zjb : a.z.sb) + cc) * 4u;
-        return toff;
+        const int cc = kind <= 1 ? col : 0;                      // (selects, not branches: the lanes of a wave differ in `isv`)
+        const unsigned ov = (unsigned)(tr * (jump ? a.vjb : a.v.sb) + cc) * 4u, oz = (unsigned)(tr * (jump ? a.zjb : a.z.sb) + cc) * 4u;
+        return isv ? ov : (has_z ? oz : toff);
     };
     const unsigned off_de = lane_off(de_v, kind_de, col_de, false), off_ae = lane_off(ae_v, kind_ae, col_ae, false);
     const unsigned joff_de = ((de_v && has_vj) || (!de_v && has_zj)) ? lane_off(de_v, kind_de, col_de, true) : toff;
@@ -262,8 +243,8 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         accA = mfx<4>(eAE, aw1e[4], accA);  accB = mfx<5>(eAE, aw1e[5], accB);
         accA = mfx<6>(eAE, aw1e[6], accA);  accB = mfx<7>(eAE, aw1e[7], accB);
         f4 hA = quad_transpose(elu_quad_scaled(accA + accB));
-        hA = hh_layer_lds(aew2, ab2, hA);
-        hA = hh_layer_lds(aew3, ab3, hA);
+        hA = hh_layer_acc(aw2, ab2, hA);
+        hA = hh_layer_acc(aw3, ab3, hA);
         f4 p0 = ab4c;
         p0 = mfn(aw4a[0], hA[0], p0);
         p0 = mfn(aw4a[1], hA[1], p0);
@@ -317,6 +298,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         const float h_ = t_nxt - t_cur;
         t_cur = t_nxt;
         const int ev_now = ev_cur;
+        const float i_k = icw;                                   // i_solution[k]: the event below replaces i0 for the DE only
         if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {       // event: i0 = g(x_k; z_jump, v_jump) with the RUNNING state (my_solvers.py:108-110)
             const float ej = row_val(zjbase + (long long)ev_now * zje, vjbase + (long long)ev_now * vje, ae_v, joff_ae);
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -342,7 +324,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         }
         zrun += zst;
         vrun += vst;
-        store_rows(xo_run, io_run, icw);      // deferred store of grid point k (the previous step's result)
+        store_rows(xo_run, io_run, i_k);      // deferred store of grid point k (the previous step's result)
         xo_run += xo_step;
         io_run += io_step;
         const f4 cz = ext_mfmas<0, 16>(w1e, eA, c0);
@@ -389,7 +371,7 @@ bool mfma_x_dae_preferred(const IntegrateDev& a) {
     if (a.kern == PSNODE_KERNEL_MFMA_TILE || a.kern == PSNODE_KERNEL_GENERIC || !mfma_x_dae_supported(a)) return false;
     return a.kern == PSNODE_KERNEL_MFMA_WAVE || a.B <= 4608;
 }
-size_t mfma_xd_pack_floats() { return (size_t)XDRegs::COUNT * 64 + (size_t)XDRegs::LDS_F4 * 4; }
+size_t mfma_xd_pack_floats() { return (size_t)XDRegs::COUNT * 64 + (size_t)XDRegs::HH_F4 * 4; }
 
 hipError_t launch_mfma_xd(const IntegrateDev& a, float* pack, hipStream_t stream) {
     PackXD p;

@@ -20,7 +20,17 @@ struct RowsArgs {
     float* out;
     long long rows, in_stride, out_stride;
     int in_dim, out_dim;
+    unsigned in_inner;          // 0: row r at in + r * in_stride; else at in + (r / in_inner) * in_outer + (r % in_inner) * in_stride
+    long long in_outer;
 };
+
+// Offset of input row r: flat, or two-level -- the [B,T,D] batch of the DataLoader read as the TIME-MAJOR rows r = t * B + b
+// (x.permute(1, 0, 2) of neural_00_ODE_02_direct_encode.py:76 without materialising it: outer = t, stride D; inner = b, stride T * D).
+__device__ __forceinline__ long long row_offset(const long long r, const long long stride, const unsigned inner, const long long outer) {
+    if (inner == 0) return r * stride;
+    const unsigned o = (unsigned)r / inner;
+    return (long long)o * outer + (long long)((unsigned)r - o * inner) * stride;
+}
 
 // NM = MFMAs of layer 1 = ceil(in_dim / 4); lane group g supplies columns NM*g + m.
 // HT = hidden tiles (hidden width 16*HT: 1 or 4), OT = output tiles (ceil(out_dim / 16): 1 or 4).  One wave owns its 16 rows
@@ -53,12 +63,12 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
     const long long tiles = (a.rows + 15) / 16;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
     constexpr int VB = NM == 2 ? 8 : 16;   // bytes of one vector load
-    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
+    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && a.in_outer % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
     const bool vec_out = a.out_dim % 4 == 0 && a.out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     for (long long t = wave; t < tiles; t += nwaves) {
         const long long row = t * 16 + j;
         const bool valid = row < a.rows;
-        const float* src = a.in + (valid ? row : a.rows - 1) * a.in_stride + NM * g;
+        const float* src = a.in + row_offset(valid ? row : a.rows - 1, a.in_stride, a.in_inner, a.in_outer) + NM * g;
         float v[NM];
         if (vec_in) {
             if constexpr (NM % 4 == 0) {
@@ -129,6 +139,8 @@ struct RowsBwdArgs {
     float *gin, *wpart;
     long long rows, in_stride, gout_stride, gin_stride;
     int in_dim, out_dim, np;
+    unsigned in_inner;          // as RowsArgs
+    long long in_outer;
 };
 
 constexpr int RSCR = 64 * 4 + 4 * 8;   // padded transpose tile (floats)
@@ -234,14 +246,14 @@ __global__ __launch_bounds__(256, ((NM == 16 && HT == 4 && OT == 1) || (NM <= 4 
     const long long tiles = (a.rows + 15) / 16;
     const long long wave = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
     constexpr int VB = NM == 2 ? 8 : 16;
-    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
+    const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && a.in_outer % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
     const bool vec_gin = a.gin && (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.gin_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.gin) % VB) == 0;
     const bool vec_go = a.out_dim % 4 == 0 && a.gout_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.gout) & 15) == 0;
     for (long long t = wave; t < tiles; t += nwaves) {
         const long long row = t * 16 + j;
         const bool valid = row < a.rows;
         const long long rc = valid ? row : a.rows - 1;
-        const float* src = a.in + rc * a.in_stride + NM * g;
+        const float* src = a.in + row_offset(rc, a.in_stride, a.in_inner, a.in_outer) + NM * g;
         float v[NM];
         if (vec_in) {
             if constexpr (NM % 4 == 0) {
@@ -456,14 +468,16 @@ extern "C" int32_t psnode_mlp_rows_supported(const psnode_mlp_f32* m) {
     return in_ok && out_ok;
 }
 
-extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride, float* out,
-                                       int64_t out_row_stride, void* stream) {
+extern "C" int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride, int64_t in_inner_rows,
+                                       int64_t in_outer_stride, float* out, int64_t out_row_stride, void* stream) {
     if (!m || !in || !out) return PSNODE_ERR_NULL;
     if (!psnode_mlp_rows_supported(m)) return PSNODE_ERR_UNSUPPORTED;
     if (!m->weight[0] || !m->weight[1] || !m->bias[0] || !m->bias[1]) return PSNODE_ERR_NULL;
     if (rows < 0 || in_row_stride < m->in_dim || out_row_stride < m->out_dim[1]) return PSNODE_ERR_DIMS;
+    if (in_inner_rows < 0 || in_inner_rows > 0xffffffffll || (in_inner_rows > 0 && (rows > 0xffffffffll || in_outer_stride < 0))) return PSNODE_ERR_DIMS;
     if (rows == 0) return PSNODE_OK;
-    RowsArgs a{m->weight[0], m->bias[0], m->weight[1], m->bias[1], in, out, rows, in_row_stride, out_row_stride, m->in_dim, m->out_dim[1]};
+    RowsArgs a{m->weight[0], m->bias[0], m->weight[1], m->bias[1], in, out, rows, in_row_stride, out_row_stride, m->in_dim, m->out_dim[1],
+               (unsigned)in_inner_rows, in_inner_rows > 0 ? in_outer_stride : 0};
     const long long tiles = (rows + 15) / 16;
     long long blocks = (tiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 workgroups per CU, grid-stride over the rest
@@ -482,19 +496,20 @@ extern "C" size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32*
 }
 
 extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride,
-                                                const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
+                                                int64_t in_inner_rows, int64_t in_outer_stride, const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
                                                 float* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !in || !grad_out || !grad_params) return PSNODE_ERR_NULL;
     if (!psnode_mlp_rows_supported(m)) return PSNODE_ERR_UNSUPPORTED;
     if (!m->weight[0] || !m->weight[1] || !m->bias[0]) return PSNODE_ERR_NULL;
     if (rows < 0 || in_row_stride < m->in_dim || gout_row_stride < m->out_dim[1] || (grad_in && gin_row_stride < m->in_dim)) return PSNODE_ERR_DIMS;
+    if (in_inner_rows < 0 || in_inner_rows > 0xffffffffll || (in_inner_rows > 0 && (rows > 0xffffffffll || in_outer_stride < 0))) return PSNODE_ERR_DIMS;
     const size_t need = psnode_mlp_rows_backward_workspace_bytes(m, rows);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int np = rows_np(m);
     const long long blocks = rows_bwd_blocks(rows);
     RowsBwdArgs a{m->weight[0], m->bias[0], m->weight[1], in, grad_out, grad_in, static_cast<float*>(workspace), rows, in_row_stride,
-                  gout_row_stride, gin_row_stride, m->in_dim, m->out_dim[1], np};
+                  gout_row_stride, gin_row_stride, m->in_dim, m->out_dim[1], np, (unsigned)in_inner_rows, in_inner_rows > 0 ? in_outer_stride : 0};
     const dim3 grid((unsigned)blocks), block(256);
     const int NM = (m->in_dim + 3) / 4, H = m->out_dim[0], OT = (m->out_dim[1] + 15) / 16;
     if (H == 16) launch_rows_bwd<1, 1>(NM, grid, block, s, a);

@@ -31,11 +31,13 @@ def _all_f32_on(dev, *tensors) -> bool:
     return all(a is None or (torch.is_tensor(a) and a.dtype == torch.float32 and a.device == dev) for a in tensors)
 
 
-def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=None):
+def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=None, x_init=None):
     """None if this integrate_ODE call cannot run fused, else (de_layers, event_t, z_jump, needs_autograd)."""
     if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() != 3 or z.dim() != 3:
         return None
-    if not _all_f32_on(x.device, z, all_initial, t):      # mixed dtypes / devices: 'auto' promises the walk, not a TypeError
+    if x_init is not None and (x_init.dim() != 2 or x_init.shape != x.shape[1:]):
+        return None
+    if not _all_f32_on(x.device, z, all_initial, t, x_init):      # mixed dtypes / devices: 'auto' promises the walk, not a TypeError
         return None
     xd, zd = x.shape[-1], z.shape[-1]
     if all_initial.dim() != 2 or all_initial.shape[-1] != xd + zd:
@@ -46,7 +48,7 @@ def plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=None):
     ok, event_t, z_jump, _ = _event_tensors(event_fn, jump_change_fn, False)
     if not ok or not _all_f32_on(x.device, event_t, z_jump):
         return None
-    needs_grad = _needs_autograd([x, z, all_initial, z_jump] + [p for wb in layers for p in wb])
+    needs_grad = _needs_autograd([x if x_init is None else x_init, z, all_initial, z_jump] + [p for wb in layers for p in wb])
     return layers, event_t, z_jump, needs_grad
 
 

@@ -9,6 +9,23 @@ from .. import _lib
 from ._common import Layers, _aligned_ptr, _empty, _f32_dev, _mlp, _split_grads, sequential_layers
 from .plan import _needs_autograd
 
+def _row_addressing(x: torch.Tensor):
+    """(tensor to keep alive, rows, row stride, inner rows, outer stride) of `x`'s last-dim rows for the row kernels.  A 3-D tensor with
+    a dense last dim goes in AS IT IS LAID OUT -- row r = i0 * n1 + i1 at i0 * stride(0) + i1 * stride(1) -- so the time-major view
+    `x.permute(1, 0, 2)` of a [B,T,D] batch (neural_00_ODE_02_direct_encode.py:76) is read in place (two clones of the dataset per
+    training step before round 5); anything else is flattened (a copy only if the flattening needs one)."""
+    d = x.shape[-1]
+    if x.dim() == 3 and (d == 1 or x.stride(2) == 1) and x.stride(0) >= 0 and x.stride(1) >= d and x.shape[0] * x.shape[1] < 2 ** 32:
+        n0, n1 = x.shape[0], x.shape[1]
+        if x.stride(0) == n1 * x.stride(1) or n0 == 1:
+            return x, n0 * n1, x.stride(1), 0, 0
+        return x, n0 * n1, x.stride(1), n1, x.stride(0)
+    x2 = x.reshape(-1, d)
+    if x2.stride(-1) != 1 and d > 1:
+        x2 = x2.contiguous()
+    return x2, x2.shape[0], max(x2.stride(0), d), 0, 0
+
+
 def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     """Fused `nn.Sequential(Linear, ELU, Linear)` over the last dim of `inp` (any leading shape) on the HIP row kernel:
     the encoders / decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:64-69)."""
@@ -21,12 +38,10 @@ def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     x = _f32_dev(inp, dev, "input")
     if x.shape[-1] != m.in_dim:
         raise ValueError(f"mlp_rows: input width {x.shape[-1]}, expected {m.in_dim}")
-    x2 = x.reshape(-1, x.shape[-1])
-    if x2.stride(-1) != 1:
-        x2 = x2.contiguous()
+    x2, rows, rstride, inner, outer = _row_addressing(x)
     out = _empty((*x.shape[:-1], layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.psnode_mlp_rows_f32(ctypes.byref(m), x2.shape[0], x2.data_ptr(), x2.stride(0), out.data_ptr(), out.shape[-1],
+        rc = lib.psnode_mlp_rows_f32(ctypes.byref(m), rows, x2.data_ptr(), rstride, inner, outer, out.data_ptr(), out.shape[-1],
                                      torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_mlp_rows_f32")
     return out
@@ -40,15 +55,12 @@ def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor,
     m = _mlp(layers, dev, "mlp", keep)
     if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
         raise ValueError("mlp_rows_backward: unsupported MLP shape")
-    x2 = _f32_dev(inp, dev, "input").reshape(-1, inp.shape[-1])
+    x2, rows, rstride, inner, outer = _row_addressing(_f32_dev(inp, dev, "input"))
     g2 = _f32_dev(grad_out, dev, "grad_out").reshape(-1, grad_out.shape[-1])
-    if x2.stride(-1) != 1:
-        x2 = x2.contiguous()
     if g2.stride(-1) != 1:
         g2 = g2.contiguous()
-    if g2.shape[0] != x2.shape[0] or g2.shape[1] != layers[-1][0].shape[0]:
+    if g2.shape[0] != rows or g2.shape[1] != layers[-1][0].shape[0]:
         raise ValueError(f"mlp_rows_backward: grad_out {tuple(grad_out.shape)} does not match input {tuple(inp.shape)}")
-    rows = x2.shape[0]
     with torch.cuda.device(dev):
         gin = _empty((*inp.shape[:-1], inp.shape[-1]), dtype=torch.float32, device=dev) if need_grad_in else None
         npar = sum(w.numel() + b.numel() for w, b in layers)
@@ -56,7 +68,7 @@ def mlp_rows_backward(layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor,
         nbytes = lib.psnode_mlp_rows_backward_workspace_bytes(ctypes.byref(m), rows)
         ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
         wp, wn = _aligned_ptr(ws)
-        rc = lib.psnode_mlp_rows_backward_f32(ctypes.byref(m), rows, x2.data_ptr(), x2.stride(0), g2.data_ptr(), g2.stride(0),
+        rc = lib.psnode_mlp_rows_backward_f32(ctypes.byref(m), rows, x2.data_ptr(), rstride, inner, outer, g2.data_ptr(), g2.stride(0),
                                               gin.data_ptr() if gin is not None else None, inp.shape[-1], gp.data_ptr(), wp, wn,
                                               torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psnode_mlp_rows_backward_f32")

@@ -197,11 +197,17 @@ class ODE_Model(nn.Module):
             # on the way there or back; the first row is encoded once more for all_initial (B rows) instead of being selected out of the
             # big tensor, whose gradient would otherwise be a zero-filled [T,B,H] tensor added to the integrator's.  Row-wise functions:
             # the values are the ones of the B-major evaluation.
+            from .neural_dae.my_solvers import FixedGridODESolver
             Xh, Zh = _rows(self.x_encoder, _tm(x)), _rows(self.z_encoder, _tm(z))
-            a0 = torch.cat((_rows(self.x_encoder, x[:, 0]), _rows(self.z_encoder, z[:, 0])), dim=-1)
+            x0h = _rows(self.x_encoder, x[:, 0])
+            a0 = torch.cat((x0h, _rows(self.z_encoder, z[:, 0])), dim=-1)
             self.event.set_event(t=event_t, z=_rows(self.z_encoder, z_jump))
-            Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh, z=Zh, all_initial=a0,
-                                               event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn)
+            # this package's solvers take the start state on its own (x_init): Xh then reaches the integrator only for its shape, and its
+            # gradient is the decoder's alone instead of that plus a [T,B,H] tensor of zeros with one row set
+            own = isinstance(self.solver, FixedGridODESolver)
+            Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh.detach() if own else Xh, z=Zh, all_initial=a0,
+                                               event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
+                                               **({"x_init": x0h} if own else {}))
             return _tm(_rows(self.x_decoder, Xh_sol)), _tm(_rows(self.x_decoder, Xh))
         Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view
         Xh = _tm(Xh_bt)

@@ -90,14 +90,20 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
         return x0 + dx, f0
 
     # ------------------------------------------------------------------ ODE
-    def integrate_ODE(self, x_func, t, x, z, all_initial, event_fn=None, jump_change_fn=None, input_true_x=False):
+    def integrate_ODE(self, x_func, t, x, z, all_initial, event_fn=None, jump_change_fn=None, input_true_x=False, x_init=None):
+        """my_solvers.py:53-79.  `x_init` (an extension, default None = upstream: the integration starts from x[0]) hands the [B,x_dim]
+        initial state over on its own: a caller whose x is a big differentiable tensor (the direct_encode models' Xh) otherwise gets
+        d loss / d x back as a [T,B,x_dim] tensor that is zero except for row 0 -- allocated, filled and ADDED to x's other gradient."""
+        if x_init is not None and input_true_x:
+            raise ValueError("integrate_ODE: x_init and input_true_x exclude each other (teacher forcing starts every step from x[k])")
         if self.fused != "off":
-            plan = _fused.plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=t)
+            plan = _fused.plan_ode(x_func, x, z, all_initial, event_fn, jump_change_fn, t=t, x_init=x_init)
             if plan is not None:
                 layers, event_t, z_jump, needs_grad = plan
                 if not needs_grad:
                     try:
-                        return _fused.ode_integrate(self.method, layers, t, x, z, all_initial, event_t=event_t, z_jump=z_jump,
+                        return _fused.ode_integrate(self.method, layers, t, x if x_init is None else x_init.unsqueeze(0), z, all_initial,
+                                                    event_t=event_t, z_jump=z_jump,
                                                     input_true_x=input_true_x, kernel=self.kernel,
                                                     check_events=self._check_events_now(event_t))
                     except UnsupportedShapeError:      # no kernel covers the shape (too wide for LDS): user callables it is
@@ -108,7 +114,7 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                                                                              t.shape[1]):
                     from ..autograd import fused_ode_integrate
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
-                                               check_events=self._check_events_now(event_t))
+                                               check_events=self._check_events_now(event_t), x_init=x_init)
                 # teacher-forced training (my_solvers.py:72-74): K4f in its recompute form; the dataset x gets no gradient
                 elif input_true_x and not x.requires_grad and self.kernel in ("auto", "mfma") and \
                         _fused.ode_backward_supported(self.method, layers, x.shape[-1], z.shape[-1], "wide"):
@@ -119,12 +125,12 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                 raise NotFusableError("integrate_ODE: call is not fusable (needs fp32 HIP tensors, a DE_Func-style ELU-MLP "
                                       "`x_dot`, ODE_Event callbacks; with autograd: a shape with a backward kernel, no teacher forcing)")
             self._note_walk("integrate_ODE", x)
-        return self._walk_ode(x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x)
+        return self._walk_ode(x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x, x_init)
 
-    def _walk_ode(self, x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x):
+    def _walk_ode(self, x_func, t, x, z, all_initial, event_fn, jump_change_fn, input_true_x, x_init=None):
         n_grid = t.shape[0]
         xs = torch.zeros(x.shape, dtype=x.dtype, device=x.device)
-        cur = x[0]
+        cur = x[0] if x_init is None else x_init
         xs[0] = cur
         for k in range(n_grid - 1):
             t0, t1, zk = t[k], t[k + 1], z[k]

@@ -527,7 +527,10 @@ def test_auto_picks_mfma_for_reference_shape():
     d.de.n_layers, d.de.in_dim, d.ae.n_layers, d.ae.in_dim = 4, 42, 4, 26
     for k, (o1, o2) in enumerate(zip((64, 64, 64, 8), (64, 64, 64, 2))):
         d.de.out_dim[k], d.ae.out_dim[k] = o1, o2
+    assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA_WAVE       # K2x: as K1x, i_dim <= 4, no teacher forcing
+    d.B = 32768
     assert lib.psnode_dae_kernel_for(ctypes.byref(d)) == _lib.KERNEL_MFMA
+    d.B = 4096
     for H, want in ((48, _lib.KERNEL_MFMA_WAVE), (100, _lib.KERNEL_MFMA)):      # in-between widths run zero-padded on the next instantiation up
         for k in range(3):
             a.de.out_dim[k] = H
