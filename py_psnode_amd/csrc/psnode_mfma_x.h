@@ -76,13 +76,21 @@ __device__ __forceinline__ void hh_block(const float (&wk)[64], const f4 hA, f4&
     accA = mfx<BB>(hA[2], wk[4 * BB + 2], accA);
     accB = mfx<BB>(hA[3], wk[4 * BB + 3], accB);
 }
+// ELU of a D tile: the log2e-scaled domain of the inference kernels (SC) or the plain one (the training forwards: their saved rows are
+// what the backward kernels read)
+template <bool SC>
+__device__ __forceinline__ f4 elu_x(const f4 v) {
+    if constexpr (SC) return elu_quad_scaled(v);
+    else return elu_quad(v);
+}
+template <bool SC = true>
 __device__ __forceinline__ f4 hh_layer(const float (&wk)[64], const float bias, const f4 hA) {
     f4 accA = f4{bias, bias, bias, bias}, accB = f4{0.f, 0.f, 0.f, 0.f};
     hh_block<0>(wk, hA, accA, accB); hh_block<1>(wk, hA, accA, accB); hh_block<2>(wk, hA, accA, accB); hh_block<3>(wk, hA, accA, accB);
     hh_block<4>(wk, hA, accA, accB); hh_block<5>(wk, hA, accA, accB); hh_block<6>(wk, hA, accA, accB); hh_block<7>(wk, hA, accA, accB);
     hh_block<8>(wk, hA, accA, accB); hh_block<9>(wk, hA, accA, accB); hh_block<10>(wk, hA, accA, accB); hh_block<11>(wk, hA, accA, accB);
     hh_block<12>(wk, hA, accA, accB); hh_block<13>(wk, hA, accA, accB); hh_block<14>(wk, hA, accA, accB); hh_block<15>(wk, hA, accA, accB);
-    return quad_transpose(elu_quad_scaled(accA + accB));
+    return quad_transpose(elu_x<SC>(accA + accB));
 }
 
 // The same layer with the weights in AccVGPRs (K2x's AE head: 128 B operands that do not fit the 256 architectural VGPRs next to the DE's).

@@ -33,11 +33,13 @@ struct XRegs {
 };
 struct PackX {
     int xd, zd, n, hreal;
+    float sc;           // log2e: the scaled ELU domain of the inference kernel; 1: the training forward (plain domain, bit-exact weights)
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
     float* out;
 };
 __global__ void pack_x_kernel(const PackX p) {
     const int H = p.hreal, n = p.n, xd = p.xd, ne = p.zd, K1 = 3 * n;
+    const float kLog2e = p.sc;                                 // (shadows the constant: 1 for the training forward's plain-domain image)
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < XRegs::COUNT * 64; idx += gridDim.x * blockDim.x) {
         const int reg = idx >> 6, l = idx & 63, b = l >> 2, c = l & 3, u = l;      // B operands: lane (b', c') = unit 4b' + c' = l
         float v = 0.0f;
@@ -78,7 +80,10 @@ __global__ void pack_x_kernel(const PackX p) {
 // every branch of the per-step bookkeeping is wall time (~4 / ~8 cycles each, nothing else to issue: 72 SALU + 19 branches were ~200 ns of
 // a 1.05 us Euler step), so the common call gets a loop without the event / teacher-forcing / odd-width code, and BOTH forms peel the last
 // step (which prefetches nothing) instead of clamping every row pointer every step.
-template <int METHOD, int NZM>
+// SAVE: the training forward (a.sact / a.sxst: what autograd would keep -- the three ELU layers' outputs [T-1,S,3,B,Hp] and the stage inputs
+// [T-1,S,B,xd], the rows K4f reads; Hp = the padded width of the backward's tile, 32 or 64).  Plain ELU domain (the pack image is unscaled).
+// The A layout after the in-quad transpose holds, per lane (b, t), units 4b .. 4b+3 of trajectory t: ONE 16-byte store per layer.
+template <int METHOD, int NZM, bool SAVE>
 __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     const bool valid = tile * 4 + c < a.B;
     const long long tr = valid ? tile * 4 + c : a.B - 1;
     const int xd = a.xd, zd = a.zd, ne = zd, n = xd + zd;
-    const bool true_x = (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
+    const bool true_x = !SAVE && (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
 
     // ---- weights -> registers (once per launch)
     const float* pw = pack + l;
@@ -158,6 +163,13 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         for (int i = l; i + 1 < nT; i += 64) any = max(any, a.ev[i]);
         fast_rt = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
     }
+    // SAVE: uniform running row bases of the saved rows + this lane's byte offsets (its trajectory's row, its four units / its two dims)
+    const int hp = SAVE ? padded_hidden(a.de.out_dim[0]) : 0;
+    const size_t sa_layer = SAVE ? (size_t)a.B * hp : 0;
+    float* sa_run = SAVE ? a.sact : nullptr;
+    float* sx_run = SAVE ? a.sxst : nullptr;
+    const unsigned saoff = SAVE ? (unsigned)(tr * hp + 4 * b) * 4u : 0u;
+    const bool sa_on = SAVE && valid && 4 * b < hp;
     auto time_loop = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };      // uniform row base (SGPR pair) as a global pointer
@@ -194,9 +206,24 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         accA = mfx<8>(s01, w1x[2], accA);  accB = mfx<12>(s01, w1x[3], accB);
         accA = mfx<0>(s23, w1x[4], accA);  accB = mfx<4>(s23, w1x[5], accB);
         accA = mfx<8>(s23, w1x[6], accA);  accB = mfx<12>(s23, w1x[7], accB);
-        f4 hA = quad_transpose(elu_quad_scaled(accA + accB));
-        hA = hh_layer(w2, b2, hA);
-        hA = hh_layer(w3, b3, hA);
+        f4 hA = quad_transpose(elu_x<!SAVE>(accA + accB));
+        if constexpr (SAVE) {                                        // rows (step, stage): the stage input, then the three layers as they appear
+            if (pair_ok) {
+                if (st01) stg<f2>((gptr<float>)(uintptr_t)sx_run, xooff, f2{s01, s23});
+            } else {
+                if (st01) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff, s01);
+                if (st23) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff + 4u, s23);
+            }
+            sx_run += xo_step;
+            if (sa_on) stg<f4>((gptr<float>)(uintptr_t)sa_run, saoff, hA);
+        }
+        hA = hh_layer<!SAVE>(w2, b2, hA);
+        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + sa_layer), saoff, hA); }
+        hA = hh_layer<!SAVE>(w3, b3, hA);
+        if constexpr (SAVE) {
+            if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + 2 * sa_layer), saoff, hA);
+            sa_run += 3 * sa_layer;
+        }
         f4 p0 = b4c[0], p1 = b4c[1];
         p0 = mfn(w4a[0], hA[0], p0); p1 = mfn(w4a[4], hA[0], p1);
         p0 = mfn(w4a[1], hA[1], p0); p1 = mfn(w4a[5], hA[1], p1);
@@ -218,8 +245,10 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     auto step = [&](const int k, float& tuse, float& euse, auto pf_tag, auto wait_tag) {
         constexpr bool PF = decltype(pf_tag)::value;
         constexpr int WAITN = decltype(wait_tag)::value;
-        if (pair_ok && WAITN == 4) __builtin_amdgcn_s_waitcnt(0x0F74);        // vmcnt(4)
-        else if (pair_ok && WAITN == 1) __builtin_amdgcn_s_waitcnt(0x0F71);   // vmcnt(1)
+        // SAVE: a step also issued 4 stores per stage (xstage + three layers, every one from at least one lane of every wave) behind its prefetch
+        constexpr int NSAVE = SAVE ? 4 * (METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4)) : 0;
+        constexpr int WN = WAITN == 0 ? 0 : WAITN + NSAVE;                    // vmcnt is 6 bits: [3:0] and [15:14] of the immediate
+        if (pair_ok && WN > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (WN & 15) | ((WN >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
         const float h_ = tuse - t_cur;
         t_cur = tuse;
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     using W0 = std::integral_constant<int, 0>;
     using W1 = std::integral_constant<int, 1>;
     using W4 = std::integral_constant<int, 4>;
-    constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38;
+    constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38 && !SAVE;
     if constexpr (TWO_AHEAD) {
         // ring of two register pairs: (t_nxt, e_nxt) serve the even steps, (t_n2, e_n2) the odd ones; a step reloads the pair it used
         float t_n2 = ldg<float>(as_g(a.t.p + (nT > 2 ? 2 : 1) * tst), toff);            // t[2]
@@ -305,11 +334,11 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     else time_loop(std::false_type{});
 }
 
-template <int METHOD>
+template <int METHOD, bool SAVE>
 hipError_t launch_x_method(const IntegrateDev& a, const float* pack, hipStream_t s) {
     const long long tiles = (a.B + 3) / 4;
     const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves);
-#define PSNODE_X(NZM_) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_>), grid, block, 0, s, a, pack); break;
+#define PSNODE_X(NZM_) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, SAVE>), grid, block, 0, s, a, pack); break;
     switch ((2 * a.zd + 3) / 4) {
         case 0: PSNODE_X(0)
         case 1: PSNODE_X(1)
@@ -327,7 +356,8 @@ hipError_t launch_x_method(const IntegrateDev& a, const float* pack, hipStream_t
 // shapes K1x takes: the ODE's `3n -> h -> h -> h -> x_dim` with h <= 64 (zero-padded to 64), x_dim <= 8, z_dim <= 8, no saved activations
 bool mfma_x_ode_supported(const IntegrateDev& a) {
     const MlpDev& m = a.de;
-    if (a.sact || a.xd < 1 || a.xd > 8 || a.zd < 0 || a.zd > 8 || a.T >= (1ll << 31)) return false;
+    if (a.xd < 1 || a.xd > 8 || a.zd < 0 || a.zd > 8 || a.T >= (1ll << 31)) return false;
+    if (a.sact && ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) || !a.sxst || ((uintptr_t)a.sact & 15) || ((uintptr_t)a.sxst & 7))) return false;
     if (m.n_layers != 4 || m.in_dim != 3 * (a.xd + a.zd) || m.out_dim[3] != a.xd) return false;
     const int h = m.out_dim[0];
     return h >= 1 && h <= 64 && m.out_dim[1] == h && m.out_dim[2] == h;
@@ -345,13 +375,21 @@ hipError_t launch_mfma_x(const IntegrateDev& a, float* pack, hipStream_t stream)
     p.w1 = a.de.w[0]; p.b1 = a.de.bias[0]; p.w2 = a.de.w[1]; p.b2 = a.de.bias[1];
     p.w3 = a.de.w[2]; p.b3 = a.de.bias[2]; p.w4 = a.de.w[3]; p.b4 = a.de.bias[3];
     p.out = pack;
+    p.sc = a.sact ? 1.0f : kLog2e;
     hipLaunchKernelGGL(pack_x_kernel, dim3(16), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.sact) {
+        switch (a.method) {
+            case PSNODE_EULER: return launch_x_method<PSNODE_EULER, true>(a, pack, stream);
+            case PSNODE_MIDPOINT: return launch_x_method<PSNODE_MIDPOINT, true>(a, pack, stream);
+            default: return launch_x_method<PSNODE_RK4_38, true>(a, pack, stream);
+        }
+    }
     switch (a.method) {
-        case PSNODE_EULER: return launch_x_method<PSNODE_EULER>(a, pack, stream);
-        case PSNODE_MIDPOINT: return launch_x_method<PSNODE_MIDPOINT>(a, pack, stream);
-        default: return launch_x_method<PSNODE_RK4_38>(a, pack, stream);
+        case PSNODE_EULER: return launch_x_method<PSNODE_EULER, false>(a, pack, stream);
+        case PSNODE_MIDPOINT: return launch_x_method<PSNODE_MIDPOINT, false>(a, pack, stream);
+        default: return launch_x_method<PSNODE_RK4_38, false>(a, pack, stream);
     }
 }
 

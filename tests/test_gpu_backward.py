@@ -196,6 +196,47 @@ def test_wide_backward_matches_fp64_autograd(method, xd, zd, H):
 
 
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("H,xd,zd,B,Tn,events", [(64, 8, 2, 4096, 5, False), (64, 8, 2, 37, 9, True), (40, 5, 3, 18, 6, True), (32, 3, 0, 7, 4, False),
+                                                 (20, 7, 8, 130, 3, False), (64, 1, 1, 4, 2, False)])
+def test_training_forward_saves_the_same_rows_on_both_mfma_integrators(method, H, xd, zd, B, Tn, events):
+    """The training forward (save=True) on K1x (one wave per 4 trajectories: the default up to 4608 trajectories) and on K1 (the 4-wave tile)
+    writes the same rows -- stage inputs [T-1,S,B,xd], the three ELU layers [T-1,S,3,B,Hp] incl. the zero padding -- to rounding, odd x_dim,
+    events, ragged tiles and the padded widths included, and K4f returns the same gradients from either."""
+    from py_psnode_amd import fused
+    g = torch.Generator().manual_seed(H * 7 + xd + B)
+    torch.manual_seed(H * 7 + xd + B)
+    lin = [nn.Linear(a_, b_) for a_, b_ in zip([3 * (xd + zd), H, H, H], [H, H, H, xd])]
+    layers = [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin]
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1).cuda()
+    r = lambda *s_: (0.1 * torch.randn(*s_, generator=g)).cuda()
+    x, z = r(Tn, B, xd), r(Tn, B, zd)
+    a0 = torch.cat((x[0], z[0]), -1)
+    ev = zj = None
+    if events and zd:
+        ev = torch.full((B, 2, 1), -1.0, device="cuda"); ev[:, 0, 0] = 0.02 * (Tn // 2)
+        zj = r(B, 2, zd)
+    G = torch.randn(Tn, B, xd, generator=g).cuda()
+    tab = fused.event_table(t, ev) if ev is not None else None
+    out = {}
+    for kern in ("tile", "wave"):
+        xs, saved = fused.ode_integrate(method, layers, t, x, z, a0, event_t=ev, z_jump=zj, save=True, kernel=kern)
+        grads = fused.ode_backward(method, layers, t, z, a0, xs, G, event_idx=tab, z_jump=zj, saved=saved)
+        out[kern] = (xs, saved, grads)
+    (xs_t, sv_t, g_t), (xs_w, sv_w, g_w) = out["tile"], out["wave"]
+    _close(xs_w, xs_t.double().cpu(), "xs")
+    assert sv_w[0].shape == sv_t[0].shape and sv_w[1].shape == sv_t[1].shape
+    _close(sv_w[1], sv_t[1].double().cpu(), "saved stage inputs")
+    _close(sv_w[0], sv_t[0].double().cpu(), "saved activations")
+    hp = sv_t[0].shape[-1]
+    if H < hp:
+        assert float(sv_w[0][..., H:].abs().max()) == 0.0, "padding units are stored as zeros"
+    for k, (a_, b_) in enumerate(zip(g_w[4], g_t[4])):
+        _close(a_, b_.double().cpu(), f"grad param {k}")
+    _close(g_w[0], g_t[0].double().cpu(), "grad x0")
+    _close(g_w[3], g_t[3].double().cpu(), "grad all_initial")
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
 @pytest.mark.parametrize("H,xd", [(128, 8), (100, 8), (128, 5), (64, 8), (32, 3)])
 def test_wide_backward_without_external_inputs_at_hidden_128(method, H, xd):
     """z_dim = 0 (no external-input slots: the NZM = 0 instances) on K4f, recompute and saved, against K5 -- the recompute instance

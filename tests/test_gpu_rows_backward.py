@@ -68,6 +68,32 @@ def test_rows_autograd_function_on_strided_3d_input():
         _close(p.grad, q.grad, 2e-5, n)
 
 
+@pytest.mark.parametrize("din,H,dout", [(8, 16, 16), (2, 16, 16), (3, 16, 5), (1, 16, 16), (8, 64, 64), (16, 16, 8)])
+@pytest.mark.parametrize("B,T", [(1, 1), (5, 1), (1, 7), (37, 11), (130, 33)])
+def test_rows_read_a_batch_major_tensor_as_time_major_rows_in_place(din, H, dout, B, T):
+    """ABI 9: the [B,T,D] batch goes in as its time-major view (x.permute(1, 0, 2), neural_00_ODE_02_direct_encode.py:76) and is read where it
+    lies -- two-level row addressing -- with the results of the contiguous copy, bit for bit, forward and backward; no copy is made."""
+    from py_psnode_amd import fused
+    from py_psnode_amd.fused import rows as R
+    torch.manual_seed(B * 100 + T + din)
+    seq = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout)).cuda()
+    layers = [(seq[0].weight.detach(), seq[0].bias.detach()), (seq[2].weight.detach(), seq[2].bias.detach())]
+    base = torch.randn(B, T, din, device="cuda")
+    view = base.permute(1, 0, 2)
+    kept, rows, rstride, inner, outer = R._row_addressing(view)
+    assert kept.data_ptr() == base.data_ptr() and rows == B * T
+    if B > 1 and T > 1:
+        assert (rstride, inner, outer) == (T * din, B, din)
+    out_v, out_c = fused.mlp_rows(layers, view), fused.mlp_rows(layers, view.contiguous())
+    assert out_v.shape == (T, B, dout) and torch.equal(out_v, out_c)
+    G = torch.randn(T, B, dout, device="cuda")
+    gin_v, gp_v = fused.mlp_rows_backward(layers, view, G)
+    gin_c, gp_c = fused.mlp_rows_backward(layers, view.contiguous(), G)
+    assert torch.equal(gin_v, gin_c) and all(torch.equal(a, b) for a, b in zip(gp_v, gp_c))
+    sl = base[:, :, :din][:, ::2] if T > 1 else base       # a strided slice along T: still two-level (inner stride 2 * din)
+    assert torch.equal(fused.mlp_rows(layers, sl.permute(1, 0, 2)), fused.mlp_rows(layers, sl.permute(1, 0, 2).contiguous()))
+
+
 @pytest.mark.parametrize("events", [False, True])
 @pytest.mark.parametrize("method", ["euler", "rk4"])
 @pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("dae02", 16, 0), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])

@@ -85,6 +85,31 @@ def test_training_walk_backpropagates():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_integrate_ode_x_init_extension_equals_the_upstream_call(method):
+    """integrate_ODE(..., x_init=s) == integrate_ODE with x[0] = s (my_solvers.py:53-79), values and gradients: the gradient reaches the
+    start state through x_init alone, x itself gets none; x_init and teacher forcing exclude each other."""
+    torch.manual_seed(3)
+    f = models.DE_Func(4, (8, 8, 8), 3).double()
+    solver = {"euler": nd.Euler, "midpoint": nd.Midpoint, "rk4": nd.RK4}[method]()
+    Tn, B = 7, 5
+    t = (torch.arange(Tn, dtype=torch.float64) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
+    x, z = 0.1 * torch.randn(Tn, B, 3, dtype=torch.float64), 0.1 * torch.randn(Tn, B, 1, dtype=torch.float64)
+    s0 = 0.1 * torch.randn(B, 3, dtype=torch.float64)
+    a0 = torch.cat((s0, z[0]), dim=-1)
+    xa = x.clone(); xa[0] = s0
+    xa.requires_grad_(True)
+    ref = solver.integrate_ODE(x_func=f, t=t, x=xa, z=z, all_initial=a0)
+    ref.pow(2).sum().backward()
+    xb, sb = x.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+    got = solver.integrate_ODE(x_func=f, t=t, x=xb, z=z, all_initial=a0, x_init=sb)
+    assert torch.equal(got, ref)
+    got.pow(2).sum().backward()
+    assert xb.grad is None and torch.allclose(sb.grad, xa.grad[0], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        solver.integrate_ODE(x_func=f, t=t, x=xb, z=z, all_initial=a0, x_init=sb, input_true_x=True)
+
+
 def test_solver_public_surface():
     s = nd.RK4()
     for attr in ("order", "step_size", "interp", "grid_constructor", "enable_cal_time", "assert_time", "cal_time", "total_time"):
