@@ -6,7 +6,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from ._common import (KERNEL_ID, Layers, METHOD_ID, _aligned_ptr, _check_jump, _check_tb, _empty, _f32_dev, _jump, _mlp, _view, _workspace, event_table)
+from ._common import (KERNEL_ID, Layers, METHOD_ID, _aligned16, _aligned_ptr, _check_jump, _check_tb, _empty, _f32_dev, _jump, _mlp, _view, _workspace, event_table)
 
 _MFMA_CLASSES = ("MFMA integrators K1 / K2 cover `in -> H -> H -> H -> out` ELU-MLPs with H <= 128 (any x_dim <= 16 for the ODE, "
                  "x_dim <= 8 and z+v+i <= 8 for the DAE), and -- weights streamed from L2 -- the ODE up to H = 192 at any x_dim <= 16 and "
@@ -74,6 +74,8 @@ def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=
     a.flags = _lib.FLAG_INPUT_TRUE_X if input_true_x else 0
     a.x_dim, a.z_dim, a.T, a.B = xd, zd, T, B
     a.de = _mlp(de_layers, dev, "de", keep)
+    if save:      # the latent-wide saving forward (K3w) reads rows as float4: a misaligned view is copied once here instead of failing in
+        x, z, z_jump = _aligned16(x), _aligned16(z), _aligned16(z_jump)      # the middle of a training step (the backward does the same)
     a.t = _view(t, dev, "t", keep)
     a.x = _view(x, dev, "x", keep)
     a.z = _view(z, dev, "z", keep)
@@ -162,6 +164,8 @@ def dae_integrate(method: str, de_layers: Layers, ae_layers: Layers, x_init, t, 
     a.x_dim, a.z_dim, a.v_dim, a.i_dim, a.T, a.B = xd, zd, vd, idim, T, B
     a.de = _mlp(de_layers, dev, "de", keep)
     a.ae = _mlp(ae_layers, dev, "ae", keep)
+    if save:      # (as ode_integrate)
+        x_init, z, v, z_jump, v_jump = _aligned16(x_init), _aligned16(z), _aligned16(v), _aligned16(z_jump), _aligned16(v_jump)
     a.t = _view(t, dev, "t", keep)
     a.x = _view(x if input_true_x else None, dev, "x", keep)
     a.z = _view(z, dev, "z", keep)
