@@ -199,11 +199,23 @@ int32_t psnode_mlp_rows_f32(const psnode_mlp_f32* mlp, int64_t rows, const float
 /* Backward of psnode_mlp_rows_f32: grad_in[r,:] (optional) and the parameter gradients as ONE flat vector in nn.Linear order
  * [W1 (H x in), b1 (H), W2 (out x H), b2 (out)], from the saved input rows and grad_out.  What loss.backward() does for the
  * encoders/decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:267-275 through :74-88).
- * Deterministic (per-wave partials in `workspace`, summed in a fixed order). */
+ * Deterministic (per-wave partials in `workspace`, summed in a fixed order).  grad_params == NULL: the partials are left unreduced in
+ * `workspace` (psnode_mlp_rows_backward_parts(mlp, rows) * param_count floats suffice) for psnode_mlp_rows_reduce_f32 below. */
 size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32* mlp, int64_t rows);
 int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* mlp, int64_t rows, const float* in, int64_t in_row_stride,
                                      int64_t in_inner_rows, int64_t in_outer_stride, const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
                                      float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
+
+/* A module applied to SEVERAL row sets in one step (x_encoder over the grid rows and the first row, z_encoder over grid rows, first row and
+ * jump rows: neural_00_ODE_02_direct_encode.py:76-82; the decoder over the solution and the reconstruction, :86-88): call
+ * psnode_mlp_rows_backward_f32 once per set with grad_params == NULL and `workspace` = that set's slice of ONE partials buffer
+ * (psnode_mlp_rows_backward_parts(mlp, rows) vectors of the module's parameter count each, sets side by side), then
+ * psnode_mlp_rows_reduce_f32 over all n_parts vectors: the module's gradient, summed in a fixed order (deterministic).  Replaces one
+ * two-launch reduction per set and autograd's `add` per parameter tensor and extra use.  (ABI 9) */
+int64_t psnode_mlp_rows_backward_parts(const psnode_mlp_f32* mlp, int64_t rows);
+size_t psnode_mlp_rows_reduce_workspace_bytes(const psnode_mlp_f32* mlp, int64_t n_parts);   /* (n_parts + 32) * param_count floats */
+int32_t psnode_mlp_rows_reduce_f32(const psnode_mlp_f32* mlp, int64_t n_parts, void* workspace, size_t workspace_bytes, float* grad_params,
+                                   void* stream);
 
 /* Backward (discretise-then-optimise) pass through psnode_ode_integrate_f32: what loss.backward() computes when it
  * walks the unrolled T-step autograd graph of integrate_ODE (neural_00_ODE_01_no_encode.py:358-360 through

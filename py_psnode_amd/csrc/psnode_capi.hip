@@ -314,27 +314,45 @@ int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {
 //      The first np_a entries go to out_a, the remaining np_b to out_b (out_b may be null when np_b == 0).
 namespace psnode {
 namespace {
+// Two launches when there are many partial vectors (K8f: 1024 per-wave vectors of 1824 parameters = 44 us in one launch): the first sums
+// each of kPartSlices slices INTO the slice's own first vector (in place -- the partials are the caller's scratch, exactly nparts vectors
+// long, and a thread reads only its own column of its own slice), the second sums the slices' first vectors.
+constexpr int kPartSlices = 16;
+__device__ __forceinline__ float sum_parts(const float* __restrict__ part, const int np, const int pidx, const int q0, const int q1, const int qs) {
+    // eight independent chains: one chain is (q1 - q0) / qs DEPENDENT loads; the order of the sum stays fixed
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int q = q0;
+    for (; q + 8 * qs <= q1; q += 8 * qs) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += part[(size_t)(q + j * qs) * np + pidx];
+    }
+    for (int j = 0; q < q1; q += qs, ++j) acc[j] += part[(size_t)q * np + pidx];
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+__global__ void reduce_partials_slices_kernel(float* __restrict__ part, int np, int nparts, int per) {
+    const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= np) return;
+    const int q0 = blockIdx.y * per, q1 = q0 + per < nparts ? q0 + per : nparts;
+    if (q0 >= nparts) return;
+    part[(size_t)q0 * np + pidx] = sum_parts(part, np, pidx, q0, q1, 1);
+}
 __global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out_a, float* __restrict__ out_b, int np_a,
-                                       int np_b, int nparts) {
+                                       int np_b, int nparts, int stride) {
     const int pidx = blockIdx.x * blockDim.x + threadIdx.x, np = np_a + np_b;
     if (pidx >= np) return;
-    // eight independent chains: one chain is nparts DEPENDENT loads (K8f: 1024 x a memory round trip = 240 us for 1824 parameters on
-    // 8 workgroups); the order of the sum stays fixed
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int q = 0;
-    for (; q + 8 <= nparts; q += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += part[(size_t)(q + j) * np + pidx];
-    }
-    for (; q < nparts; ++q) acc[q & 7] += part[(size_t)q * np + pidx];
-    const float total = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const float total = sum_parts(part, np, pidx, 0, nparts, stride);
     if (pidx < np_a) out_a[pidx] = total;
     else out_b[pidx - np_a] = total;
 }
 }  // namespace
 hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s) {
     const int np = np_a + np_b;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np + 63) / 64), dim3(64), 0, s, part, out_a, out_b, np_a, np_b, nparts);   // 64-wide: more CUs
+    int stride = 1;
+    if (nparts >= 8 * kPartSlices) {       // many vectors: sum kPartSlices slices in place first (the partials are scratch: nothing reads them again)
+        stride = (nparts + kPartSlices - 1) / kPartSlices;
+        hipLaunchKernelGGL(reduce_partials_slices_kernel, dim3((np + 63) / 64, kPartSlices), dim3(64), 0, s, const_cast<float*>(part), np, nparts, stride);
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np + 63) / 64), dim3(64), 0, s, part, out_a, out_b, np_a, np_b, nparts, stride);   // 64-wide: more CUs
     return hipGetLastError();
 }
 }  // namespace psnode

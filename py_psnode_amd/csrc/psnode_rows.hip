@@ -423,16 +423,23 @@ __global__ void rows_reduce_stage1(const float* __restrict__ part, float* __rest
     const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (pidx >= np) return;
     const int per = (nparts + kRedSlices - 1) / kRedSlices, q0 = blockIdx.y * per, q1 = q0 + per < nparts ? q0 + per : nparts;
-    float acc = 0.0f;
-    for (int q = q0; q < q1; ++q) acc += part[(size_t)q * np + pidx];
-    mid[(size_t)blockIdx.y * np + pidx] = acc;
+    // eight independent chains (one chain = `per` DEPENDENT memory round trips: 31 us for 72 partials per slice); the order stays fixed
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += part[(size_t)(q + j) * np + pidx];
+    }
+    for (int j = 0; q < q1; ++q, ++j) acc[j] += part[(size_t)q * np + pidx];
+    mid[(size_t)blockIdx.y * np + pidx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 __global__ void rows_reduce_stage2(const float* __restrict__ mid, float* __restrict__ out, int np) {
     const int pidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (pidx >= np) return;
-    float acc = 0.0f;
-    for (int q = 0; q < kRedSlices; ++q) acc += mid[(size_t)q * np + pidx];
-    out[pidx] = acc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kRedSlices; ++q) acc[q & 7] += mid[(size_t)q * np + pidx];
+    out[pidx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 template <int HT, int OT>
@@ -498,12 +505,13 @@ extern "C" size_t psnode_mlp_rows_backward_workspace_bytes(const psnode_mlp_f32*
 extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t rows, const float* in, int64_t in_row_stride,
                                                 int64_t in_inner_rows, int64_t in_outer_stride, const float* grad_out, int64_t gout_row_stride, float* grad_in, int64_t gin_row_stride,
                                                 float* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!m || !in || !grad_out || !grad_params) return PSNODE_ERR_NULL;
+    if (!m || !in || !grad_out) return PSNODE_ERR_NULL;      // grad_params == NULL: leave the per-wave partials in `workspace`, unreduced
     if (!psnode_mlp_rows_supported(m)) return PSNODE_ERR_UNSUPPORTED;
     if (!m->weight[0] || !m->weight[1] || !m->bias[0]) return PSNODE_ERR_NULL;
     if (rows < 0 || in_row_stride < m->in_dim || gout_row_stride < m->out_dim[1] || (grad_in && gin_row_stride < m->in_dim)) return PSNODE_ERR_DIMS;
     if (in_inner_rows < 0 || in_inner_rows > 0xffffffffll || (in_inner_rows > 0 && (rows > 0xffffffffll || in_outer_stride < 0))) return PSNODE_ERR_DIMS;
-    const size_t need = psnode_mlp_rows_backward_workspace_bytes(m, rows);
+    const size_t need = grad_params ? psnode_mlp_rows_backward_workspace_bytes(m, rows)
+                                    : (size_t)rows_bwd_blocks(rows) * 4 * rows_np(m) * sizeof(float);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PSNODE_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int np = rows_np(m);
@@ -516,9 +524,36 @@ extern "C" int32_t psnode_mlp_rows_backward_f32(const psnode_mlp_f32* m, int64_t
     else if (OT == 1) launch_rows_bwd<4, 1>(NM, grid, block, s, a);
     else launch_rows_bwd<4, 4>(NM, grid, block, s, a);
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
+    if (!grad_params) return PSNODE_OK;
     float* mid = static_cast<float*>(workspace) + (size_t)blocks * 4 * np;
     hipLaunchKernelGGL(rows_reduce_stage1, dim3((np + 255) / 256, kRedSlices), dim3(256), 0, s, static_cast<const float*>(workspace), mid, np,
                        (int)(blocks * 4));
+    hipLaunchKernelGGL(rows_reduce_stage2, dim3((np + 255) / 256), dim3(256), 0, s, mid, grad_params, np);
+    return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
+}
+
+// One module applied to several row sets in a step (x_encoder over the grid rows AND the first row, z_encoder over grid rows, first row and
+// jump rows: neural_00_ODE_02_direct_encode.py:76-82): every set's backward leaves its per-wave partials side by side in ONE buffer
+// (psnode_mlp_rows_backward_f32 with grad_params == NULL), and one fixed-order reduction over all of them forms the module's gradient --
+// instead of one two-launch reduction per set and an autograd `add` per parameter tensor and extra use.
+extern "C" int64_t psnode_mlp_rows_backward_parts(const psnode_mlp_f32* m, int64_t rows) {
+    if (!m || !psnode_mlp_rows_supported(m) || rows < 0) return 0;
+    return rows_bwd_blocks(rows) * 4;
+}
+extern "C" size_t psnode_mlp_rows_reduce_workspace_bytes(const psnode_mlp_f32* m, int64_t n_parts) {
+    if (!m || !psnode_mlp_rows_supported(m) || n_parts < 0) return 0;
+    return ((size_t)n_parts + kRedSlices) * rows_np(m) * sizeof(float);
+}
+extern "C" int32_t psnode_mlp_rows_reduce_f32(const psnode_mlp_f32* m, int64_t n_parts, void* workspace, size_t workspace_bytes,
+                                              float* grad_params, void* stream) {
+    if (!m || !workspace || !grad_params) return PSNODE_ERR_NULL;
+    if (!psnode_mlp_rows_supported(m)) return PSNODE_ERR_UNSUPPORTED;
+    if (n_parts < 1 || n_parts > 0x7fffffffll) return PSNODE_ERR_DIMS;
+    if (workspace_bytes < psnode_mlp_rows_reduce_workspace_bytes(m, n_parts) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PSNODE_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = rows_np(m);
+    float* mid = static_cast<float*>(workspace) + (size_t)n_parts * np;
+    hipLaunchKernelGGL(rows_reduce_stage1, dim3((np + 255) / 256, kRedSlices), dim3(256), 0, s, static_cast<const float*>(workspace), mid, np, (int)n_parts);
     hipLaunchKernelGGL(rows_reduce_stage2, dim3((np + 255) / 256), dim3(256), 0, s, mid, grad_params, np);
     return hipGetLastError() == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }

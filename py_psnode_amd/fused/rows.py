@@ -91,6 +91,73 @@ class _RowsMlp(torch.autograd.Function):
         return (gin, *gp)
 
 
+def mlp_rows_backward_multi(layers: Layers, inps, grad_outs, need_grad_in):
+    """Backward of ONE module applied to several row sets (`inps[k]`, `grad_outs[k]`; a None grad_out = that output was unused): every
+    set's kernel leaves its per-wave partials side by side in one buffer, one fixed-order reduction forms the module's gradient
+    (psnode_mlp_rows_reduce_f32) -- no reduction per set, no autograd `add` per parameter tensor and extra use.
+    Returns ([grad_in or None per set], [dW1, db1, dW2, db2])."""
+    lib = _lib.load()
+    live = [k for k, g in enumerate(grad_outs) if g is not None]
+    dev = inps[0].device
+    keep: list = []
+    m = _mlp(layers, dev, "mlp", keep)
+    if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
+        raise ValueError("mlp_rows_backward_multi: unsupported MLP shape")
+    npar = sum(w.numel() + b.numel() for w, b in layers)
+    gins = [None] * len(inps)
+    with torch.cuda.device(dev):
+        gp = _empty(npar, dtype=torch.float32, device=dev)
+        if not live:
+            return gins, _split_grads(gp.zero_(), layers)
+        sets = []
+        for k in live:
+            x2, rows, rstride, inner, outer = _row_addressing(_f32_dev(inps[k], dev, "input"))
+            g2 = _f32_dev(grad_outs[k], dev, "grad_out").reshape(-1, grad_outs[k].shape[-1])
+            if g2.stride(-1) != 1:
+                g2 = g2.contiguous()
+            if g2.shape[0] != rows or g2.shape[1] != layers[-1][0].shape[0]:
+                raise ValueError(f"mlp_rows_backward_multi: grad_out {tuple(grad_outs[k].shape)} does not match input {tuple(inps[k].shape)}")
+            sets.append((k, x2, rows, rstride, inner, outer, g2, int(lib.psnode_mlp_rows_backward_parts(ctypes.byref(m), rows))))
+        n_parts = sum(s_[-1] for s_ in sets)
+        nbytes = lib.psnode_mlp_rows_reduce_workspace_bytes(ctypes.byref(m), n_parts)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        off = 0
+        for k, x2, rows, rstride, inner, outer, g2, parts in sets:
+            gin = _empty(tuple(inps[k].shape), dtype=torch.float32, device=dev) if need_grad_in[k] else None
+            gins[k] = gin
+            _lib.check(lib.psnode_mlp_rows_backward_f32(ctypes.byref(m), rows, x2.data_ptr(), rstride, inner, outer, g2.data_ptr(), g2.stride(0),
+                                                        gin.data_ptr() if gin is not None else None, inps[k].shape[-1], None, wp + off,
+                                                        parts * npar * 4, st), "psnode_mlp_rows_backward_f32")
+            off += parts * npar * 4
+        _lib.check(lib.psnode_mlp_rows_reduce_f32(ctypes.byref(m), n_parts, wp, wn, gp.data_ptr(), st), "psnode_mlp_rows_reduce_f32")
+    return gins, _split_grads(gp, layers)
+
+
+class _RowsMlpMulti(torch.autograd.Function):
+    """One module over several row sets in one autograd node (see mlp_rows_backward_multi)."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2, *inps):
+        ctx.save_for_backward(w1, b1, w2, b2, *inps)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None (its set is skipped), not as a tensor of zeros
+        return tuple(mlp_rows([(w1, b1), (w2, b2)], a) for a in inps)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        w1, b1, w2, b2, *inps = ctx.saved_tensors
+        gins, gp = mlp_rows_backward_multi([(w1.detach(), b1.detach()), (w2.detach(), b2.detach())], [a.detach() for a in inps], grad_outs,
+                                           ctx.needs_input_grad[4:])
+        return (*gp, *gins)
+
+
+def mlp_rows_autograd_multi(seq, *inps):
+    """`tuple(seq(a) for a in inps)` for a recognised Linear-ELU-Linear on the row kernels, ONE autograd node for all of them."""
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    return _RowsMlpMulti.apply(lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, *inps)
+
+
 def mlp_rows_autograd(seq, inp: torch.Tensor) -> torch.Tensor:
     """`seq(inp)` for a recognised Linear-ELU-Linear on the row kernels, differentiable w.r.t. the input and the parameters."""
     lin = [m for m in seq if isinstance(m, nn.Linear)]

@@ -51,6 +51,18 @@ def _rows(seq, inp):
     return fused.mlp_rows_autograd(seq, inp) if needs_grad else fused.mlp_rows(layers, inp)
 
 
+def _rows_multi(seq, *inps):
+    """`tuple(seq(a) for a in inps)` -- ONE autograd node on the row kernels when every call is fusable and something needs a gradient
+    (the module's gradient is then one fixed-order reduction over all the sets' partials instead of a reduction per set and an autograd
+    `add` per parameter tensor and extra use); otherwise call by call (`_rows`)."""
+    from . import fused
+    if len(inps) > 1 and torch.is_grad_enabled() and not (fused._overrides_forward_hooks(seq) or any(fused._overrides_forward_hooks(m) for m in seq)):
+        if all(fused.rows_layers_of(seq, a, allow_grad=True) is not None for a in inps) and \
+                (any(a.requires_grad for a in inps) or any(p.requires_grad for p in seq.parameters())):
+            return fused.mlp_rows_autograd_multi(seq, *inps)
+    return tuple(_rows(seq, a) for a in inps)
+
+
 class RowsSequential(nn.Sequential):
     """An `nn.Sequential(Linear, ELU, Linear)` -- same children, same parameters, same state-dict keys -- whose forward runs on the
     fused HIP row kernels (psnode_mlp_rows_f32 / _backward_f32) whenever the call is fusable (fp32 HIP tensor, hidden 16 / 64), and
@@ -198,17 +210,18 @@ class ODE_Model(nn.Module):
             # big tensor, whose gradient would otherwise be a zero-filled [T,B,H] tensor added to the integrator's.  Row-wise functions:
             # the values are the ones of the B-major evaluation.
             from .neural_dae.my_solvers import FixedGridODESolver
-            Xh, Zh = _rows(self.x_encoder, _tm(x)), _rows(self.z_encoder, _tm(z))
-            x0h = _rows(self.x_encoder, x[:, 0])
-            a0 = torch.cat((x0h, _rows(self.z_encoder, z[:, 0])), dim=-1)
-            self.event.set_event(t=event_t, z=_rows(self.z_encoder, z_jump))
+            Xh, x0h = _rows_multi(self.x_encoder, _tm(x), x[:, 0])
+            Zh, z0h, zjh = _rows_multi(self.z_encoder, _tm(z), z[:, 0], z_jump)
+            a0 = torch.cat((x0h, z0h), dim=-1)
+            self.event.set_event(t=event_t, z=zjh)
             # this package's solvers take the start state on its own (x_init): Xh then reaches the integrator only for its shape, and its
             # gradient is the decoder's alone instead of that plus a [T,B,H] tensor of zeros with one row set
             own = isinstance(self.solver, FixedGridODESolver)
             Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh.detach() if own else Xh, z=Zh, all_initial=a0,
                                                event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
                                                **({"x_init": x0h} if own else {}))
-            return _tm(_rows(self.x_decoder, Xh_sol)), _tm(_rows(self.x_decoder, Xh))
+            x_pred, x_re = _rows_multi(self.x_decoder, Xh_sol, Xh)
+            return _tm(x_pred), _tm(x_re)
         Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view
         Xh = _tm(Xh_bt)
         Zh = _tm(_rows(self.z_encoder, z))
@@ -306,16 +319,19 @@ class DAE_Model(nn.Module):
         enc_z = (lambda a: a) if self.z_encoder is None else (lambda a: _rows(self.z_encoder, a))
         Xh0 = _rows(self.x_encoder, x0)
         if _time_major_route(x):      # HIP route: time-major latent tensors, first row re-encoded for all_initial (see ODE_Model.forward)
-            Xh, Ih = _rows(self.x_encoder, _tm(x)), _rows(self.i_encoder, _tm(i))
-            Zh, Vh = enc_z(_tm(z)), _rows(self.v_encoder, _tm(v))
-            a0 = torch.cat((Xh0, enc_z(z[:, 0]), _rows(self.v_encoder, v[:, 0]), _rows(self.i_encoder, i[:, 0])), dim=-1)
-            self.event.set_event(t=event_t, z=enc_z(z_jump), v=_rows(self.v_encoder, v_jump))
+            Xh = _rows(self.x_encoder, _tm(x))
+            Ih, i0h = _rows_multi(self.i_encoder, _tm(i), i[:, 0])
+            Vh, v0h, vjh = _rows_multi(self.v_encoder, _tm(v), v[:, 0], v_jump)
+            Zh, z0h, zjh = (_tm(z), z[:, 0], z_jump) if self.z_encoder is None else _rows_multi(self.z_encoder, _tm(z), z[:, 0], z_jump)
+            a0 = torch.cat((Xh0, z0h, v0h, i0h), dim=-1)
+            self.event.set_event(t=event_t, z=zjh, v=vjh)
             Xh_sol, Ih_sol = self.solver.integrate_DAE(x_init=Xh0, x_func=self.de_func, i_func=self.ae_func, t=_tm(t), x=Xh,
                                                        z=Zh, v=Vh, i=Ih, all_initial=a0, event_fn=self.event.event_fn,
                                                        jump_change_fn=self.event.jump_change_fn)
-            x_pred = _rows(self.x_decoder, Xh_sol)
+            x_pred, x_re = _rows_multi(self.x_decoder, Xh_sol, Xh)
+            i_pred, i_re = _rows_multi(self.i_decoder, Ih_sol, Ih)
             x_pred[0] = x0                                         # neural_01_DAE_02_direct_encode.py:150
-            return _tm(x_pred), _tm(_rows(self.i_decoder, Ih_sol)), _tm(_rows(self.x_decoder, Xh)), _tm(_rows(self.i_decoder, Ih))
+            return _tm(x_pred), _tm(i_pred), _tm(x_re), _tm(i_re)
         Xh_bt, Ih_bt = _rows(self.x_encoder, x), _rows(self.i_encoder, i)
         Xh, Zh, Vh, Ih = _tm(Xh_bt), _tm(enc_z(z)), _tm(_rows(self.v_encoder, v)), _tm(Ih_bt)
         a0 = torch.cat((Xh0, Zh[0], Vh[0], Ih[0]), dim=-1)

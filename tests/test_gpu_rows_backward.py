@@ -94,6 +94,49 @@ def test_rows_read_a_batch_major_tensor_as_time_major_rows_in_place(din, H, dout
     assert torch.equal(fused.mlp_rows(layers, sl.permute(1, 0, 2)), fused.mlp_rows(layers, sl.permute(1, 0, 2).contiguous()))
 
 
+@pytest.mark.parametrize("din,H,dout", [(8, 16, 16), (2, 16, 16), (16, 16, 8), (8, 64, 64), (64, 64, 2)])
+def test_one_module_over_several_row_sets_is_one_autograd_node(din, H, dout):
+    """models._rows_multi: x_encoder over the grid rows AND the first row (z_encoder: and the jump rows; the decoder: solution and
+    reconstruction) as ONE autograd node -- every set's backward leaves its partials in one buffer, psnode_mlp_rows_reduce_f32 sums them in a
+    fixed order.  Equals the per-set route (sum of the per-set parameter gradients, the same input gradients), skips an unused output, is
+    deterministic, and matches fp64 autograd."""
+    from py_psnode_amd import fused
+    torch.manual_seed(din + dout)
+    seq = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout)).cuda()
+    B, T = 37, 11
+    big = torch.randn(B, T, din, device="cuda")
+    a = big.permute(1, 0, 2).requires_grad_(True) if din == 64 else big.permute(1, 0, 2)     # a strided time-major view, a [B, din] slice, a [B, 2, din] tensor
+    b, c = big[:, 0], torch.randn(B, 2, din, device="cuda", requires_grad=True)
+    Ga, Gb, Gc = torch.randn(T, B, dout, device="cuda"), torch.randn(B, dout, device="cuda"), torch.randn(B, 2, dout, device="cuda")
+
+    def run(multi, use_b=True):
+        seq.zero_grad(set_to_none=True)
+        if c.grad is not None:
+            c.grad = None
+        outs = fused.mlp_rows_autograd_multi(seq, a, b, c) if multi else tuple(fused.mlp_rows_autograd(seq, q) for q in (a, b, c))
+        loss = (outs[0] * Ga).sum() + (outs[2] * Gc).sum() + ((outs[1] * Gb).sum() if use_b else 0.0)
+        loss.backward()
+        return [o.detach().clone() for o in outs], [p.grad.clone() for p in seq.parameters()], c.grad.clone()
+
+    o_m, g_m, gc_m = run(True)
+    o_s, g_s, gc_s = run(False)
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(o_m, o_s)) and torch.equal(gc_m, gc_s)
+    for k, (x_, y_) in enumerate(zip(g_m, g_s)):
+        _close(x_, y_, 2e-6, f"param {k}: one reduction vs per-set reductions + add")
+    o_m2, g_m2, _ = run(True)
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(g_m, g_m2)), "deterministic"
+    _, g_nb, _ = run(True, use_b=False)          # an unused output: its set is skipped (no zeros are materialised)
+    _, g_nb_s, _ = run(False, use_b=False)
+    for k, (x_, y_) in enumerate(zip(g_nb, g_nb_s)):
+        _close(x_, y_, 2e-6, f"param {k} with an unused output")
+    ref = nn.Sequential(nn.Linear(din, H), nn.ELU(), nn.Linear(H, dout)).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in seq.state_dict().items()})
+    ((ref(a.detach().double().cpu()) * Ga.double().cpu()).sum() + (ref(b.double().cpu()) * Gb.double().cpu()).sum()
+     + (ref(c.detach().double().cpu()) * Gc.double().cpu()).sum()).backward()
+    for (n, p), q in zip(seq.named_parameters(), g_m):
+        _close(q, dict(ref.named_parameters())[n].grad, 2e-5, n)
+
+
 @pytest.mark.parametrize("events", [False, True])
 @pytest.mark.parametrize("method", ["euler", "rk4"])
 @pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("dae02", 16, 0), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])
