@@ -292,9 +292,19 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
     const float* zrun = zbase + zst;        // row k + 1
     const float* vrun = vbase + vst;
 
+    // vmcnt counts in order and a step issues its loads IN FRONT of its stores (x row: one 8-byte store at even x_dim; i row: one store -- both
+    // from at least lane 0 of every wave), so "the loads have arrived" is vmcnt(2) and the stores' acknowledgement stays out of the step.
+    // Measured, same box (profiles/r05u_dae_tile_vs_wave.txt against r05n_...): RK4 4.41 -> 4.24 ms at dae01, but Euler 2.05 -> 2.09 and
+    // Midpoint 2.74 -> 2.82 (and requesting the AE head's row a step earlier, with one wait per step, lost at all three: r05v_...) -- so RK4
+    // alone takes it; the others, and odd x_dim (a second x store that not every wave issues), wait for everything.
+    auto wait_loads = [&]() {
+        if (METHOD == PSNODE_RK4_38 && pair_ok) __builtin_amdgcn_s_waitcnt(0x0F72);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // the first step's inputs (no store is in flight yet for vmcnt(2) to skip)
     auto step = [&](const int k, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this step's inputs were requested a whole step ago
+        wait_loads();                           // this step's inputs were requested a whole step ago
         const float h_ = t_nxt - t_cur;
         t_cur = t_nxt;
         const int ev_now = ev_cur;
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
             X23 = s23 + (k1b + 3.0f * (k2b + k3b) + k4b) * h_ * 0.125f;
         }
         // i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]): un-jumped inputs of the right grid point (my_solvers.py:121)
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // (requested at the top of this step)
+        wait_loads();                           // (requested at the top of this step, in front of its two stores)
         icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : e_ae);
     };
 #pragma unroll 1
