@@ -88,7 +88,8 @@ struct EluS {
     float knee, neg_t0;
     __device__ __forceinline__ float operator()(const float x) const {
 #ifndef PSNODE_ELU_EXPM1
-        return fmaxf(x, __builtin_amdgcn_exp2f(fminf(x, 0.0f) * kLog2e) - 1.0f);
+        // (round 5: the clamp of the negative side rides on v_exp_f32's output modifier -- bit-identical, psnode_common.h: elu_pair)
+        return fmaxf(x, __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * kLog2e), 0.0f, 1.0f) - 1.0f);
 #endif
         const float xc = __builtin_amdgcn_fmed3f(x, knee, 0.0f), xe = fminf(x, knee), xp = fmaxf(x, 0.0f);
         const float u = __builtin_amdgcn_exp2f(xe * kLog2e) + neg_t0;
@@ -143,34 +144,72 @@ __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const Laten
     if constexpr (ENC) {
         if (wv >= 4) {
             // ---------------- reconstruction waves: x_re[t] = x_decoder(x_encoder(x[t]))  (neural_00_ODE_02_direct_encode.py:87)
+            // Round 5: on MFMA, K3b's way (psnode_rows.hip) -- a tile is 16 grid points of ONE trajectory, the hidden / latent tiles stay in
+            // registers through all four layers (D rows of one layer are the B operands of the next: no exchange), 14 MFMAs + 2 ELU quads per
+            // 16 rows.  The DPP form of rounds 2-4 (a lane per (trajectory, unit), 4 rows per 76 v_fmac_f32_dpp) cost ~110 issue cycles per
+            // row on the SIMD the latency-bound integration wave shares; this is ~35, and the waves are done after a tenth of the launch.
             if (!a.xre) return;
-            float w1e[16], w2e[16], w1d[16], w2d[16];
-            load_row(w1e, a.xenc.w1, a.xd, u, 0, a.xd);
-            load_row(w2e, a.xenc.w2, LH, u, 0, LH);
-            load_row(w1d, a.xdec.w1, LH, u, 0, LH);
-            load_row(w2d, a.xdec.w2, LH, u, 0, LH, u < a.xd);
-            const float b1e = a.xenc.b1[u], b2e = a.xenc.b2[u], b1d = a.xdec.b1[u], b2d = u < a.xd ? a.xdec.b2[u] : 0.0f;
-            const int xq = (a.xd + 3) >> 2;
-            const float* xp = a.x.p + b * a.x.sb + (u < a.xd ? u : 0);
-            float* op = a.xre + b * a.xre_sb + u;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            auto mf = [](const float wa, const float vb, const f4 c) -> f4 { return __builtin_amdgcn_mfma_f32_16x16x4f32(wa, vb, c, 0, 0, 0); };
+            const int g = lane >> 4, j = lane & 15;      // lane group g = k-slot of the MFMAs, j = the tile's row (B, D) / the weight's row (A)
+            const int xd = a.xd, nm = (xd + 3) >> 2;     // first-layer MFMAs of the encoder: lane group g supplies input columns nm g + m
+            float w1e[4], w2e[4], w1d[4], w2d[4];
+            f4 b1e, b2e, b1d, b2d;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int c = nm * g + m;
+                w1e[m] = (m < nm && c < xd) ? a.xenc.w1[j * xd + c] : 0.0f;
+                w2e[m] = a.xenc.w2[j * LH + 4 * g + m];
+                w1d[m] = a.xdec.w1[j * LH + 4 * g + m];
+                w2d[m] = j < xd ? a.xdec.w2[j * LH + 4 * g + m] : 0.0f;
+                b1e[m] = a.xenc.b1[4 * g + m];
+                b2e[m] = a.xenc.b2[4 * g + m];
+                b1d[m] = a.xdec.b1[4 * g + m];
+                b2d[m] = 4 * g + m < xd ? a.xdec.b2[4 * g + m] : 0.0f;
+            }
+            const long long bw = (long long)blockIdx.x * DTB + (wv & 3) * 4;      // this wave's four trajectories
+            const int ntraj = a.B - bw >= 4 ? 4 : (int)(a.B - bw);
+            if (ntraj <= 0) return;
             const long long xst = a.x.st;
-            float xq_[PF];     // rows PF ahead in a register ring (see the integration loop)
+            auto load_tile = [&](const int q, const long long t0, float (&v)[4]) {          // rows t0 .. t0 + 15 of trajectory bw + q
+                const long long r = t0 + j, rc = r < nT ? r : nT - 1;
+                const float* src = a.x.p + (bw + q) * a.x.sb + rc * xst + nm * g;
 #pragma unroll
-            for (int j = 0; j < PF; ++j) xq_[j] = (u < a.xd && j < nT) ? xp[j * xst] : 0.0f;
-            for (long long k = 0; k < nT; k += PF) {
+                for (int m = 0; m < 4; ++m) v[m] = (m < nm && nm * g + m < xd) ? src[m] : 0.0f;
+            };
+            float vn[4];
+            load_tile(0, 0, vn);
+            int q = 0, qn = 0;              // (q, t0): the tile in hand; (qn, tn): the one requested ahead
+            long long t0 = 0, tn = 0;
+            for (;;) {
+                float v[4];
 #pragma unroll
-                for (int j = 0; j < PF; ++j) {
-                    const long long r = k + j;
-                    if (r < nT) {
-                        const float xcur = xq_[j];
-                        if (r + PF < nT) xq_[j] = u < a.xd ? xp[(r + PF) * xst] : 0.0f;
-                        const float he = elu(dot_in(b1e, xcur, w1e, xq));
-                        const float xh = dot16(b2e, he, w2e);
-                        const float hd = elu(dot16(b1d, xh, w1d));
-                        const float o = dot16(b2d, hd, w2d);
-                        if (valid && u < a.xd) op[r * a.xre_st] = o;
-                    }
+                for (int m = 0; m < 4; ++m) v[m] = vn[m];
+                tn += 16;
+                if (tn >= nT) { tn = 0; ++qn; }
+                const bool more = qn < ntraj;
+                if (more) load_tile(qn, tn, vn);                     // one tile ahead
+                f4 acc = b1e;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (m < nm) acc = mf(w1e[m], v[m], acc);
+                const f4 he = elu_quad(acc);
+                f4 pA = mf(w2e[0], he[0], b2e), pB = mf(w2e[1], he[1], f4{0.f, 0.f, 0.f, 0.f});
+                pA = mf(w2e[2], he[2], pA); pB = mf(w2e[3], he[3], pB);
+                const f4 xh = pA + pB;                               // the latent rows: unit 4g + r of row j
+                pA = mf(w1d[0], xh[0], b1d); pB = mf(w1d[1], xh[1], f4{0.f, 0.f, 0.f, 0.f});
+                pA = mf(w1d[2], xh[2], pA); pB = mf(w1d[3], xh[3], pB);
+                const f4 hd = elu_quad(pA + pB);
+                pA = mf(w2d[0], hd[0], b2d); pB = mf(w2d[1], hd[1], f4{0.f, 0.f, 0.f, 0.f});
+                pA = mf(w2d[2], hd[2], pA); pB = mf(w2d[3], hd[3], pB);
+                const f4 o = pA + pB;
+                const long long r = t0 + j;
+                if (r < nT) {
+                    float* dst = a.xre + (bw + q) * a.xre_sb + r * a.xre_st + 4 * g;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) if (4 * g + m < xd) dst[m] = o[m];
                 }
+                if (!more) break;
+                q = qn; t0 = tn;
             }
             return;
         }
@@ -288,7 +327,68 @@ __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const Laten
         tq[j] = live ? tp[(j + 1) * tst] : 0.0f;
         zring[j] = live ? load_z(j, __builtin_amdgcn_readlane(evb, j)) : 0.0f;
     }
-    for (long long k = 0; k + 1 < nT; k += PF) {
+    // FAST main loop (round 5, K1x's lesson: with one latency-bound wave per SIMD every scalar instruction and branch of the per-step bookkeeping is
+    // wall time -- 64-bit end-of-grid tests on the VALU, the event-table block test, the divergent `lane carries a z column` load, 64-bit
+    // address products were ~20 branches and ~50 SALU instructions per step): whole chunks of PF steps whose prefetches stay inside the grid,
+    // no event in the table (scanned once), 32-bit counters, uniform running row bases + one 32-bit lane offset per array.  The general loop
+    // below finishes the grid from wherever this one stops (same ring invariant: slot j holds the inputs of step k + j).
+    long long k = 0;
+    {
+        const int nTi = (int)nT;
+        const unsigned long long span_t = (unsigned long long)a.B * (unsigned long long)(a.t.sb < 0 ? 0 : a.t.sb) * 4ull;
+        const unsigned long long span_z = (unsigned long long)a.B * (unsigned long long)(a.z.sb < 0 ? 0 : a.z.sb) * 4ull + 64ull;
+        const unsigned long long span_o = (unsigned long long)a.B * (ENC ? a.xd : LH) * 4ull;
+        bool fast = nT < (1ll << 31) && !a.xh_out && a.t.sb >= 0 && a.z.sb >= 0 && span_t < (1ull << 32) && span_z < (1ull << 32) && span_o < (1ull << 32);
+        if (fast && a.ev) {
+            int any = -1;
+            for (int i = lane; i + 1 < nTi; i += 64) any = max(any, a.ev[i]);
+            fast = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
+        }
+        if (fast && 2 * PF < nTi) {
+            auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };
+            const unsigned toff = (unsigned)(b * a.t.sb) * 4u;
+            const unsigned zoff = (unsigned)(b * a.z.sb + (u < zlanes ? u : 0)) * 4u;     // lanes without a column read column 0 (finite) against a zero weight
+            const int od = ENC ? a.xd : LH;
+            const unsigned ooff = (unsigned)(b * od + (u < od ? u : 0)) * 4u;
+            const bool st_ok = valid && u < od;
+            const float* trun = a.t.p + (PF + 1) * tst;          // step 0 refills its slot with t[PF + 1] / the z row of step PF
+            const float* zrun = a.z.p + PF * zst;
+            float* orun = a.xo + a.B * od;                       // step 0 writes row 1
+            const long long ostep = a.B * od;
+            int ki = 0;
+            for (; ki + 2 * PF < nTi; ki += PF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const float h_ = tq[j] - t_cur;
+                    t_cur = tq[j];
+                    const float zraw = zring[j];
+                    tq[j] = ldg<float>(as_g(trun), toff);
+                    zring[j] = ldg<float>(as_g(zrun), zoff);
+                    trun += tst;
+                    zrun += zst;
+                    const float cz = dot16(c0, encode_z(zraw), fz);
+                    const float k1 = rhs(x, cz);
+                    if constexpr (METHOD == PSNODE_EULER) {
+                        x = x + h_ * k1;
+                    } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+                        const float k2 = rhs(x + k1 * (0.5f * h_), cz);
+                        x = x + h_ * k2;
+                    } else {
+                        const float k2 = rhs(x + h_ * k1 * kOneThird, cz);
+                        const float k3 = rhs(x + h_ * (k2 - k1 * kOneThird), cz);
+                        const float k4 = rhs(x + h_ * (k1 - k2 + k3), cz);
+                        x = x + (k1 + 3.0f * (k2 + k3) + k4) * h_ * 0.125f;
+                    }
+                    float o = x;
+                    if constexpr (ENC) o = dot16(b2d, elu(dot16(b1d, x, w1d)), w2d);
+                    if (st_ok) stg<float>((gptr<float>)(uintptr_t)orun, ooff, o);
+                    orun += ostep;
+                }
+            }
+            k = ki;
+        }
+    }
+    for (; k + 1 < nT; k += PF) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const long long st = k + j;
