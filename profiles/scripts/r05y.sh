@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call y: K3f -- reconstruction waves on MFMA tiles, clamp-form ELU, FAST main loop: the ODE_02 / latent tests, config 3 forward time
+# round 5, call y: K3f two-role form (row-wise MLPs on the partner wave, MFMA tiles, LDS rings): the ODE_02 / latent tests, config 3 forward time
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 python -m pytest tests/test_gpu_encoded.py tests/test_gpu_parity.py tests/test_grad_goldens.py tests/test_gpu_example.py -m gpu -q --tb=short -k "ode02 or encoded or g4 or model or example or latent or event" 2>&1 | tail -12 > $O/r05y_pytest.txt
 for r in 1 2; do for m in rk4 euler midpoint; do

@@ -129,6 +129,263 @@ __device__ __forceinline__ void load_row(float (&w)[16], const float* m, const i
     for (int j = 0; j < 16; ++j) w[j] = (row_ok && j < count) ? m[(long long)u * ld + c0 + j] : 0.0f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K3f, two-role form of the fused model (round 5): the plain inference call -- no event in the table, no latent trajectory wanted, 32-bit row
+// offsets.  The integration wave keeps ONLY the latent stages; everything that is a row-wise MLP moves to its partner wave (wave w + 4, same
+// SIMD) and onto MFMA tiles of 16 grid points (psnode_rows.hip's plan: D rows of one layer are the B operands of the next):
+//   ahead of the chain   cz'[r] = F_z . z_encoder(z[r-1])          (zd -> H -> H, the two linear maps folded: 1 + 4 MFMAs per 16 rows and trajectory)
+//   behind it            x_pred[r] = x_decoder(Xh_solution[r])     (H -> H -> xd: 4 + 4)
+//   beside it            x_re[r] = x_decoder(x_encoder(x[r]))      (2 + 4 + 4, folded likewise)
+// handed over through two LDS rings of 2 x 16 rows per chain wave (cz' in, latent state out), ONE workgroup barrier per 16 steps.  Per step the
+// chain wave is left with  cz = c0 + cz'[r] (one ds_read),  S x (dot16, ELU, dot16),  the RK update and one ds_write: 185 instead of 250 VALU
+// instructions at RK4, 60 instead of 125 at Euler -- the encoder of z, the decoder and their ELUs were 30 + 43 dependent VALU instructions
+// of every step of a latency-bound wave.
+typedef float f4l __attribute__((ext_vector_type(4)));
+constexpr int kRingRows = 32, kRingFloats = kRingRows * 64;       // per chain wave and ring: [row & 31][trajectory 4][unit 16]
+
+__device__ __forceinline__ f4l mf16(const float wa, const float vb, const f4l c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(wa, vb, c, 0, 0, 0); }
+// one H -> (<= 16) layer of a tile: A = the lane's four weights (k-slots 4g .. 4g+3 of output row j), B = the four rows of the input tile
+__device__ __forceinline__ f4l layer16(const float (&w)[4], const f4l in, const f4l bias) {
+    f4l pA = mf16(w[0], in[0], bias), pB = mf16(w[1], in[1], f4l{0.f, 0.f, 0.f, 0.f});
+    pA = mf16(w[2], in[2], pA); pB = mf16(w[3], in[3], pB);
+    return pA + pB;
+}
+
+template <int METHOD>
+__device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __restrict__ lds, const int lane, const int wv) {
+    const int nT = (int)a.T, nblk = (nT + 15) >> 4, cw = wv & 3;
+    float* czr = lds + cw * kRingFloats;
+    float* xr = lds + 4 * kRingFloats + cw * kRingFloats;
+    const long long bw = (long long)blockIdx.x * DTB + cw * 4;           // the pair's four trajectories
+    const int xd = a.xd, zd = a.zd;
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ rows wave
+        const int g = lane >> 4, j = lane & 15;
+        const int nme = (xd + 3) >> 2, nmz = (zd + 3) >> 2;
+        float w1e[4], w1d[4], w2d[4], w1z[4];
+        f4l b1e, b1d, b2d, b1z;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ce = nme * g + m, cz_ = nmz * g + m, k4 = 4 * g + m;
+            w1e[m] = (m < nme && ce < xd) ? a.xenc.w1[j * xd + ce] : 0.0f;
+            w1d[m] = a.xdec.w1[j * LH + k4];
+            w2d[m] = j < xd ? a.xdec.w2[j * LH + k4] : 0.0f;
+            w1z[m] = (m < nmz && cz_ < zd) ? a.zenc.w1[j * zd + cz_] : 0.0f;
+            b1e[m] = a.xenc.b1[k4]; b1d[m] = a.xdec.b1[k4]; b2d[m] = k4 < xd ? a.xdec.b2[k4] : 0.0f;
+            b1z[m] = a.zenc.b1[k4];
+        }
+        // Two pairs of layers have no ELU between them and are folded once per launch (one 16 x 16 x 16 product each, fp32 FMAs in k order):
+        //   cz' = F_z (W2z h + b2z)           = (F_z W2z) h + F_z b2z                  z_encoder's output layer and the DE's z block
+        //   dec L1 (enc L2 (h)) in x_re       = (W1d W2e) h + (W1d b2e + b1d)          x_encoder's output layer and x_decoder's input layer
+        // 8 MFMAs less per 16 rows and trajectory (31 -> 23); each product is rounded once more than the unfolded chain (1e-7 relative).
+        float mz[4], mr[4];
+        f4l bzp, brp;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k4 = 4 * g + m;
+            float sz_ = 0.0f, sr_ = 0.0f, bz_ = 0.0f, br_ = a.xdec.b1[k4];
+            for (int k = 0; k < LH; ++k) {
+                const float fjk = a.de_w1[j * 6 * LH + 5 * LH + k] + a.de_w1[j * 6 * LH + 3 * LH + k];
+                sz_ = fmaf(fjk, a.zenc.w2[k * LH + k4], sz_);
+                sr_ = fmaf(a.xdec.w1[j * LH + k], a.xenc.w2[k * LH + k4], sr_);
+                const float fuk = a.de_w1[k4 * 6 * LH + 5 * LH + k] + a.de_w1[k4 * 6 * LH + 3 * LH + k];
+                bz_ = fmaf(fuk, a.zenc.b2[k], bz_);
+                br_ = fmaf(a.xdec.w1[k4 * LH + k], a.xenc.b2[k], br_);
+            }
+            mz[m] = sz_; mr[m] = sr_; bzp[m] = bz_; brp[m] = br_;
+        }
+        const int ntraj = a.B - bw >= 4 ? 4 : (a.B - bw > 0 ? (int)(a.B - bw) : 0);
+        const bool recon = a.xre != nullptr;
+        // Raw inputs of a block travel a block ahead of their use: z rows r - 1 (the external input of the step that ENDS at row r), x rows r.
+        // The four trajectories' tiles are written as straight-line code (a trajectory beyond the batch re-reads the first one and stores
+        // nothing): four independent MFMA chains for the scheduler to interleave -- one tile alone is a dependent chain of 14.
+        float vz[4][4], vx[4][4];
+        auto request_z = [&](const int blk) {
+            const int r = 16 * blk + j, rz = r - 1 < 0 ? 0 : (r - 1 < nT ? r - 1 : nT - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* sz = a.z.p + (bw + (q < ntraj ? q : 0)) * a.z.sb + (long long)rz * a.z.st + nmz * g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) vz[q][m] = (m < nmz && nmz * g + m < zd) ? sz[m] : 0.0f;
+            }
+        };
+        auto request_x = [&](const int blk) {
+            const int r = 16 * blk + j, rx = r < nT ? r : nT - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* sx = a.x.p + (bw + (q < ntraj ? q : 0)) * a.x.sb + (long long)rx * a.x.st + nme * g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) vx[q][m] = (m < nme && nme * g + m < xd) ? sx[m] : 0.0f;
+            }
+        };
+        auto ztiles = [&](const int blk) {           // from the registers request_z(blk) filled
+            const int slot = (16 * blk + j) & (kRingRows - 1);
+            f4l acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q] = b1z;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (m < nmz) acc[q] = mf16(w1z[m], vz[q][m], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = layer16(mz, elu_quad(acc[q]), bzp);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4l*>(czr + slot * 64 + q * 16 + 4 * g) = acc[q];
+        };
+        auto decode4 = [&](f4l (&xh)[4], float* base, const long long st_t, const long long st_b, const int r, auto l1_done) {   // rows of x_decoder, stored
+            if constexpr (!decltype(l1_done)::value) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xh[q] = layer16(w1d, xh[q], b1d);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xh[q] = layer16(w2d, elu_quad(xh[q]), b2d);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < ntraj && r < nT) {
+                    float* dst = base + (bw + q) * st_b + (long long)r * st_t + 4 * g;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) if (4 * g + m < xd) dst[m] = xh[q][m];
+                }
+            }
+        };
+        auto recon_tiles = [&](const int blk) {
+            f4l acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q] = b1e;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (m < nme) acc[q] = mf16(w1e[m], vx[q][m], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = layer16(mr, elu_quad(acc[q]), brp);      // = x_decoder's first layer of the encoded row
+            decode4(acc, a.xre, a.xre_st, a.xre_sb, 16 * blk + j, std::true_type{});
+        };
+        auto decode_tiles = [&](const int blk) {
+            const int r = 16 * blk + j, slot = r & (kRingRows - 1);
+            f4l xh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xh[q] = *reinterpret_cast<const f4l*>(xr + slot * 64 + q * 16 + 4 * g);
+            decode4(xh, a.xo, a.B * xd, xd, r, std::false_type{});
+        };
+        request_z(0);
+        ztiles(0);
+        request_z(1);
+        if (recon) request_x(0);
+        __syncthreads();                             // cz' of block 0 is in the ring
+        for (int n = 0; n < nblk; ++n) {
+            if (n + 1 < nblk) {
+                ztiles(n + 1);                       // (z rows requested during block n - 1)
+                request_z(n + 2);
+            }
+            if (recon) {
+                recon_tiles(n);                      // (x rows requested during block n - 1)
+                request_x(n + 1);
+            }
+            if (n >= 1) decode_tiles(n - 1);
+            __syncthreads();                         // the chain has written block n's states and may read block n + 1's cz'
+        }
+        decode_tiles(nblk - 1);
+        return;
+    }
+    // ---------------------------------------------------------------------- integration wave
+    const int u = lane & 15, row = lane >> 4;
+    const long long b_raw = bw + row;
+    const long long b = b_raw < a.B ? b_raw : a.B - 1;
+    EluS elu;
+    elu.knee = elu_knee();
+    elu.neg_t0 = -__builtin_amdgcn_exp2f(elu.knee * kLog2e);
+    float fx[16], w2[16];
+    {
+        float ws[16], wd[16];
+        load_row(ws, a.de_w1, 6 * LH, u, 4 * LH, LH);
+        load_row(wd, a.de_w1, 6 * LH, u, 2 * LH, LH);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) fx[jj] = ws[jj] + wd[jj];
+    }
+    load_row(w2, a.de_w2, LH, u, 0, LH);
+    const float b2 = a.de_b2[u];
+    float x, c0 = a.de_b1[u];
+    {   // Xh[0], Zh[0] (all_initial) and the constant part of L1 -- once per launch, on the DPP dot products
+        float wa[16], wb[16];
+        load_row(wa, a.xenc.w1, xd, u, 0, xd);
+        load_row(wb, a.xenc.w2, LH, u, 0, LH);
+        const float xraw = u < xd ? a.x.p[b * a.x.sb + u] : 0.0f;
+        const float a0x = dot16(a.xenc.b2[u], elu(dot_in(a.xenc.b1[u], xraw, wa, (xd + 3) >> 2)), wb);
+        load_row(wa, a.zenc.w1, zd, u, 0, zd);
+        load_row(wb, a.zenc.w2, LH, u, 0, LH);
+        const float zraw = a.z.p[b * a.z.sb + (u < zd ? u : 0)];
+        const float a0z = dot16(a.zenc.b2[u], elu(dot_in(a.zenc.b1[u], zraw, wa, (zd + 3) >> 2)), wb);
+        x = a0x;
+        load_row(wa, a.de_w1, 6 * LH, u, 0, LH);
+        load_row(wb, a.de_w1, 6 * LH, u, 2 * LH, LH);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) wa[jj] -= wb[jj];
+        c0 = dot16(c0, a0x, wa);
+        load_row(wa, a.de_w1, 6 * LH, u, LH, LH);
+        load_row(wb, a.de_w1, 6 * LH, u, 3 * LH, LH);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) wa[jj] -= wb[jj];
+        c0 = dot16(c0, a0z, wa);
+    }
+    auto rhs = [&](const float xs, const float cz) -> float { return dot16(b2, elu(dot16(cz, xs, fx)), w2); };
+    auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };
+    const unsigned toff = (unsigned)(b * a.t.sb) * 4u;
+    const long long tst = a.t.st;
+    xr[lane] = x;                                    // row 0 = the start state
+    float t_cur = ldg<float>(as_g(a.t.p), toff);
+    float tq[4];                                     // slot j of a chunk of four rows: t[row]
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) tq[jj] = ldg<float>(as_g(a.t.p + (long long)(jj < nT ? jj : nT - 1) * tst), toff);
+    const float* trun = a.t.p + 4 * tst;             // the row the next refill reads (full chunks only)
+    __syncthreads();                                 // cz' of block 0
+    auto step_row = [&](const int r, const float tr) {        // the step that ends at row r >= 1
+        const float h_ = tr - t_cur;
+        const int so = (r & (kRingRows - 1)) * 64 + lane;
+        const float cz = c0 + czr[so];
+        const float k1 = rhs(x, cz);
+        if constexpr (METHOD == PSNODE_EULER) {
+            x = x + h_ * k1;
+        } else if constexpr (METHOD == PSNODE_MIDPOINT) {
+            const float k2 = rhs(x + k1 * (0.5f * h_), cz);
+            x = x + h_ * k2;
+        } else {
+            const float k2 = rhs(x + h_ * k1 * kOneThird, cz);
+            const float k3 = rhs(x + h_ * (k2 - k1 * kOneThird), cz);
+            const float k4 = rhs(x + h_ * (k1 - k2 + k3), cz);
+            x = x + (k1 + 3.0f * (k2 + k3) + k4) * h_ * 0.125f;
+        }
+        xr[so] = x;
+    };
+    int r0 = 0;
+    for (int n = 0; n < nblk; ++n) {
+        for (int c = 0; c < 4; ++c, r0 += 4) {
+            if (r0 >= 4 && r0 + 8 <= nT) {           // a full chunk whose refills stay inside the grid: no per-row tests
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float tr = tq[jj];
+                    tq[jj] = ldg<float>(as_g(trun), toff);
+                    trun += tst;
+                    step_row(r0 + jj, tr);
+                    t_cur = tr;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = r0 + jj;
+                    const float tr = tq[jj];
+                    const int rn = r + 4 < nT ? r + 4 : nT - 1;
+                    tq[jj] = ldg<float>(as_g(a.t.p + (long long)rn * tst), toff);
+                    if (r >= 1 && r < nT) step_row(r, tr);
+                    if (r < nT) t_cur = tr;
+                }
+                trun = a.t.p + (long long)(r0 + 8) * tst;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int METHOD, bool ENC>
 __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const LatentDppDev a) {
     const int lane = threadIdx.x & 63, u = lane & 15, row = lane >> 4;
@@ -142,6 +399,21 @@ __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const Laten
     elu.neg_t0 = -__builtin_amdgcn_exp2f(elu.knee * kLog2e);
 
     if constexpr (ENC) {
+        // the plain inference call takes the two-role form (enc_two_role above); the decision is uniform over the workgroup
+        __shared__ float ring[ENC ? 8 * kRingFloats : 1];
+        {
+            const unsigned long long span_t = (unsigned long long)a.B * (unsigned long long)(a.t.sb < 0 ? 0 : a.t.sb) * 4ull;
+            bool two = nT >= 2 && nT < (1ll << 31) && !a.xh_out && a.t.sb >= 0 && span_t < (1ull << 32);
+            if (two && a.ev) {
+                int any = -1;
+                for (int i = lane; i + 1 < (int)nT; i += 64) any = max(any, a.ev[i]);
+                two = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
+            }
+            if (two) {
+                enc_two_role<METHOD>(a, ring, lane, wv);
+                return;
+            }
+        }
         if (wv >= 4) {
             // ---------------- reconstruction waves: x_re[t] = x_decoder(x_encoder(x[t]))  (neural_00_ODE_02_direct_encode.py:87)
             // Round 5: on MFMA, K3b's way (psnode_rows.hip) -- a tile is 16 grid points of ONE trajectory, the hidden / latent tiles stay in
