@@ -62,18 +62,6 @@ __device__ __forceinline__ float dot16(const float init, const float src, const 
           "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
     return acc;
 }
-// acc[j] += src[row lane j] * own, j < 16: the rank-1 update of a lane's row of a weight-gradient block (backward kernel).
-// Two v_nop = the DPP hazard's two wait states (no initialisation to hide them behind here).
-#define PSNODE_DPP_RANK1(N) "v_fmac_f32_dpp %" #N ", %16, %17 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void outer16(float (&acc)[16], const float src, const float own) {
-    asm("v_nop\n\tv_nop\n\t" PSNODE_DPP_RANK1(0) PSNODE_DPP_RANK1(1) PSNODE_DPP_RANK1(2) PSNODE_DPP_RANK1(3) PSNODE_DPP_RANK1(4)
-        PSNODE_DPP_RANK1(5) PSNODE_DPP_RANK1(6) PSNODE_DPP_RANK1(7) PSNODE_DPP_RANK1(8) PSNODE_DPP_RANK1(9) PSNODE_DPP_RANK1(10)
-        PSNODE_DPP_RANK1(11) PSNODE_DPP_RANK1(12) PSNODE_DPP_RANK1(13) PSNODE_DPP_RANK1(14) PSNODE_DPP_RANK1(15)
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]),
-          "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
-        : "v"(src), "v"(own));
-}
-#undef PSNODE_DPP_RANK1
 #undef PSNODE_DPP_FMAC
 #undef PSNODE_DPP_HEAD
 // first layer of an encoder: in-features `quads`*4 <= 16 (the weights beyond in_dim are zero), wave-uniform choice
@@ -698,14 +686,16 @@ __global__ __launch_bounds__(ENC ? 512 : 256) void latent_dpp_kernel(const Laten
 // loss.backward() computes through integrate_ODE between the encoders and the decoder of neural_00_ODE_02_direct_encode.py:74-89.
 // Replaces K8 (one MFMA wave per 16 trajectories = one wave per CU at B = 4096, 3.85 ms) -- 1024 waves instead of 256.
 //   forward recompute per stage  pre = cz + F_x . X_s ; h = ELU(pre) ; k_s = b2 + W2 . h                       (dot16 x2 + ELU)
-//   backward per stage           dW2[u][:] += gk[u] * h[:]              (outer16: the lane's row of the gradient block)
+//   backward per stage           dW2[u][:] += gk[u] * h[:]              (one MFMA over the wave's four trajectories, see below)
 //                                d1 = (W2^T gk) * ELU'(pre)             (dot16 with the lane's COLUMN of W2)
 //                                dF_x[u][:] += d1[u] * X_s[:] ;  gX_s = F_x^T d1
 //   per step                     dF_z[u][:] += D1[u] * z[:] ; gz = F_z^T D1 ,  D1 = sum_s d1 (the external block is frozen)
 //   per launch                   d all_initial = (Wa - Wd)^T sum_t D1 ;  dWa = sum_t D1 (x) a0 ;  dWd = dF - dWa ;  dWs = dF
-// Every lane accumulates the gradient of ITS row of each block for ITS trajectory in registers over the whole launch; the four
-// trajectories of a wave are summed with two xor-shuffles at the end, one partial vector per wave, summed by reduce_partials in
-// a fixed order (deterministic).  No LDS, no barrier, any alignment.
+// Weight gradients (round 5): dW[u][j] += sum over the wave's four trajectories of own[traj][u] * src[traj][j] IS one v_mfma_f32_16x16x4_f32
+// with the two registers as they stand -- lane (traj, u) is element A[u][k = traj] of the first and B[k = traj][j = u] of the second -- so
+// every rank-1 update of rounds 2-4 (16 v_fmac_f32_dpp + 2 v_nop per block and stage: 9 x 18 = 162 of the ~600 VALU instructions of an RK4
+// step) is ONE MFMA, the accumulators are 4 registers per block instead of 16 (D: lane (g, j) holds dW[4g + r][j]) and already summed over
+// the trajectories.  One partial vector per wave, summed by reduce_partials in a fixed order (deterministic).  No LDS, no barrier, any alignment.
 struct LatentBwdDppDev {
     int method, n_events;
     long long T, B;
@@ -760,9 +750,9 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
         c0 = dot16(c0, a0z, wa);
     }
 
-    float aW2[16], aFx[16], aFz[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) aW2[j] = aFx[j] = aFz[j] = 0.0f;
+    typedef float f4b __attribute__((ext_vector_type(4)));
+    auto rank1 = [](f4b& acc, const float src, const float own) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(own, src, acc, 0, 0, 0); };
+    f4b aW2 = f4b{0.f, 0.f, 0.f, 0.f}, aFx = aW2, aFz = aW2;
     float S1 = 0.0f, SB2 = 0.0f, gcarry = 0.0f;
 
     const float* tp = a.t.p + b * a.t.sb;
@@ -802,7 +792,90 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
         tq[j] = zq_[j] = xq[j] = gq[j] = 0.0f; evq[j] = -1;
         if (nT - 2 - j >= 0) fetch(j, nT - 2 - j);
     }
-    for (long long kc = nT - 2; kc >= 0; kc -= PF) {
+    // one step of the sweep from its inputs; `emit(gz of the step)` stores the external input's gradient
+    auto sweep_step = [&](const float h_, const float zk, const float x0, const float g1, auto emit) {
+        const float cz = dot16(c0, zk, fz);
+        // ---- phase A: stage evaluations from the saved state
+        float X[S], hh[S], ks[S];
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < st; ++jj) acc += rk_a(METHOD, st, jj) * ks[jj];
+            X[st] = st == 0 ? x0 : x0 + h_ * acc;
+            hh[st] = elu(dot16(cz, X[st], fx));
+            ks[st] = dot16(b2, hh[st], w2);
+        }
+        // ---- phase B: stages backwards
+        float gks[S], gx0 = g1, D1 = 0.0f;
+#pragma unroll
+        for (int st = 0; st < S; ++st) gks[st] = (h_ * rk_b(METHOD, st)) * g1;
+#pragma unroll
+        for (int st = S - 1; st >= 0; --st) {
+            const float gk = gks[st];
+            SB2 += gk;
+            rank1(aW2, hh[st], gk);                                // dW2[u][:] += gk[u] h[:]
+            const float d1 = dot16(0.0f, gk, w2T) * dact(hh[st]);  // (W2^T gk)[u] ELU'
+            D1 += d1;
+            rank1(aFx, X[st], d1);                                 // dF_x[u][:] += d1[u] X_s[:]
+            const float gx = dot16(0.0f, d1, fxT);
+            gx0 += gx;
+#pragma unroll
+            for (int jj = 0; jj < st; ++jj) gks[jj] += (h_ * rk_a(METHOD, st, jj)) * gx;
+        }
+        S1 += D1;
+        // ---- external block: frozen over the stages
+        const float gzv = dot16(0.0f, D1, fzT);
+        rank1(aFz, zk, D1);
+        emit(gzv);
+        gcarry = gx0;
+    };
+    // FAST main loop (round 5, as the forward kernel's): no event in the table, 32-bit counters and row offsets, uniform running row bases,
+    // whole chunks of PF steps whose prefetches stay inside the grid; the general loop below takes over wherever this one stops.
+    long long kc = nT - 2;
+    {
+        const unsigned long long rows_b = (unsigned long long)a.B * LH * 4ull;
+        const unsigned long long span_t = (unsigned long long)a.B * (unsigned long long)(a.t.sb < 0 ? 0 : a.t.sb) * 4ull;
+        const unsigned long long span_z = (unsigned long long)a.B * (unsigned long long)(a.z.sb < 0 ? 0 : a.z.sb) * 4ull + 64ull;
+        bool fast = nT < (1ll << 31) && nT >= 2 * PF + 2 && a.t.sb >= 0 && a.z.sb >= 0 && rows_b < (1ull << 32) && span_t < (1ull << 32) && span_z < (1ull << 32);
+        if (fast && a.ev) {
+            int any = -1;
+            for (int i = lane; i + 1 < (int)nT; i += 64) any = max(any, a.ev[i]);
+            fast = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
+        }
+        if (fast) {
+            auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };
+            const unsigned toff = (unsigned)(b * a.t.sb) * 4u, zoff = (unsigned)(b * a.z.sb + u) * 4u, roff = (unsigned)(b * LH + u) * 4u;
+            const long long rstep = a.B * LH;
+            int ki = (int)nT - 2;                                     // the step in hand; its slot is refilled with step ki - PF
+            const float* trun = a.t.p + (long long)(ki - PF) * tst;
+            const float* zrun = a.z.p + (long long)(ki - PF) * zst;
+            const float* xrun = a.xs + (long long)(ki - PF) * rstep;
+            const float* grun = a.gout + (long long)(ki - PF + 1) * rstep;
+            float* gzrun = (a.gz ? a.gz : a.gx0) + (long long)(a.gz ? ki : 0) * rstep;      // (no gz wanted: a base that is never stored through)
+            const bool st_gz = valid && a.gz != nullptr;
+            for (; ki - (2 * PF - 1) >= 0; ki -= PF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const float h_ = t_hi - tq[j];
+                    t_hi = tq[j];
+                    const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
+                    tq[j] = ldg<float>(as_g(trun), toff);
+                    zq_[j] = ldg<float>(as_g(zrun), zoff);
+                    xq[j] = ldg<float>(as_g(xrun), roff);
+                    const float gl = ldg<float>(as_g(grun), roff);
+                    gq[j] = valid ? gl : 0.0f;
+                    trun -= tst; zrun -= zst; xrun -= rstep; grun -= rstep;
+                    sweep_step(h_, zk, x0, g1, [&](const float gzv) {
+                        if (st_gz) stg<float>((gptr<float>)(uintptr_t)gzrun, roff, gzv);
+                    });
+                    if (st_gz || a.gz) gzrun -= rstep;
+                }
+            }
+            kc = ki;
+        }
+    }
+    for (; kc >= 0; kc -= PF) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const long long k = kc - j;
@@ -812,44 +885,12 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
                 const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
                 const int ev = evq[j];
                 if (k - PF >= 0) fetch(j, k - PF);
-                const float cz = dot16(c0, zk, fz);
-                // ---- phase A: stage evaluations from the saved state
-                float X[S], hh[S], ks[S];
-#pragma unroll
-                for (int st = 0; st < S; ++st) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int jj = 0; jj < st; ++jj) acc += rk_a(METHOD, st, jj) * ks[jj];
-                    X[st] = st == 0 ? x0 : x0 + h_ * acc;
-                    hh[st] = elu(dot16(cz, X[st], fx));
-                    ks[st] = dot16(b2, hh[st], w2);
-                }
-                // ---- phase B: stages backwards
-                float gks[S], gx0 = g1, D1 = 0.0f;
-#pragma unroll
-                for (int st = 0; st < S; ++st) gks[st] = (h_ * rk_b(METHOD, st)) * g1;
-#pragma unroll
-                for (int st = S - 1; st >= 0; --st) {
-                    const float gk = gks[st];
-                    SB2 += gk;
-                    outer16(aW2, hh[st], gk);                              // dW2[u][:] += gk[u] h[:]
-                    const float d1 = dot16(0.0f, gk, w2T) * dact(hh[st]);  // (W2^T gk)[u] ELU'
-                    D1 += d1;
-                    outer16(aFx, X[st], d1);                               // dF_x[u][:] += d1[u] X_s[:]
-                    const float gx = dot16(0.0f, d1, fxT);
-                    gx0 += gx;
-#pragma unroll
-                    for (int jj = 0; jj < st; ++jj) gks[jj] += (h_ * rk_a(METHOD, st, jj)) * gx;
-                }
-                S1 += D1;
-                // ---- external block: frozen over the stages
-                const float gzv = dot16(0.0f, D1, fzT);
-                outer16(aFz, zk, D1);
-                if (valid) {
-                    if (ev >= 0) { if (a.gzj) a.gzj[(b * a.n_events + ev) * LH + u] = gzv; }
-                    if (a.gz) a.gz[(k * a.B + b) * LH + u] = ev >= 0 ? 0.0f : gzv;
-                }
-                gcarry = gx0;
+                sweep_step(h_, zk, x0, g1, [&](const float gzv) {
+                    if (valid) {
+                        if (ev >= 0) { if (a.gzj) a.gzj[(b * a.n_events + ev) * LH + u] = gzv; }
+                        if (a.gz) a.gz[(k * a.B + b) * LH + u] = ev >= 0 ? 0.0f : gzv;
+                    }
+                });
             }
         }
     }
@@ -859,11 +900,9 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
         a.gx0[b * LH + u] = gcarry + row_of(a.gout, 0);
         if (a.gz && nT >= 1) a.gz[((nT - 1) * a.B + b) * LH + u] = 0.0f;      // z[T-1] is never read
     }
-    float cax[16], caz[16];     // dWa of this trajectory: sum_t(D1)[u] * a0[:]
-#pragma unroll
-    for (int j = 0; j < 16; ++j) cax[j] = caz[j] = 0.0f;
-    outer16(cax, a0x, S1);
-    outer16(caz, a0z, S1);
+    f4b cax = f4b{0.f, 0.f, 0.f, 0.f}, caz = cax;     // dWa: sum over the trajectories of sum_t(D1)[u] * a0[:]
+    rank1(cax, a0x, S1);
+    rank1(caz, a0z, S1);
     {   // d all_initial = (Wa - Wd)^T sum_t(D1): the lane's column of each a0 block
         float wt[16];
 #pragma unroll
@@ -874,28 +913,30 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
         const float gaz = dot16(0.0f, S1, wt);
         if (valid) { a.ga0[b * 2 * LH + u] = gax; a.ga0[b * 2 * LH + LH + u] = gaz; }
     }
-    // ---- sum the wave's four trajectories (fixed order), one partial per wave in nn.Linear order [W1 (16 x 96), b1, W2, b2]
+    // ---- one partial per wave in nn.Linear order [W1 (16 x 96), b1, W2, b2]: the MFMA accumulators hold rows 4g .. 4g+3, column j of every block,
+    //      summed over the wave's trajectories; the two bias sums take the xor-shuffles
     auto rows4 = [](float v) -> float {
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         return v;
     };
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { aW2[j] = rows4(aW2[j]); aFx[j] = rows4(aFx[j]); aFz[j] = rows4(aFz[j]); cax[j] = rows4(cax[j]); caz[j] = rows4(caz[j]); }
     S1 = rows4(S1);
     SB2 = rows4(SB2);
-    if (row == 0) {
+    {
         float* wp = a.wpart + ((size_t)blockIdx.x * 4 + wv) * BNP;
-        float* r = wp + u * BK1;
+        const int g = lane >> 4, j = lane & 15;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            r[j] = cax[j];                       r[LH + j] = caz[j];
-            r[2 * LH + j] = aFx[j] - cax[j];     r[3 * LH + j] = aFz[j] - caz[j];
-            r[4 * LH + j] = aFx[j];              r[5 * LH + j] = aFz[j];
-            wp[LH * BK1 + LH + u * LH + j] = aW2[j];
+        for (int r = 0; r < 4; ++r) {
+            float* rr = wp + (4 * g + r) * BK1;
+            rr[j] = cax[r];                       rr[LH + j] = caz[r];
+            rr[2 * LH + j] = aFx[r] - cax[r];     rr[3 * LH + j] = aFz[r] - caz[r];
+            rr[4 * LH + j] = aFx[r];              rr[5 * LH + j] = aFz[r];
+            wp[LH * BK1 + LH + (4 * g + r) * LH + j] = aW2[r];
         }
-        wp[LH * BK1 + u] = S1;
-        wp[LH * BK1 + LH + LH * LH + u] = SB2;
+        if (row == 0) {
+            wp[LH * BK1 + u] = S1;
+            wp[LH * BK1 + LH + LH * LH + u] = SB2;
+        }
     }
 }
 
