@@ -11,6 +11,7 @@ kt headline python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extr
 kt ode01_euler $B --method euler
 kt dae01 $B --workload dae01
 kt dae01_euler $B --workload dae01 --method euler
+kt ode02 $B --workload ode02 --warmup 10
 kt train_ode01 $B --train
 kt train_ode01_euler $B --train --method euler
 kt train_dae01 $B --train --workload dae01
@@ -20,6 +21,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc ode01_euler $c integrate_x $B --method euler
   pmc dae01 $c integrate_xd $B --workload dae01
   pmc dae01_euler $c integrate_xd $B --workload dae01 --method euler
+  pmc ode02 $c latent_dpp $B --workload ode02 --warmup 10
 done
 cd $R
 export GRAFT_REPO_ROOT=$R
