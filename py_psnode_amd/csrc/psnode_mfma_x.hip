@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         constexpr int WAITN = decltype(wait_tag)::value;
         // SAVE: a step also issued 4 stores per stage (xstage + three layers, every one from at least one lane of every wave) behind its prefetch
         constexpr int NSAVE = SAVE ? 4 * (METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4)) : 0;
-        constexpr int WN = WAITN == 0 ? 0 : WAITN + NSAVE;                    // vmcnt is 6 bits: [3:0] and [15:14] of the immediate
+        constexpr int WN = WAITN == 0 ? 0 : (WAITN == 4 ? 4 + 2 * NSAVE : WAITN + NSAVE);   // (two steps of look-ahead: two steps' stores); 6 bits: [3:0], [15:14]
         if (pair_ok && WN > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (WN & 15) | ((WN >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
         const float h_ = tuse - t_cur;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     using W0 = std::integral_constant<int, 0>;
     using W1 = std::integral_constant<int, 1>;
     using W4 = std::integral_constant<int, 4>;
-    constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38 && !SAVE;
+    constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38;
     if constexpr (TWO_AHEAD) {
         // ring of two register pairs: (t_nxt, e_nxt) serve the even steps, (t_n2, e_n2) the odd ones; a step reloads the pair it used
         float t_n2 = ldg<float>(as_g(a.t.p + (nT > 2 ? 2 : 1) * tst), toff);            // t[2]
