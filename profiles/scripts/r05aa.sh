@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call aa: K8f's rank-1 gradient updates as MFMAs over the wave's four trajectories: tests, ODE_02 training step, glue
+# round 5, call aa: K8f -- rank-1 updates as MFMAs, FAST loop, phase A on the partner wave (MFMA tiles, LDS ring): tests, ODE_02 training step, glue
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 python -m pytest tests/test_grad_goldens.py tests/test_gpu_rows_backward.py tests/test_gpu_backward.py tests/test_gpu_determinism.py tests/test_gpu_fuzz.py tests/test_gpu_example.py tests/test_gpu_encoded.py -m gpu -q --tb=short 2>&1 | tail -12 > $O/r05aa_pytest.txt
 python profiles/scripts/fuzz_models.py 21 150 2>&1 | grep -v amdgpu | tail -3 >> $O/r05aa_pytest.txt

@@ -710,15 +710,113 @@ struct LatentBwdDppDev {
 };
 constexpr int BK1 = 6 * LH, BNP = LH * BK1 + LH + LH * LH + LH;   // in_features of L1; parameters W1, b1, W2, b2
 
+// Two roles (round 5, the plain call: no event in the table, 32-bit row offsets): phase A -- the recomputation of the stage inputs X_s and
+// hidden rows h_s of a step from the saved state -- does not depend on the adjoint, so the steps of a block are independent of each other:
+// the PARTNER wave (wave w + 4, same SIMD) runs it for 4 steps x 4 trajectories at a time as ONE 16-row MFMA tile (K3b's plan: cz = c0 + F_z Zh,
+// then per stage pre = cz + F_x X_s, h_s = ELU, k_s = b2 + W2 h_s: 4 + 8 S MFMAs per 4 steps) and hands X_1.., h_0.. over through an LDS ring of
+// two blocks, ONE workgroup barrier per 4 steps.  On the sweep wave phase A was 8 dependent 16-term DPP dot products + 4 ELUs of every RK4
+// step (~190 of ~440 VALU instructions); it becomes 2 S - 1 ds_read_b32.
+constexpr int kBwdVals = 7;                                  // values per (row, unit) in the ring: h_0 .. h_{S-1}, X_1 .. X_{S-1}
+constexpr int kBwdRing = 2 * 16 * kBwdVals * 16;             // floats per sweep wave: [block & 1][trajectory 4 x step 4][value][unit]
+
 template <int METHOD>
-__global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const LatentBwdDppDev a) {
+__global__ __launch_bounds__(512) void latent_ode_backward_dpp_kernel(const LatentBwdDppDev a) {
     constexpr int S = rk_stages(METHOD);
     const int lane = threadIdx.x & 63, u = lane & 15, row = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long b_raw = (long long)blockIdx.x * DTB + wv * 4 + row;
+    const long long b_raw = (long long)blockIdx.x * DTB + (wv & 3) * 4 + row;
     const bool valid = b_raw < a.B;
     const long long b = valid ? b_raw : a.B - 1;
     const long long nT = a.T;
+    __shared__ float pring[4 * kBwdRing];
+    // the FAST form and its number of 4-step blocks: one decision for the whole workgroup
+    int nchunk = 0;
+    {
+        const unsigned long long rows_b = (unsigned long long)a.B * LH * 4ull;
+        const unsigned long long span_t = (unsigned long long)a.B * (unsigned long long)(a.t.sb < 0 ? 0 : a.t.sb) * 4ull;
+        const unsigned long long span_z = (unsigned long long)a.B * (unsigned long long)(a.z.sb < 0 ? 0 : a.z.sb) * 4ull + 64ull;
+        bool fast = nT < (1ll << 31) && nT >= 2 * PF + 2 && a.t.sb >= 0 && a.z.sb >= 0 && rows_b < (1ull << 32) && span_t < (1ull << 32) && span_z < (1ull << 32);
+        if (fast && a.ev) {
+            int any = -1;
+            for (int i = lane; i + 1 < (int)nT; i += 64) any = max(any, a.ev[i]);
+            fast = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
+        }
+        if (fast) nchunk = ((int)nT - 2 - (2 * PF - 1)) / PF + 1;      // blocks whose prefetches stay inside the grid (nT >= 2 PF + 2: >= 1)
+    }
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ partner wave: phase A on MFMA tiles
+        if (nchunk == 0) return;
+        const int g = lane >> 4, j = lane & 15, q = j >> 2, si = j & 3;      // tile row j = (trajectory q, step si of the block)
+        float* ring = pring + (wv - 4) * kBwdRing;
+        const long long bq_raw = (long long)blockIdx.x * DTB + (wv - 4) * 4 + q;
+        const long long bq = bq_raw < a.B ? bq_raw : a.B - 1;
+        float FxA[4], FzA[4], W2A[4], WaxA[4], WazA[4];
+        f4l b2t, c0t, a0xv, a0zv;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k4 = 4 * g + m;
+            const float* r = a.de_w1 + (long long)j * BK1;                     // A operands: lane (g, i = j) holds M[i][4g + m]
+            FxA[m] = r[4 * LH + k4] + r[2 * LH + k4];
+            FzA[m] = r[5 * LH + k4] + r[3 * LH + k4];
+            W2A[m] = a.de_w2[j * LH + k4];
+            WaxA[m] = r[k4] - r[2 * LH + k4];
+            WazA[m] = r[LH + k4] - r[3 * LH + k4];
+            b2t[m] = a.de_b2[k4];
+            c0t[m] = a.de_b1[k4];
+            a0xv[m] = a.a0[bq * 2 * LH + k4];
+            a0zv[m] = a.a0[bq * 2 * LH + LH + k4];
+        }
+        c0t = layer16(WazA, a0zv, layer16(WaxA, a0xv, c0t));                  // b1 + (Wa - Wd) a0: constant per trajectory
+        const int ki0 = (int)nT - 2;
+        f4l xn, zn;
+        float tln, thn;
+        auto request = [&](const int bi) {                                     // the saved state, Zh row and clock of step k = ki0 - 4 bi - si
+            const long long k = ki0 - 4 * bi - si;
+            const float* xr_ = a.xs + (k * a.B + bq) * LH + 4 * g;
+            const float* zr_ = a.z.p + bq * a.z.sb + k * a.z.st + 4 * g;
+            const float* tr_ = a.t.p + bq * a.t.sb + k * a.t.st;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { xn[m] = xr_[m]; zn[m] = zr_[m]; }
+            tln = tr_[0]; thn = tr_[a.t.st];
+        };
+        auto produce = [&](const int bi, const f4l x0v, const f4l zv, const float h_) {
+            float* dst = ring + (((bi & 1) * 16 + j) * kBwdVals) * 16 + 4 * g;
+            const f4l cz = layer16(FzA, zv, c0t);
+            f4l ks[S];
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                f4l X = x0v;
+                if (st > 0) {
+                    f4l acc = f4l{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < st; ++jj) acc += rk_a(METHOD, st, jj) * ks[jj];
+                    X = x0v + h_ * acc;
+                    *reinterpret_cast<f4l*>(dst + (S + st - 1) * 16) = X;
+                }
+                const f4l hh = elu_quad(layer16(FxA, X, cz));
+                *reinterpret_cast<f4l*>(dst + st * 16) = hh;
+                ks[st] = layer16(W2A, hh, b2t);
+            }
+        };
+        request(0);
+        {
+            const f4l x0v = xn, zv = zn;
+            const float h_ = thn - tln;
+            if (nchunk > 1) request(1);
+            produce(0, x0v, zv, h_);
+        }
+        __syncthreads();
+        for (int bi = 0; bi < nchunk; ++bi) {
+            if (bi + 1 < nchunk) {
+                const f4l x0v = xn, zv = zn;
+                const float h_ = thn - tln;
+                if (bi + 2 < nchunk) request(bi + 2);
+                produce(bi + 1, x0v, zv, h_);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     EluS elu;
     elu.knee = elu_knee();
     elu.neg_t0 = -__builtin_amdgcn_exp2f(elu.knee * kLog2e);
@@ -793,10 +891,10 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
         if (nT - 2 - j >= 0) fetch(j, nT - 2 - j);
     }
     // one step of the sweep from its inputs; `emit(gz of the step)` stores the external input's gradient
-    auto sweep_step = [&](const float h_, const float zk, const float x0, const float g1, auto emit) {
+    // phase A on the sweep wave itself (the general loop): stage evaluations from the saved state
+    auto phase_a_dpp = [&](const float h_, const float zk, const float x0, float (&X)[S], float (&hh)[S]) {
         const float cz = dot16(c0, zk, fz);
-        // ---- phase A: stage evaluations from the saved state
-        float X[S], hh[S], ks[S];
+        float ks[S];
 #pragma unroll
         for (int st = 0; st < S; ++st) {
             float acc = 0.0f;
@@ -806,6 +904,10 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
             hh[st] = elu(dot16(cz, X[st], fx));
             ks[st] = dot16(b2, hh[st], w2);
         }
+    };
+    auto sweep_step = [&](const float h_, const float zk, const float x0, const float g1, auto phase_a, auto emit) {
+        float X[S], hh[S];
+        phase_a(h_, zk, x0, X, hh);
         // ---- phase B: stages backwards
         float gks[S], gx0 = g1, D1 = 0.0f;
 #pragma unroll
@@ -833,47 +935,49 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
     // FAST main loop (round 5, as the forward kernel's): no event in the table, 32-bit counters and row offsets, uniform running row bases,
     // whole chunks of PF steps whose prefetches stay inside the grid; the general loop below takes over wherever this one stops.
     long long kc = nT - 2;
-    {
-        const unsigned long long rows_b = (unsigned long long)a.B * LH * 4ull;
-        const unsigned long long span_t = (unsigned long long)a.B * (unsigned long long)(a.t.sb < 0 ? 0 : a.t.sb) * 4ull;
-        const unsigned long long span_z = (unsigned long long)a.B * (unsigned long long)(a.z.sb < 0 ? 0 : a.z.sb) * 4ull + 64ull;
-        bool fast = nT < (1ll << 31) && nT >= 2 * PF + 2 && a.t.sb >= 0 && a.z.sb >= 0 && rows_b < (1ull << 32) && span_t < (1ull << 32) && span_z < (1ull << 32);
-        if (fast && a.ev) {
-            int any = -1;
-            for (int i = lane; i + 1 < (int)nT; i += 64) any = max(any, a.ev[i]);
-            fast = __builtin_amdgcn_ballot_w64(any >= 0) == 0;
-        }
-        if (fast) {
-            auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };
-            const unsigned toff = (unsigned)(b * a.t.sb) * 4u, zoff = (unsigned)(b * a.z.sb + u) * 4u, roff = (unsigned)(b * LH + u) * 4u;
-            const long long rstep = a.B * LH;
-            int ki = (int)nT - 2;                                     // the step in hand; its slot is refilled with step ki - PF
-            const float* trun = a.t.p + (long long)(ki - PF) * tst;
-            const float* zrun = a.z.p + (long long)(ki - PF) * zst;
-            const float* xrun = a.xs + (long long)(ki - PF) * rstep;
-            const float* grun = a.gout + (long long)(ki - PF + 1) * rstep;
-            float* gzrun = (a.gz ? a.gz : a.gx0) + (long long)(a.gz ? ki : 0) * rstep;      // (no gz wanted: a base that is never stored through)
-            const bool st_gz = valid && a.gz != nullptr;
-            for (; ki - (2 * PF - 1) >= 0; ki -= PF) {
+    if (nchunk > 0) {
+        auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };
+        const unsigned toff = (unsigned)(b * a.t.sb) * 4u, zoff = (unsigned)(b * a.z.sb + u) * 4u, roff = (unsigned)(b * LH + u) * 4u;
+        const long long rstep = a.B * LH;
+        int ki = (int)nT - 2;                                     // the step in hand; its slot is refilled with step ki - PF
+        const float* trun = a.t.p + (long long)(ki - PF) * tst;
+        const float* zrun = a.z.p + (long long)(ki - PF) * zst;
+        const float* xrun = a.xs + (long long)(ki - PF) * rstep;
+        const float* grun = a.gout + (long long)(ki - PF + 1) * rstep;
+        float* gzrun = (a.gz ? a.gz : a.gx0) + (long long)(a.gz ? ki : 0) * rstep;      // (no gz wanted: a base that is never stored through)
+        const bool st_gz = valid && a.gz != nullptr;
+        const float* ring = pring + wv * kBwdRing + (row * 4) * kBwdVals * 16 + u;      // this lane's trajectory, step 0 of block slot 0
+        __syncthreads();                                          // block 0 of the partner's rows is in the ring
+        for (int bi = 0; bi < nchunk; ++bi, ki -= PF) {
+            const float* rb = ring + (bi & 1) * 16 * kBwdVals * 16;
 #pragma unroll
-                for (int j = 0; j < PF; ++j) {
-                    const float h_ = t_hi - tq[j];
-                    t_hi = tq[j];
-                    const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
-                    tq[j] = ldg<float>(as_g(trun), toff);
-                    zq_[j] = ldg<float>(as_g(zrun), zoff);
-                    xq[j] = ldg<float>(as_g(xrun), roff);
-                    const float gl = ldg<float>(as_g(grun), roff);
-                    gq[j] = valid ? gl : 0.0f;
-                    trun -= tst; zrun -= zst; xrun -= rstep; grun -= rstep;
-                    sweep_step(h_, zk, x0, g1, [&](const float gzv) {
-                        if (st_gz) stg<float>((gptr<float>)(uintptr_t)gzrun, roff, gzv);
-                    });
-                    if (st_gz || a.gz) gzrun -= rstep;
-                }
+            for (int j = 0; j < PF; ++j) {
+                const float h_ = t_hi - tq[j];
+                t_hi = tq[j];
+                const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
+                tq[j] = ldg<float>(as_g(trun), toff);
+                zq_[j] = ldg<float>(as_g(zrun), zoff);
+                xq[j] = ldg<float>(as_g(xrun), roff);
+                const float gl = ldg<float>(as_g(grun), roff);
+                gq[j] = valid ? gl : 0.0f;
+                trun -= tst; zrun -= zst; xrun -= rstep; grun -= rstep;
+                sweep_step(h_, zk, x0, g1,
+                           [&](const float, const float, const float x0_, float (&X)[S], float (&hh)[S]) {
+                               const float* rv = rb + j * kBwdVals * 16;
+#pragma unroll
+                               for (int st = 0; st < S; ++st) {
+                                   hh[st] = rv[st * 16];
+                                   X[st] = st == 0 ? x0_ : rv[(S + st - 1) * 16];
+                               }
+                           },
+                           [&](const float gzv) {
+                               if (st_gz) stg<float>((gptr<float>)(uintptr_t)gzrun, roff, gzv);
+                           });
+                if (st_gz || a.gz) gzrun -= rstep;
             }
-            kc = ki;
+            __syncthreads();                                      // the partner may overwrite this block's slot; the next block is complete
         }
+        kc = ki;
     }
     for (; kc >= 0; kc -= PF) {
 #pragma unroll
@@ -885,7 +989,7 @@ __global__ __launch_bounds__(256) void latent_ode_backward_dpp_kernel(const Late
                 const float zk = zq_[j], x0 = xq[j], g1 = gcarry + gq[j];
                 const int ev = evq[j];
                 if (k - PF >= 0) fetch(j, k - PF);
-                sweep_step(h_, zk, x0, g1, [&](const float gzv) {
+                sweep_step(h_, zk, x0, g1, phase_a_dpp, [&](const float gzv) {
                     if (valid) {
                         if (ev >= 0) { if (a.gzj) a.gzj[(b * a.n_events + ev) * LH + u] = gzv; }
                         if (a.gz) a.gz[(k * a.B + b) * LH + u] = ev >= 0 ? 0.0f : gzv;
@@ -983,7 +1087,7 @@ int latent_bwd_dpp_launch(const psnode_ode_bwd_args_f32* p, float* workspace, hi
     a.xs = p->xs; a.gout = p->grad_xs; a.gx0 = p->grad_x0; a.gz = p->grad_z; a.gzj = p->grad_z_jump; a.ga0 = p->grad_all_initial;
     a.wpart = workspace;
     const int nwg = (int)((p->B + DTB - 1) / DTB);
-    const dim3 grid((unsigned)nwg), block(256);
+    const dim3 grid((unsigned)nwg), block(512);      // 4 sweep waves + their 4 partner waves (phase A on MFMA tiles)
     switch (p->method) {
         case PSNODE_EULER: hipLaunchKernelGGL((latent_ode_backward_dpp_kernel<PSNODE_EULER>), grid, block, 0, s, a); break;
         case PSNODE_MIDPOINT: hipLaunchKernelGGL((latent_ode_backward_dpp_kernel<PSNODE_MIDPOINT>), grid, block, 0, s, a); break;
