@@ -70,6 +70,26 @@ def test_encoded_forward_matches_oracle(method, B, Tn, xd, zd):
     assert traj_rel_err(xh.cpu(), ref_xs, bdim=1) <= TOL_GPU
 
 
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("B,Tn,xd,zd", [(37, 23, 8, 2), (16, 16, 5, 3), (1, 2, 1, 1), (19, 17, 8, 2), (64, 33, 16, 16), (3, 150, 12, 9), (130, 48, 8, 2)])
+def test_two_role_form_equals_the_one_role_form_and_the_oracle(method, B, Tn, xd, zd):
+    """Round 5: a call without events runs K3f in its two-role form (the z encoder, the decoder and the reconstruction on the partner wave's MFMA
+    tiles, handed over through LDS rings, one barrier per 16 steps); asking for the latent trajectory (want_latent) keeps the one-role path.
+    Both against each other and against the oracle -- grids that end inside a 16-row block, one block, more blocks than the ring holds,
+    ragged trajectory tiles, every input width."""
+    xe, ze, xdec, de, t, x, z, _, _ = _case(B, Tn, xd, zd, seed=B * 7 + Tn, events=False)
+    want = _oracle(method, xe, ze, xdec, de, t, x, z, None, None)
+    args = (method, _dev(xe), _dev(ze), _dev(xdec), _dev(de), t.cuda(), x.cuda(), z.cuda())
+    p2, r2, _ = fused().ode_encoded_integrate(*args)
+    p1, r1, xh1 = fused().ode_encoded_integrate(*args, want_latent=True)
+    assert xh1 is not None
+    for got, ref, what in ((p2, want[0], "x_pred two-role"), (r2, want[1], "x_re two-role"), (p1, want[0], "x_pred one-role"), (r1, want[1], "x_re one-role")):
+        assert traj_rel_err(got.cpu(), ref, bdim=0) <= TOL_GPU, what
+    assert traj_rel_err(p2.cpu(), p1.cpu(), bdim=0) <= 2e-6 and traj_rel_err(r2.cpu(), r1.cpu(), bdim=0) <= 2e-6
+    pn, rn, _ = fused().ode_encoded_integrate(*args, want_recon=False)      # no reconstruction wanted: the partner still encodes z and decodes
+    assert rn is None and torch.equal(pn, p2)
+
+
 def test_encoded_forward_strided_inputs_and_no_recon():
     """Inputs as non-contiguous slices of wider tensors (element strides travel through the C ABI); reconstruction skipped."""
     B, Tn, xd, zd = 19, 15, 8, 2
