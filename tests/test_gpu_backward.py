@@ -708,7 +708,9 @@ def test_dae_backward_kernel_selection():
 
 
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-@pytest.mark.parametrize("B,Tn,events", [(21, 9, True), (16, 5, False), (1, 2, False), (3, 1, False), (37, 12, True)])
+@pytest.mark.parametrize("B,Tn,events", [(21, 9, True), (16, 5, False), (1, 2, False), (3, 1, False), (37, 12, True),
+                                         # round 5: no event -> the FAST / two-role form (>= 10 grid points): one block, a tail, many blocks, ragged tiles
+                                         (16, 10, False), (5, 11, False), (37, 14, False), (130, 33, False), (2, 64, False), (19, 150, False)])
 def test_latent16_ode_backward_kernel_matches_generic(method, B, Tn, events):
     """K8 (single-wave MFMA backward of the hidden-16 latent ODE, kernel='mfma') against K5 (generic, checked against fp64
     autograd in test_generic_backward_kernel_ode) with events, per-trajectory clocks, ragged tiles and T in {1, 2}; AUTO picks K8."""
@@ -732,6 +734,7 @@ def test_latent16_ode_backward_kernel_matches_generic(method, B, Tn, events):
         tab = fused.event_table(t.cuda(), ev)
     G = torch.randn(Tn, B, H, generator=g).cuda()
     xs = fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj)
+    _close(xs, fused.ode_integrate(method, layers, t.cuda(), x_in, z, a0, event_t=ev, z_jump=zj, kernel="generic").double().cpu(), "forward (K3f vs K0)")
     out = {k: fused.ode_backward(method, layers, t.cuda(), z, a0, xs, G, event_idx=tab, z_jump=zj, kernel=k) for k in ("mfma", "generic", "auto")}
     names = ["grad x0", "grad z", "grad z_jump", "grad all_initial"]
     for nme, a, b, c in zip(names, out["mfma"][:4], out["generic"][:4], out["auto"][:4]):
