@@ -327,10 +327,13 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
     for (int jj = 0; jj < 4; ++jj) tq[jj] = ldg<float>(as_g(a.t.p + (long long)(jj < nT ? jj : nT - 1) * tst), toff);
     const float* trun = a.t.p + 4 * tst;             // the row the next refill reads (full chunks only)
     __syncthreads();                                 // cz' of block 0
+    float czv = czr[64 + lane];                      // cz' of the row in hand, read a step ahead of its use (row 1 first; rows of the NEXT block
+                                                     // only behind the barrier that completes them)
     auto step_row = [&](const int r, const float tr) {        // the step that ends at row r >= 1
         const float h_ = tr - t_cur;
         const int so = (r & (kRingRows - 1)) * 64 + lane;
-        const float cz = c0 + czr[so];
+        const float cz = c0 + czv;
+        if (((r + 1) & 15) != 0) czv = czr[((r + 1) & (kRingRows - 1)) * 64 + lane];
         const float k1 = rhs(x, cz);
         if constexpr (METHOD == PSNODE_EULER) {
             x = x + h_ * k1;
@@ -371,6 +374,7 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
             }
         }
         __syncthreads();
+        czv = czr[(r0 & (kRingRows - 1)) * 64 + lane];           // first row of the next block
     }
 }
 
