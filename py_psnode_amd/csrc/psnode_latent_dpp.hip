@@ -186,29 +186,37 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
         const int ntraj = a.B - bw >= 4 ? 4 : (a.B - bw > 0 ? (int)(a.B - bw) : 0);
         const bool recon = a.xre != nullptr;
         // Raw inputs of a block travel a block ahead of their use: z rows r - 1 (the external input of the step that ENDS at row r), x rows r.
-        // The four trajectories' tiles are written as straight-line code (a trajectory beyond the batch re-reads the first one and stores
-        // nothing): four independent MFMA chains for the scheduler to interleave -- one tile alone is a dependent chain of 14.
+        // A tile is 4 grid points x the pair's 4 trajectories (row j = (step j >> 2, trajectory j & 3)): a block of 16 steps is four tiles, written as
+        // straight-line code -- four independent MFMA chains for the scheduler to interleave (one tile alone is a dependent chain of 10) -- and the
+        // rows a store instruction writes are the 4 trajectories of one grid point side by side (128 contiguous bytes of the time-major output;
+        // 16 grid points of ONE trajectory per tile scattered every 32-byte row into its own DRAM page).  A trajectory beyond the batch re-reads
+        // the first one and stores nothing.
+        const int tj = j & 3, ts = j >> 2;
+        const bool tok = tj < ntraj;
+        const long long btj = bw + (tok ? tj : 0);
         float vz[4][4], vx[4][4];
         auto request_z = [&](const int blk) {
-            const int r = 16 * blk + j, rz = r - 1 < 0 ? 0 : (r - 1 < nT ? r - 1 : nT - 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float* sz = a.z.p + (bw + (q < ntraj ? q : 0)) * a.z.sb + (long long)rz * a.z.st + nmz * g;
+                const int r = 16 * blk + 4 * q + ts, rz = r - 1 < 0 ? 0 : (r - 1 < nT ? r - 1 : nT - 1);
+                const float* sz = a.z.p + btj * a.z.sb + (long long)rz * a.z.st + nmz * g;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) vz[q][m] = (m < nmz && nmz * g + m < zd) ? sz[m] : 0.0f;
             }
         };
         auto request_x = [&](const int blk) {
-            const int r = 16 * blk + j, rx = r < nT ? r : nT - 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float* sx = a.x.p + (bw + (q < ntraj ? q : 0)) * a.x.sb + (long long)rx * a.x.st + nme * g;
+                const int r = 16 * blk + 4 * q + ts, rx = r < nT ? r : nT - 1;
+                const float* sx = a.x.p + btj * a.x.sb + (long long)rx * a.x.st + nme * g;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) vx[q][m] = (m < nme && nme * g + m < xd) ? sx[m] : 0.0f;
             }
         };
+        auto ring_at = [&](float* ring_, const int blk, const int q) -> float* {      // ring row of tile q's row of this lane: [row & 31][trajectory][unit]
+            return ring_ + ((16 * blk + 4 * q + ts) & (kRingRows - 1)) * 64 + tj * 16 + 4 * g;
+        };
         auto ztiles = [&](const int blk) {           // from the registers request_z(blk) filled
-            const int slot = (16 * blk + j) & (kRingRows - 1);
             f4l acc[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -219,9 +227,9 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = layer16(mz, elu_quad(acc[q]), bzp);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4l*>(czr + slot * 64 + q * 16 + 4 * g) = acc[q];
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4l*>(ring_at(czr, blk, q)) = acc[q];
         };
-        auto decode4 = [&](f4l (&xh)[4], float* base, const long long st_t, const long long st_b, const int r, auto l1_done) {   // rows of x_decoder, stored
+        auto decode4 = [&](f4l (&xh)[4], float* base, const long long st_t, const long long st_b, const int blk, auto l1_done) {   // rows of x_decoder, stored
             if constexpr (!decltype(l1_done)::value) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xh[q] = layer16(w1d, xh[q], b1d);
@@ -230,8 +238,9 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
             for (int q = 0; q < 4; ++q) xh[q] = layer16(w2d, elu_quad(xh[q]), b2d);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q < ntraj && r < nT) {
-                    float* dst = base + (bw + q) * st_b + (long long)r * st_t + 4 * g;
+                const int r = 16 * blk + 4 * q + ts;
+                if (tok && r < nT) {
+                    float* dst = base + (bw + tj) * st_b + (long long)r * st_t + 4 * g;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) if (4 * g + m < xd) dst[m] = xh[q][m];
                 }
@@ -247,14 +256,13 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = layer16(mr, elu_quad(acc[q]), brp);      // = x_decoder's first layer of the encoded row
-            decode4(acc, a.xre, a.xre_st, a.xre_sb, 16 * blk + j, std::true_type{});
+            decode4(acc, a.xre, a.xre_st, a.xre_sb, blk, std::true_type{});
         };
         auto decode_tiles = [&](const int blk) {
-            const int r = 16 * blk + j, slot = r & (kRingRows - 1);
             f4l xh[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xh[q] = *reinterpret_cast<const f4l*>(xr + slot * 64 + q * 16 + 4 * g);
-            decode4(xh, a.xo, a.B * xd, xd, r, std::false_type{});
+            for (int q = 0; q < 4; ++q) xh[q] = *reinterpret_cast<const f4l*>(ring_at(xr, blk, q));
+            decode4(xh, a.xo, a.B * xd, xd, blk, std::false_type{});
         };
         request_z(0);
         ztiles(0);
