@@ -31,6 +31,40 @@ __device__ __forceinline__ long long row_offset(const long long r, const long lo
     const unsigned o = (unsigned)r / inner;
     return (long long)o * outer + (long long)((unsigned)r - o * inner) * stride;
 }
+// Which rows a 16-row tile holds.  Flat input: rows 16 t .. 16 t + 15.  Two-level input whose OUTER index is the contiguous one (the time-major
+// view of a [B,T,D] batch: outer = t, pitch D; inner = b, pitch T D): a tile is 4 outer x 4 inner indices -- 4 grid points of 4 trajectories:
+// the input comes in runs of 4 D floats and the output / gradient rows in runs of 4 rows -- instead of 16 trajectories of one grid point
+// (16 reads of D floats, T D floats apart: every 32-byte sector from its own DRAM page).
+struct TileWalk {
+    long long rows, stride, outer_stride;
+    unsigned inner, outer_n, tiles_o, tiles_i;
+    bool square;
+    long long tiles;
+    __device__ __forceinline__ TileWalk(long long rows_, long long stride_, unsigned inner_, long long outer_stride_)
+        : rows(rows_), stride(stride_), outer_stride(outer_stride_), inner(inner_) {
+        square = inner > 0 && outer_stride < stride;
+        outer_n = inner > 0 ? (unsigned)(rows / inner) : 0u;
+        tiles_o = (outer_n + 3u) / 4u;
+        tiles_i = (inner + 3u) / 4u;
+        tiles = square ? (long long)tiles_i * tiles_o : (rows + 15) / 16;
+    }
+    // row index (clamped into the set when the tile runs over an edge), validity and input offset of tile row j
+    __device__ __forceinline__ void at(const long long t, const int j, long long& row, bool& valid, long long& in_off) const {
+        if (square) {
+            const unsigned ti = (unsigned)t / tiles_o, to = (unsigned)t - ti * tiles_o;       // consecutive tiles: consecutive outer blocks of one inner block
+            const unsigned i = 4u * ti + ((unsigned)j & 3u), o = 4u * to + ((unsigned)j >> 2);
+            valid = i < inner && o < outer_n;
+            const unsigned ic = i < inner ? i : inner - 1u, oc = o < outer_n ? o : outer_n - 1u;
+            row = (long long)oc * inner + ic;
+            in_off = (long long)oc * outer_stride + (long long)ic * stride;
+        } else {
+            const long long r = t * 16 + j;
+            valid = r < rows;
+            row = valid ? r : rows - 1;
+            in_off = row_offset(row, stride, inner, outer_stride);
+        }
+    }
+};
 
 // NM = MFMAs of layer 1 = ceil(in_dim / 4); lane group g supplies columns NM*g + m.
 // HT = hidden tiles (hidden width 16*HT: 1 or 4), OT = output tiles (ceil(out_dim / 16): 1 or 4).  One wave owns its 16 rows
@@ -60,15 +94,17 @@ __global__ __launch_bounds__(256) void rows_kernel(const RowsArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b2r[ot][r] = 16 * ot + 4 * g + r < a.out_dim ? a.b2[16 * ot + 4 * g + r] : 0.0f;
     }
-    const long long tiles = (a.rows + 15) / 16;
+    const TileWalk walk(a.rows, a.in_stride, a.in_inner, a.in_outer);
+    const long long tiles = walk.tiles;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
     constexpr int VB = NM == 2 ? 8 : 16;   // bytes of one vector load
     const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && a.in_outer % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
     const bool vec_out = a.out_dim % 4 == 0 && a.out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     for (long long t = wave; t < tiles; t += nwaves) {
-        const long long row = t * 16 + j;
-        const bool valid = row < a.rows;
-        const float* src = a.in + row_offset(valid ? row : a.rows - 1, a.in_stride, a.in_inner, a.in_outer) + NM * g;
+        long long row, in_off;
+        bool valid;
+        walk.at(t, j, row, valid, in_off);
+        const float* src = a.in + in_off + NM * g;
         float v[NM];
         if (vec_in) {
             if constexpr (NM % 4 == 0) {
@@ -243,17 +279,18 @@ __global__ __launch_bounds__(256, ((NM == 16 && HT == 4 && OT == 1) || (NM <= 4 
         return f4{s[0], s[16], s[32], s[48]};
     };
 
-    const long long tiles = (a.rows + 15) / 16;
+    const TileWalk walk(a.rows, a.in_stride, a.in_inner, a.in_outer);
+    const long long tiles = walk.tiles;
     const long long wave = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
     constexpr int VB = NM == 2 ? 8 : 16;
     const bool vec_in = (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.in_stride % (VB / 4) == 0 && a.in_outer % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.in) % VB) == 0;
     const bool vec_gin = a.gin && (NM == 2 || NM % 4 == 0) && a.in_dim == 4 * NM && a.gin_stride % (VB / 4) == 0 && (reinterpret_cast<uintptr_t>(a.gin) % VB) == 0;
     const bool vec_go = a.out_dim % 4 == 0 && a.gout_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.gout) & 15) == 0;
     for (long long t = wave; t < tiles; t += nwaves) {
-        const long long row = t * 16 + j;
-        const bool valid = row < a.rows;
-        const long long rc = valid ? row : a.rows - 1;
-        const float* src = a.in + row_offset(rc, a.in_stride, a.in_inner, a.in_outer) + NM * g;
+        long long row, in_off;
+        bool valid;
+        walk.at(t, j, row, valid, in_off);
+        const float* src = a.in + in_off + NM * g;
         float v[NM];
         if (vec_in) {
             if constexpr (NM % 4 == 0) {
