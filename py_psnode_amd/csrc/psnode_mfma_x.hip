@@ -247,7 +247,11 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         constexpr int WAITN = decltype(wait_tag)::value;
         // SAVE: a step also issued 4 stores per stage (xstage + three layers, every one from at least one lane of every wave) behind its prefetch
         constexpr int NSAVE = SAVE ? 4 * (METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4)) : 0;
-        constexpr int WN = WAITN == 0 ? 0 : (WAITN == 4 ? 4 + 2 * NSAVE : WAITN + NSAVE);   // (two steps of look-ahead: two steps' stores); 6 bits: [3:0], [15:14]
+        // ring of R steps of look-ahead (wait tag 100 + R): behind the loads in hand sit the rest of their own step (row store + saved rows) and
+        // R - 1 whole steps (2 loads + row store + saved rows each); the legacy tags 1 / 4 are R = 1 / 2.  6 bits: [3:0], [15:14]
+        constexpr int RDEPTH = WAITN >= 100 ? WAITN - 100 : (WAITN == 4 ? 2 : 1);
+        constexpr int WN = WAITN == 0 ? 0 : (1 + NSAVE) + (RDEPTH - 1) * (3 + NSAVE);
+        static_assert(WN <= 63, "vmcnt is 6 bits");
         if (pair_ok && WN > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (WN & 15) | ((WN >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
         const float h_ = tuse - t_cur;
@@ -302,7 +306,43 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     using W1 = std::integral_constant<int, 1>;
     using W4 = std::integral_constant<int, 4>;
     constexpr bool TWO_AHEAD = FAST && METHOD != PSNODE_RK4_38;
-    if constexpr (TWO_AHEAD) {
+    // The saving forward: its 4 S stores per step retire IN ORDER in front of the next loads, so with one step of look-ahead a step cannot start
+    // before the previous step's rows are acknowledged -- 17 KB in flight per wave, 3.2 TB/s (a plain fill writes this HBM at 6.9 TB/s,
+    // profiles/r05ai_hbm_write_bw.txt).  A ring of R steps gives the stores R steps to drain: R = 3 at RK4 (55 operations behind the loads; vmcnt
+    // holds 63), 4 at Euler / Midpoint.
+    constexpr int RING = (SAVE && FAST) ? (METHOD == PSNODE_RK4_38 ? 3 : (METHOD == PSNODE_MIDPOINT ? 4 : 4)) : 0;
+    if constexpr (RING > 0) {
+        using WR = std::integral_constant<int, 100 + RING>;
+        float tq[RING], eq[RING];                    // slot j: t[k + 1] and the external value of step k, k = j (mod RING)
+        tq[0] = t_nxt; eq[0] = e_nxt;
+#pragma unroll
+        for (int j = 1; j < RING; ++j) {
+            const int rt = j + 1 < nT ? j + 1 : nT - 1, rz = j < nT ? j : nT - 1;
+            tq[j] = ldg<float>(as_g(a.t.p + (long long)rt * tst), toff);
+            eq[j] = ldg<float>(as_g(zbase + (long long)rz * zst), zoff);
+        }
+        trun = a.t.p + (long long)(RING + 1) * tst;   // the next refill: t[RING + 1], row RING -- requested by step 0
+        zrun = zbase + (long long)RING * zst;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        int k = 0;
+        for (; k + 2 * RING + 1 <= nT; k += RING) {  // RING steps that all prefetch: the last one requests row k + 2 RING - 1 <= T - 2
+#pragma unroll
+            for (int j = 0; j < RING; ++j) step(k + j, tq[j], eq[j], std::true_type{}, WR{});
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);           // the last (up to 2 RING) steps: what the ring holds has arrived; refills wait on the spot
+        int slot = 0;                                 // k is a multiple of RING here
+        for (; k + 1 < nT; ++k) {
+            const bool pf = k + RING + 2 <= nT;       // t[k + RING + 1] exists
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {
+                if (slot == j) {
+                    if (pf) step(k, tq[j], eq[j], std::true_type{}, W0{});
+                    else step(k, tq[j], eq[j], std::false_type{}, W0{});
+                }
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+        }
+    } else if constexpr (TWO_AHEAD) {
         // ring of two register pairs: (t_nxt, e_nxt) serve the even steps, (t_n2, e_n2) the odd ones; a step reloads the pair it used
         float t_n2 = ldg<float>(as_g(a.t.p + (nT > 2 ? 2 : 1) * tst), toff);            // t[2]
         float e_n2 = ldg<float>(as_g(zbase + zst), zoff);                                 // external row of step 1 (row 1 exists: T >= 2)
