@@ -111,6 +111,67 @@ __device__ __forceinline__ void quarter(const float (&wreg)[64], const float hc,
 #undef STEP
 }
 
+// mode 9: the 64 MFMAs of a layer with the B operands READ FROM AccVGPRs (inline asm, `a` constraint -- K2x's hh_layer_acc): is an AGPR source slower?
+template <int BB>
+__device__ __forceinline__ void block_acc(const float (&wk)[64], const f4 hA, f4& accA, f4& accB) {
+    asm volatile(
+        "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0"
+        : "+v"(accA), "+v"(accB)
+        : "v"(hA[0]), "v"(hA[1]), "v"(hA[2]), "v"(hA[3]), "a"(wk[4 * BB + 0]), "a"(wk[4 * BB + 1]), "a"(wk[4 * BB + 2]), "a"(wk[4 * BB + 3]), "n"(BB));
+}
+// mode 10: the same asm with the B operands in VGPRs (`v` constraint): the asm form's own cost
+template <int BB>
+__device__ __forceinline__ void block_vgpr(const float (&wk)[64], const f4 hA, f4& accA, f4& accB) {
+    asm volatile(
+        "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%10\n\t"
+        "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%10\n\t"
+        "s_nop 0"
+        : "+v"(accA), "+v"(accB)
+        : "v"(hA[0]), "v"(hA[1]), "v"(hA[2]), "v"(hA[3]), "v"(wk[4 * BB + 0]), "v"(wk[4 * BB + 1]), "v"(wk[4 * BB + 2]), "v"(wk[4 * BB + 3]), "n"(BB));
+}
+template <bool ACC>
+__global__ __launch_bounds__(64) void bench_asm(float* out, long long* cyc, int niter, const float* __restrict__ wsrc) {
+    const int l = threadIdx.x;
+    float wreg[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wreg[i] = wsrc[i * 64 + l];
+    f4 h = f4{0.1f + 0.001f * l, 0.2f, 0.3f, 0.4f};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < niter; ++it) {
+        f4 a0 = f4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#define BLK(B_) if constexpr (ACC) block_acc<B_>(wreg, h, a0, a1); else block_vgpr<B_>(wreg, h, a0, a1);
+        BLK(0) BLK(1) BLK(2) BLK(3) BLK(4) BLK(5) BLK(6) BLK(7) BLK(8) BLK(9) BLK(10) BLK(11) BLK(12) BLK(13) BLK(14) BLK(15)
+#undef BLK
+        asm volatile("s_nop 3" : "+v"(a0), "+v"(a1));
+        h = (a0 + a1) * 1e-3f;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + l] = h[0] + h[1] + h[2] + h[3];
+    if (blockIdx.x == 0 && l == 0) *cyc = t1 - t0;
+}
+template <bool ACC>
+void run_asm(const char* name, int nwg, float* out, long long* cyc, const float* w) {
+    const int niter = 4000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    bench_asm<ACC><<<nwg, 64>>>(out, cyc, 10, w);
+    hipEventRecord(e0);
+    bench_asm<ACC><<<nwg, 64>>>(out, cyc, niter, w);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long c; hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
+    printf("%-58s waves/SIMD=%d : %7.1f ns per layer (wall), s_memtime %.2f ticks\n", name, nwg / 1024, ms * 1e6 / niter, (double)c / niter);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void bench(float* out, long long* cyc, int niter, const float* __restrict__ wsrc) {
     const int l = threadIdx.x;
@@ -267,6 +328,8 @@ int main() {
     printf("mapping check (64 x 4x4x1 CBSZ=4/ABID=b + in-quad transpose vs a double-precision matvec): max abs diff %.3g %s\n", worst,
            worst < 1e-4 ? "OK" : "WRONG");
     run<0>("64 x 4x4x1 (2 chains), nothing else", 1024, out, cyc, w);
+    run_asm<false>("64 x 4x4x1 as ONE asm block per 4 k, B in VGPRs", 1024, out, cyc, w);
+    run_asm<true>("64 x 4x4x1 as ONE asm block per 4 k, B read from AccVGPRs", 1024, out, cyc, w);
     run<1>("64 x 4x4x1 + in-quad transpose", 1024, out, cyc, w);
     run<2>("64 x 4x4x1 + ELU + transpose (the whole layer)", 1024, out, cyc, w);
     run<3>("the whole layer, 4 accumulator chains", 1024, out, cyc, w);
