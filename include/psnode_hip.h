@@ -217,6 +217,21 @@ size_t psnode_mlp_rows_reduce_workspace_bytes(const psnode_mlp_f32* mlp, int64_t
 int32_t psnode_mlp_rows_reduce_f32(const psnode_mlp_f32* mlp, int64_t n_parts, void* workspace, size_t workspace_bytes, float* grad_params,
                                    void* stream);
 
+/* The RECONSTRUCTION branch of the direct_encode ODE model at hidden 16 as ONE row kernel each way (ABI 9):
+ *   x_re = x_decoder(x_encoder(x))        neural_00_ODE_02_direct_encode.py:87     (x_encoder in <= 16 -> 16 -> 16, x_decoder 16 -> 16 -> out <= 16)
+ * and its share of loss.backward() (:267-275).  The encoded rows never reach memory: the forward reads x and writes x_re, the backward reads x
+ * and dL/dx_re and returns the parameter gradients of BOTH modules as one flat vector
+ *   [W1e (16 x in), b1e (16), W2e (16 x 16), b2e (16) | W1d (16 x 16), b1d (16), W2d (out x 16), b2d (out)]        (nn.Linear order)
+ * (deterministic: per-wave partials in `workspace`, summed in a fixed order).  Input rows are addressed as in psnode_mlp_rows_f32. */
+int32_t psnode_recon_rows_supported(const psnode_mlp_f32* encoder, const psnode_mlp_f32* decoder);
+int32_t psnode_recon_rows_f32(const psnode_mlp_f32* encoder, const psnode_mlp_f32* decoder, int64_t rows, const float* in, int64_t in_row_stride,
+                              int64_t in_inner_rows, int64_t in_outer_stride, float* out, int64_t out_row_stride, void* stream);
+int64_t psnode_recon_rows_param_count(const psnode_mlp_f32* encoder, const psnode_mlp_f32* decoder);
+size_t psnode_recon_rows_backward_workspace_bytes(const psnode_mlp_f32* encoder, const psnode_mlp_f32* decoder, int64_t rows);
+int32_t psnode_recon_rows_backward_f32(const psnode_mlp_f32* encoder, const psnode_mlp_f32* decoder, int64_t rows, const float* in,
+                                       int64_t in_row_stride, int64_t in_inner_rows, int64_t in_outer_stride, const float* grad_out,
+                                       int64_t gout_row_stride, float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward (discretise-then-optimise) pass through psnode_ode_integrate_f32: what loss.backward() computes when it
  * walks the unrolled T-step autograd graph of integrate_ODE (neural_00_ODE_01_no_encode.py:358-360 through
  * my_solvers.py:66-78), in one launch.  Inputs: the forward arguments, the forward result xs and dL/dxs.

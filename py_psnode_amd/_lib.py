@@ -38,6 +38,8 @@ EXPORTS = (
     "psnode_masked_mse_workspace_bytes", "psnode_masked_mse_f32",
     "psnode_mlp_rows_backward_workspace_bytes", "psnode_mlp_rows_backward_f32",
     "psnode_mlp_rows_backward_parts", "psnode_mlp_rows_reduce_workspace_bytes", "psnode_mlp_rows_reduce_f32",
+    "psnode_recon_rows_supported", "psnode_recon_rows_f32", "psnode_recon_rows_param_count", "psnode_recon_rows_backward_workspace_bytes",
+    "psnode_recon_rows_backward_f32",
     "psnode_ode_encoded_supported", "psnode_ode_encoded_integrate_f32",
     "psnode_dae_encoded_supported", "psnode_dae_encoded_workspace_bytes", "psnode_dae_encoded_integrate_f32",
     "psnode_latent_backward_wide_supported", "psnode_latent_backward_wide_workspace_bytes", "psnode_latent_backward_wide_f32",
@@ -250,6 +252,18 @@ def load():
     lib.psnode_mlp_rows_reduce_workspace_bytes.argtypes = [ctypes.POINTER(MlpF32), c_int64]
     lib.psnode_mlp_rows_reduce_f32.restype = c_int32
     lib.psnode_mlp_rows_reduce_f32.argtypes = [ctypes.POINTER(MlpF32), c_int64, c_void_p, c_size_t, c_void_p, c_void_p]
+    P = ctypes.POINTER(MlpF32)
+    lib.psnode_recon_rows_supported.restype = c_int32
+    lib.psnode_recon_rows_supported.argtypes = [P, P]
+    lib.psnode_recon_rows_f32.restype = c_int32
+    lib.psnode_recon_rows_f32.argtypes = [P, P, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
+    lib.psnode_recon_rows_param_count.restype = c_int64
+    lib.psnode_recon_rows_param_count.argtypes = [P, P]
+    lib.psnode_recon_rows_backward_workspace_bytes.restype = c_size_t
+    lib.psnode_recon_rows_backward_workspace_bytes.argtypes = [P, P, c_int64]
+    lib.psnode_recon_rows_backward_f32.restype = c_int32
+    lib.psnode_recon_rows_backward_f32.argtypes = [P, P, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
+                                                   c_void_p]
     lib.psnode_masked_mse_workspace_bytes.restype = c_size_t
     lib.psnode_masked_mse_workspace_bytes.argtypes = [ctypes.POINTER(LossArgsF32)]
     lib.psnode_masked_mse_f32.restype = c_int32

@@ -193,7 +193,8 @@ __device__ __forceinline__ void enc_two_role(const LatentDppDev& a, float* __res
         // the first one and stores nothing.
         const int tj = j & 3, ts = j >> 2;
         const bool tok = tj < ntraj;
-        const long long btj = bw + (tok ? tj : 0);
+        const long long btj_raw = bw + (tok ? tj : 0);
+        const long long btj = btj_raw < a.B ? btj_raw : a.B - 1;      // (a pair whose trajectories all lie beyond the batch: bw itself is out of range)
         float vz[4][4], vx[4][4];
         auto request_z = [&](const int blk) {
 #pragma unroll

@@ -158,6 +158,80 @@ def mlp_rows_autograd_multi(seq, *inps):
     return _RowsMlpMulti.apply(lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, *inps)
 
 
+# ----------------------------------------------------------------------------- the reconstruction branch in one kernel each way (K3r)
+def recon_rows_supported(enc_layers: Layers, dec_layers: Layers, inp: torch.Tensor) -> bool:
+    """x_decoder(x_encoder(inp)) on the fused reconstruction kernels: fp32 HIP tensor, encoder in <= 16 -> 16 -> 16, decoder 16 -> 16 -> out <= 16."""
+    if inp.device.type != "cuda" or inp.dtype != torch.float32 or inp.numel() == 0 or len(enc_layers) != 2 or len(dec_layers) != 2:
+        return False
+    keep: list = []
+    return bool(_lib.load().psnode_recon_rows_supported(ctypes.byref(_mlp(enc_layers, inp.device, "encoder", keep)),
+                                                        ctypes.byref(_mlp(dec_layers, inp.device, "decoder", keep))))
+
+
+def recon_rows(enc_layers: Layers, dec_layers: Layers, inp: torch.Tensor) -> torch.Tensor:
+    """x_re = decoder(encoder(inp)) over the last dim (neural_00_ODE_02_direct_encode.py:87) in ONE launch: the encoded rows never reach memory."""
+    lib = _lib.load()
+    dev = inp.device
+    keep: list = []
+    me, md = _mlp(enc_layers, dev, "encoder", keep), _mlp(dec_layers, dev, "decoder", keep)
+    x = _f32_dev(inp, dev, "input")
+    if x.shape[-1] != me.in_dim:
+        raise ValueError(f"recon_rows: input width {x.shape[-1]}, expected {me.in_dim}")
+    x2, rows, rstride, inner, outer = _row_addressing(x)
+    out = _empty((*x.shape[:-1], dec_layers[-1][0].shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.psnode_recon_rows_f32(ctypes.byref(me), ctypes.byref(md), rows, x2.data_ptr(), rstride, inner, outer, out.data_ptr(),
+                                             out.shape[-1], torch.cuda.current_stream(dev).cuda_stream), "psnode_recon_rows_f32")
+    return out
+
+
+def recon_rows_backward(enc_layers: Layers, dec_layers: Layers, inp: torch.Tensor, grad_out: torch.Tensor):
+    """Parameter gradients of both modules from the raw rows and dL/dx_re: ([dW1e, db1e, dW2e, db2e], [dW1d, db1d, dW2d, db2d])."""
+    lib = _lib.load()
+    dev = inp.device
+    keep: list = []
+    me, md = _mlp(enc_layers, dev, "encoder", keep), _mlp(dec_layers, dev, "decoder", keep)
+    x2, rows, rstride, inner, outer = _row_addressing(_f32_dev(inp, dev, "input"))
+    g2 = _f32_dev(grad_out, dev, "grad_out").reshape(-1, grad_out.shape[-1])
+    if g2.stride(-1) != 1:
+        g2 = g2.contiguous()
+    if g2.shape[0] != rows or g2.shape[1] != dec_layers[-1][0].shape[0]:
+        raise ValueError(f"recon_rows_backward: grad_out {tuple(grad_out.shape)} does not match input {tuple(inp.shape)}")
+    with torch.cuda.device(dev):
+        npar = int(lib.psnode_recon_rows_param_count(ctypes.byref(me), ctypes.byref(md)))
+        gp = _empty(npar, dtype=torch.float32, device=dev)
+        nbytes = lib.psnode_recon_rows_backward_workspace_bytes(ctypes.byref(me), ctypes.byref(md), rows)
+        ws = _empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        _lib.check(lib.psnode_recon_rows_backward_f32(ctypes.byref(me), ctypes.byref(md), rows, x2.data_ptr(), rstride, inner, outer, g2.data_ptr(),
+                                                      g2.stride(0), gp.data_ptr(), wp, wn, torch.cuda.current_stream(dev).cuda_stream),
+                   "psnode_recon_rows_backward_f32")
+    ne = sum(w.numel() + b.numel() for w, b in enc_layers)
+    return _split_grads(gp[:ne], enc_layers), _split_grads(gp[ne:], dec_layers)
+
+
+class _ReconRows(torch.autograd.Function):
+    """decoder(encoder(inp)) for DATA rows (inp gets no gradient): saves the input rows only; the backward recomputes everything in one kernel."""
+
+    @staticmethod
+    def forward(ctx, inp, w1e, b1e, w2e, b2e, w1d, b1d, w2d, b2d):
+        ctx.save_for_backward(inp, w1e, b1e, w2e, b2e, w1d, b1d, w2d, b2d)
+        return recon_rows([(w1e, b1e), (w2e, b2e)], [(w1d, b1d), (w2d, b2d)], inp)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inp, w1e, b1e, w2e, b2e, w1d, b1d, w2d, b2d = (q.detach() for q in ctx.saved_tensors)
+        ge, gd = recon_rows_backward([(w1e, b1e), (w2e, b2e)], [(w1d, b1d), (w2d, b2d)], inp, grad_out)
+        return (None, *ge, *gd)
+
+
+def recon_rows_autograd(encoder, decoder, inp: torch.Tensor) -> torch.Tensor:
+    """`decoder(encoder(inp))` for two recognised Linear-ELU-Linear modules, differentiable w.r.t. their parameters (inp must not need a gradient)."""
+    le = [m for m in encoder if isinstance(m, nn.Linear)]
+    ld = [m for m in decoder if isinstance(m, nn.Linear)]
+    return _ReconRows.apply(inp, le[0].weight, le[0].bias, le[1].weight, le[1].bias, ld[0].weight, ld[0].bias, ld[1].weight, ld[1].bias)
+
+
 def mlp_rows_autograd(seq, inp: torch.Tensor) -> torch.Tensor:
     """`seq(inp)` for a recognised Linear-ELU-Linear on the row kernels, differentiable w.r.t. the input and the parameters."""
     lin = [m for m in seq if isinstance(m, nn.Linear)]

@@ -63,6 +63,21 @@ def _rows_multi(seq, *inps):
     return tuple(_rows(seq, a) for a in inps)
 
 
+def _recon(encoder, decoder, inp):
+    """`decoder(encoder(inp))` of DATA rows on the fused reconstruction kernels (K3r), or None when the pair is not fusable there (hooks, other
+    widths, an input that needs a gradient itself, CPU)."""
+    from . import fused
+    if inp.requires_grad or inp.device.type != "cuda" or os.environ.get("PSNODE_NO_RECON") == "1":
+        return None
+    if any(fused._overrides_forward_hooks(m) for seq in (encoder, decoder) for m in (seq, *seq)):
+        return None
+    le, ld = fused.sequential_layers(encoder), fused.sequential_layers(decoder)
+    if le is None or ld is None or not fused.recon_rows_supported(le, ld, inp):
+        return None
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for seq in (encoder, decoder) for p in seq.parameters())
+    return fused.recon_rows_autograd(encoder, decoder, inp) if needs_grad else fused.recon_rows(le, ld, inp)
+
+
 class RowsSequential(nn.Sequential):
     """An `nn.Sequential(Linear, ELU, Linear)` -- same children, same parameters, same state-dict keys -- whose forward runs on the
     fused HIP row kernels (psnode_mlp_rows_f32 / _backward_f32) whenever the call is fusable (fp32 HIP tensor, hidden 16 / 64), and
@@ -210,16 +225,26 @@ class ODE_Model(nn.Module):
             # big tensor, whose gradient would otherwise be a zero-filled [T,B,H] tensor added to the integrator's.  Row-wise functions:
             # the values are the ones of the B-major evaluation.
             from .neural_dae.my_solvers import FixedGridODESolver
-            Xh, x0h = _rows_multi(self.x_encoder, _tm(x), x[:, 0])
+            own = isinstance(self.solver, FixedGridODESolver)
             Zh, z0h, zjh = _rows_multi(self.z_encoder, _tm(z), z[:, 0], z_jump)
+            # this package's solvers take the start state on its own (x_init): Xh then reaches the integrator only for its shape, and its
+            # gradient is the decoder's alone instead of that plus a [T,B,H] tensor of zeros with one row set.  With that, the encoded rows
+            # Xh = x_encoder(x) have ONE consumer left -- the reconstruction x_decoder(Xh) -- and at hidden 16 that whole branch is one
+            # kernel each way (fused.recon_rows_autograd, K3r): Xh never reaches memory.
+            x_re = _recon(self.x_encoder, self.x_decoder, _tm(x)) if own else None
+            if x_re is not None:
+                x0h = _rows(self.x_encoder, x[:, 0])
+                Xh_shape = x0h.detach().unsqueeze(0).expand(x.shape[1], -1, -1)       # [T,B,H] for the solver's shape checks only
+            else:
+                Xh, x0h = _rows_multi(self.x_encoder, _tm(x), x[:, 0])
+                Xh_shape = Xh.detach() if own else Xh
             a0 = torch.cat((x0h, z0h), dim=-1)
             self.event.set_event(t=event_t, z=zjh)
-            # this package's solvers take the start state on its own (x_init): Xh then reaches the integrator only for its shape, and its
-            # gradient is the decoder's alone instead of that plus a [T,B,H] tensor of zeros with one row set
-            own = isinstance(self.solver, FixedGridODESolver)
-            Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh.detach() if own else Xh, z=Zh, all_initial=a0,
+            Xh_sol = self.solver.integrate_ODE(x_func=self.de_func, t=_tm(t), x=Xh_shape, z=Zh, all_initial=a0,
                                                event_fn=self.event.event_fn, jump_change_fn=self.event.jump_change_fn,
                                                **({"x_init": x0h} if own else {}))
+            if x_re is not None:
+                return _tm(_rows(self.x_decoder, Xh_sol)), _tm(x_re)
             x_pred, x_re = _rows_multi(self.x_decoder, Xh_sol, Xh)
             return _tm(x_pred), _tm(x_re)
         Xh_bt = _rows(self.x_encoder, x)                          # [B,T,H]; the solver gets the usual permuted view

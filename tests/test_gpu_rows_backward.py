@@ -139,6 +139,50 @@ def test_one_module_over_several_row_sets_is_one_autograd_node(din, H, dout):
         _close(q, dict(ref.named_parameters())[n].grad, 2e-5, n)
 
 
+@pytest.mark.parametrize("din,dout", [(8, 8), (2, 2), (5, 3), (16, 16), (1, 1), (12, 7)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (37, 11), (130, 33), (16, 16)])
+def test_reconstruction_branch_in_one_kernel_each_way(din, dout, B, T):
+    """K3r (psnode_recon_rows_f32 / _backward_f32): x_decoder(x_encoder(x)) of neural_00_ODE_02_direct_encode.py:87 at hidden 16 with the encoded
+    rows never in memory -- forward against the two row kernels it replaces and against fp64, the parameter gradients of BOTH modules against
+    fp64 autograd and against the unfused route, on the time-major view of a [B,T,D] batch (read in place) and on a contiguous copy; ragged
+    row counts; deterministic."""
+    from py_psnode_amd import fused
+    torch.manual_seed(din * 31 + dout + B)
+    enc = nn.Sequential(nn.Linear(din, 16), nn.ELU(), nn.Linear(16, 16)).cuda()
+    dec = nn.Sequential(nn.Linear(16, 16), nn.ELU(), nn.Linear(16, dout)).cuda()
+    base = torch.randn(B, T, din, device="cuda")
+    view = base.permute(1, 0, 2)
+    G = torch.randn(T, B, dout, device="cuda")
+    le, ld = fused.sequential_layers(enc), fused.sequential_layers(dec)
+    assert fused.recon_rows_supported(le, ld, view)
+
+    def grads(fn, inp):
+        enc.zero_grad(set_to_none=True); dec.zero_grad(set_to_none=True)
+        out = fn(inp)
+        (out * G).sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in (*enc.parameters(), *dec.parameters())]
+
+    o_f, g_f = grads(lambda a: fused.recon_rows_autograd(enc, dec, a), view)
+    o_c, g_c = grads(lambda a: fused.recon_rows_autograd(enc, dec, a), view.contiguous())
+    o_u, g_u = grads(lambda a: fused.mlp_rows_autograd(dec, fused.mlp_rows_autograd(enc, a)), view)
+    assert o_f.shape == (T, B, dout) and torch.equal(o_f, o_c) and all(torch.equal(a, b) for a, b in zip(g_f, g_c))
+    assert torch.equal(o_f, fused.recon_rows(le, ld, view))
+    _close(o_f, o_u, 2e-6, "x_re vs the two row kernels")
+    for k, (a, b) in enumerate(zip(g_f, g_u)):
+        _close(a, b, 2e-5, f"param {k} vs the unfused route")
+    e64 = nn.Sequential(nn.Linear(din, 16), nn.ELU(), nn.Linear(16, 16)).double()
+    d64 = nn.Sequential(nn.Linear(16, 16), nn.ELU(), nn.Linear(16, dout)).double()
+    e64.load_state_dict({k: v.double().cpu() for k, v in enc.state_dict().items()})
+    d64.load_state_dict({k: v.double().cpu() for k, v in dec.state_dict().items()})
+    y64 = d64(e64(view.double().cpu()))
+    (y64 * G.double().cpu()).sum().backward()
+    _close(o_f, y64, 2e-6, "x_re vs fp64")
+    for k, (a, p) in enumerate(zip(g_f, (*e64.parameters(), *d64.parameters()))):
+        _close(a, p.grad, 2e-5, f"param {k} vs fp64 autograd")
+    _, g_2 = grads(lambda a: fused.recon_rows_autograd(enc, dec, a), view)
+    assert all(torch.equal(a, b) for a, b in zip(g_f, g_2)), "deterministic"
+
+
 @pytest.mark.parametrize("events", [False, True])
 @pytest.mark.parametrize("method", ["euler", "rk4"])
 @pytest.mark.parametrize("tag,H,zd", [("ode02", 16, 2), ("dae02", 16, 2), ("dae02", 16, 0), ("ode02", 64, 2), ("dae02", 64, 2), ("dae02", 64, 0)])
@@ -190,7 +234,7 @@ def _direct_encode_case(tag, H, zd, method, events, B, T):
     out, gfn = run(m32, lambda a: a, "cuda")
     # the reconstruction comes off the row kernel (time-major on the HIP route: a permuted view of its output)
     node = gfn.next_functions[0][0] if type(gfn).__name__ == "PermuteBackward0" else gfn
-    assert type(node).__name__.startswith("_RowsMlp"), type(node).__name__
+    assert type(node).__name__.startswith(("_RowsMlp", "_ReconRows")), type(node).__name__      # (ODE_02 at hidden 16: the fused reconstruction, K3r)
     for a, b in zip(out, ref):
         _close(a, b, 1e-5, "model output")
     for (n, p), (_, q) in zip(m32.named_parameters(), m64.named_parameters()):
