@@ -205,6 +205,86 @@ def bytes_per_state_step(w):
     return rd + wr
 
 
+def executed_flops_per_state_step(w, p, method, kname):
+    """Flops the dispatched kernel ISSUES per state-step (SQ_INSTS_MFMA x flop per instruction / trajectories per wave for the MFMA
+    integrators -- the per-step instruction counts are those of profiles/r05g_k1x_rk4_pmc_sq.txt, r05_dae01_pmc_sq.txt; the folded
+    VALU count for K3f) next to SURVEY 8(d)'s DENSE count of flops_per_state_step(): L1's `a0 | s - a0 | s` image is folded to one
+    block and the external-input block runs once per step, so a kernel executes fewer flops than the dense graph has.  None where no
+    per-kernel constant is known (frac_executed is then null)."""
+    stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+    if w["kind"] == "dae02_model":
+        return flops_per_state_step(w, p, method)            # that count is already the executed one (see there)
+    if w["kind"] == "ode02_model" and kname == "valu_dpp" and w.get("E", w["H"]) == w["H"]:
+        H, xd, zd = w["H"], w["xd"], w["zd"]
+        lat = stages * 2 * H * H + H * H                      # per stage: x block of L1 + L2; per step: the folded z block
+        encdec = (xd * H + H * H) + (zd * H + H * H) + 2 * (H * H + H * xd)
+        return 2 * (lat + encdec)
+    if kname == "mfma_wave" and w["H"] <= 64 and w["kind"] in ("ode", "dae"):
+        # v_mfma_f32_4x4x1_16B_f32 = 16 blocks x 16 MAC = 512 flop per wave of 4 trajectories
+        per_stage = 8 + 64 + 64 + 8                            # L1 (x dims), two H->H layers, L4 (split-K)
+        if w["kind"] == "ode":
+            n_mfma = stages * per_stage + 4 * ((2 * w["zd"] + 3) // 4)
+        else:
+            n_mfma = stages * per_stage + 16 + 148               # + the DE's per-step constant + the AE head (740 per RK4 step)
+        return n_mfma * 512 / 4
+    if kname == "mfma" and w["kind"] == "ode" and w["H"] in (32, 64, 128) and w["xd"] <= 8:
+        nw = w["H"] // 16                                      # K1: nw waves x 16 trajectories on v_mfma_f32_16x16x4_f32 (2048 flop)
+        per_wave_stage = 2 + 2 * 4 * nw + 4
+        n_mfma = nw * (stages * per_wave_stage + (2 * w["zd"] + 3) // 4)
+        return n_mfma * 2048 / 16
+    return None
+
+
+def roofline_fracs(w, p, method, kname, ss, kernel_ms, train=False):
+    """Both flop conventions on every line: frac_dense prices SURVEY 8(d)'s dense count (what `frac` is),
+    frac_executed the flops the kernel issues -- pipe utilisation."""
+    dense = flops_per_state_step(w, p, method) * (3 if train else 1)
+    ex = executed_flops_per_state_step(w, p, method, kname)
+    if ex is not None and train:
+        ex = None                                               # the backward kernels' issue counts are reported by the train lines themselves
+    to_frac = lambda f: f * ss / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS
+    return {"frac_dense": to_frac(dense), "frac_executed": to_frac(ex) if ex is not None else None,
+            "flop_dense_per_state_step": dense, "flop_executed_per_state_step": ex}
+
+
+def oracle_subset_check(w, p_cpu, method, outs, nb=32, steps=100):
+    """gpu_vs_oracle for one line: the first `nb` trajectories x first `steps` grid steps of the TIMED batch (events are decided by
+    trajectory 0, which is among them; trajectories do not interact) through oracle/psnode_oracle.py on the host, against the same slice
+    of the fused path's outputs -- under both metrics of tests/helpers.py.  The checker, never the thing measured."""
+    from oracle import psnode_oracle as O
+    B, T_s = w["B"], min(steps + 1, w["T"])
+    nb = min(nb, B)
+    sub = {}
+    for k, v in p_cpu.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == B:
+            sub[k] = v[:nb]
+        else:
+            sub[k] = v
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 8))
+    try:
+        ref = run_oracle(O, w, sub, method, T_s)
+    finally:
+        torch.set_num_threads(old)
+    ref = ref if isinstance(ref, (tuple, list)) else (ref,)
+    model = w["kind"] in ("ode02_model", "dae02_model")
+    per_traj, elem = 0.0, 0.0
+    for got, r in zip(outs, ref):
+        r = r.double()
+        if model:                                               # model outputs are [B,T,D]; the oracle's are [T,B,D] or [B,T,D]
+            y = got[:nb, :T_s].double().cpu()
+            if r.shape != y.shape:
+                r = r.permute(1, 0, 2)
+            y, r = y.permute(1, 0, 2), r.permute(1, 0, 2)
+        else:
+            y = got[:T_s, :nb].double().cpu()
+        d = (y - r).abs()
+        per_traj = max(per_traj, float((d.amax((0, 2)) / r.abs().amax((0, 2)).clamp_min(1e-3)).max()))
+        elem = max(elem, float((d / r.abs().clamp_min(1e-3)).max()))
+    return {"sample": f"first {nb} trajectories x first {T_s - 1} steps of the timed batch, {len(list(zip(outs, ref)))} output tensor(s)",
+            "per_trajectory_rel_err": per_traj, "elementwise_rel_err": elem, "tolerance": "1e-5 per trajectory (north_star)"}
+
+
 def cpu_baseline(w, p_cpu, method, budget_s=12.0, gpu_out=None):
     """The CPU oracle on the node's host cores (bounded sample).  gpu_out = the fused path's first output [T,B,D] for the same batch:
     its error against the oracle's sample is reported under BOTH metrics of tests/helpers.py (north_star's per-trajectory one and
@@ -354,14 +434,38 @@ def _extra_line(lib, _lib, fused, workload, w, method, dev, steps, warmup, note)
     kname = kernel_name_for(lib, _lib, fused, w, p, method, "auto", dev)
     ach = flops * ss / (avg * 1e-3) / 1e12
     bound = "valu_fp32" if kname == "valu_dpp" else "mfma"     # K3f issues no MFMA: it is priced against the same fp32 datapath peak
+    if w["kind"] == "dae02_model":
+        # ONE convention on every line: `frac` = the DENSE count of SURVEY 8(d) (4 x 13 H^2 + 8 H^2 MACs per RK4
+        # step for the latent integrator + the encoders / decoders); the executed count (zero-order hold folded) is frac_executed
+        H = w["H"]
+        stages = {"euler": 1, "midpoint": 2, "rk4": 4}[method]
+        nblk = 4 if w["zd"] else 3
+        dense_lat = stages * (3 * nblk * H * H + H * H) + ((nblk - 1 + nblk) * H * H + H * H)
+        dense = 2 * dense_lat + (flops - 2 * (stages * 2 * H * H + (nblk - 1) * H * H + nblk * H * H))
+        ach_dense = dense * ss / (avg * 1e-3) / 1e12
+    else:
+        dense, ach_dense = flops, ach
+    fr = roofline_fracs(w, p_cpu, method, kname, ss, avg)
+    if w["kind"] == "dae02_model":
+        fr["frac_dense"], fr["flop_dense_per_state_step"] = ach_dense / PEAK_FP32_TFLOPS, dense
+    try:
+        check = oracle_subset_check(w, p_cpu, method, outs)
+    except Exception as e:      # the checker must never take the measured line down with it
+        check = {"error": f"{type(e).__name__}: {e}"}
     return {"workload": f"{workload} {method}: B={B} x {T - 1} steps, H{w['H']}" + (f" [{note}]" if note else ""), "kernel": kname, "steps": steps, "warmup": warmup,
             "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
             "outputs_finite": bool(torch.isfinite(outs[0]).all()),
-            "roofline": {"bound": bound, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+            "gpu_vs_oracle": check,
+            "roofline": {"bound": bound, "achieved": ach_dense, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_dense / PEAK_FP32_TFLOPS,
+                         "frac_dense": fr["frac_dense"], "frac_executed": fr["frac_executed"],
+                         "frac_note": "frac = frac_dense: SURVEY 8(d)'s dense flop count over the measured kernel time (it can exceed 1 where folding "
+                                      "L1's a0 | s - a0 | s image and the zero-order hold removes most of the dense graph's work); frac_executed "
+                                      "= the flops the kernel issues = pipe utilisation",
+                         "flop_executed_per_state_step": fr["flop_executed_per_state_step"],
                          "traffic": traffic_for(workload, method, kname, B, T, w["H"] if w["H"] != WORKLOADS[workload]["H"] else None),
                          "traffic_source": "profiles/pmc_traffic.json",
                          "kernel_ms": avg, "kernel_ms_median": med,
-                         "flop_per_state_step": flops, "bytes_per_state_step": bts,
+                         "flop_per_state_step": dense, "bytes_per_state_step": bts,
                          "hbm_achieved_GBs": bts * ss / (avg * 1e-3) / 1e9}}
 
 
@@ -834,6 +938,7 @@ def main():
                                           pipelined, chunk_model) if dist is not None else None,
             "roofline": {"bound": "valu_fp32" if kname == "valu_dpp" else "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic is not None else None,
+                         **{k: v for k, v in roofline_fracs(w, p_cpu, args.method, kname, state_steps_launch, kern_avg_ms, args.train).items()},
                          "kernel_ms": kern_avg_ms, "kernel_ms_median": kern_med_ms,
                          "kernel_ms_min": kern_ms[0], "kernel_ms_max": kern_ms[-1], "flop_per_state_step": flops,
                          "hbm_achieved_GBs": ach_gbs, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": ach_gbs / PEAK_HBM_GBS,

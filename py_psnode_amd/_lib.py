@@ -23,7 +23,9 @@ ABI_VERSION = 9          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: rou
                          #  6: psnode_dae_encoded_*: the DAE_02 model forward in one launch;
                          #  7: psnode_latent_backward_wide_*: the adjoint sweep of the latent integrators at hidden widths other than 16 / 64;
                          #  8: the split backward forms are gone -- no psnode_ode_backward_wide_*, no k0 / k1 / stored DE rows in
-                         #     psnode_dae_bwd_wide_args_f32 -- and PSNODE_KERNEL_MFMA_TILE / _WAVE select K1 / K1x for forward ODE calls)
+                         #     psnode_dae_bwd_wide_args_f32 -- and PSNODE_KERNEL_MFMA_TILE / _WAVE select K1 / K1x for forward ODE calls;
+                         #  9: row addressing (inner rows / outer stride) in psnode_mlp_rows_*, psnode_recon_rows_*, psnode_mlp_rows_reduce_f32 /
+                         #     _backward_parts: the row kernels read [B,T,D] batches as time-major rows in place)
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)

@@ -99,7 +99,6 @@ class _FusedOde(torch.autograd.Function):
     @staticmethod
     def forward(ctx, method, kernel, event_idx, t, x0, z, all_initial, z_jump, *params):
         layers = [(params[k], params[k + 1]) for k in range(0, len(params), 2)]
-        ctx.x_true = None
         global last_saved_bytes
         ctx.x_true = False
         if x0.dim() == 3:        # teacher forcing (my_solvers.py:72-74): x0 is the whole dataset x [T,B,xd]; nothing is saved, K4f recomputes

@@ -290,7 +290,8 @@ int32_t psnode_ode_kernel_for(const psnode_ode_args_f32* a) {
     memset(&d, 0, sizeof(d));
     d.method = a->method; d.flags = a->flags; d.xd = a->x_dim; d.zd = a->z_dim; d.T = a->T; d.B = a->B;
     bind_dims(a->de, d.de);
-    if (!mfma_ode_supported(d)) return PSNODE_KERNEL_GENERIC;
+    d.kern = a->kernel;                                              // a forced _TILE / _WAVE / GENERIC is what the call would run
+    if (a->kernel == PSNODE_KERNEL_GENERIC || !mfma_ode_supported(d)) return PSNODE_KERNEL_GENERIC;
     d.sact = a->save_act;
     return mfma_x_ode_preferred(d) ? PSNODE_KERNEL_MFMA_WAVE : PSNODE_KERNEL_MFMA;      // (_WAVE: K1x -- the one-wave-per-4-trajectories integrator)
 }
@@ -303,7 +304,8 @@ int32_t psnode_dae_kernel_for(const psnode_dae_args_f32* a) {
     d.T = a->T; d.B = a->B;
     bind_dims(a->de, d.de);
     bind_dims(a->ae, d.ae);
-    if (!mfma_dae_supported(d)) return PSNODE_KERNEL_GENERIC;
+    d.kern = a->kernel;
+    if (a->kernel == PSNODE_KERNEL_GENERIC || !mfma_dae_supported(d)) return PSNODE_KERNEL_GENERIC;
     d.sact = a->save_act;
     return mfma_x_dae_preferred(d) ? PSNODE_KERNEL_MFMA_WAVE : PSNODE_KERNEL_MFMA;      // (_WAVE: K2x)
 }
@@ -345,12 +347,12 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, float* __
     else out_b[pidx - np_a] = total;
 }
 }  // namespace
-hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s) {
+hipError_t launch_reduce_partials(float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s) {
     const int np = np_a + np_b;
     int stride = 1;
     if (nparts >= 8 * kPartSlices) {       // many vectors: sum kPartSlices slices in place first (the partials are scratch: nothing reads them again)
         stride = (nparts + kPartSlices - 1) / kPartSlices;
-        hipLaunchKernelGGL(reduce_partials_slices_kernel, dim3((np + 63) / 64, kPartSlices), dim3(64), 0, s, const_cast<float*>(part), np, nparts, stride);
+        hipLaunchKernelGGL(reduce_partials_slices_kernel, dim3((np + 63) / 64, kPartSlices), dim3(64), 0, s, part, np, nparts, stride);
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((np + 63) / 64), dim3(64), 0, s, part, out_a, out_b, np_a, np_b, nparts, stride);   // 64-wide: more CUs
     return hipGetLastError();

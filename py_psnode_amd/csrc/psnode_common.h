@@ -245,8 +245,10 @@ bool mfma_x_dae_supported(const IntegrateDev& a);
 bool mfma_x_dae_preferred(const IntegrateDev& a);
 size_t mfma_xd_pack_floats();
 hipError_t launch_mfma_xd(const IntegrateDev& a, float* pack, hipStream_t stream);
-// psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel)
-hipError_t launch_reduce_partials(const float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
+// psnode_capi.hip: fixed-order sum of per-workgroup partial vectors (parameter gradients of every backward kernel).  `part` is SCRATCH and
+// is DESTROYED: with 128 or more vectors the first pass sums slices in place (the first vector of each slice then holds the slice's sum),
+// so a buffer cannot be reduced twice.  The summation order is fixed for a given nparts (it changes at the 128-vector threshold).
+hipError_t launch_reduce_partials(float* part, float* out_a, float* out_b, int np_a, int np_b, int nparts, hipStream_t s);
 // K4f (psnode_backward_fused.hip): one-launch MFMA backward of the ODE integrator at hidden <= 128 (zero-padded to 32 / 64 / 128), x_dim <= 8, z_dim <= 8
 bool fused_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
 size_t fused_bwd_workspace_floats(const psnode_ode_bwd_args_f32* a);

@@ -132,5 +132,14 @@ __device__ __forceinline__ f4 ext_mfmas(const float (&we)[16], const float eA, f
 
 constexpr int kXWaves = 4;      // independent waves per workgroup (one per SIMD)
 
+// K1x / K2x address a row as <uniform 64-bit row base> + <32-bit per-lane BYTE offset>: (trajectory * batch stride + column) * 4 must fit
+// 32 bits and the batch stride must not be negative (a B-major dataset view of >= 4 GiB, or a negative stride from a C
+// caller, would wrap silently).  Views that do not qualify stay on K1 / K2 (64-bit indexing); a forced _WAVE call returns UNSUPPORTED.
+inline bool span32_ok(const long long B, const long long sb, const long long cols) {
+    if (sb < 0 || B < 1) return false;
+    const unsigned long long last = (unsigned long long)(B - 1) * (unsigned long long)sb + (unsigned long long)cols;
+    return last < (1ull << 30);                                  // elements: x 4 bytes < 2^32
+}
+
 }  // namespace
 }  // namespace psnode

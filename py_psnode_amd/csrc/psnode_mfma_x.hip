@@ -400,7 +400,14 @@ bool mfma_x_ode_supported(const IntegrateDev& a) {
     if (a.sact && ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) || !a.sxst || ((uintptr_t)a.sact & 15) || ((uintptr_t)a.sxst & 7))) return false;
     if (m.n_layers != 4 || m.in_dim != 3 * (a.xd + a.zd) || m.out_dim[3] != a.xd) return false;
     const int h = m.out_dim[0];
-    return h >= 1 && h <= 64 && m.out_dim[1] == h && m.out_dim[2] == h;
+    if (!(h >= 1 && h <= 64 && m.out_dim[1] == h && m.out_dim[2] == h)) return false;
+    // 32-bit per-lane byte offsets (span32_ok): every row the time loop addresses that way, once the pointers are known
+    if (a.t.p && !span32_ok(a.B, a.t.sb, 1)) return false;
+    if (a.zd > 0 && a.z.p && !span32_ok(a.B, a.z.sb, a.zd)) return false;
+    if (a.zd > 0 && a.zj && !span32_ok(a.B, a.zjb, a.zd)) return false;
+    if ((a.flags & PSNODE_FLAG_INPUT_TRUE_X) && a.x.p && !span32_ok(a.B, a.x.sb, a.xd)) return false;
+    if (!span32_ok(a.B, a.xd, a.xd) || (a.sact && !span32_ok(a.B, 64, 64))) return false;      // output rows [B,xd], saved rows [B,Hp]
+    return true;
 }
 // ... and the calls it takes them for: forced (PSNODE_KERNEL_MFMA_WAVE), or up to one wave per SIMD unless the 4-wave tile is forced
 bool mfma_x_ode_preferred(const IntegrateDev& a) {

@@ -375,7 +375,14 @@ bool mfma_x_dae_supported(const IntegrateDev& a) {
     const MlpDev &d = a.de, &g = a.ae;
     if (d.n_layers != 4 || g.n_layers != 4 || d.in_dim != 3 * n || d.out_dim[3] != a.xd || g.in_dim != n + a.xd + nzv || g.out_dim[3] != a.id) return false;
     const int h = d.out_dim[0];
-    return h >= 1 && h <= 64 && d.out_dim[1] == h && d.out_dim[2] == h && g.out_dim[0] == h && g.out_dim[1] == h && g.out_dim[2] == h;
+    if (!(h >= 1 && h <= 64 && d.out_dim[1] == h && d.out_dim[2] == h && g.out_dim[0] == h && g.out_dim[1] == h && g.out_dim[2] == h)) return false;
+    // 32-bit per-lane byte offsets (psnode_mfma_x.h: span32_ok): every row the time loop addresses that way, once the pointers are known
+    if (a.t.p && !span32_ok(a.B, a.t.sb, 1)) return false;
+    if (a.zd > 0 && a.z.p && !span32_ok(a.B, a.z.sb, a.zd)) return false;
+    if (a.vd > 0 && a.v.p && !span32_ok(a.B, a.v.sb, a.vd)) return false;
+    if (a.zd > 0 && a.zj && !span32_ok(a.B, a.zjb, a.zd)) return false;
+    if (a.vd > 0 && a.vj && !span32_ok(a.B, a.vjb, a.vd)) return false;
+    return span32_ok(a.B, a.xd, a.xd) && span32_ok(a.B, a.id, a.id);                           // output rows [B,xd] / [B,id]
 }
 bool mfma_x_dae_preferred(const IntegrateDev& a) {
     if (a.kern == PSNODE_KERNEL_MFMA_TILE || a.kern == PSNODE_KERNEL_GENERIC || !mfma_x_dae_supported(a)) return false;

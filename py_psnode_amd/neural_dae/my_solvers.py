@@ -111,7 +111,7 @@ class FixedGridODESolver(metaclass=abc.ABCMeta):
                             raise
                 # training: fused forward + fused backward when the backward kernel covers the shape
                 elif not input_true_x and _autograd().ode_training_supported(self.method, layers, x.shape[-1], z.shape[-1], t.shape[0],
-                                                                             t.shape[1]):
+                                                                             t.shape[1], kernel=self.kernel):
                     from ..autograd import fused_ode_integrate
                     return fused_ode_integrate(self.method, self.kernel, layers, t, x, z, all_initial, event_t, z_jump,
                                                check_events=self._check_events_now(event_t), x_init=x_init)

@@ -110,6 +110,44 @@ def test_k1_and_k1x_agree_and_auto_picks_by_batch(B, Tn):
         assert torch.equal(auto, wave if B <= 4608 else tile)
 
 
+def test_wave_integrators_refuse_views_whose_byte_offsets_do_not_fit_32_bits():
+    """K1x / K2x address rows as <uniform row base> + <32-bit per-lane byte offset>.  A view whose batch stride
+    spans >= 4 GiB (a B-major dataset of that size handed over as the scripts' permute(1,0,2) view) would wrap: AUTO must fall back to the
+    64-bit-indexed K1 and give the same numbers, a forced `wave` must be refused."""
+    from py_psnode_amd import _lib
+    B, Tn, xd, zd = 6, 9, 8, 2
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=xd, zd=zd, seed=17, H=64)
+    f = fused()
+    want = f.ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel="tile")
+    SB = (1 << 30) // (B - 1) + 8                            # (B - 1) * SB elements * 4 bytes >= 4 GiB
+    big = torch.zeros((B - 1) * SB + Tn * zd + 64, device="cuda")
+    zv = torch.as_strided(big, (Tn, B, zd), (zd, SB, 1))     # time-major view of "B-major" memory with a huge batch stride
+    zv.copy_(z.cuda())
+    got = f.ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), zv, a0.cuda(), kernel="auto")
+    assert torch.equal(got, want), "AUTO must take the 64-bit-indexed tile kernel for this view"
+    with pytest.raises(_lib.UnsupportedShapeError):
+        f.ode_integrate("rk4", dl(ls), t.cuda(), x.cuda(), zv, a0.cuda(), kernel="wave")
+    del big, zv
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kernel", ("tile", "wave"))
+@pytest.mark.parametrize("method", METHODS)
+def test_saving_and_plain_forward_agree(method, kernel):
+    """the inference instances run the hidden layers in the log2e-scaled ELU domain, the training forwards (which save the
+    rows the backward kernels read) in the plain one -- the same model and inputs under no_grad and under grad agree to rounding, on both
+    MFMA integrators, and both with the oracle."""
+    B, Tn = 70, 40
+    ls, t, x, z, a0 = _synthetic_ode(B, Tn, xd=8, zd=2, seed=29, H=64)
+    f = fused()
+    plain = f.ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel=kernel)
+    saving, saved = f.ode_integrate(method, dl(ls), t.cuda(), x.cuda(), z.cuda(), a0.cuda(), kernel=kernel, save=True)
+    assert saved is not None
+    ref = O.integrate_ode(method, ls, t, x, z, a0)
+    assert rel_err(plain.cpu(), saving.cpu()) <= 2e-6
+    assert rel_err(plain.cpu(), ref) <= TOL_GPU and rel_err(saving.cpu(), ref) <= TOL_GPU
+
+
 @pytest.mark.parametrize("kernel", ("tile", "wave"))
 @pytest.mark.parametrize("method", METHODS)
 def test_g3_on_both_mfma_dae_integrators(method, kernel):
