@@ -52,7 +52,7 @@ def dae_training_supported(method, de, ae, x_dim, z_dim, v_dim, i_dim, T, B) -> 
 def _want_saved(method, kernel, layers, x_dim, z_dim, T, B):
     if fused.latent_wide_shape(layers, None, x_dim, z_dim):      # K3w saves, K9w reads: the only fused backward at these widths (the solver
         return True                                              # asked latent_wide_training_fits before it came here)
-    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma"):
+    if SAVE_ACTIVATIONS == "0" or T < 2 or kernel not in ("auto", "mfma", "wave", "tile"):
         return False
     Hp = fused.ode_save_hidden(method, layers, x_dim, z_dim, kernel)
     latent = len(layers) == 2            # the direct_encode latent shape at hidden 64: K3c saves, K9 reads
@@ -125,6 +125,9 @@ class _FusedOde(torch.autograd.Function):
         xs, saved = res if save else (res, None)
         last_saved_bytes = sum(q.numel() * q.element_size() for q in saved) if saved is not None else 0
         ctx.method = method
+        ctx.bwd_kernel = {"wave": "wave", "tile": "tile"}.get(kernel, "auto")      # a forced forward form forces its backward counterpart (K4x / K4f)
+        if ctx.bwd_kernel != "auto" and not fused.ode_backward_supported(method, layers, x0.shape[-1], z.shape[-1], ctx.bwd_kernel):
+            ctx.bwd_kernel = "auto"                                                    # ... where that counterpart exists for the shape
         ctx.has_jump = z_jump is not None
         ctx.has_saved = saved is not None
         ctx.event_idx = event_idx
@@ -153,7 +156,8 @@ class _FusedOde(torch.autograd.Function):
                 gz = torch.zeros_like(z)
             return (None, None, None, None, None, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)   # (no gradient for the dataset x)
         gx0, gz, gzj, ga0, gpar = fused.ode_backward(ctx.method, layers, t, z, a0, xs, grad_xs, event_idx=ctx.event_idx, z_jump=z_jump,
-                                                     need_grad_z=need_z, saved=acts)
+                                                     need_grad_z=need_z, saved=acts, need_grad_zj=bool(ctx.needs_input_grad[7]),
+                                                     kernel=ctx.bwd_kernel if acts is not None else "auto")
         if gz is None and need_z:
             gz = torch.zeros_like(z)
         return (None, None, None, None, gx0, gz, ga0, gzj if ctx.needs_input_grad[7] else None, *gpar)

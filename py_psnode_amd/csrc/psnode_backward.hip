@@ -1,5 +1,6 @@
 // C ABI of the backward passes (include/psnode_hip.h: psnode_ode_backward_*, psnode_dae_backward_*): argument validation and the
 // dispatch among the backward kernel families --
+//   K4x (psnode_backward_x.hip)          ODE, hidden 33..64 with saved rows, up to one wave per SIMD: one wave = 4 trajectories, no LDS (round 6)
 //   K4f (psnode_backward_fused.hip)      ODE, in -> H -> H -> H -> x at hidden <= 128: one launch, saved-activation and recompute forms
 //   K8f / K9 (psnode_latent_dpp.hip / psnode_latent64_bwd*.hip)   the latent integrators of the direct_encode models at hidden 16 / 64
 //   K8 (psnode_latent_bwd.hip)           the latent DAE at hidden 16
@@ -38,7 +39,8 @@ bool use_latent64_bwd(const psnode_ode_bwd_args_f32* a) {   // K9: the only fuse
 
 extern "C" int32_t psnode_ode_backward_supported(const psnode_ode_bwd_args_f32* a) {
     if (!a || a->method < PSNODE_EULER || a->method > PSNODE_RK4_38) return 0;
-    if (a->kernel == PSNODE_KERNEL_MFMA_WIDE) return fused_bwd_shape_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA_WIDE || a->kernel == PSNODE_KERNEL_MFMA_TILE) return fused_bwd_shape_ok(a);
+    if (a->kernel == PSNODE_KERNEL_MFMA_WAVE) return bwd_x_shape_ok(a);       // K4x (needs the saved rows at launch)
     if (a->kernel == PSNODE_KERNEL_MFMA) return fused_bwd_shape_ok(a) || use_latent_bwd(a) || use_latent64_bwd(a);
     return use_fused_bwd(a) || use_latent_bwd(a) || use_latent64_bwd(a) || ode_generic_ok(a);
 }
@@ -53,6 +55,7 @@ extern "C" size_t psnode_ode_backward_workspace_bytes(const psnode_ode_bwd_args_
     if (latent_bwd_shape_ok(a)) floats = latent_bwd_workspace_floats(a->B) > floats ? latent_bwd_workspace_floats(a->B) : floats;
     if (latent64_ode_bwd_shape_ok(a)) floats = latent64_ode_bwd_workspace_floats(a->B) > floats ? latent64_ode_bwd_workspace_floats(a->B) : floats;
     if (fused_bwd_shape_ok(a)) { const size_t f3 = fused_bwd_workspace_floats(a); floats = f3 > floats ? f3 : floats; }
+    if (bwd_x_shape_ok(a)) { const size_t f4 = bwd_x_workspace_floats(a); floats = f4 > floats ? f4 : floats; }
     return floats * sizeof(float);
 }
 
@@ -68,13 +71,16 @@ extern "C" int32_t psnode_ode_backward_f32(const psnode_ode_bwd_args_f32* a, voi
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255u) || workspace_bytes < psnode_ode_backward_workspace_bytes(a))
         return PSNODE_ERR_WORKSPACE;
     if ((a->saved_act != nullptr) != (a->saved_xstage != nullptr)) return PSNODE_ERR_NULL;
-    if (a->saved_act && !use_fused_bwd(a) && !use_latent64_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4f and K9 read them
+    if (a->kernel == PSNODE_KERNEL_MFMA_WAVE && !bwd_x_preferred(a)) return PSNODE_ERR_UNSUPPORTED;   // K4x: saved rows, no teacher forcing
+    if (a->kernel == PSNODE_KERNEL_MFMA_TILE && !fused_bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;
+    if (a->saved_act && !use_fused_bwd(a) && !use_latent64_bwd(a)) return PSNODE_ERR_UNSUPPORTED;      // only K4x, K4f and K9 read them
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a->flags & ~PSNODE_FLAG_INPUT_TRUE_X) return PSNODE_ERR_UNSUPPORTED;
     if (a->flags & PSNODE_FLAG_INPUT_TRUE_X) {      // teacher-forced backward: K4f (recompute form) is the kernel that has it
         if (a->kernel == PSNODE_KERNEL_GENERIC || a->saved_act || !fused_bwd_shape_ok(a)) return PSNODE_ERR_UNSUPPORTED;
         return fused_bwd_launch(a, static_cast<float*>(workspace), s);
     }
+    if (bwd_x_preferred(a)) return bwd_x_launch(a, static_cast<float*>(workspace), s);      // K4x: up to one wave per SIMD at hidden 33..64
     if (use_latent_bwd(a)) return latent_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_latent64_bwd(a)) return latent64_ode_bwd_launch(a, static_cast<float*>(workspace), s);
     if (use_fused_bwd(a)) return fused_bwd_launch(a, static_cast<float*>(workspace), s);

@@ -253,6 +253,11 @@ hipError_t launch_reduce_partials(float* part, float* out_a, float* out_b, int n
 bool fused_bwd_shape_ok(const psnode_ode_bwd_args_f32* a);
 size_t fused_bwd_workspace_floats(const psnode_ode_bwd_args_f32* a);
 int fused_bwd_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
+// K4x (psnode_backward_x.hip): the exchange-free backward of the ODE integrator at hidden 33..64 -- one wave = 4 trajectories, saved rows only
+bool bwd_x_shape_ok(const psnode_ode_bwd_args_f32* a);
+bool bwd_x_preferred(const psnode_ode_bwd_args_f32* a);
+size_t bwd_x_workspace_floats(const psnode_ode_bwd_args_f32* a);
+int bwd_x_launch(const psnode_ode_bwd_args_f32* a, float* workspace, hipStream_t s);
 // K7f (psnode_dae_backward_fused.hip): the DAE backward at hidden <= 128 with the DE's parameter gradients formed in the kernel
 size_t dae_fused_bwd_workspace_floats(const psnode_dae_bwd_wide_args_f32* a);
 int dae_fused_bwd_launch(const psnode_dae_bwd_wide_args_f32* a, float* workspace, hipStream_t s);

@@ -30,10 +30,13 @@ def ode_backward_supported(method: str, de_layers: Layers, x_dim: int, z_dim: in
 
 
 def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs, event_idx=None, z_jump=None, need_grad_z: bool = True,
-                 kernel: str = "auto", saved=None, input_true_x: bool = False):
+                 kernel: str = "auto", saved=None, input_true_x: bool = False, need_grad_zj: bool = True):
     """Backward pass of `ode_integrate` in one launch.  `saved` = what `ode_integrate(save=True)` returned next to
     xs: K4f then skips the recompute of the stage evaluations.  input_true_x: backward of a teacher-forced call (my_solvers.py:72-74) --
     `xs` must then be the DATASET x the forward call started every step from; K4f (hidden <= 128, x_dim <= 8) only.
+    need_grad_z / need_grad_zj = False: dL/dz / dL/dz_jump are not formed (the scripts' z and z_jump are dataset tensors: K4x then runs
+    without its per-step dL/dz layer, and the [B,nE,zd] zero fill is not made).
+    kernel: "wave" = K4x (one wave per 4 trajectories; hidden 33..64, saved rows), "wide" / "tile" = K4f; "auto" picks between them.
     Returns (grad_x0 [B,xd], grad_z [T,B,zd] | None, grad_z_jump | None, grad_all_initial [B,n], [grad W1, b1, ..., W4, b4])."""
     lib = _lib.load()
     dev = xs.device
@@ -66,6 +69,7 @@ def ode_backward(method: str, de_layers: Layers, t, z, all_initial, xs, grad_xs,
         a.z_jump, a.zj_stride_b, a.zj_stride_e = _jump(z_jump, dev, "z_jump", keep)
         if z_jump is not None and zd > 0:
             a.n_events = z_jump.shape[1]
+        if z_jump is not None and zd > 0 and need_grad_zj:
             gzj = torch.zeros((B, z_jump.shape[1], zd), dtype=torch.float32, device=dev)
             a.grad_z_jump = gzj.data_ptr()
     with torch.cuda.device(dev):
