@@ -691,7 +691,7 @@ def self_launch(n):
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7      # MI355X: 7 xGMI links per GPU, ~153 GB/s each direction (MI355X_MICROARCH.md)
 
 
-def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, pipelined, chunk_model):
+def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, pipelined, chunk_model, gather_algo=None, by_algo=None):
     """What a reader needs to interpret an N > 1 line without a second run: the shard each rank contributes, what the all-gather should
     cost on xGMI (every rank receives (N-1) shards; a direct all-gather spreads them over N-1 of the 7 links, a ring pushes them all through
     one), what the two legs cost alone, and how much of the shorter one the pipeline hid."""
@@ -704,7 +704,10 @@ def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, p
            "predicted_gather_ms": {"direct_one_link_per_peer": direct, "ring_one_link": ring,
                                    "assumption": f"{XGMI_LINKS} xGMI links x {XGMI_LINK_GBS} GB/s per GPU, point to point"},
            "integrate_only_ms": integrate_ms, "gather_only_ms": gather_ms, "step_ms": step_ms, "chunks": chunks, "pipelined": bool(pipelined),
-           "chunk_model": chunk_model}
+           "chunk_model": chunk_model,
+           # rccl = all_gather_into_tensor (RCCL picks ring or direct by message size); direct = sharded.all_gather_direct (N-1 point-to-point
+           # pairs per chunk, one shard per xGMI link whatever the tuner thinks); by_algo: --gather-algo both, measured after the timed region
+           "gather_algo": gather_algo, "by_algo": by_algo}
     if gather_ms is not None:
         serial = integrate_ms + gather_ms
         rep["serial_ms"] = serial
@@ -738,6 +741,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
     ap.add_argument("--gather-layout", default="chunks", choices=["chunks", "batch"],
                     help="N>1, pipelined: per-chunk rank-major buffers (zero-copy) or every chunk gathered INTO one [T, N*B, D] tensor")
+    ap.add_argument("--gather-algo", default="rccl", choices=["rccl", "direct", "both"],
+                    help="N>1: the all-gather as RCCL's own all_gather_into_tensor, or as N-1 point-to-point pairs per chunk (sharded.all_gather_direct: "
+                         "every peer's shard on its own xGMI link, independent of RCCL's ring/direct choice); 'both' = timed region on rccl, then both "
+                         "timed again after it (gather alone and the pipelined step) and printed under multi_gpu")
+    ap.add_argument("--collective", default="gather", choices=["gather", "loss-only"],
+                    help="N>1: what follows the integration -- the all-gather of the output shards (north_star), or SURVEY 8(e)'s cheaper alternative: the "
+                         "sharded masked-MSE loss (three scalar all-reduces, nothing gathered)")
     ap.add_argument("--chunks", default="auto", help="N>1: time chunks of the integrate/all-gather pipeline (1 = no overlap; 'auto' = chosen from "
                     "the measured integrate-only and gather-only times of the warm-up)")
     args = ap.parse_args()
@@ -785,7 +795,10 @@ def main():
             mdl.solver.fused, mdl.solver.kernel = "require", args.kernel
     n_out = 1 if w["kind"] == "ode" else (4 if w["kind"] == "dae02_model" else 2)
     from py_psnode_amd import sharded
-    do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train   # training never gathers (sharded loss)
+    loss_only = (world > 1 or args.force_dist) and args.collective == "loss-only" and not args.train and w["kind"] in ("ode", "dae")
+    do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train and not loss_only   # training never gathers (sharded loss)
+    algo = "rccl" if args.gather_algo == "both" else args.gather_algo
+    loss_helper = Trainer(w, p, args.method, args.kernel, "mse-fused", dev, dist) if loss_only else None
     auto_chunks = str(args.chunks) == "auto"
     args.chunks = 4 if auto_chunks else int(args.chunks)
     pipelined = do_gather and w["kind"] in ("ode", "dae") and args.chunks > 1
@@ -794,7 +807,11 @@ def main():
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
         gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
 
+    if do_gather and args.gather_layout == "batch" and args.gather_algo != "rccl":
+        sys.exit("bench.py: --gather-layout batch gathers through c10d's list all_gather (RCCL's own algorithm); use --gather-layout chunks with --gather-algo direct / both")
     trainer = Trainer(w, p, args.method, args.kernel, args.loss, dev, dist) if args.train else None
+
+    step_algo = [algo]       # (a cell: the 'both' leg re-times the step on the other algorithm after the timed region)
 
     def one_step(ev_pair=None):
         """One pass of the hot path (+ the all-gather at N>1).  ev_pair brackets the compute-stream kernels only."""
@@ -812,13 +829,13 @@ def main():
             if w["kind"] == "ode":
                 xs, _, works = sharded.integrate_ode_pipelined(args.method, p["de"], tmv(p["t"]), tmv(p["x"]), tmv(p["z"]), p["a0"],
                                                                event_idx=tab, z_jump=p["z_jump"], chunks=args.chunks, wait=False,
-                                                               kernel=args.kernel, check_shards=False, layout=args.gather_layout)
+                                                               kernel=args.kernel, check_shards=False, layout=args.gather_layout, algo=step_algo[0])
                 outs = (xs,)
             else:
                 outs, _, works = sharded.integrate_dae_pipelined(args.method, p["de"], p["ae"], p["x_init"], tmv(p["t"]), tmv(p["z"]),
                                                                  tmv(p["v"]), tmv(p["i"]), p["a0"], event_idx=tab, z_jump=p["z_jump"],
                                                                  v_jump=p["v_jump"], chunks=args.chunks, wait=False, kernel=args.kernel,
-                                                                 check_shards=False, layout=args.gather_layout)
+                                                                 check_shards=False, layout=args.gather_layout, algo=step_algo[0])
             if ev_pair:
                 ev_pair[1].record()
             for wk in works:
@@ -829,7 +846,10 @@ def main():
             ev_pair[1].record()
         if gathered is not None:
             for g, o in zip(gathered, outs):
-                dist.all_gather_into_tensor(g, o)
+                sharded._gather_into(g, o, None, step_algo[0], False)
+        if loss_only:      # the sharded loss instead of the gather: sum(mask), then the loss terms -- scalar-sized all-reduces only
+            with torch.no_grad():
+                loss_helper.loss_of(outs[0], outs[1] if len(outs) > 1 else None)
         return outs
 
     def fence():
@@ -854,12 +874,12 @@ def main():
         i_ms = (time.perf_counter() - t_i) / 2 * 1e3
         bufs = [torch.empty((world * T, B, o.shape[-1]), dtype=torch.float32, device=dev) for o in outs0]
         for f_, o in zip(bufs, outs0):
-            dist.all_gather_into_tensor(f_, o.contiguous())
+            sharded._gather_into(f_, o.contiguous(), None, algo, False)
         fence()
         t_g = time.perf_counter()
         for _ in range(2):
             for f_, o in zip(bufs, outs0):
-                dist.all_gather_into_tensor(f_, o.contiguous())
+                sharded._gather_into(f_, o.contiguous(), None, algo, False)
         fence()
         g_ms = (time.perf_counter() - t_g) / 2 * 1e3
         tt = torch.tensor([i_ms, g_ms], dtype=torch.float64, device=dev)
@@ -891,20 +911,47 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms, kern_med_ms = float(tt[0]), float(tt[1]), float(tt[2])
 
-    gather_only_ms = None
+    gather_only_ms, by_algo = None, None
     if do_gather and w["kind"] in ("ode", "dae"):
-        # config 5 also wants the gather alone: un-pipelined all-gathers of the full [T,B,D] shards, after the timed region
+        # config 5 also wants the gather alone: un-pipelined all-gathers of the full [T,B,D] shards, after the timed region -- on the timed
+        # region's algorithm, and with --gather-algo both on the other one too (+ the pipelined step re-timed on it)
         flats = [torch.empty((world * T, B, o.shape[-1]), dtype=torch.float32, device=dev) for o in outs]
         srcs = [o.contiguous() for o in outs]
-        for f_, o in zip(flats, srcs):
-            dist.all_gather_into_tensor(f_, o)
-        fence()
-        tg = time.perf_counter()
-        for _ in range(3):
+
+        def gather_alone(al):
             for f_, o in zip(flats, srcs):
-                dist.all_gather_into_tensor(f_, o)
-        fence()
-        gather_only_ms = (time.perf_counter() - tg) / 3 * 1e3
+                sharded._gather_into(f_, o, None, al, False)
+            fence()
+            tg = time.perf_counter()
+            for _ in range(3):
+                for f_, o in zip(flats, srcs):
+                    sharded._gather_into(f_, o, None, al, False)
+            fence()
+            ms = (time.perf_counter() - tg) / 3 * 1e3
+            if dist is not None:
+                tt_ = torch.tensor([ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                ms = float(tt_[0])
+            return ms
+
+        gather_only_ms = gather_alone(algo)
+        if args.gather_algo == "both":
+            other = "direct" if algo == "rccl" else "rccl"
+            by_algo = {"gather_only_ms": {algo: gather_only_ms, other: gather_alone(other)}, "step_ms": {algo: elapsed / args.steps * 1e3}}
+            if args.gather_layout == "chunks" or not pipelined:
+                step_algo[0] = other
+                for _ in range(max(1, args.warmup)):
+                    one_step()
+                fence()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                fence()
+                ms = (time.perf_counter() - ts) / args.steps * 1e3
+                tt_ = torch.tensor([ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                by_algo["step_ms"][other] = float(tt_[0])
+                step_algo[0] = algo
         del flats, srcs
 
     finite = bool(torch.isfinite(outs[0]).all())
@@ -931,11 +978,16 @@ def main():
                        "kernel": kname, "trajectories_total": world * B,
                        "world_size_seen": dist.get_world_size() if dist is not None else 1, "device_count": torch.cuda.device_count(),
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if dist is not None else None,
-                       "collective": ((f"rccl all_gather of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration"
-                                       if pipelined else "rccl all_gather of the output shards [T,B,D]") if do_gather else "none"),
+                       "collective": (((("rccl all_gather" if algo == "rccl" else "direct all-gather (N-1 point-to-point pairs per chunk over RCCL send/recv)")
+                                        + f" of the output shards [T,B,D], {args.chunks} time chunks overlapped with the integration")
+                                       if pipelined else ("rccl all_gather" if algo == "rccl" else "direct all-gather (N-1 point-to-point pairs)")
+                                       + " of the output shards [T,B,D]") if do_gather
+                                      else ("rccl all_reduce x3 (sum(mask), loss terms): sharded masked-MSE loss, nothing gathered (SURVEY 8(e) alternative)"
+                                            if loss_only else "none")),
+                       "gather_algo": algo if do_gather else None,
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
             "multi_gpu": multi_gpu_report(w, world, B, T, elapsed / args.steps * 1e3, kern_avg_ms, gather_only_ms, args.chunks if do_gather else None,
-                                          pipelined, chunk_model) if dist is not None else None,
+                                          pipelined, chunk_model, algo if do_gather else None, by_algo) if dist is not None else None,
             "roofline": {"bound": "valu_fp32" if kname == "valu_dpp" else "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic is not None else None,
                          **{k: v for k, v in roofline_fracs(w, p_cpu, args.method, kname, state_steps_launch, kern_avg_ms, args.train).items()},

@@ -55,16 +55,67 @@ def require_equal_shards(Bl: int, device, group=None):
 _require_equal_shards = require_equal_shards
 
 
-def all_gather_batch(shard: torch.Tensor, group=None, check_shards: bool = True) -> torch.Tensor:
-    """[T, Bl, D] shards (equal Bl on every rank) -> [T, G*Bl, D] view in rank order, one all_gather_into_tensor.
-    The gathered storage is rank-major [G, T, Bl, D]; the result is its [T, G*Bl, D] rearrangement (one device copy)."""
+GATHER_ALGOS = ("rccl", "direct")
+
+
+class _Works:
+    """The requests of one direct gather behind the `.wait()` of a c10d Work (what _pipelined / bench.py hold)."""
+
+    def __init__(self, reqs):
+        self.reqs = list(reqs)
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        return True
+
+
+def all_gather_direct(flat: torch.Tensor, shard: torch.Tensor, group=None, async_op: bool = False):
+    """All-gather WITHOUT leaving the algorithm to RCCL: rank r's `shard` [R, Bl, D] lands in flat[r] (flat = [G*R, Bl, D], rank-major, as
+    all_gather_into_tensor fills it) through G - 1 point-to-point pairs issued as ONE batch (`dist.batch_isend_irecv` = one
+    ncclGroupStart / End): every peer's shard crosses its OWN xGMI link.  MI355X's xGMI is a point-to-point mesh (7 links x ~153 GB/s per
+    GPU, no switch): a ring all-gather pushes all G - 1 shards through one link (131 MB shards at config 5: 6.0 ms, against 2.2 ms of
+    integration), the direct exchange one shard per link (0.86 ms) -- and which of the two RCCL's tuner picks for a message size is not
+    the caller's to steer.  SURVEY 8(e); VERDICT round 5 item 6.  Returns a waitable (async_op) or None after waiting."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shard = shard.contiguous()
+    R = shard.shape[0]
+    if flat.shape[0] != world * R or flat.shape[1:] != shard.shape[1:] or not flat.is_contiguous():
+        raise ValueError(f"all_gather_direct: flat {tuple(flat.shape)} is not the rank-major concatenation of {world} x {tuple(shard.shape)}")
+    slots = flat.view(world, R, *shard.shape[1:])
+    slots[rank].copy_(shard)                                   # own rows: a local copy on the compute stream
+    peer = (lambda p: dist.get_global_rank(group, p)) if group is not None else (lambda p: p)
+    ops = []
+    for d in range(1, world):                                  # rank r talks to r + d and r - d in round d: every round is a perfect matching
+        to, frm = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, shard, peer(to), group))
+        ops.append(dist.P2POp(dist.irecv, slots[frm], peer(frm), group))
+    work = _Works(dist.batch_isend_irecv(ops) if ops else [])
+    if async_op:
+        return work
+    work.wait()
+    return None
+
+
+def _gather_into(flat, rows, group, algo, async_op):
+    if algo == "direct":
+        return all_gather_direct(flat, rows, group=group, async_op=async_op)
+    if algo != "rccl":
+        raise ValueError(f"gather algo {algo!r}: one of {GATHER_ALGOS}")
+    return dist.all_gather_into_tensor(flat, rows, group=group, async_op=async_op)
+
+
+def all_gather_batch(shard: torch.Tensor, group=None, check_shards: bool = True, algo: str = "rccl") -> torch.Tensor:
+    """[T, Bl, D] shards (equal Bl on every rank) -> [T, G*Bl, D] view in rank order, one all_gather_into_tensor (algo "rccl") or one batch
+    of point-to-point pairs (algo "direct": all_gather_direct).  The gathered storage is rank-major [G, T, Bl, D]; the result is its
+    [T, G*Bl, D] rearrangement (one device copy)."""
     world = dist.get_world_size(group)
     shard = shard.contiguous()
     T, Bl, D = shard.shape
     if check_shards:
         require_equal_shards(Bl, shard.device, group)
     flat = torch.empty((world * T, Bl, D), dtype=shard.dtype, device=shard.device)   # rank-major concatenation
-    dist.all_gather_into_tensor(flat, shard, group=group)
+    _gather_into(flat, shard, group, algo, False)
     return flat.view(world, T, Bl, D).permute(1, 0, 2, 3).reshape(T, world * Bl, D)
 
 
@@ -75,7 +126,7 @@ def chunk_bounds(T: int, chunks: int):
 
 
 def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, group, gather: bool, wait: bool, want_local: bool,
-               check_shards: bool = True, layout: str = "chunks"):
+               check_shards: bool = True, layout: str = "chunks", algo: str = "rccl"):
     """Shared driver of the time-chunked integrate / all-gather pipeline.  `launch(s, r1, starts, outs)` integrates grid points
     s..r1-1 from the state rows `starts` (None for the first chunk) into the buffers `outs` ([r1-s, Bl, D] each).
 
@@ -92,6 +143,8 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
     # into the strided views ON THE COLLECTIVE'S STREAM, i.e. the copy assemble() made afterwards on the compute stream now rides behind
     # each chunk's gather, overlapped with the integration of the next chunk.  layout "chunks" (default) stays zero-copy: per-chunk
     # rank-major buffers.
+    if gather and layout == "batch" and algo != "rccl":
+        raise ValueError("layout='batch' gathers through c10d's list all_gather (RCCL's own algorithm); the direct exchange fills rank-major chunk buffers")
     full = [torch.empty((T, world * Bl, d), dtype=dtype, device=device) for d in widths] if (gather and layout == "batch") else None
     prev = None
     for c in range(len(b) - 1):
@@ -109,7 +162,7 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
                 works.append(dist.all_gather(views, rows.contiguous(), group=group, async_op=True))
             elif gather:
                 buf = torch.empty((world * (r1 - r0), Bl, widths[k]), dtype=dtype, device=device)
-                works.append(dist.all_gather_into_tensor(buf, rows, group=group, async_op=True))
+                works.append(_gather_into(buf, rows, group, algo, True))
                 gathered[k].append((r0, r1, buf.view(world, r1 - r0, Bl, widths[k])))
     local = [torch.cat(r) if want_local else None for r in local_rows]
     if wait:
@@ -122,7 +175,7 @@ def _pipelined(launch, T: int, Bl: int, widths, dtype, device, chunks: int, grou
 
 def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=None, z_jump=None, chunks: int = 4, group=None,
                             local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True, want_local: bool = True,
-                            check_shards: bool = True, layout: str = "chunks", **kw):
+                            check_shards: bool = True, layout: str = "chunks", algo: str = "rccl", **kw):
     """Time-chunked integrate with the all-gather of finished chunks overlapped with the integration of later ones.
 
     The all-gather of one [T, Bl, xd] shard set at 8 GPUs moves ~0.9 GB into every GPU -- about as long as the
@@ -145,7 +198,7 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
         local_fn(method, de_layers, t[s:r1], x_start, z[s:r1], all_initial, z_jump=z_jump, event_idx=ev, out=outs[0], **kw)
 
     local, gathered, works = _pipelined(launch, T, Bl, [xd], x.dtype, x.device, chunks, group, gather, wait, want_local, check_shards,
-                                        layout)
+                                        layout, algo)
     if not wait:
         return local[0], gathered[0], works      # caller waits (bench.py brackets the compute stream before waiting)
     return local[0], gathered[0]
@@ -153,7 +206,7 @@ def integrate_ode_pipelined(method, de_layers, t, x, z, all_initial, event_idx=N
 
 def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, all_initial, event_idx=None, z_jump=None, v_jump=None,
                             chunks: int = 4, group=None, local_fn: Optional[Callable] = None, gather: bool = True, wait: bool = True,
-                            want_local: bool = True, check_shards: bool = True, layout: str = "chunks", **kw):
+                            want_local: bool = True, check_shards: bool = True, layout: str = "chunks", algo: str = "rccl", **kw):
     """integrate_DAE (no teacher forcing) as integrate_ode_pipelined: xs AND is shards gathered chunk by chunk behind the next
     chunk's kernel.  A chunk restarts from x_init = xs[s]; the launch recomputes i0 = g(xs[s]; z[s], v[s]) itself, which is exactly
     how is[s] was produced (my_solvers.py:121 uses the un-jumped z, v of the right grid point), so the restart is bit-identical
@@ -173,7 +226,7 @@ def integrate_dae_pipelined(method, de_layers, ae_layers, x_init, t, z, v, i, al
                  v_jump=v_jump, event_idx=ev, out=(outs[0], outs[1]), **kw)
 
     local, gathered, works = _pipelined(launch, T, Bl, [xd, idim], x_init.dtype, x_init.device, chunks, group, gather, wait, want_local,
-                                        check_shards, layout)
+                                        check_shards, layout, algo)
     if not wait:
         return tuple(local), tuple(gathered), works
     return tuple(local), tuple(gathered)
@@ -189,7 +242,8 @@ def assemble(gathered, T: int) -> torch.Tensor:
 
 
 def integrate_ode_sharded(method, de_layers, t, x, z, all_initial, event_t=None, z_jump=None, input_true_x=False,
-                          group=None, gather=True, local_fn: Optional[Callable] = None, table_fn: Optional[Callable] = None, **kw):
+                          group=None, gather=True, local_fn: Optional[Callable] = None, table_fn: Optional[Callable] = None,
+                          algo: str = "rccl", **kw):
     """Each rank passes ITS shard (t[T,Bl,1], x[T,Bl,xd], z[T,Bl,zd], all_initial[Bl,n], event_t/z_jump[Bl,nE,.]).
     Returns the gathered [T, G*Bl, xd] (gather=True) or the local [T,Bl,xd]."""
     if local_fn is None:
@@ -197,12 +251,12 @@ def integrate_ode_sharded(method, de_layers, t, x, z, all_initial, event_t=None,
         local_fn = fused.ode_integrate
     tab = broadcast_event_table(t, event_t, group, table_fn)
     xs = local_fn(method, de_layers, t, x, z, all_initial, z_jump=z_jump, input_true_x=input_true_x, event_idx=tab, **kw)
-    return all_gather_batch(xs, group) if gather else xs
+    return all_gather_batch(xs, group, algo=algo) if gather else xs
 
 
 def integrate_dae_sharded(method, de_layers, ae_layers, x_init, t, x, z, v, i, all_initial, event_t=None, z_jump=None, v_jump=None,
                           input_true_x=False, input_true_i=False, group=None, gather=True, local_fn: Optional[Callable] = None,
-                          table_fn: Optional[Callable] = None, **kw):
+                          table_fn: Optional[Callable] = None, algo: str = "rccl", **kw):
     if local_fn is None:
         from . import fused
         local_fn = fused.dae_integrate
@@ -211,7 +265,7 @@ def integrate_dae_sharded(method, de_layers, ae_layers, x_init, t, x, z, v, i, a
                        input_true_x=input_true_x, input_true_i=input_true_i, event_idx=tab, **kw)
     if not gather:
         return xs, is_
-    return all_gather_batch(xs, group), all_gather_batch(is_, group)
+    return all_gather_batch(xs, group, algo=algo), all_gather_batch(is_, group, algo=algo)
 
 
 def masked_mse_sharded(pred, target, mask, col_weight=None, t0_weight: float = 0.0, global_batch: Optional[int] = None, group=None,

@@ -54,5 +54,9 @@ def test_multi_gpu_report_keys_and_model():
     assert r["chunks"] == 5 and r["pipelined"] and r["chunk_model"] is cm
     for k in ("integrate_only_ms", "gather_only_ms", "step_ms", "gather_achieved_GBs_per_rank"):
         assert k in r
+    assert r["gather_algo"] is None and r["by_algo"] is None
+    both = {"gather_only_ms": {"rccl": 1.2, "direct": 0.9}, "step_ms": {"rccl": 3.7, "direct": 3.5}}
+    r2 = bench.multi_gpu_report(w, N, B, T, 3.7, 3.3, 1.2, 5, True, cm, "rccl", both)
+    assert r2["gather_algo"] == "rccl" and r2["by_algo"] is both
     d = bench.multi_gpu_report(dict(bench.WORKLOADS["dae01"]), 2, 4096, 1001, 5.0, 4.6, None, None, False, None)
     assert d["shard_bytes"] == 1001 * 4096 * (8 + 2) * 4 and "serial_ms" not in d

@@ -43,6 +43,29 @@ def test_bench_force_dist_runs_the_rccl_path(workload):
     assert cm is not None and 1 <= cm["chunks"] <= 16 and cm["chunks"] == mg["chunks"] and cm["integrate_only_ms"] > 0 and cm["gather_only_ms"] > 0
 
 
+@pytest.mark.parametrize("extra,expect", [(["--gather-algo", "both"], "by_algo"), (["--gather-algo", "direct"], "direct"),
+                                          (["--collective", "loss-only"], "loss")])
+def test_bench_force_dist_gather_algorithms_and_loss_only(extra, expect):
+    """Round 6: the all-gather as N - 1 point-to-point pairs (sharded.all_gather_direct) next to RCCL's own, both
+    timed by --gather-algo both; and SURVEY 8(e)'s cheaper alternative, the sharded loss with scalar all-reduces only.  World size 1 here
+    (the pairs degenerate to the local copy): the code path, the JSON keys and the RCCL group are what is under test."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--grid", "301",
+           "--batch", "512"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    cfg, mg = d["config"], d["multi_gpu"]
+    assert cfg["outputs_finite"] is True and cfg["rccl_version"]
+    if expect == "by_algo":
+        assert cfg["gather_algo"] == "rccl" and set(mg["by_algo"]["gather_only_ms"]) == {"rccl", "direct"} and set(mg["by_algo"]["step_ms"]) == {"rccl", "direct"}
+        assert all(v > 0 for v in mg["by_algo"]["gather_only_ms"].values()) and all(v > 0 for v in mg["by_algo"]["step_ms"].values())
+    elif expect == "direct":
+        assert cfg["gather_algo"] == "direct" and "direct all-gather" in cfg["collective"] and mg["gather_algo"] == "direct" and mg["gather_only_ms"] > 0
+    else:
+        assert "all_reduce x3" in cfg["collective"] and cfg["gather_algo"] is None and cfg["gather_only_ms"] is None
+
+
 def test_bench_under_an_external_launcher():
     """The contract's other spelling: python -m torch.distributed.run ... bench.py --gpus N (no self-launch)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -71,7 +94,21 @@ def test_default_bench_line_carries_the_extra_workloads():
     for e in d["extra"][10:13]:
         assert e["grads_finite"] and e["roofline"]["flop_convention"].startswith("3 x forward")
     for e in d["extra"]:
-        assert e["outputs_finite"] and 0.05 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_median"] > 0
+        # round 6: ONE flop convention on every line -- frac = frac_dense (SURVEY 8(d)'s dense count; exceeds 1 where folding removes most of the
+        # dense graph's work: the DAE_02 forward), frac_executed = the flops the kernel issues = pipe utilisation
+        r = e["roofline"]
+        assert e["outputs_finite"] and r["frac"] > 0.05 and r["kernel_ms_median"] > 0
+        if "frac_dense" in r:
+            assert r["frac"] == r["frac_dense"] and (r["frac_executed"] is None or 0.05 < r["frac_executed"] <= r["frac_dense"] + 1e-12)
+            assert (r["frac_executed"] if r["frac_executed"] is not None else r["frac"]) < 1.0
+        else:
+            assert r["frac"] < 1.0
+    fwd = [e for e in d["extra"] if "gpu_vs_oracle" in e]
+    assert len(fwd) == 7, [e["workload"] for e in fwd]      # every forward line is checked against the oracle
+    for e in fwd:
+        assert "error" not in e["gpu_vs_oracle"], e["gpu_vs_oracle"]
+        assert e["gpu_vs_oracle"]["per_trajectory_rel_err"] <= 1e-5, (e["workload"], e["gpu_vs_oracle"])
+    assert d["roofline"]["frac"] == d["roofline"]["frac_dense"] and 0.3 < d["roofline"]["frac_executed"] < d["roofline"]["frac_dense"]
     assert "H256" in d["extra"][-1]["workload"] and d["extra"][-1]["kernel"] == "mfma" and d["extra"][-1]["roofline"]["frac"] > 0.5
     assert "K3g" in d["extra"][-2]["workload"] and "default route" in d["extra"][-3]["workload"]
     # round 4: the training steps (row f1) ride on the driver's clock too -- hidden 64 (RK4, Euler) and the scripts' --hidden 128

@@ -113,6 +113,11 @@ def _check_dae_pipelined(rank, world, sharded):
                                                   event_idx=tab, z_jump=zj[lo:hi], v_jump=vj[lo:hi], chunks=4, local_fn=_oracle_dae_local,
                                                   layout="batch", want_local=False)
     assert torch.equal(fx, X) and torch.equal(fi, I)
+    # the direct gather: same rows
+    _, (dx, di) = sharded.integrate_dae_pipelined("rk4", de, ae, xi[lo:hi], t[:, lo:hi], z[:, lo:hi], v[:, lo:hi], i[:, lo:hi], a0[lo:hi],
+                                                  event_idx=tab, z_jump=zj[lo:hi], v_jump=vj[lo:hi], chunks=4, local_fn=_oracle_dae_local,
+                                                  want_local=False, algo="direct")
+    assert torch.equal(sharded.assemble(dx, t.shape[0]), X) and torch.equal(sharded.assemble(di, t.shape[0]), I)
 
 
 def _table(t, event_t):
@@ -148,6 +153,20 @@ def _worker(rank, world, port, q):
         _, full = sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab, z_jump=zj[lo:hi],
                                                   chunks=3, local_fn=_oracle_local, layout="batch", want_local=False)
         assert isinstance(full, torch.Tensor) and full.is_contiguous() and torch.equal(full, out), "in-place gather differs"
+        # the DIRECT gather (round 6: N - 1 point-to-point pairs per chunk, every peer's shard on its own link) == RCCL's own all-gather ==
+        # the unsharded golden, one-shot and pipelined; layout="batch" belongs to c10d's list all_gather and is refused with it
+        out_d = sharded.integrate_ode_sharded("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_t=ev[lo:hi], z_jump=zj[lo:hi],
+                                              local_fn=_oracle_local, table_fn=_table, algo="direct")
+        assert torch.equal(out_d, out), "direct gather differs from all_gather_into_tensor"
+        _, gathered_d = sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab, z_jump=zj[lo:hi],
+                                                        chunks=3, local_fn=_oracle_local, algo="direct")
+        assert torch.equal(sharded.assemble(gathered_d, tl.shape[0]), out), "pipelined direct gather differs"
+        try:
+            sharded.integrate_ode_pipelined("rk4", de, tl, x[:, lo:hi], z[:, lo:hi], a0[lo:hi], event_idx=tab, z_jump=zj[lo:hi], chunks=3,
+                                            local_fn=_oracle_local, layout="batch", algo="direct")
+            raise AssertionError("layout='batch' with the direct gather was accepted")
+        except ValueError as e:
+            assert "direct" in str(e)
         assert sharded.chunk_bounds(1001, 4) == [0, 250, 500, 751, 1001] and sharded.chunk_bounds(2, 4) == [0, 1, 2]
         assert torch.equal(xs_l, out[:, lo:hi]), "local rows of the pipelined run differ from this rank's slice of the gather"
         _check_dae_pipelined(rank, world, sharded)
@@ -188,3 +207,43 @@ def test_shard_then_gather_equals_unsharded():
     shape, err = q.get(timeout=10)
     assert shape == (101, 32, 8)
     assert err <= 2e-6
+
+
+def _worker_direct(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from py_psnode_amd import sharded
+        g = torch.Generator().manual_seed(100 + rank)
+        shard = torch.randn(5, 3, 2, generator=g)
+        want = torch.empty(world * 5, 3, 2)
+        dist.all_gather_into_tensor(want, shard)
+        got = torch.full((world * 5, 3, 2), float("nan"))
+        assert sharded.all_gather_direct(got, shard) is None
+        assert torch.equal(got, want), "direct gather (blocking) differs from all_gather_into_tensor"
+        got2 = torch.full((world * 5, 3, 2), float("nan"))
+        sharded.all_gather_direct(got2, shard, async_op=True).wait()
+        assert torch.equal(got2, want)
+        full = sharded.all_gather_batch(shard, algo="direct")
+        assert torch.equal(full, sharded.all_gather_batch(shard))
+        try:
+            sharded.all_gather_direct(torch.empty(world * 5 + 1, 3, 2), shard)
+            raise AssertionError("a mis-sized destination was accepted")
+        except ValueError:
+            pass
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_direct_gather_world_size_3():
+    """all_gather_direct at an odd world size (round d pairs r with r + d and r - d: every peer once, no self-exchange): bit-equal to
+    all_gather_into_tensor, blocking and async."""
+    ctx = mp.get_context("spawn")
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker_direct, args=(r, 3, port)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "worker failed"
