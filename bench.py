@@ -550,6 +550,14 @@ class Trainer:
 TRAIN_EXTRAS = [("ode01", "rk4", 64), ("dae01", "rk4", 64), ("ode01", "euler", 64), ("dae01", "euler", 64), ("ode01", "rk4", 128), ("dae01", "rk4", 128)]
 
 
+def backward_kernel_name(fused, w, p, method):
+    """Which backward kernel AUTO runs for a saved-activation training step of this workload (round 6: K4x, the one-wave-per-4-trajectories
+    backward, takes the ODE at hidden 33..64 up to 4608 trajectories per GPU; K4f / K7f otherwise)."""
+    if w["kind"] == "dae":
+        return "k7f+k7h"
+    return "k4x" if (w["B"] <= 4608 and fused.ode_backward_supported(method, p["de"], w["xd"], w["zd"], "wave")) else "k4f"
+
+
 def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
     """One training workload on the driver's clock: `steps` forward + loss + backward passes at B=4096 x 1000 steps.  roofline.frac on
     the 3x-forward flop convention (forward + data gradients + weight gradients); kernel time per family from HIP events between the
@@ -582,6 +590,7 @@ def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
            "steps": steps, "warmup": warmup, "value": ss * steps / elapsed, "unit": "state-steps/s", "ms_per_step": elapsed / steps * 1e3,
            "outputs_finite": bool(torch.isfinite(outs[0]).all()), "grads_finite": grads_ok,
            "saved_bytes": int(tr.pag.last_saved_bytes),
+           "backward_kernel": backward_kernel_name(fused, w, p, method),
            "host_enqueue_ms": None,
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                         "flop_convention": "3 x forward flops per state-step", "flop_per_state_step": flops,

@@ -14,6 +14,9 @@ defects").  Input: `hipcc -S --cuda-device-only` listings (one per translation u
   C  asm-vmem-sgpr      an inline-asm VMEM instruction reads an SGPR written by a VALU instruction < 5 wait states earlier
                         (the hazard recognizer does not look inside inline asm).  [found on the way: the LDS-DMA of K4f / K7f]
 
+  D  asm-mfma-operand   an inline-asm MFMA reads as A / B operand a VGPR written by a VALU instruction < 2 wait states earlier (round 6:
+                        K4x's gradient blocks carry a leading s_nop only where a VALU producer can precede them)
+
 usage: isa_lint.py file.s [file.s ...] [--verbose]      exit code 1 if anything is flagged"""
 import re
 import sys
@@ -262,6 +265,33 @@ def lint_kernel(name, body, report):
         if len(hist) > 16:
             hist.pop(0)
 
+    # ---- D: an inline-asm MFMA reads, as its A / B operand, a VGPR that a (non-MFMA) VALU instruction wrote < 2 wait states earlier.  The
+    # hazard recognizer pads compiler-visible MFMAs; it does not look inside inline asm, so an asm block that relies on "the previous
+    # instruction is my own MFMA" (K4x's gradient blocks without a leading s_nop, round 6) must be checked in the code that ships: a
+    # spilled operand coming back through v_accvgpr_read right in front of the block would be exactly that.
+    hist = []
+    for ln, t, asm, _ in ins:
+        op = t.split()[0]
+        if asm and op.startswith("v_mfma"):
+            ops = operands(t)
+            used = set()
+            for o in ops[1:3]:
+                used |= regs(o.split()[0])
+            ws = 0
+            for tx, w, was_asm in reversed(hist):
+                ox = tx.split()[0]
+                if ox.startswith("v_") and not ox.startswith("v_mfma"):
+                    dst = operands(tx)
+                    if dst and regs(dst[0].split()[0]) & used and ws < 2:
+                        report("D asm-mfma-operand", name, ln, f"`{t}` {ws} wait states after `{tx}` (needs 2)")
+                        break
+                ws += w
+                if ws >= 2:
+                    break
+        hist.append((t, ws_of(t), asm))
+        if len(hist) > 8:
+            hist.pop(0)
+
 
 total = {}
 kernels = 0
@@ -290,7 +320,7 @@ for path in files:
                 cur = None
 
 rc = 0
-GATING = ("A spill-under-exec", "B mfma-edge", "C asm-vmem-sgpr", "A' agpr-copy-under-exec")
+GATING = ("A spill-under-exec", "B mfma-edge", "C asm-vmem-sgpr", "A' agpr-copy-under-exec", "D asm-mfma-operand")
 # (A': VGPR -> AGPR copies are EXEC-masked like scratch stores -- a value parked in an AGPR from inside a divergent arm and read back
 #  outside of it is the same defect.  Gating since the region model follows every structure the backend emits for these kernels; its
 #  first real catch was a row index of K7f's round-4 code, parked in a25 inside one arm of a nested ?:.)

@@ -91,32 +91,38 @@ struct BwdXDev {
 // Two gradient tiles, four trajectories: acc_x += A_t (block K_x + TS t) (x) B_t.  The accumulators are AccVGPRs for the whole launch (the
 // allocator would bring VGPR-form accumulators back and forth); a tile's dependent MFMAs are two issue slots apart (the other tile's + s_nop 0).
 // Wait states inside the block are its own business (the hazard recognizer does not look): s_nop 1 = VALU write -> MFMA operand read.
-template <int K0, int K1, int TS>
+// LEAD: the block may directly follow the VALU instruction that wrote one of its operands (s_nop 1); the later blocks of a run over the
+// same operands follow an MFMA block and need none (76 blocks per stage: the two cycles each were 4 % of a step).
+#define PSNODE_WG_BODY                                                          \
+        "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"            \
+        "v_mfma_f32_4x4x1_16b_f32 %1, %2, %6, %1 cbsz:4 abid:%14\n\t"            \
+        "s_nop 0\n\t"                                                            \
+        "v_mfma_f32_4x4x1_16b_f32 %0, %3, %7, %0 cbsz:4 abid:%11\n\t"            \
+        "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%15\n\t"            \
+        "s_nop 0\n\t"                                                            \
+        "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%12\n\t"            \
+        "v_mfma_f32_4x4x1_16b_f32 %1, %4, %8, %1 cbsz:4 abid:%16\n\t"            \
+        "s_nop 0\n\t"                                                            \
+        "v_mfma_f32_4x4x1_16b_f32 %0, %5, %9, %0 cbsz:4 abid:%13\n\t"            \
+        "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%17\n\t"            \
+        "s_nop 0"
+#define PSNODE_WG_OPS                                                                                                     \
+        : "+a"(acc0), "+a"(acc1)                                                                                          \
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]),                            \
+          "n"(K0), "n"(K0 + TS), "n"(K0 + 2 * TS), "n"(K0 + 3 * TS), "n"(K1), "n"(K1 + TS), "n"(K1 + 2 * TS), "n"(K1 + 3 * TS)
+template <int K0, int K1, int TS, bool LEAD = true>
 __device__ __forceinline__ void wg_pair(f4& acc0, f4& acc1, const float a0, const float a1, const float a2, const float a3, const f4 bv) {
     if constexpr (PSNODE_K4X_ABL == 1) return;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0 cbsz:4 abid:%10\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %1, %2, %6, %1 cbsz:4 abid:%14\n\t"
-        "s_nop 0\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %0, %3, %7, %0 cbsz:4 abid:%11\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %1, %3, %7, %1 cbsz:4 abid:%15\n\t"
-        "s_nop 0\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0 cbsz:4 abid:%12\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %1, %4, %8, %1 cbsz:4 abid:%16\n\t"
-        "s_nop 0\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %0, %5, %9, %0 cbsz:4 abid:%13\n\t"
-        "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1 cbsz:4 abid:%17\n\t"
-        "s_nop 0"
-        : "+a"(acc0), "+a"(acc1)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]),
-          "n"(K0), "n"(K0 + TS), "n"(K0 + 2 * TS), "n"(K0 + 3 * TS), "n"(K1), "n"(K1 + TS), "n"(K1 + 2 * TS), "n"(K1 + 3 * TS));
+    if constexpr (LEAD) asm volatile("s_nop 1\n\t" PSNODE_WG_BODY PSNODE_WG_OPS);
+    else asm volatile(PSNODE_WG_BODY PSNODE_WG_OPS);
 }
+#undef PSNODE_WG_BODY
+#undef PSNODE_WG_OPS
 // all 16 tiles of one H -> H matrix: dW^T[k-slot][unit] += h (x) delta over the wave's four trajectories
 template <int KK>
 __device__ __forceinline__ void wgrad_tiles(f4 (&acc)[16], const f4 h, const f4 d) {
     if constexpr (KK < 16) {
-        wg_pair<KK, KK + 1, 0>(acc[KK], acc[KK + 1], h[0], h[1], h[2], h[3], d);
+        wg_pair<KK, KK + 1, 0, (KK == 0)>(acc[KK], acc[KK + 1], h[0], h[1], h[2], h[3], d);
         wgrad_tiles<KK + 2>(acc, h, d);
     }
 }
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(64 * kXWaves) void ode_backward_x_kernel(const BwdX
             wgrad_tiles<0>(aW2, h1, d2);                              // dW2 += delta2 (x) h1
             S1D += d1;
             wg_pair<0, 1, 4>(aW1[0], aW1[1], cin, cin, cin, cin, d1);  // dW1[:, stage input | z] += delta1 (x) (s | z)
-            if (n > 8) wg_pair<2, 3, 4>(aW1[2], aW1[3], cin, cin, cin, cin, d1);
+            if (n > 8) wg_pair<2, 3, 4, false>(aW1[2], aW1[3], cin, cin, cin, cin, d1);
             const f4 d1A = quad_transpose(d1);
             if constexpr (GZ) { if constexpr (S > 1) sstepA += d1A; else sstepA = d1A; }
             float dsa, dsb;

@@ -67,6 +67,14 @@ ASM_VMEM = HEAD + """\tv_readlane_b32 s6, v255, 11
 """ + TAIL
 ASM_VMEM_FIXED = ASM_VMEM.replace("s_nop 0", "s_nop 2")
 
+# round 6, K4x: a gradient block without a leading s_nop right behind the v_accvgpr_read that brings a spilled operand back
+ASM_MFMA_OPERAND = HEAD + """\tv_accvgpr_read_b32 v5, a173
+\t;;#ASMSTART
+\tv_mfma_f32_4x4x1_16b_f32 a[0:3], v5, v36, a[0:3] cbsz:4 abid:2
+\t;;#ASMEND
+""" + TAIL
+ASM_MFMA_OPERAND_FIXED = ASM_MFMA_OPERAND.replace("\t;;#ASMSTART\n", "\t;;#ASMSTART\n\ts_nop 1\n")
+
 
 def _lint(tmp_path, text):
     f = tmp_path / "k.s"
@@ -96,6 +104,13 @@ def test_lint_flags_inline_asm_vmem_behind_a_valu_written_sgpr(tmp_path):
     assert rc == 0, out
 
 
+def test_lint_flags_an_inline_asm_mfma_behind_the_valu_write_of_its_operand(tmp_path):
+    rc, out = _lint(tmp_path, ASM_MFMA_OPERAND)
+    assert rc == 1 and "[D asm-mfma-operand] 1 site" in out, out
+    rc, out = _lint(tmp_path, ASM_MFMA_OPERAND_FIXED)
+    assert rc == 0 and "[D asm-mfma-operand] 0 site" in out, out
+
+
 def test_shipped_listings_are_clean():
     lists = sorted(glob.glob(os.path.join(ROOT, "build", "obj", "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
     if len(lists) < 20:
@@ -103,5 +118,5 @@ def test_shipped_listings_are_clean():
         pytest.skip("no device listings here (build/obj/ is made by `make` in the build container and does not travel)")
     r = subprocess.run([sys.executable, LINT] + lists, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-4000:]
-    for kind in ("[A spill-under-exec] 0 site", "[B mfma-edge] 0 site", "[C asm-vmem-sgpr] 0 site"):
+    for kind in ("[A spill-under-exec] 0 site", "[B mfma-edge] 0 site", "[C asm-vmem-sgpr] 0 site", "[D asm-mfma-operand] 0 site"):
         assert kind in r.stdout, r.stdout[-2000:]
