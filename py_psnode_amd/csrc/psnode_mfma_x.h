@@ -109,6 +109,7 @@ __device__ __forceinline__ void hh_block_acc(const float (&wk)[64], const f4 hA,
         : "+v"(accA), "+v"(accB)
         : "v"(hA[0]), "v"(hA[1]), "v"(hA[2]), "v"(hA[3]), "a"(wk[4 * BB + 0]), "a"(wk[4 * BB + 1]), "a"(wk[4 * BB + 2]), "a"(wk[4 * BB + 3]), "n"(BB));
 }
+template <bool SC = true>
 __device__ __forceinline__ f4 hh_layer_acc(const float (&wk)[64], const float bias, const f4 hA) {
     f4 accA = f4{bias, bias, bias, bias}, accB = f4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_nop 1" : "+v"(accA), "+v"(accB));           // VALU write -> MFMA SrcC read
@@ -117,7 +118,7 @@ __device__ __forceinline__ f4 hh_layer_acc(const float (&wk)[64], const float bi
     hh_block_acc<8>(wk, hA, accA, accB); hh_block_acc<9>(wk, hA, accA, accB); hh_block_acc<10>(wk, hA, accA, accB); hh_block_acc<11>(wk, hA, accA, accB);
     hh_block_acc<12>(wk, hA, accA, accB); hh_block_acc<13>(wk, hA, accA, accB); hh_block_acc<14>(wk, hA, accA, accB); hh_block_acc<15>(wk, hA, accA, accB);
     asm volatile("s_nop 3" : "+v"(accA), "+v"(accB));           // MFMA write (2 passes) -> VALU read
-    return quad_transpose(elu_quad_scaled(accA + accB));
+    return quad_transpose(elu_x<SC>(accA + accB));
 }
 
 template <int Q0, int NQ>

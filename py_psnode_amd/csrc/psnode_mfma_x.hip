@@ -83,6 +83,9 @@ __global__ void pack_x_kernel(const PackX p) {
 // SAVE: the training forward (a.sact / a.sxst: what autograd would keep -- the three ELU layers' outputs [T-1,S,3,B,Hp] and the stage inputs
 // [T-1,S,B,xd], the rows K4f reads; Hp = the padded width of the backward's tile, 32 or 64).  Plain ELU domain (the pack image is unscaled).
 // The A layout after the in-quad transpose holds, per lane (b, t), units 4b .. 4b+3 of trajectory t: ONE 16-byte store per layer.
+#ifndef PSNODE_K1X_SAVE_ABL
+#define PSNODE_K1X_SAVE_ABL 0     // timing-only ablations of the saving forward (saved rows WRONG): 1 = no saved-row store is issued, 2 = every stage
+#endif                            // stores to the rows of (step 0, stage 0) (the same instructions, no HBM traffic)
 template <int METHOD, int NZM, bool SAVE>
 __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
     const int l = threadIdx.x & 63;
@@ -165,11 +168,17 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     }
     // SAVE: uniform running row bases of the saved rows + this lane's byte offsets (its trajectory's row, its four units / its two dims)
     const int hp = SAVE ? padded_hidden(a.de.out_dim[0]) : 0;
-    const size_t sa_layer = SAVE ? (size_t)a.B * hp : 0;
+    // (ablations 3 / 4, timing only: the same bytes in a TILE-major order -- a wave's three layer rows of a stage in one 3 KB run (3), all
+    //  S stages of a step in one 3 S KB run (4) -- to see whether the saving forward's write stall depends on DRAM locality)
+    constexpr int kStg = METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4);
+    const size_t sa_layer = SAVE ? (PSNODE_K1X_SAVE_ABL >= 3 ? (size_t)256 : (size_t)a.B * hp) : 0;
+    const size_t sa_stage = SAVE ? (PSNODE_K1X_SAVE_ABL == 4 ? (size_t)768 : 3 * (size_t)a.B * hp) : 0;
     float* sa_run = SAVE ? a.sact : nullptr;
     float* sx_run = SAVE ? a.sxst : nullptr;
-    const unsigned saoff = SAVE ? (unsigned)(tr * hp + 4 * b) * 4u : 0u;
-    const bool sa_on = SAVE && valid && 4 * b < hp;
+    const unsigned saoff = !SAVE ? 0u : (PSNODE_K1X_SAVE_ABL == 3 ? (unsigned)(tile * 768 + c * 64 + 4 * b) * 4u
+                                         : (PSNODE_K1X_SAVE_ABL == 4 ? (unsigned)(tile * 768 * kStg + c * 64 + 4 * b) * 4u
+                                                                     : (unsigned)(tr * hp + 4 * b) * 4u));
+    const bool sa_on = SAVE && valid && 4 * b < hp && PSNODE_K1X_SAVE_ABL != 1;
     auto time_loop = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };      // uniform row base (SGPR pair) as a global pointer
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
                 if (st01) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff, s01);
                 if (st23) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff + 4u, s23);
             }
-            sx_run += xo_step;
+            if constexpr (PSNODE_K1X_SAVE_ABL != 2) sx_run += xo_step;
             if (sa_on) stg<f4>((gptr<float>)(uintptr_t)sa_run, saoff, hA);
         }
         hA = hh_layer<!SAVE>(w2, b2, hA);
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         hA = hh_layer<!SAVE>(w3, b3, hA);
         if constexpr (SAVE) {
             if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + 2 * sa_layer), saoff, hA);
-            sa_run += 3 * sa_layer;
+            if constexpr (PSNODE_K1X_SAVE_ABL != 2) sa_run += sa_stage;
         }
         f4 p0 = b4c[0], p1 = b4c[1];
         p0 = mfn(w4a[0], hA[0], p0); p1 = mfn(w4a[4], hA[0], p1);
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
             X01 = s01 + (k1a + 3.0f * (k2a + k3a) + k4a) * h_ * 0.125f;
             X23 = s23 + (k1b + 3.0f * (k2b + k3b) + k4b) * h_ * 0.125f;
         }
+        if constexpr (SAVE && PSNODE_K1X_SAVE_ABL == 4) sa_run += 3 * (size_t)a.B * hp * kStg - (size_t)768 * kStg;
     };
     using W0 = std::integral_constant<int, 0>;
     using W1 = std::integral_constant<int, 1>;

@@ -40,6 +40,7 @@ struct XDRegs {      // register image pack[reg][lane]; the AE's H -> H matrices
 };
 struct PackXD {
     int xd, zd, vd, id, hreal;
+    float sc;           // log2e: the scaled ELU domain of the inference kernel; 1: the training forward (plain domain, bit-exact weights)
     const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;             // DE
     const float *aw1, *ab1, *aw2, *ab2, *aw3, *ab3, *aw4, *ab4;     // AE
     float* out;
@@ -48,6 +49,7 @@ struct PackXD {
 __global__ void pack_xd_kernel(const PackXD p) {
     const int H = p.hreal, xd = p.xd, nzv = p.zd + p.vd, id = p.id, ne = nzv + id, n = xd + ne, K1 = 3 * n, K1a = n + xd + nzv;
     const int total = XDRegs::COUNT * 64 + XDRegs::HH_F4 * 4;
+    const float kLog2e = p.sc;                                 // (shadows the constant: 1 for the training forward's plain-domain image)
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         float v = 0.0f;
         if (idx >= XDRegs::COUNT * 64) {          // AE H -> H image: [layer][kq][lane] f4, component cc = W[unit = lane][k = 4 kq + cc]
@@ -117,7 +119,10 @@ __device__ __forceinline__ void row_sum1(float& a) {
         : "+v"(a));
 }
 
-template <int METHOD>
+// SAVE (round 6): the DAE training forward -- what autograd would keep, in the formats K2's saving instances write and K7f / K7h read:
+// DE rows a.sact [T-1,S,3,B,Hp] + stage inputs a.sxst [T-1,S,B,xd] as K1x; the AE head's three layers per grid point a.saeact [3,T,B,Hp]
+// and per event a.sevact [nE,3,B,Hp]; the event's i0 in DE-slot layout a.sevi [nE,B,16].  Plain ELU domain (unscaled pack image).
+template <int METHOD, bool SAVE>
 __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const IntegrateDev a, const float* __restrict__ pack) {
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -212,6 +217,15 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         return *(gptr<const float>)((gptr<const char>)(uintptr_t)rp + off);
     };
 
+    // SAVE: uniform running row bases + this lane's byte offset (its trajectory's row, its four units); xo_step doubles as the stage-input stride
+    const long long xo_step = a.B * xd, io_step = a.B * idim;
+    const int hp = SAVE ? padded_hidden(a.de.out_dim[0]) : 0;
+    const size_t sa_layer = SAVE ? (size_t)a.B * hp : 0, sae_layer = SAVE ? (size_t)a.T * a.B * hp : 0;
+    float* sa_run = SAVE ? a.sact : nullptr;
+    float* sx_run = SAVE ? a.sxst : nullptr;
+    float* sae_run = SAVE ? a.saeact : nullptr;                     // the AE head's rows of the NEXT grid point to be evaluated
+    const unsigned saoff = SAVE ? (unsigned)(tr * hp + 4 * b) * 4u : 0u;
+    const bool sa_on = SAVE && valid && 4 * b < hp;
     // DE right-hand side in the state layout (K1x's rhs)
     auto rhs = [&](const float s01, const float s23, const f4 cz, float& k01, float& k23) {
         f4 accA = cz, accB = f4{0.f, 0.f, 0.f, 0.f};
@@ -219,9 +233,24 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         accA = mfx<8>(s01, w1x[2], accA);  accB = mfx<12>(s01, w1x[3], accB);
         accA = mfx<0>(s23, w1x[4], accA);  accB = mfx<4>(s23, w1x[5], accB);
         accA = mfx<8>(s23, w1x[6], accA);  accB = mfx<12>(s23, w1x[7], accB);
-        f4 hA = quad_transpose(elu_quad_scaled(accA + accB));
-        hA = hh_layer(w2, b2, hA);
-        hA = hh_layer(w3, b3, hA);
+        f4 hA = quad_transpose(elu_x<!SAVE>(accA + accB));
+        if constexpr (SAVE) {                                        // rows (step, stage): the stage input, then the three layers as they appear
+            if (pair_ok) {
+                if (st01) stg<f2>((gptr<float>)(uintptr_t)sx_run, xooff, f2{s01, s23});
+            } else {
+                if (st01) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff, s01);
+                if (st23) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff + 4u, s23);
+            }
+            sx_run += xo_step;
+            if (sa_on) stg<f4>((gptr<float>)(uintptr_t)sa_run, saoff, hA);
+        }
+        hA = hh_layer<!SAVE>(w2, b2, hA);
+        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + sa_layer), saoff, hA); }
+        hA = hh_layer<!SAVE>(w3, b3, hA);
+        if constexpr (SAVE) {
+            if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + 2 * sa_layer), saoff, hA);
+            sa_run += 3 * sa_layer;
+        }
         f4 p0 = b4c[0], p1 = b4c[1];
         p0 = mfn(w4a[0], hA[0], p0); p1 = mfn(w4a[4], hA[0], p1);
         p0 = mfn(w4a[1], hA[1], p0); p1 = mfn(w4a[5], hA[1], p1);
@@ -232,7 +261,8 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         row_sum2(k01, k23);
     };
     // AE head g(x; z | v): returns, in every lane of row rho, algebraic variable drow(rho) of the lane's trajectory
-    auto ae_eval = [&](const float s01, const float s23, const float eAE) -> float {
+    // (SAVE: `rows` = uniform base of the head's layer-0 rows [B,Hp] of this grid point / event, `lstride` floats to the next layer)
+    auto ae_eval = [&](const float s01, const float s23, const float eAE, float* rows = nullptr, const size_t lstride = 0) -> float {
         f4 accA = c0a, accB = f4{0.f, 0.f, 0.f, 0.f};
         accA = mfx<0>(s01, aw1x[0], accA);  accB = mfx<4>(s01, aw1x[1], accB);
         accA = mfx<8>(s01, aw1x[2], accA);  accB = mfx<12>(s01, aw1x[3], accB);
@@ -242,9 +272,12 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         accA = mfx<2>(eAE, aw1e[2], accA);  accB = mfx<3>(eAE, aw1e[3], accB);
         accA = mfx<4>(eAE, aw1e[4], accA);  accB = mfx<5>(eAE, aw1e[5], accB);
         accA = mfx<6>(eAE, aw1e[6], accA);  accB = mfx<7>(eAE, aw1e[7], accB);
-        f4 hA = quad_transpose(elu_quad_scaled(accA + accB));
-        hA = hh_layer_acc(aw2, ab2, hA);
-        hA = hh_layer_acc(aw3, ab3, hA);
+        f4 hA = quad_transpose(elu_x<!SAVE>(accA + accB));
+        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)rows, saoff, hA); }
+        hA = hh_layer_acc<!SAVE>(aw2, ab2, hA);
+        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(rows + lstride), saoff, hA); }
+        hA = hh_layer_acc<!SAVE>(aw3, ab3, hA);
+        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(rows + 2 * lstride), saoff, hA); }
         f4 p0 = ab4c;
         p0 = mfn(aw4a[0], hA[0], p0);
         p0 = mfn(aw4a[1], hA[1], p0);
@@ -276,10 +309,10 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
     float e_ae = row_val(zbase, vbase, ae_v, off_ae);
     float t_cur = ldg<float>(as_g(a.t.p), toff);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    float icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : e_ae);
+    float icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : e_ae, sae_run, sae_layer);
+    if constexpr (SAVE) sae_run += sa_layer;
     float* xo_run = a.xo;
     float* io_run = a.io;
-    const long long xo_step = a.B * xd, io_step = a.B * idim;
     if (nT < 2) { store_rows(xo_run, io_run, icw); return; }
 
     int evb = load_evb(0);
@@ -297,14 +330,24 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
     // Measured, same box (profiles/r05u_dae_tile_vs_wave.txt against r05n_...): RK4 4.41 -> 4.24 ms at dae01, but Euler 2.05 -> 2.09 and
     // Midpoint 2.74 -> 2.82 (and requesting the AE head's row a step earlier, with one wait per step, lost at all three: r05v_...) -- so RK4
     // alone takes it; the others, and odd x_dim (a second x store that not every wave issues), wait for everything.
-    auto wait_loads = [&]() {
-        if (METHOD == PSNODE_RK4_38 && pair_ok) __builtin_amdgcn_s_waitcnt(0x0F72);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    // SAVE: behind a step's loads sit its two row stores and 4 S saved-row stores (every one issued by every wave); the AE head at the end of
+    // the step adds three more in front of the next step's first wait
+    constexpr int kStg = METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4);
+    auto wait_loads = [&](auto top_tag) {
+        constexpr bool TOP = decltype(top_tag)::value;
+        if constexpr (SAVE) {
+            constexpr int WN = 2 + 4 * kStg + (TOP ? 3 : 0);
+            if (pair_ok) __builtin_amdgcn_s_waitcnt(0x0F70 | (WN & 15) | ((WN >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else {
+            if (METHOD == PSNODE_RK4_38 && pair_ok) __builtin_amdgcn_s_waitcnt(0x0F72);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);         // the first step's inputs (no store is in flight yet for vmcnt(2) to skip)
     auto step = [&](const int k, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        wait_loads();                           // this step's inputs were requested a whole step ago
+        wait_loads(std::true_type{});           // this step's inputs were requested a whole step ago
         const float h_ = t_nxt - t_cur;
         t_cur = t_nxt;
         const int ev_now = ev_cur;
@@ -312,7 +355,16 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
         if (__builtin_amdgcn_readfirstlane(ev_now) >= 0) {       // event: i0 = g(x_k; z_jump, v_jump) with the RUNNING state (my_solvers.py:108-110)
             const float ej = row_val(zjbase + (long long)ev_now * zje, vjbase + (long long)ev_now * vje, ae_v, joff_ae);
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : ej);
+            icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : ej, SAVE ? a.sevact + (size_t)ev_now * 3 * sa_layer : nullptr, sa_layer);
+            if constexpr (SAVE) {     // the event's i0 in the DE's slot layout [nE,B,16]: slots nzv + d (the `s - a0` block) and ne + nzv + d
+                const int d = xd_drow(rho);
+                if (storer && d < idim) {
+                    float* er = a.sevi + ((size_t)ev_now * a.B + tr) * 16;
+                    er[nzv + d] = icw;
+                    er[ne + nzv + d] = icw;
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // (an event step: the counted waits below assume the regular store sequence)
+            }
         }
         // the lane's DE slot: a z | v column (loaded) or the row's algebraic variable; the `s - a0` block subtracts a0
         float eA = kind_de == 2 ? icw : e_de_nxt;
@@ -357,8 +409,9 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
             X23 = s23 + (k1b + 3.0f * (k2b + k3b) + k4b) * h_ * 0.125f;
         }
         // i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]): un-jumped inputs of the right grid point (my_solvers.py:121)
-        wait_loads();                           // (requested at the top of this step, in front of its two stores)
-        icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : e_ae);
+        wait_loads(std::false_type{});          // (requested at the top of this step, in front of its stores)
+        icw = ae_eval(X01, X23, kind_ae == 3 ? 0.0f : e_ae, sae_run, sae_layer);
+        if constexpr (SAVE) sae_run += sa_layer;
     };
 #pragma unroll 1
     for (int k = 0; k + 2 < nT; ++k) step(k, std::false_type{});
@@ -371,7 +424,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_xd_kernel(const Integr
 // shapes K2x takes (K2's classes at hidden <= 64, i_dim <= 4), inference without teacher forcing
 bool mfma_x_dae_supported(const IntegrateDev& a) {
     const int nzv = a.zd + a.vd, ne = nzv + a.id, n = a.xd + ne;
-    if (a.sact || a.flags || a.xd < 1 || a.xd > 8 || a.zd < 0 || a.vd < 0 || a.id < 1 || a.id > 4 || nzv < 1 || ne > 8 || a.T >= (1ll << 31)) return false;
+    if (a.flags || a.xd < 1 || a.xd > 8 || a.zd < 0 || a.vd < 0 || a.id < 1 || a.id > 4 || nzv < 1 || ne > 8 || a.T >= (1ll << 31)) return false;
     const MlpDev &d = a.de, &g = a.ae;
     if (d.n_layers != 4 || g.n_layers != 4 || d.in_dim != 3 * n || d.out_dim[3] != a.xd || g.in_dim != n + a.xd + nzv || g.out_dim[3] != a.id) return false;
     const int h = d.out_dim[0];
@@ -382,10 +435,19 @@ bool mfma_x_dae_supported(const IntegrateDev& a) {
     if (a.vd > 0 && a.v.p && !span32_ok(a.B, a.v.sb, a.vd)) return false;
     if (a.zd > 0 && a.zj && !span32_ok(a.B, a.zjb, a.zd)) return false;
     if (a.vd > 0 && a.vj && !span32_ok(a.B, a.vjb, a.vd)) return false;
+    if (a.sact) {      // the training forward: every save buffer present and aligned for the 16-byte / 8-byte stores, 32-bit row offsets
+        if (!a.sxst || !a.saeact || (a.ev && (!a.sevact || !a.sevi))) return false;
+        if (((uintptr_t)a.sact & 15) || ((uintptr_t)a.sxst & 7) || ((uintptr_t)a.saeact & 15) || ((uintptr_t)a.sevact & 15)) return false;
+        if (!span32_ok(a.B, 64, 64)) return false;
+    }
     return span32_ok(a.B, a.xd, a.xd) && span32_ok(a.B, a.id, a.id);                           // output rows [B,xd] / [B,id]
 }
 bool mfma_x_dae_preferred(const IntegrateDev& a) {
     if (a.kern == PSNODE_KERNEL_MFMA_TILE || a.kern == PSNODE_KERNEL_GENERIC || !mfma_x_dae_supported(a)) return false;
+    // The SAVING instance is forced-only: measured (profiles/r06_k2x_save_time.txt, B = 4096 x 1000 steps) it is 5.54 ms at RK4 / 2.42 ms at
+    // Euler against K2's 5.10 / 2.19 -- the 16.3 GB of rows cost a lone wave 1.3 ms of write back-pressure (nothing else to issue), K2's waves
+    // only 0.4 ms (their exchange bubbles absorb it).  Inference (no rows): K2x 4.23 vs 4.68 ms.
+    if (a.sact) return a.kern == PSNODE_KERNEL_MFMA_WAVE;
     return a.kern == PSNODE_KERNEL_MFMA_WAVE || a.B <= 4608;
 }
 size_t mfma_xd_pack_floats() { return (size_t)XDRegs::COUNT * 64 + (size_t)XDRegs::HH_F4 * 4; }
@@ -398,16 +460,21 @@ hipError_t launch_mfma_xd(const IntegrateDev& a, float* pack, hipStream_t stream
     p.aw1 = a.ae.w[0]; p.ab1 = a.ae.bias[0]; p.aw2 = a.ae.w[1]; p.ab2 = a.ae.bias[1];
     p.aw3 = a.ae.w[2]; p.ab3 = a.ae.bias[2]; p.aw4 = a.ae.w[3]; p.ab4 = a.ae.bias[3];
     p.out = pack;
+    p.sc = a.sact ? 1.0f : kLog2e;
     hipLaunchKernelGGL(pack_xd_kernel, dim3(32), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long long tiles = (a.B + 3) / 4;
     const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves);
+#define PSNODE_XD(M_)                                                                                          \
+    if (a.sact) hipLaunchKernelGGL((integrate_xd_kernel<M_, true>), grid, block, 0, stream, a, pack);          \
+    else hipLaunchKernelGGL((integrate_xd_kernel<M_, false>), grid, block, 0, stream, a, pack);
     switch (a.method) {
-        case PSNODE_EULER: hipLaunchKernelGGL((integrate_xd_kernel<PSNODE_EULER>), grid, block, 0, stream, a, pack); break;
-        case PSNODE_MIDPOINT: hipLaunchKernelGGL((integrate_xd_kernel<PSNODE_MIDPOINT>), grid, block, 0, stream, a, pack); break;
-        default: hipLaunchKernelGGL((integrate_xd_kernel<PSNODE_RK4_38>), grid, block, 0, stream, a, pack); break;
+        case PSNODE_EULER: PSNODE_XD(PSNODE_EULER) break;
+        case PSNODE_MIDPOINT: PSNODE_XD(PSNODE_MIDPOINT) break;
+        default: PSNODE_XD(PSNODE_RK4_38) break;
     }
+#undef PSNODE_XD
     return hipGetLastError();
 }
 

@@ -152,3 +152,61 @@ def test_wave_backward_is_refused_without_saved_rows_and_outside_its_class():
     assert fused.ode_backward_supported("rk4", layers, 8, 2, "wave")
     lin32 = _case(8, 6, 8, 2, 32, seed=3, events=False)[0]
     assert not fused.ode_backward_supported("rk4", [(m.weight.detach().cuda(), m.bias.detach().cuda()) for m in lin32], 8, 2, "wave")
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("H,xd,zd,vd,idim,B,Tn,events", [(64, 8, 2, 2, 2, 4096, 4, False), (64, 8, 2, 2, 2, 37, 9, True), (40, 5, 1, 1, 1, 18, 6, True),
+                                                         (32, 3, 1, 0, 1, 7, 4, False), (64, 8, 2, 2, 4, 21, 7, True), (20, 2, 2, 4, 2, 130, 3, False),
+                                                         (64, 8, 0, 2, 2, 5, 12, True), (64, 1, 1, 1, 1, 1, 2, False)])
+def test_dae_training_forward_saves_the_same_rows_on_both_mfma_integrators(method, H, xd, zd, vd, idim, B, Tn, events):
+    """Round 6: K2x has SAVE instances (`kernel="wave"`; AUTO keeps K2 for the saving forward, which measures faster).  Both integrators write the
+    same five tensors (DE rows, stage inputs, the AE head's rows per grid point and per event, the event's i0 in slot layout) to rounding,
+    incl. the zero padding, odd x_dim, z_dim == 0, two events and a ragged last wave; K7f (+ K7h) returns the same gradients from either,
+    whichever wrote the rows."""
+    from py_psnode_amd import fused
+    g = torch.Generator().manual_seed(H * 11 + xd + B + idim)
+    torch.manual_seed(H * 11 + xd + B + idim)
+    n = xd + zd + vd + idim
+    mk = lambda dims: [(l.weight.detach().cuda(), l.bias.detach().cuda()) for l in [nn.Linear(dims[k], dims[k + 1]) for k in range(len(dims) - 1)]]
+    de, ae = mk([3 * n, H, H, H, xd]), mk([n + xd + zd + vd, H, H, H, idim])
+    r = lambda *s_: (0.1 * torch.randn(*s_, generator=g)).cuda()
+    t = (torch.arange(Tn, dtype=torch.float32) * 0.02).view(Tn, 1, 1).repeat(1, B, 1).cuda()
+    z, v, xi, i0 = r(Tn, B, zd), r(Tn, B, vd), r(B, xd), r(B, idim)
+    a0 = torch.cat((xi, z[0], v[0], i0), -1)
+    ev = zj = vj = None
+    if events and Tn > 3:
+        ev = torch.stack([t[1, :, :], t[Tn - 2, :, :]], dim=1).contiguous()
+        zj, vj = r(B, 2, zd), r(B, 2, vd)
+    Gx, Gi = torch.randn(Tn, B, xd, generator=g).cuda(), torch.randn(Tn, B, idim, generator=g).cuda()
+    xe, ie = torch.zeros(Tn, B, 0, device="cuda"), torch.zeros(Tn, B, idim, device="cuda")
+    tab = fused.event_table(t, ev) if ev is not None else None
+    out = {}
+    for kern in ("tile", "wave", "auto"):
+        xs, is_, saved = fused.dae_integrate(method, de, ae, xi, t, xe, z, v, ie, a0, event_t=ev, z_jump=zj, v_jump=vj, save=True, kernel=kern)
+        grads = fused.dae_backward(method, de, ae, t, z, v, a0, xs, is_, Gx, Gi, event_idx=tab, z_jump=zj, v_jump=vj, saved=saved)
+        out[kern] = (xs, is_, saved, grads)
+    (xs_t, is_t, sv_t, g_t), (xs_w, is_w, sv_w, g_w) = out["tile"], out["wave"]
+    _close(xs_w, xs_t, "xs", 1e-5); _close(is_w, is_t, "is", 1e-5)
+    names = ["DE rows", "stage inputs", "AE head rows", "event AE rows", "event i0 (slot layout)"]
+    for nme, p, q in zip(names, sv_w, sv_t):
+        assert (p is None) == (q is None), nme
+        if p is not None:
+            assert p.shape == q.shape, nme
+            if nme.startswith("event i0"):      # K2 fills every slot, K2x the algebraic ones (what K7f reads): compare those
+                nzv, ne = zd + vd, zd + vd + idim
+                cols = [nzv + d for d in range(idim)] + [ne + nzv + d for d in range(idim)]
+                _close(p[..., cols], q[..., cols], nme, 1e-5)
+            else:
+                _close(p, q, nme, 1e-5)
+    hp = sv_t[0].shape[-1]
+    if H < hp and Tn > 1:
+        assert float(sv_w[0][..., H:].abs().max()) == 0.0 and float(sv_w[2][..., H:].abs().max()) == 0.0, "padding units are stored as zeros"
+    for key in ("x_init", "z", "v", "z_jump", "v_jump", "all_initial"):
+        assert (g_w[key] is None) == (g_t[key] is None), key
+        if g_w[key] is not None:
+            _close(g_w[key], g_t[key], key)
+    for grp in ("de", "ae"):
+        for k, (p, q) in enumerate(zip(g_w[grp], g_t[grp])):
+            _close(p, q, f"grad {grp} {k}")
+    # AUTO keeps K2 for the SAVING forward (K2x's is forced-only: measured slower, psnode_mfma_xd.hip: mfma_x_dae_preferred)
+    assert torch.equal(out["auto"][0], xs_t) and torch.equal(out["auto"][2][2], sv_t[2]), "AUTO must run K2's saving instance"
