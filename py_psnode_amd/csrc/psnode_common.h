@@ -319,9 +319,12 @@ hipError_t launch_latent_wide(const IntegrateDev& a, bool dae, float* pack, hipS
 // ELU'(pre) from h = ELU(pre): 1 for pre > 0 (h > 0), exp(pre) = h + 1 otherwise -- written min(h, 0) + 1 (identical values; one clamp
 // + one packed add per pair instead of add + compare + select per value: VALU instructions are wall time next to fp32 MFMAs)
 typedef float psnode_f4_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float elu_grad(float h) { return fminf(h, 0.0f) + 1.0f; }
+// (round 6: min(h, 0) written med3(h, -2, 0) -- the same value for every ELU output (h > -1) in ONE VOP3 instruction; fminf costs a
+//  canonicalising v_max in front of the v_min for a value that comes from memory: 8 -> 4 instructions per tile, found in K4f's ISA)
+__device__ __forceinline__ float elu_grad(float h) { return __builtin_amdgcn_fmed3f(h, -2.0f, 0.0f) + 1.0f; }
 __device__ __forceinline__ psnode_f4_ elu_grad_quad(psnode_f4_ h) {
-    return psnode_f4_{fminf(h[0], 0.0f), fminf(h[1], 0.0f), fminf(h[2], 0.0f), fminf(h[3], 0.0f)} + 1.0f;
+    return psnode_f4_{__builtin_amdgcn_fmed3f(h[0], -2.0f, 0.0f), __builtin_amdgcn_fmed3f(h[1], -2.0f, 0.0f),
+                      __builtin_amdgcn_fmed3f(h[2], -2.0f, 0.0f), __builtin_amdgcn_fmed3f(h[3], -2.0f, 0.0f)} + 1.0f;
 }
 
 // Addressing idiom of the time-loop kernels: <uniform row base in SGPRs> + <32-bit per-lane BYTE offset> = the hardware's
