@@ -700,7 +700,8 @@ def self_launch(n):
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7      # MI355X: 7 xGMI links per GPU, ~153 GB/s each direction (MI355X_MICROARCH.md)
 
 
-def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, pipelined, chunk_model, gather_algo=None, by_algo=None):
+def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, pipelined, chunk_model, gather_algo=None, by_algo=None,
+                     algo_choice=None):
     """What a reader needs to interpret an N > 1 line without a second run: the shard each rank contributes, what the all-gather should
     cost on xGMI (every rank receives (N-1) shards; a direct all-gather spreads them over N-1 of the 7 links, a ring pushes them all through
     one), what the two legs cost alone, and how much of the shorter one the pipeline hid."""
@@ -716,7 +717,7 @@ def multi_gpu_report(w, world, B, T, step_ms, integrate_ms, gather_ms, chunks, p
            "chunk_model": chunk_model,
            # rccl = all_gather_into_tensor (RCCL picks ring or direct by message size); direct = sharded.all_gather_direct (N-1 point-to-point
            # pairs per chunk, one shard per xGMI link whatever the tuner thinks); by_algo: --gather-algo both, measured after the timed region
-           "gather_algo": gather_algo, "by_algo": by_algo}
+           "gather_algo": gather_algo, "by_algo": by_algo, "algo_choice": algo_choice}
     if gather_ms is not None:
         serial = integrate_ms + gather_ms
         rep["serial_ms"] = serial
@@ -750,10 +751,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (RCCL group, gather) even at world size 1")
     ap.add_argument("--gather-layout", default="chunks", choices=["chunks", "batch"],
                     help="N>1, pipelined: per-chunk rank-major buffers (zero-copy) or every chunk gathered INTO one [T, N*B, D] tensor")
-    ap.add_argument("--gather-algo", default="rccl", choices=["rccl", "direct", "both"],
+    ap.add_argument("--gather-algo", default="auto", choices=["auto", "rccl", "direct", "both"],
                     help="N>1: the all-gather as RCCL's own all_gather_into_tensor, or as N-1 point-to-point pairs per chunk (sharded.all_gather_direct: "
-                         "every peer's shard on its own xGMI link, independent of RCCL's ring/direct choice); 'both' = timed region on rccl, then both "
-                         "timed again after it (gather alone and the pipelined step) and printed under multi_gpu")
+                         "every peer's shard on its own xGMI link, independent of RCCL's ring/direct choice); 'auto' (default) = both are timed alone in "
+                         "the untimed warm-up and the faster one runs the timed region (every rank picks the same one: max over ranks); 'both' = timed "
+                         "region on rccl, then both timed again after it (gather alone and the pipelined step) and printed under multi_gpu")
     ap.add_argument("--collective", default="gather", choices=["gather", "loss-only"],
                     help="N>1: what follows the integration -- the all-gather of the output shards (north_star), or SURVEY 8(e)'s cheaper alternative: the "
                          "sharded masked-MSE loss (three scalar all-reduces, nothing gathered)")
@@ -806,7 +808,8 @@ def main():
     from py_psnode_amd import sharded
     loss_only = (world > 1 or args.force_dist) and args.collective == "loss-only" and not args.train and w["kind"] in ("ode", "dae")
     do_gather = (world > 1 or args.force_dist) and not args.no_gather and not args.train and not loss_only   # training never gathers (sharded loss)
-    algo = "rccl" if args.gather_algo == "both" else args.gather_algo
+    algo = "rccl" if args.gather_algo in ("both", "auto") else args.gather_algo
+    algo_choice = None
     loss_helper = Trainer(w, p, args.method, args.kernel, "mse-fused", dev, dist) if loss_only else None
     auto_chunks = str(args.chunks) == "auto"
     args.chunks = 4 if auto_chunks else int(args.chunks)
@@ -816,6 +819,8 @@ def main():
         widths = [w["xd"]] + ([w["id"]] if w["kind"] == "dae" else [])
         gathered = [torch.empty((world * T, B, d), dtype=torch.float32, device=dev) for d in widths]
 
+    if do_gather and args.gather_layout == "batch" and args.gather_algo == "auto":
+        args.gather_algo = "rccl"                # (the list all_gather into strided views is RCCL's own: nothing to choose)
     if do_gather and args.gather_layout == "batch" and args.gather_algo != "rccl":
         sys.exit("bench.py: --gather-layout batch gathers through c10d's list all_gather (RCCL's own algorithm); use --gather-layout chunks with --gather-algo direct / both")
     trainer = Trainer(w, p, args.method, args.kernel, args.loss, dev, dist) if args.train else None
@@ -869,6 +874,31 @@ def main():
 
     if do_gather:
         sharded.require_equal_shards(B, dev)     # once, outside the timed region: every rank holds B trajectories (weak scaling)
+    if do_gather and args.gather_algo == "auto" and w["kind"] in ("ode", "dae"):
+        # --gather-algo auto: time the gather of the full shards alone on both algorithms (untimed region) and keep the faster one.  xGMI is
+        # a point-to-point mesh: if RCCL's tuner rings 131 MB messages the direct exchange wins by up to (N - 1) x; if it already spreads the
+        # shards over the links the two tie and RCCL's own path stays.  Max over ranks, so that every rank picks the same algorithm.
+        outs_a = run_fused(fused, w, p, args.method, args.kernel)
+        bufs_a = [torch.empty((world * T, B, o.shape[-1]), dtype=torch.float32, device=dev) for o in outs_a]
+        srcs_a = [o.contiguous() for o in outs_a]
+        probe = {}
+        for al in ("rccl", "direct"):
+            for f_, o in zip(bufs_a, srcs_a):
+                sharded._gather_into(f_, o, None, al, False)
+            fence()
+            t_a = time.perf_counter()
+            for _ in range(2):
+                for f_, o in zip(bufs_a, srcs_a):
+                    sharded._gather_into(f_, o, None, al, False)
+            fence()
+            probe[al] = (time.perf_counter() - t_a) / 2 * 1e3
+        tt = torch.tensor([probe["rccl"], probe["direct"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        probe = {"rccl": float(tt[0]), "direct": float(tt[1])}
+        algo = "direct" if probe["direct"] < 0.9 * probe["rccl"] else "rccl"       # (a tie keeps RCCL's own collective)
+        step_algo[0] = algo
+        algo_choice = {"probe_gather_only_ms": probe, "picked": algo, "rule": "direct if it is > 10 % faster than rccl in the warm-up probe"}
+        del bufs_a, srcs_a, outs_a
     chunk_model = None
     if do_gather and w["kind"] in ("ode", "dae") and auto_chunks:
         # --chunks auto: measure the two legs alone (untimed region), then pick the chunk count of the pipeline from them.  Model: with c
@@ -996,7 +1026,7 @@ def main():
                        "gather_algo": algo if do_gather else None,
                        "outputs_finite": finite, "integrate_only_ms": kern_avg_ms, "gather_only_ms": gather_only_ms},
             "multi_gpu": multi_gpu_report(w, world, B, T, elapsed / args.steps * 1e3, kern_avg_ms, gather_only_ms, args.chunks if do_gather else None,
-                                          pipelined, chunk_model, algo if do_gather else None, by_algo) if dist is not None else None,
+                                          pipelined, chunk_model, algo if do_gather else None, by_algo, algo_choice) if dist is not None else None,
             "roofline": {"bound": "valu_fp32" if kname == "valu_dpp" else "mfma", "achieved": ach_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic is not None else None,
                          **{k: v for k, v in roofline_fracs(w, p_cpu, args.method, kname, state_steps_launch, kern_avg_ms, args.train).items()},

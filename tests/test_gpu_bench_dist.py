@@ -30,7 +30,14 @@ def test_bench_force_dist_runs_the_rccl_path(workload):
     cfg = d["config"]
     assert d["n_gpus"] == 1 and cfg["outputs_finite"] is True
     assert cfg["world_size_seen"] == 1 and cfg["device_count"] >= 1 and cfg["rccl_version"]
-    assert "rccl all_gather" in cfg["collective"]
+    # --gather-algo auto (default, round 6): both algorithms are probed in the warm-up and the faster one runs the timed region; the
+    # in-place batch layout is RCCL's own list all_gather
+    assert ("rccl all_gather" in cfg["collective"]) or ("direct all-gather" in cfg["collective"])
+    if workload == "dae01":
+        assert cfg["gather_algo"] == "rccl"
+    else:
+        ch = d["multi_gpu"]["algo_choice"]
+        assert ch["picked"] == cfg["gather_algo"] and set(ch["probe_gather_only_ms"]) == {"rccl", "direct"}
     assert cfg["integrate_only_ms"] > 0 and cfg["gather_only_ms"] is not None and cfg["gather_only_ms"] > 0
     assert d["roofline"]["frac"] > 0
     # round 5: the block that makes an N > 1 line self-explaining -- shard bytes, the xGMI prediction, both legs alone, what the pipeline
