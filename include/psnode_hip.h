@@ -50,8 +50,9 @@ typedef enum { PSNODE_EULER = 0, PSNODE_MIDPOINT = 1, PSNODE_RK4_38 = 2 } psnode
 /* kernel selection: AUTO picks the MFMA kernel when the shape has one, else the generic kernel */
 typedef enum {
     PSNODE_KERNEL_AUTO = 0, PSNODE_KERNEL_GENERIC = 1, PSNODE_KERNEL_MFMA = 2,
-    PSNODE_KERNEL_MFMA_TILE = 4,     /* forward calls only: K1 / K2, the 4-waves-per-16-trajectory-tile MFMA integrators, where AUTO / MFMA would pick K1x / K2x */
-    PSNODE_KERNEL_MFMA_WAVE = 5,     /* forward calls only: K1x / K2x, the one-wave-per-4-trajectories (exchange-free) MFMA integrators; UNSUPPORTED outside their shapes */
+    PSNODE_KERNEL_MFMA_TILE = 4,     /* K1 / K2, the 4-waves-per-16-trajectory-tile MFMA integrators, where AUTO / MFMA would pick K1x / K2x; psnode_ode_backward_f32: K4f */
+    PSNODE_KERNEL_MFMA_WAVE = 5,     /* K1x / K2x, the one-wave-per-4-trajectories (exchange-free) MFMA integrators (incl. their saving instances);
+                                        psnode_ode_backward_f32: K4x, the backward of the same form (hidden 33..64, saved rows); UNSUPPORTED outside their shapes */
     PSNODE_KERNEL_MFMA_WIDE = 3      /* backward calls only: the one-launch MFMA backward K4f (hidden <= 128 zero-padded to 32 / 64 / 128); since ABI 8
                                         (K4 removed) the same kernel AUTO / MFMA pick for these shapes */
 } psnode_kernel;
@@ -238,13 +239,14 @@ int32_t psnode_recon_rows_backward_f32(const psnode_mlp_f32* encoder, const psno
  * Outputs: dL/dx[0], dL/dz (per grid point; steps that took a jump put their gradient into grad_z_jump instead),
  * dL/dall_initial and dL/d(parameters) as ONE flat vector in nn.Linear order
  * [W1 (64 x 3n), b1, W2, b2, W3, b3, W4 (x_dim x 64), b4] (psnode_ode_backward_param_count floats).
- * Kernels: MFMA backwards for the shape classes 3n -> 64 -> 64 -> 64 -> x_dim (x_dim <= 8, z_dim <= 4) and the latent
+ * Kernels: MFMA backwards for the shape classes 3n -> h -> h -> h -> x_dim (h <= 128, x_dim <= 8, z_dim <= 8; K4x / K4f) and the latent
  * 6H -> H -> H with x_dim = z_dim = H in {16, 64} (16-byte aligned rows); the generic backward for any MLP whose activations
  * fit the 160 KB LDS (its parameter-gradient accumulators move to the workspace when they do not).  No teacher forcing;
  * t carries no gradient.  Deterministic (per-workgroup partials summed in a fixed order). */
 typedef struct {
     int32_t method;
-    int32_t kernel;                  /* psnode_kernel: AUTO = MFMA backward when the shape has one, else generic */
+    int32_t kernel;                  /* psnode_kernel: AUTO = MFMA backward when the shape has one (K4x with saved rows at hidden 33..64 up to 4608
+                                        trajectories, else K4f), else generic; _MFMA_WAVE / _MFMA_TILE / _MFMA_WIDE force K4x / K4f / K4f */
     int32_t x_dim, z_dim;
     int64_t T, B;
     psnode_mlp_f32 de;
