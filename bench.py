@@ -612,15 +612,32 @@ def train_extra_line(fused, workload, method, hidden, dev, steps=10, warmup=3):
 
 
 MODEL_TRAIN_EXTRAS = [("dae02", "rk4"), ("dae02", "euler"), ("ode02", "rk4")]
+# Round 6: the direct_encode models at the scripts' argparse default --hidden 128 (neural_00_ODE_02_direct_encode.py:
+# 160-162, neural_01_DAE_02_direct_encode.py:246-248): K3w / K9w with their weight gradients still contracted by library GEMMs -- on the line so
+# that the cost is visible.  Euler = the solver the scripts ship with.
+MODEL_H128_EXTRAS = [("ode02", "euler", 128), ("dae02", "euler", 128)]
 
 
-def model_train_extra_line(workload, method, dev, steps=8, warmup=3):
+def safe_line(label, fn):
+    """An extra workload must never take the measured headline down with it: a failure becomes an entry that says so."""
+    try:
+        return fn()
+    except Exception as e:      # noqa: BLE001
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        return {"workload": label, "error": f"{type(e).__name__}: {e}"[:400]}
+
+
+def model_train_extra_line(workload, method, dev, steps=8, warmup=3, hidden=None):
     """Training step of a direct_encode MODEL as the script runs it (neural_01_DAE_02_direct_encode.py:359-370 / neural_00_ODE_02_direct_encode.py:267-275):
     encoders -> fused latent integrator -> decoders -> the script's loss (K6) -> backward through all of it (row-MLP backward kernels, K9 / K8f),
     B=4096 x 1000 steps at the hidden width the script ships with.  roofline.frac on the 3x-forward executed-flop convention."""
     from py_psnode_amd import loss as L, models
     from py_psnode_amd import neural_dae as nd
     w = dict(WORKLOADS[workload])
+    if hidden:
+        w["H"] = hidden
     B, T, H = w["B"], w["T"], w["H"]
     g = torch.Generator().manual_seed(0)
     r = lambda *s: (0.1 * torch.randn(*s, generator=g)).to(dev)
@@ -1066,6 +1083,11 @@ def main():
                 res["extra"] += [train_extra_line(fused, wl, m, h, dev) for wl, m, h in TRAIN_EXTRAS]
                 res["extra"] += [model_train_extra_line(wl, m, dev) for wl, m in MODEL_TRAIN_EXTRAS]
             res["extra"] += [extra_line(lib, _lib, fused, wl, m, dev, steps=5, warmup=3, hidden=h, env=e, note=n) for wl, m, h, e, n in LATE_EXTRAS]
+            if not args.no_train_extras:
+                for wl, m, h in MODEL_H128_EXTRAS:
+                    res["extra"].append(safe_line(f"{wl} {m}: H{h} forward", lambda: extra_line(lib, _lib, fused, wl, m, dev, steps=3, warmup=2, hidden=h,
+                                                                                              note="the scripts' argparse default --hidden 128")))
+                    res["extra"].append(safe_line(f"{wl} {m} MODEL TRAIN H{h}", lambda: model_train_extra_line(wl, m, dev, steps=3, warmup=2, hidden=h)))
             outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method, gpu_out=None if args.train else outs[0])

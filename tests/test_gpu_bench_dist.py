@@ -97,7 +97,13 @@ def test_default_bench_line_carries_the_extra_workloads():
     train = ["ode01 rk4 TRAIN", "dae01 rk4 TRAIN", "ode01 euler TRAIN", "dae01 euler TRAIN", "ode01 rk4 TRAIN", "dae01 rk4 TRAIN"]
     model_train = ["dae02 rk4 MODEL TRAIN", "dae02 euler MODEL TRAIN", "ode02 rk4 MODEL TRAIN"]      # whole direct_encode training steps (round 4)
     late = ["dae02 rk4", "dae02 rk4", "ode01 rk4"]       # DAE_02 forward on both routes, hidden 256 (streamed weights)
-    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train + model_train + late
+    # round 6: the direct_encode models at the scripts' argparse default --hidden 128 (forward + model training step, Euler)
+    h128 = ["ode02 euler", "ode02 euler MODEL TRAIN", "dae02 euler", "dae02 euler MODEL TRAIN"]
+    assert [n.split(" (")[0] for n in names] == ["dae01 rk4", "ode02 rk4", "ode01 euler", "dae01 euler"] + train + model_train + late + h128
+    for e in d["extra"][-4:]:
+        assert "error" not in e, e
+        assert "H128" in e["workload"] and e["outputs_finite"]
+    d["extra"] = d["extra"][:-4]                      # (the index-based checks below address the lines in front of them)
     for e in d["extra"][10:13]:
         assert e["grads_finite"] and e["roofline"]["flop_convention"].startswith("3 x forward")
     for e in d["extra"]:
@@ -111,7 +117,7 @@ def test_default_bench_line_carries_the_extra_workloads():
         else:
             assert r["frac"] < 1.0
     fwd = [e for e in d["extra"] if "gpu_vs_oracle" in e]
-    assert len(fwd) == 7, [e["workload"] for e in fwd]      # every forward line is checked against the oracle
+    assert len(fwd) == 7, [e["workload"] for e in fwd]      # (+ the two hidden-128 forwards, cut off above)      # every forward line is checked against the oracle
     for e in fwd:
         assert "error" not in e["gpu_vs_oracle"], e["gpu_vs_oracle"]
         assert e["gpu_vs_oracle"]["per_trajectory_rel_err"] <= 1e-5, (e["workload"], e["gpu_vs_oracle"])
