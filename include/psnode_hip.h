@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSNODE_ABI_VERSION 9
+#define PSNODE_ABI_VERSION 10
 #define PSNODE_MAX_LAYERS 8      /* Linear layers per MLP */
 #define PSNODE_MAX_WIDTH 1024    /* widest layer OUTPUT the kernels accept */
 #define PSNODE_MAX_IN_WIDTH 2048 /* widest first-layer INPUT (the latent DE of DAE_02 at --hidden 128 is 12 x 128 = 1536 wide) */
@@ -217,6 +217,50 @@ int64_t psnode_mlp_rows_backward_parts(const psnode_mlp_f32* mlp, int64_t rows);
 size_t psnode_mlp_rows_reduce_workspace_bytes(const psnode_mlp_f32* mlp, int64_t n_parts);   /* (n_parts + 32) * param_count floats */
 int32_t psnode_mlp_rows_reduce_f32(const psnode_mlp_f32* mlp, int64_t n_parts, void* workspace, size_t workspace_bytes, float* grad_params,
                                    void* stream);
+
+/* K10 (ABI 10): tall-skinny contraction over rows,  C[m][n] = sum_r A[r][m] * B[r][n]  (+ colsum_a[m] = sum_r A[r][m], optional), on MFMA
+ * with the rows as the contraction index: the weight gradients that are not accumulated inside a sweep kernel -- K9w's blocks over its
+ * stored rows at the direct_encode models' hidden widths other than 16 / 64 (the scripts' argparse default --hidden 128:
+ * neural_00_ODE_02_direct_encode.py:160-162, what loss.backward() forms for de_func there) -- instead of a library GEMM.
+ * M, N <= 128 and multiples of 4; lda / ldb (elements) multiples of 4; A, B 16-byte aligned; C row-major [M, N].  Deterministic
+ * (per-workgroup partials in `workspace`, summed in a fixed order). */
+typedef struct {
+    int64_t rows;
+    int32_t M, N;
+    const float* A;                  /* [rows, M], row stride lda */
+    int64_t lda;
+    const float* B;                  /* [rows, N], row stride ldb */
+    int64_t ldb;
+    float* C;                        /* [M, N] */
+    float* colsum_a;                 /* [M] or NULL */
+} psnode_gemm_tn_args_f32;
+int32_t psnode_gemm_tn_supported(const psnode_gemm_tn_args_f32* args);
+size_t psnode_gemm_tn_workspace_bytes(const psnode_gemm_tn_args_f32* args);
+int32_t psnode_gemm_tn_f32(const psnode_gemm_tn_args_f32* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K11 (ABI 10): one linear layer over rows with a fused epilogue,  Y[r][n] = epi(sum_k X[r][k] * Wm[n][k] + bias[n]),  K, N <= 128:
+ * the forward AND backward of the direct_encode encoders / decoders (nn.Sequential(Linear, ELU, Linear) over every (b, t) row,
+ * neural_00_ODE_02_direct_encode.py:64-69, 74-88) at the hidden widths psnode_mlp_rows_f32 does not carry (the scripts' argparse default
+ * --hidden 128), and the row-wise products of the latent-wide backward.  Wm[n][k] = W[n * w_stride_n + k * w_stride_k]: an nn.Linear
+ * weight [N, K] as it is (w_stride_n = K, w_stride_k = 1) or read transposed (a [K, N] tensor: w_stride_n = 1, w_stride_k = N).
+ * epi: 0 identity, 1 ELU(alpha = 1), 2 multiply by ELU'(Hh[r][n]) where Hh holds ELU OUTPUTS (the delta of a hidden layer).
+ * bias may be NULL.  Row strides in elements; no workspace. */
+typedef struct {
+    int64_t rows;
+    int32_t K, N;
+    const float* X;                  /* [rows, K], row stride ldx */
+    int64_t ldx;
+    const float* W;
+    int64_t w_stride_n, w_stride_k;
+    const float* bias;               /* [N] or NULL */
+    int32_t epi;
+    const float* Hh;                 /* epi == 2: [rows, N], row stride ldh */
+    int64_t ldh;
+    float* Y;                        /* [rows, N], row stride ldy */
+    int64_t ldy;
+} psnode_linear_rows_args_f32;
+int32_t psnode_linear_rows_supported(const psnode_linear_rows_args_f32* args);
+int32_t psnode_linear_rows_f32(const psnode_linear_rows_args_f32* args, void* stream);
 
 /* The RECONSTRUCTION branch of the direct_encode ODE model at hidden 16 as ONE row kernel each way (ABI 9):
  *   x_re = x_decoder(x_encoder(x))        neural_00_ODE_02_direct_encode.py:87     (x_encoder in <= 16 -> 16 -> 16, x_decoder 16 -> 16 -> out <= 16)

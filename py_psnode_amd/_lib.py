@@ -15,7 +15,7 @@ EULER, MIDPOINT, RK4_38 = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_MFMA_WIDE, KERNEL_MFMA_TILE, KERNEL_MFMA_WAVE = 0, 1, 2, 3, 4, 5
 FLAG_INPUT_TRUE_X, FLAG_INPUT_TRUE_I = 1, 2
 
-ABI_VERSION = 9          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
+ABI_VERSION = 10         # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: round-2 exports + arg structs, folded forward image;
                          #  3: save_act / save_xstage in the ODE forward args, saved_* in the backward args, psnode_ode_save_hidden;
                          #  4: the DAE's save_* / saved_* / fused-DE outputs in psnode_dae_args_f32 / psnode_dae_bwd_wide_args_f32,
                          #     psnode_dae_save_hidden;
@@ -25,7 +25,9 @@ ABI_VERSION = 9          # == PSNODE_ABI_VERSION of include/psnode_hip.h (2: rou
                          #  8: the split backward forms are gone -- no psnode_ode_backward_wide_*, no k0 / k1 / stored DE rows in
                          #     psnode_dae_bwd_wide_args_f32 -- and PSNODE_KERNEL_MFMA_TILE / _WAVE select K1 / K1x for forward ODE calls;
                          #  9: row addressing (inner rows / outer stride) in psnode_mlp_rows_*, psnode_recon_rows_*, psnode_mlp_rows_reduce_f32 /
-                         #     _backward_parts: the row kernels read [B,T,D] batches as time-major rows in place)
+                         #     _backward_parts: the row kernels read [B,T,D] batches as time-major rows in place;
+                         # 10: psnode_gemm_tn_* / psnode_linear_rows_*: the contraction over rows (K10) and the row-linear layer (K11) that replace library GEMMs; the `kernel` field of
+                         #     psnode_ode_bwd_args_f32 selects K4x (_MFMA_WAVE) / K4f (_MFMA_TILE, _MFMA_WIDE))
 LIB_NAME = "libpsnode_hip.so"
 # PSNODE_LIB_PATH lets kernel experiments (profiles/scripts/*) load an alternative build of the same ABI
 LIB_PATH = os.environ.get("PSNODE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -47,6 +49,8 @@ EXPORTS = (
     "psnode_latent_backward_wide_supported", "psnode_latent_backward_wide_workspace_bytes", "psnode_latent_backward_wide_f32",
     "psnode_dae_backward_wide_supported", "psnode_dae_backward_wide_workspace_bytes", "psnode_dae_backward_wide_f32",
     "psnode_dae_backward_wide_ae_floats",
+    "psnode_gemm_tn_supported", "psnode_gemm_tn_workspace_bytes", "psnode_gemm_tn_f32",
+    "psnode_linear_rows_supported", "psnode_linear_rows_f32",
 )
 
 
@@ -162,6 +166,17 @@ class DaeHeadGradsArgsF32(ctypes.Structure):
     _fields_ = [("R", c_int64), ("B", c_int64), ("hidden", c_int32), ("n_zv", c_int32), ("act", c_void_p * 3), ("act_row_stride", c_int64),
                 ("delta", c_void_p * 3), ("gi", c_void_p), ("u", c_void_p), ("aw1", c_void_p), ("aw1_cols", c_int32), ("zv_col0", c_int32),
                 ("grad_zv", c_void_p), ("sa1", c_void_p), ("out", c_void_p)]
+
+
+class GemmTnArgsF32(ctypes.Structure):
+    _fields_ = [("rows", c_int64), ("M", c_int32), ("N", c_int32), ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64),
+                ("C", c_void_p), ("colsum_a", c_void_p)]
+
+
+class LinearRowsArgsF32(ctypes.Structure):
+    _fields_ = [("rows", c_int64), ("K", c_int32), ("N", c_int32), ("X", c_void_p), ("ldx", c_int64), ("W", c_void_p),
+                ("w_stride_n", c_int64), ("w_stride_k", c_int64), ("bias", c_void_p), ("epi", c_int32), ("Hh", c_void_p), ("ldh", c_int64),
+                ("Y", c_void_p), ("ldy", c_int64)]
 
 
 class LossArgsF32(ctypes.Structure):
@@ -294,6 +309,16 @@ def load():
     lib.psnode_dae_backward_wide_f32.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32), c_void_p, c_size_t, c_void_p]
     lib.psnode_dae_backward_wide_ae_floats.restype = c_size_t
     lib.psnode_dae_backward_wide_ae_floats.argtypes = [ctypes.POINTER(DaeBwdWideArgsF32)]
+    lib.psnode_linear_rows_supported.restype = c_int32
+    lib.psnode_linear_rows_supported.argtypes = [ctypes.POINTER(LinearRowsArgsF32)]
+    lib.psnode_linear_rows_f32.restype = c_int32
+    lib.psnode_linear_rows_f32.argtypes = [ctypes.POINTER(LinearRowsArgsF32), c_void_p]
+    lib.psnode_gemm_tn_supported.restype = c_int32
+    lib.psnode_gemm_tn_supported.argtypes = [ctypes.POINTER(GemmTnArgsF32)]
+    lib.psnode_gemm_tn_workspace_bytes.restype = c_size_t
+    lib.psnode_gemm_tn_workspace_bytes.argtypes = [ctypes.POINTER(GemmTnArgsF32)]
+    lib.psnode_gemm_tn_f32.restype = c_int32
+    lib.psnode_gemm_tn_f32.argtypes = [ctypes.POINTER(GemmTnArgsF32), c_void_p, c_size_t, c_void_p]
     _lib = lib
     return lib
 

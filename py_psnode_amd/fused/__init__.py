@@ -16,7 +16,7 @@ from .forward import (_MFMA_CLASSES, _k0_warned, _mfma_miss, _note_k0, ode_integ
 from .backward_ode import (_bwd_args, ode_backward_supported, ode_backward)  # noqa: F401
 from .backward_dae import (dae_backward_supported, dae_backward_wide_supported, dae_backward_wide, _dae_backward_wide_sliced, dae_backward)  # noqa: F401
 from .latent import (latent_wide_shape, latent_backward_wide)  # noqa: F401
-from .rows import (mlp_rows, mlp_rows_backward, mlp_rows_backward_multi, _RowsMlp, _RowsMlpMulti, mlp_rows_autograd, mlp_rows_autograd_multi, rows_layers_of, recon_rows_supported, recon_rows, recon_rows_backward, _ReconRows,
+from .rows import (mlp_rows, mlp_rows_backward, mlp_rows_backward_multi, _RowsMlp, _RowsMlpMulti, mlp_rows_autograd, mlp_rows_autograd_multi, rows_layers_of, recon_rows_supported, recon_rows, recon_rows_backward, _ReconRows, linear_rows, wide_mlp_rows, wide_rows_class, _WideRowsMlp,
                    recon_rows_autograd)  # noqa: F401
 from .encoded import (ode_encoded_supported, ode_encoded_integrate, _dae_encoded_args, dae_encoded_supported, dae_encoded_integrate)  # noqa: F401
 from .plan import (_event_tensors, _needs_autograd, _all_f32_on, plan_ode, plan_dae)  # noqa: F401

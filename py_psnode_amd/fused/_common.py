@@ -298,9 +298,46 @@ def _pad_rows(m: torch.Tensor, rows: int) -> torch.Tensor:
     return m if m.shape[0] == rows else torch.cat((m, m.new_zeros((rows - m.shape[0],) + tuple(m.shape[1:]))), 0)
 
 
+def gemm_tn(a2: torch.Tensor, b2: torch.Tensor, want_colsum: bool = False):
+    """K10 (psnode_gemm_tn_f32): a2^T @ b2 for tall-skinny fp32 [R, p], [R, q] row tensors on the hand-written MFMA contraction kernel
+    (rows as the contraction index, deterministic partial sums); with want_colsum also sum_r a2[r, :].  None if the shapes / alignment
+    are outside the kernel's class (p, q <= 128 and multiples of 4, 16-byte aligned rows) -- the caller then decides."""
+    if a2.dim() != 2 or b2.dim() != 2 or a2.shape[0] != b2.shape[0] or a2.device.type != "cuda" or a2.dtype != torch.float32 or b2.dtype != torch.float32:
+        return None
+    if a2.stride(1) != 1:
+        a2 = a2.contiguous()
+    if b2.stride(1) != 1:
+        b2 = b2.contiguous()
+    if a2.shape[0] == 0:      # nothing to contract (an empty tensor has no device pointer to hand over)
+        if a2.shape[1] > 128 or b2.shape[1] > 128 or (a2.shape[1] & 3) or (b2.shape[1] & 3):
+            return None
+        c = torch.zeros((a2.shape[1], b2.shape[1]), dtype=torch.float32, device=a2.device)
+        return (c, torch.zeros(a2.shape[1], dtype=torch.float32, device=a2.device)) if want_colsum else c
+    lib = _lib.load()
+    a = _lib.GemmTnArgsF32()
+    a.rows, a.M, a.N = a2.shape[0], a2.shape[1], b2.shape[1]
+    a.A, a.lda, a.B, a.ldb = a2.data_ptr(), a2.stride(0) if a2.shape[0] > 1 else a2.shape[1], b2.data_ptr(), b2.stride(0) if b2.shape[0] > 1 else b2.shape[1]
+    if not lib.psnode_gemm_tn_supported(ctypes.byref(a)):
+        return None
+    dev = a2.device
+    with torch.cuda.device(dev):
+        c = _empty((a.M, a.N), dtype=torch.float32, device=dev)
+        cs = _empty((a.M,), dtype=torch.float32, device=dev) if want_colsum else None
+        a.C = c.data_ptr()
+        a.colsum_a = cs.data_ptr() if cs is not None else None
+        ws = _empty(lib.psnode_gemm_tn_workspace_bytes(ctypes.byref(a)) + 256, dtype=torch.uint8, device=dev)
+        wp, wn = _aligned_ptr(ws)
+        _lib.check(lib.psnode_gemm_tn_f32(ctypes.byref(a), wp, wn, torch.cuda.current_stream(dev).cuda_stream), "psnode_gemm_tn_f32")
+    return (c, cs) if want_colsum else c
+
+
 def _gemm_tn(a2: torch.Tensor, b2: torch.Tensor, groups: int) -> torch.Tensor:
-    """a2^T @ b2 for tall-skinny [N, p], [N, q] (N in the millions): `groups` independent partial products + one sum, so the library
-    GEMM has parallelism over the contraction (one [p,N]x[N,q] call runs on a handful of workgroups: 21 vs 124 TFLOP/s at p=q=128)."""
+    """a2^T @ b2 for tall-skinny [N, p], [N, q] (N in the millions).  Round 6: on K10 (gemm_tn above) whenever the shapes are in its class
+    -- every call of the latent-wide backward at hidden % 4 == 0 --; otherwise (odd widths) `groups` independent library partial products
+    + one sum."""
+    c = gemm_tn(a2, b2)
+    if c is not None:
+        return c
     N = a2.shape[0]
     groups = max(1, min(groups, 256))     # the [groups, p, q] partial products are materialised: cap them (small B x long T chunks)
     while groups > 1 and N % groups:

@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from ._common import Layers, METHOD_ID, _aligned_ptr, _empty, _f32_dev, _gemm_tn, _mlp, _view
+from ._common import Layers, METHOD_ID, _aligned_ptr, _empty, _f32_dev, _gemm_tn, _mlp, _view, gemm_tn
 
 def latent_wide_shape(de_layers: Layers, ae_layers: Optional[Layers], x_dim: int, z_dim: int, v_dim: int = 0, i_dim: int = 0) -> bool:
     """The latent shapes of the direct_encode models at a hidden width the dedicated latent kernels do not take (every H <= 128 with
@@ -94,8 +94,8 @@ def latent_backward_wide(method: str, de_layers: Layers, ae_layers: Optional[Lay
         R = lambda q: q.reshape(-1, H)
         g = {"z_jump": None, "v_jump": None, "z": None, "v": None}
         if T >= 2:
-            gW2 = _gemm_tn(R(gk), R(s_act), G)
-            gb2 = R(gk).sum(0)
+            both = gemm_tn(R(gk), R(s_act), want_colsum=True)      # K10: the contraction and the bias gradient (column sums) in one pass
+            gW2, gb2 = both if both is not None else (_gemm_tn(R(gk), R(s_act), G), R(gk).sum(0))
             Px = _gemm_tn(R(d1), R(s_xst), G)
             # the external blocks each step used: the grid point's rows or, at a jump step, the jump rows; (DAE) i_k or the event's i0
             used = []
@@ -136,8 +136,8 @@ def latent_backward_wide(method: str, de_layers: Layers, ae_layers: Optional[Lay
             # ---- the AE head: rows per grid point (un-jumped inputs) and per event taken (x of the jump step, jump rows)
             (A1, _ab1), (A2, _ab2) = [(w.detach(), b.detach()) for w, b in ae_layers]
             ah = s_ae[0]
-            gA2 = _gemm_tn(R(gi), R(ah), T)
-            gab2 = R(gi).sum(0)
+            both = gemm_tn(R(gi), R(ah), want_colsum=True)
+            gA2, gab2 = both if both is not None else (_gemm_tn(R(gi), R(ah), T), R(gi).sum(0))
             cols = [_gemm_tn(R(da1), R(xs_c), T)]
             if zd:
                 cols.append(_gemm_tn(R(da1), R(z.detach().contiguous()), T))

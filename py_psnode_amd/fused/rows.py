@@ -1,6 +1,7 @@
 """Encoder / decoder row MLPs of the direct_encode models (`nn.Sequential(Linear, ELU, Linear)` over the last dim) on the HIP row
 kernels K3b, forward and backward, with an autograd bridge."""
 import ctypes
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -26,11 +27,120 @@ def _row_addressing(x: torch.Tensor):
     return x2, x2.shape[0], max(x2.stride(0), d), 0, 0
 
 
+# ----------------------------------------------------------------------------- K11 / K10: the row MLPs at every other width <= 128
+def linear_rows(x2: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = 0, hh: Optional[torch.Tensor] = None,
+                transposed: bool = False, out_shape=None) -> torch.Tensor:
+    """K11 (psnode_linear_rows_f32): Y = epi(x2 @ Wm^T + bias) over the rows of a contiguous-row fp32 [R, K] tensor.  Wm = W ([N, K], an
+    nn.Linear weight) or, with transposed=True, W^T (W is [K, N]: `x2 @ W`).  epi 0 identity / 1 ELU / 2 multiply by ELU'(hh), hh = ELU
+    outputs [R, N]."""
+    lib = _lib.load()
+    dev = x2.device
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    R, K = x2.shape
+    Wc = W.detach()
+    N = Wc.shape[1] if transposed else Wc.shape[0]
+    a = _lib.LinearRowsArgsF32()
+    a.rows, a.K, a.N = R, K, N
+    a.X, a.ldx = x2.data_ptr(), x2.stride(0) if R > 1 else K
+    a.W = Wc.data_ptr()
+    a.w_stride_n, a.w_stride_k = (Wc.stride(1), Wc.stride(0)) if transposed else (Wc.stride(0), Wc.stride(1))
+    bc = None
+    if bias is not None:
+        bc = bias.detach().contiguous()
+        a.bias = bc.data_ptr()
+    a.epi = epi
+    if epi == 2:
+        if hh is None or hh.shape != (R, N) or hh.stride(-1) != 1:
+            raise ValueError("linear_rows(epi=2): hh must be a contiguous-row [R, N] tensor of ELU outputs")
+        a.Hh, a.ldh = hh.data_ptr(), hh.stride(0) if R > 1 else N
+    with torch.cuda.device(dev):
+        # (out_shape: the caller's [..., N] shape with prod(...) = R -- allocated in that shape, so that an autograd Function can hand it out
+        #  without a view created inside its forward, which autograd refuses to see modified in place: `x_pred[0] = x0` of the DAE script)
+        y = _empty(tuple(out_shape) if out_shape is not None else (R, N), dtype=torch.float32, device=dev)
+        a.Y, a.ldy = y.data_ptr(), N
+        if not lib.psnode_linear_rows_supported(ctypes.byref(a)):
+            raise ValueError(f"linear_rows: K = {K}, N = {N} outside the kernel's class (<= 128)")
+        if R:
+            _lib.check(lib.psnode_linear_rows_f32(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream), "psnode_linear_rows_f32")
+    return y
+
+
+def _pad4(t2: torch.Tensor) -> torch.Tensor:
+    """[R, n] -> contiguous [R, 4 ceil(n / 4)] (zero columns behind): K10 contracts float4 row segments."""
+    n = t2.shape[1]
+    if n % 4 == 0:
+        return t2 if t2.stride(1) == 1 and t2.stride(0) % 4 == 0 and t2.data_ptr() % 16 == 0 else t2.contiguous()
+    out = torch.zeros((t2.shape[0], (n + 3) // 4 * 4), dtype=t2.dtype, device=t2.device)
+    out[:, :n] = t2
+    return out
+
+
+def wide_rows_class(layers) -> bool:
+    """Linear(in, H) ELU Linear(H, out) with every width <= 128: what K11 / K10 carry (any width; K3b keeps hidden 16 / 64)."""
+    if layers is None or len(layers) != 2:
+        return False
+    H, din, dout = layers[0][0].shape[0], layers[0][0].shape[1], layers[1][0].shape[0]
+    return layers[1][0].shape[1] == H and 1 <= H <= 128 and 1 <= din <= 128 and 1 <= dout <= 128
+
+
+def _k3b_class(layers) -> bool:
+    if layers is None or len(layers) != 2:
+        return False
+    H, din, dout = layers[0][0].shape[0], layers[0][0].shape[1], layers[1][0].shape[0]
+    return H in (16, 64) and (din <= 16 or (din == 64 and H == 64)) and (dout <= 16 or dout == H)
+
+
+def wide_mlp_rows(layers: Layers, inp: torch.Tensor, want_hidden: bool = False):
+    """The two-layer row MLP on K11: h = ELU(x W1^T + b1) (one launch, ELU fused), y = h W2^T + b2 (one launch)."""
+    (W1, b1), (W2, b2) = layers
+    x2 = inp.reshape(-1, inp.shape[-1])
+    h = linear_rows(x2, W1, b1, epi=1)
+    y = linear_rows(h, W2, b2, out_shape=(*inp.shape[:-1], W2.shape[0]))
+    return (y, x2, h) if want_hidden else y
+
+
+class _WideRowsMlp(torch.autograd.Function):
+    """Linear-ELU-Linear over rows at the widths K3b does not carry, hand-written both ways (round 6): forward 2 x K11; backward
+    delta = (g W2) * ELU'(h) (K11, epilogue 2), grad_in = delta W1 (K11), dW2 | db2 = g^T h | colsum g and dW1 | db1 = delta^T x | colsum
+    delta (K10).  Saves the input rows and the hidden rows."""
+
+    @staticmethod
+    def forward(ctx, inp, w1, b1, w2, b2):
+        y, x2, h = wide_mlp_rows([(w1.detach(), b1.detach()), (w2.detach(), b2.detach())], inp.detach(), want_hidden=True)
+        ctx.save_for_backward(x2, h, w1, w2)
+        ctx.in_shape = inp.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ._common import gemm_tn
+        x2, h, w1, w2 = ctx.saved_tensors
+        w1, w2 = w1.detach(), w2.detach()
+        dout, H, din = w2.shape[0], w2.shape[1], w1.shape[1]
+        g2 = gy.reshape(-1, dout)
+        if g2.stride(-1) != 1:
+            g2 = g2.contiguous()
+        delta = linear_rows(g2, w2, None, epi=2, hh=h, transposed=True)                 # [R, H] = (g2 @ W2) * ELU'(h)
+        gin = linear_rows(delta, w1, None, transposed=True, out_shape=ctx.in_shape) if ctx.needs_input_grad[0] else None
+        hp = _pad4(h)
+        if hp.shape[1] <= 128 and ((dout + 3) // 4 * 4) <= 128:
+            c2, s2 = gemm_tn(_pad4(g2), hp, want_colsum=True)
+            dW2, db2 = c2[:dout, :H], s2[:dout]
+            c1, s1 = gemm_tn(_pad4(delta), _pad4(x2), want_colsum=True)
+            dW1, db1 = c1[:H, :din], s1[:H]
+        else:
+            dW2, db2, dW1, db1 = g2.t() @ h, g2.sum(0), delta.t() @ x2, delta.sum(0)
+        return gin, dW1.contiguous(), db1.contiguous(), dW2.contiguous(), db2.contiguous()
+
+
 def mlp_rows(layers: Layers, inp: torch.Tensor) -> torch.Tensor:
     """Fused `nn.Sequential(Linear, ELU, Linear)` over the last dim of `inp` (any leading shape) on the HIP row kernel:
     the encoders / decoders of the direct_encode models (neural_00_ODE_02_direct_encode.py:64-69)."""
     lib = _lib.load()
     dev = inp.device
+    if not _k3b_class(layers) and wide_rows_class(layers):
+        return wide_mlp_rows([(w.detach(), b.detach()) for w, b in layers], _f32_dev(inp, dev, "input"))
     keep: list = []
     m = _mlp(layers, dev, "mlp", keep)
     if not lib.psnode_mlp_rows_supported(ctypes.byref(m)):
@@ -153,8 +263,11 @@ class _RowsMlpMulti(torch.autograd.Function):
 
 
 def mlp_rows_autograd_multi(seq, *inps):
-    """`tuple(seq(a) for a in inps)` for a recognised Linear-ELU-Linear on the row kernels, ONE autograd node for all of them."""
+    """`tuple(seq(a) for a in inps)` for a recognised Linear-ELU-Linear on the row kernels, ONE autograd node for all of them (K3b's
+    widths; at the other widths one K11 / K10 node per set)."""
     lin = [m for m in seq if isinstance(m, nn.Linear)]
+    if not _k3b_class([(lin[0].weight, lin[0].bias), (lin[1].weight, lin[1].bias)]):
+        return tuple(_WideRowsMlp.apply(a, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias) for a in inps)
     return _RowsMlpMulti.apply(lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, *inps)
 
 
@@ -235,6 +348,8 @@ def recon_rows_autograd(encoder, decoder, inp: torch.Tensor) -> torch.Tensor:
 def mlp_rows_autograd(seq, inp: torch.Tensor) -> torch.Tensor:
     """`seq(inp)` for a recognised Linear-ELU-Linear on the row kernels, differentiable w.r.t. the input and the parameters."""
     lin = [m for m in seq if isinstance(m, nn.Linear)]
+    if not _k3b_class([(lin[0].weight, lin[0].bias), (lin[1].weight, lin[1].bias)]):
+        return _WideRowsMlp.apply(inp, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
     return _RowsMlp.apply(inp, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
 
 
@@ -246,8 +361,7 @@ def rows_layers_of(seq, inp: torch.Tensor, allow_grad: bool = False):
     layers = sequential_layers(seq)
     if layers is None or len(layers) != 2:
         return None
-    H, din, dout = layers[0][0].shape[0], layers[0][0].shape[1], layers[1][0].shape[0]
-    if H not in (16, 64) or not (din <= 16 or (din == 64 and H == 64)) or not (dout <= 16 or dout == H):
+    if not _k3b_class(layers) and not wide_rows_class(layers):      # K3b at hidden 16 / 64, K11 / K10 at every other width <= 128
         return None
     if not allow_grad and _needs_autograd([inp] + [p for wb in layers for p in wb]):
         return None

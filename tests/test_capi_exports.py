@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.psnode_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.psnode_abi_version() == _lib.ABI_VERSION == 10
     assert b"gfx950" in lib.psnode_build_info()
     assert lib.psnode_status_string(0) == b"ok" and b"NULL" in lib.psnode_status_string(-1)
 
