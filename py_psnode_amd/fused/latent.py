@@ -123,16 +123,18 @@ def latent_backward_wide(method: str, de_layers: Layers, ae_layers: Optional[Lay
                 raw = torch.where(hit, torch.zeros_like(raw), raw)
             grid_target[:T - 1] += raw
         Fb = lambda blk: W1[:, 2 * n + H * blk:2 * n + H * (blk + 1)] + W1[:, n + H * blk:n + H * (blk + 1)]
+        from .rows import linear_rows
+        rows_x_w = lambda rows2, Wkn: linear_rows(rows2, Wkn, None, transposed=True)      # [R, K] @ [K, N] on K11 (no library GEMM over T*B rows)
         if zd and need_grad_z:
             g["z"] = torch.zeros((T, B, H), **f32)
             g["z_jump"] = torch.zeros((B, n_ev, H), **f32) if evl is not None else None
             if T >= 2:
-                route((R(d1s) @ Fb(1)).view(T - 1, B, H), g["z"], g["z_jump"])
+                route(rows_x_w(R(d1s), Fb(1)).view(T - 1, B, H), g["z"], g["z_jump"])
         if dae:
             g["v"] = torch.zeros((T, B, H), **f32)
             g["v_jump"] = torch.zeros((B, n_ev, H), **f32) if evl is not None else None
             if T >= 2:
-                route((R(d1s) @ Fb(nblk - 2)).view(T - 1, B, H), g["v"], g["v_jump"])
+                route(rows_x_w(R(d1s), Fb(nblk - 2)).view(T - 1, B, H), g["v"], g["v_jump"])
             # ---- the AE head: rows per grid point (un-jumped inputs) and per event taken (x of the jump step, jump rows)
             (A1, _ab1), (A2, _ab2) = [(w.detach(), b.detach()) for w, b in ae_layers]
             ah = s_ae[0]
@@ -156,10 +158,10 @@ def latent_backward_wide(method: str, de_layers: Layers, ae_layers: Optional[Lay
             g["ae"] = [gA1, Sa1.sum(0), gA2, gab2]
             Ab = lambda q: A1[:, n + H * q:n + H * (q + 1)]          # q: 0 = x, then z (if any), v
             if zd and need_grad_z:
-                g["z"] += (R(da1) @ Ab(1)).view(T, B, H)
+                g["z"] += rows_x_w(R(da1), Ab(1)).view(T, B, H)
                 if g["z_jump"] is not None:
                     g["z_jump"] += (R(da1_ev) @ Ab(1)).view(n_ev, B, H).permute(1, 0, 2)
-            g["v"] += (R(da1) @ Ab(nblk - 2)).view(T, B, H)
+            g["v"] += rows_x_w(R(da1), Ab(nblk - 2)).view(T, B, H)
             if g["v_jump"] is not None:
                 g["v_jump"] += (R(da1_ev) @ Ab(nblk - 2)).view(n_ev, B, H).permute(1, 0, 2)
     g["x_init"] = gx0
