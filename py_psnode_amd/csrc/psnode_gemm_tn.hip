@@ -52,49 +52,76 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnDev a) {
 #pragma unroll
     for (int q = 0; q < MQ; ++q) csum[q] = zero4;
 
+    // Column quads beyond the matrix are read from column 0 and NOT zeroed: C[m][n] depends on column m of A and column n of B only, and
+    // the entries of invalid columns are never stored.  Rows: the main loop takes full quads of rows without any predicate (the first
+    // version selected zeros behind every load: the selects sat right behind the loads, the wave waited out each round trip on the spot
+    // and the look-ahead was gone -- found in the ISA); the last, partial quad is one masked step.
     // (B: exactly the wave's NQ components of its quad -- 4 or 8 bytes at b_off + cb0 -- so that no register is indexed at run time)
-    auto load = [&](const long long s, f4 (&av)[MQ], float (&bv)[NQ]) {
-        const long long row = r0 + 4 * s + k;
-        const bool on = row < r1;
-        const long long rc = on ? row : r1 - 1;
-        const float* pa = a.A + rc * a.lda;
-        const float* pb = a.B + rc * a.ldb + b_off + cb0;
+    const int nrows = (int)(r1 > r0 ? r1 - r0 : 0), nfull = nrows >> 2, rem = nrows & 3;
+    const float* pa = a.A + (r0 + k) * a.lda;
+    const float* pb = a.B + (r0 + k) * a.ldb + b_off + cb0;
+    const long long sa = 4 * a.lda, sb = 4 * a.ldb;
+    auto load = [&](f4 (&av)[MQ], float (&bv)[NQ]) {
 #pragma unroll
-        for (int q = 0; q < MQ; ++q) {
-            const f4 v = *reinterpret_cast<const f4*>(pa + a_off[q]);
-            av[q] = (on && a_on[q]) ? v : zero4;
-        }
+        for (int q = 0; q < MQ; ++q) av[q] = *reinterpret_cast<const f4*>(pa + a_off[q]);
         if constexpr (NQ == 2) {
             const float2 v = *reinterpret_cast<const float2*>(pb);
-            bv[0] = (on && b_on) ? v.x : 0.0f;
-            bv[1] = (on && b_on) ? v.y : 0.0f;
+            bv[0] = v.x; bv[1] = v.y;
         } else {
-            const float v = *pb;
-            bv[0] = (on && b_on) ? v : 0.0f;
+            bv[0] = *pb;
+        }
+        pa += sa; pb += sb;
+    };
+    auto mfmas = [&](const f4 (&av)[MQ], const float (&bv)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            csum[q] += av[q];                           // (every wave: 2 packed adds next to 16 MFMAs; wave 0 writes them)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) acc[4 * q + c][u] = tn_mfma(av[q][c], bv[u], acc[4 * q + c][u]);
         }
     };
-    const long long nsteps = (r1 - r0 + 3) / 4;
     f4 av[MQ], an[MQ];
     float bv[NQ], bn[NQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q) { av[q] = zero4; an[q] = zero4; }
 #pragma unroll
     for (int u = 0; u < NQ; ++u) { bv[u] = 0.0f; bn[u] = 0.0f; }
-    if (nsteps > 0) load(0, av, bv);
-    for (long long s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) load(s + 1, an, bn);        // the next four rows, requested in front of this step's MFMAs
-#pragma unroll
-        for (int q = 0; q < MQ; ++q) {
-            if (w == 0) csum[q] += av[q];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) acc[4 * q + c][u] = tn_mfma(av[q][c], bv[u], acc[4 * q + c][u]);
+    if (nfull > 0) {
+        // two register sets, the loop written out twice: a set is requested a whole 16-MFMA batch before it is used and never copied
+        load(av, bv);
+        int s = 0;
+        // (sched_barrier: left to the scheduler, the first consumers of a freshly requested set -- its column-sum adds -- are hoisted to right
+        //  behind the loads and the wave waits out the round trip there)
+        for (; s + 2 < nfull; s += 2) {
+            load(an, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(av, bv);
+            __builtin_amdgcn_sched_barrier(0);
+            load(av, bv);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(an, bn);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (s + 1 < nfull) {                            // two steps left: the set in hand and one more
+            load(an, bn);
+            mfmas(av, bv);
+            mfmas(an, bn);
+        } else {
+            mfmas(av, bv);                              // one step left
+        }
+    }
+    if (rem > 0) {                                      // the last 1..3 rows: lane groups k >= rem contribute zeros
+        const bool on = k < rem;
+        const long long row = r0 + 4ll * nfull + (on ? k : 0);
+        const float* qa = a.A + row * a.lda;
+        const float* qb_ = a.B + row * a.ldb + b_off + cb0;
 #pragma unroll
-        for (int q = 0; q < MQ; ++q) av[q] = an[q];
+        for (int q = 0; q < MQ; ++q) { const f4 v = *reinterpret_cast<const f4*>(qa + a_off[q]); av[q] = on ? v : zero4; }
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) bv[u] = bn[u];
+        for (int u = 0; u < NQ; ++u) { const float v = qb_[u]; bv[u] = on ? v : 0.0f; }
+        mfmas(av, bv);
     }
     // tile (q, c) x (qb, cb): lane (g = k, j), register r  ->  C[64 q + 4 (4 g + r) + c][64 qb + 4 j + cb]
     float* wp = a.part + (size_t)blockIdx.x * ((size_t)a.M * a.N + a.M);
