@@ -86,13 +86,75 @@ __global__ void pack_x_kernel(const PackX p) {
 #ifndef PSNODE_K1X_SAVE_ABL
 #define PSNODE_K1X_SAVE_ABL 0     // timing-only ablations of the saving forward (saved rows WRONG): 1 = no saved-row store is issued, 2 = every stage
 #endif                            // stores to the rows of (step 0, stage 0) (the same instructions, no HBM traffic)
-template <int METHOD, int NZM, bool SAVE>
-__global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
+// ROLES (round 6): the two-role form of the SAVING forward.  A lone wave per SIMD has nothing to issue while one of its 13 saved-row
+// stores per stage waits for a queue slot: the 13.1 GB of rows cost K1x +0.9 ms (0.6 of it only when the bytes really go to HBM,
+// profiles/r06_k1x_save_ablations.txt) while the 4-wave tile kernels lose half of that in their exchange bubbles.  So the stores move to a
+// PARTNER wave (wave w + 4 of the workgroup, one more wave per SIMD: K1x needs 211 registers): the compute wave drops a stage's rows -- the
+// stage input and the three layers exactly as it would have stored them -- into an LDS ring (3 ds_write_b128 + 1 ds_write_b64), the partner
+// drains it to memory.  Ring = 2 halves of 4 stage slots per pair (28 KB; 112 KB per workgroup), ONE workgroup barrier per 4 stages: the
+// compute wave fills half h while the partner drains half h ^ 1; the partner arrives at the barrier with its ds_reads done and its global
+// stores still in flight, so their acknowledgement never holds the compute wave.
+constexpr int kXSlotFloats = 3 * 256 + 128;          // per stage: three layers [64 lanes][4] + the stage input [64 lanes][2]
+constexpr int kXRingFloats = 2 * 4 * kXSlotFloats;   // per pair: 2 halves x 4 stage slots
+
+template <int METHOD>
+__device__ __forceinline__ void x_store_role(const IntegrateDev& a, const float* __restrict__ ring, const int l, const int pw) {
+    constexpr int S = METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4);
+    const int b = l >> 2, c = l & 3, rho = l >> 4;
+    const long long tile = (long long)blockIdx.x * kXWaves + pw;
+    const bool valid = tile * 4 + c < a.B;
+    const long long tr = valid ? tile * 4 + c : a.B - 1;
+    const int xd = a.xd, nT = (int)a.T;
+    const int d01 = 4 * (rho >> 1) + 2 * (rho & 1), d23 = d01 + 1;
+    const bool storer = (b & 3) == 0 && valid, st01 = storer && d01 < xd, st23 = storer && d23 < xd, pair_ok = (xd & 1) == 0;
+    const int hp = padded_hidden(a.de.out_dim[0]);
+    const size_t sa_layer = (size_t)a.B * hp;
+    const long long xo_step = a.B * xd;
+    const unsigned saoff = (unsigned)(tr * hp + 4 * b) * 4u, xooff = (unsigned)(tr * xd + d01) * 4u;
+    const bool sa_on = valid && 4 * b < hp;
+    float* sa_run = a.sact;
+    float* sx_run = a.sxst;
+    const int nstages = nT >= 2 ? (nT - 1) * S : 0, groups = (nstages + 3) >> 2;
+    const float* mine = ring + (size_t)pw * kXRingFloats;
+    for (int g = 0; g < groups; ++g) {
+        lds_barrier();                                   // group g is complete in half g & 1
+        const float* hb = mine + (g & 1) * 4 * kXSlotFloats;
+        const int nslot = nstages - 4 * g < 4 ? nstages - 4 * g : 4;
+        for (int sl = 0; sl < nslot; ++sl) {
+            const float* sp = hb + sl * kXSlotFloats;
+            const f4 h0 = *reinterpret_cast<const f4*>(sp + 4 * l), h1 = *reinterpret_cast<const f4*>(sp + 256 + 4 * l),
+                     h2 = *reinterpret_cast<const f4*>(sp + 512 + 4 * l);
+            const f2 xs = *reinterpret_cast<const f2*>(sp + 768 + 2 * l);
+            if (pair_ok) {
+                if (st01) stg<f2>((gptr<float>)(uintptr_t)sx_run, xooff, xs);
+            } else {
+                if (st01) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff, xs[0]);
+                if (st23) stg<float>((gptr<float>)(uintptr_t)sx_run, xooff + 4u, xs[1]);
+            }
+            if (sa_on) {
+                stg<f4>((gptr<float>)(uintptr_t)sa_run, saoff, h0);
+                stg<f4>((gptr<float>)(uintptr_t)(sa_run + sa_layer), saoff, h1);
+                stg<f4>((gptr<float>)(uintptr_t)(sa_run + 2 * sa_layer), saoff, h2);
+            }
+            sx_run += xo_step;
+            sa_run += 3 * sa_layer;
+        }
+    }
+}
+
+template <int METHOD, int NZM, bool SAVE, bool ROLES = false>
+__global__ __launch_bounds__(64 * kXWaves * (ROLES ? 2 : 1)) void integrate_x_kernel(const IntegrateDev a, const float* __restrict__ pack) {
+    static_assert(!ROLES || SAVE, "the two-role form is the saving forward's");
+    extern __shared__ __attribute__((aligned(16))) float xring[];
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (ROLES) {
+        if (wv >= kXWaves) { x_store_role<METHOD>(a, xring, l, wv - kXWaves); return; }
+    }
     const int b = l >> 2, c = l & 3, rho = l >> 4;
     const long long tile = (long long)blockIdx.x * kXWaves + wv;
-    if (tile * 4 >= a.B) return;                                   // (nothing is shared between the waves: a surplus wave just leaves)
+    if (!ROLES && tile * 4 >= a.B) return;                          // (nothing is shared between the waves: a surplus wave just leaves; with
+                                                                    //  ROLES it stays for the barriers, every lane invalid)
     const bool valid = tile * 4 + c < a.B;
     const long long tr = valid ? tile * 4 + c : a.B - 1;
     const int xd = a.xd, zd = a.zd, ne = zd, n = xd + zd;
@@ -179,6 +241,8 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
                                          : (PSNODE_K1X_SAVE_ABL == 4 ? (unsigned)(tile * 768 * kStg + c * 64 + 4 * b) * 4u
                                                                      : (unsigned)(tr * hp + 4 * b) * 4u));
     const bool sa_on = SAVE && valid && 4 * b < hp && PSNODE_K1X_SAVE_ABL != 1;
+    float* ring_mine = ROLES ? xring + (size_t)wv * kXRingFloats : nullptr;
+    int ring_sl = 0, ring_half = 0;                                  // ROLES: slot inside the half being filled, the half (uniform)
     auto time_loop = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     auto as_g = [](const float* q) { return (gptr<const float>)(uintptr_t)q; };      // uniform row base (SGPR pair) as a global pointer
@@ -216,7 +280,11 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         accA = mfx<0>(s23, w1x[4], accA);  accB = mfx<4>(s23, w1x[5], accB);
         accA = mfx<8>(s23, w1x[6], accA);  accB = mfx<12>(s23, w1x[7], accB);
         f4 hA = quad_transpose(elu_x<!SAVE>(accA + accB));
-        if constexpr (SAVE) {                                        // rows (step, stage): the stage input, then the three layers as they appear
+        float* slot = ROLES ? ring_mine + (ring_half * 4 + ring_sl) * kXSlotFloats : nullptr;
+        if constexpr (ROLES) {                                       // the stage's rows into the ring slot; the partner wave stores them
+            *reinterpret_cast<f2*>(slot + 768 + 2 * l) = f2{s01, s23};
+            *reinterpret_cast<f4*>(slot + 4 * l) = hA;
+        } else if constexpr (SAVE) {                                 // rows (step, stage): the stage input, then the three layers as they appear
             if (pair_ok) {
                 if (st01) stg<f2>((gptr<float>)(uintptr_t)sx_run, xooff, f2{s01, s23});
             } else {
@@ -227,9 +295,13 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
             if (sa_on) stg<f4>((gptr<float>)(uintptr_t)sa_run, saoff, hA);
         }
         hA = hh_layer<!SAVE>(w2, b2, hA);
-        if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + sa_layer), saoff, hA); }
+        if constexpr (ROLES) *reinterpret_cast<f4*>(slot + 256 + 4 * l) = hA;
+        else if constexpr (SAVE) { if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + sa_layer), saoff, hA); }
         hA = hh_layer<!SAVE>(w3, b3, hA);
-        if constexpr (SAVE) {
+        if constexpr (ROLES) {
+            *reinterpret_cast<f4*>(slot + 512 + 4 * l) = hA;
+            if (++ring_sl == 4) { lds_barrier(); ring_sl = 0; ring_half ^= 1; }       // a half is complete: hand it over, fill the other one
+        } else if constexpr (SAVE) {
             if (sa_on) stg<f4>((gptr<float>)(uintptr_t)(sa_run + 2 * sa_layer), saoff, hA);
             if constexpr (PSNODE_K1X_SAVE_ABL != 2) sa_run += sa_stage;
         }
@@ -255,7 +327,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
         constexpr bool PF = decltype(pf_tag)::value;
         constexpr int WAITN = decltype(wait_tag)::value;
         // SAVE: a step also issued 4 stores per stage (xstage + three layers, every one from at least one lane of every wave) behind its prefetch
-        constexpr int NSAVE = SAVE ? 4 * (METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4)) : 0;
+        constexpr int NSAVE = (SAVE && !ROLES) ? 4 * (METHOD == PSNODE_EULER ? 1 : (METHOD == PSNODE_MIDPOINT ? 2 : 4)) : 0;
         // ring of R steps of look-ahead (wait tag 100 + R): behind the loads in hand sit the rest of their own step (row store + saved rows) and
         // R - 1 whole steps (2 loads + row store + saved rows each); the legacy tags 1 / 4 are R = 1 / 2.  6 bits: [3:0], [15:14]
         constexpr int RDEPTH = WAITN >= 100 ? WAITN - 100 : (WAITN == 4 ? 2 : 1);
@@ -320,7 +392,7 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     // before the previous step's rows are acknowledged -- 17 KB in flight per wave, 3.2 TB/s (a plain fill writes this HBM at 6.9 TB/s,
     // profiles/r05ai_hbm_write_bw.txt).  A ring of R steps gives the stores R steps to drain: R = 3 at RK4 (55 operations behind the loads; vmcnt
     // holds 63), 4 at Euler / Midpoint.
-    constexpr int RING = (SAVE && FAST) ? (METHOD == PSNODE_RK4_38 ? 3 : (METHOD == PSNODE_MIDPOINT ? 4 : 4)) : 0;
+    constexpr int RING = (SAVE && !ROLES && FAST) ? (METHOD == PSNODE_RK4_38 ? 3 : (METHOD == PSNODE_MIDPOINT ? 4 : 4)) : 0;
     if constexpr (RING > 0) {
         using WR = std::integral_constant<int, 100 + RING>;
         float tq[RING], eq[RING];                    // slot j: t[k + 1] and the external value of step k, k = j (mod RING)
@@ -382,13 +454,30 @@ __global__ __launch_bounds__(64 * kXWaves) void integrate_x_kernel(const Integra
     };      // time_loop
     if (fast_rt) time_loop(std::true_type{});
     else time_loop(std::false_type{});
+    if constexpr (ROLES) { if (ring_sl != 0) lds_barrier(); }        // the last, partial half
 }
 
+#ifndef PSNODE_K1X_SAVE_ROLES
+#define PSNODE_K1X_SAVE_ROLES 0      // 1: the saving forward in a two-role form (a partner wave per SIMD drains an LDS ring of saved rows to memory).
+                                     // Measured SLOWER on the same box (profiles/r06_k1x_save_roles_ab.txt: RK4 4.09 vs 4.00 ms, Euler 1.21 vs 1.11):
+                                     // the cost of saving is the bytes reaching HBM, not the compute wave's store issue.  Kept as an experiment.
+#endif
 template <int METHOD, bool SAVE>
 hipError_t launch_x_method(const IntegrateDev& a, const float* pack, hipStream_t s) {
+    constexpr bool ROLES = SAVE && PSNODE_K1X_SAVE_ROLES;
     const long long tiles = (a.B + 3) / 4;
-    const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves);
-#define PSNODE_X(NZM_) hipLaunchKernelGGL((integrate_x_kernel<METHOD, NZM_, SAVE>), grid, block, 0, s, a, pack); break;
+    const dim3 grid((unsigned)((tiles + kXWaves - 1) / kXWaves)), block(64 * kXWaves * (ROLES ? 2 : 1));
+    const size_t lds = ROLES ? (size_t)kXWaves * kXRingFloats * sizeof(float) : 0;
+#define PSNODE_X(NZM_)                                                                                                            \
+    {                                                                                                                             \
+        auto kern = &integrate_x_kernel<METHOD, NZM_, SAVE, ROLES>;                                                               \
+        if (lds > 48 * 1024) {                                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                        \
+        }                                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, pack);                                                                   \
+    }                                                                                                                             \
+    break;
     switch ((2 * a.zd + 3) / 4) {
         case 0: PSNODE_X(0)
         case 1: PSNODE_X(1)
