@@ -12,6 +12,7 @@ mkdir -p $D
 AGPR="psnode_dae_backward.hip psnode_latent64_bwd.hip"
 objs=()
 for o in $R/build/obj/*.o; do
+  case $o in *-hip-amdgcn-*) continue;; esac
   b=$(basename $o .o)
   skip=0; for f in "$@"; do [ "$f" = "$b.hip" ] && skip=1; done
   [ $skip = 0 ] && objs+=($o)

@@ -12,12 +12,12 @@ constexpr size_t kAlignFloats = 64;   // 256-byte alignment of every workspace s
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t transposed_floats(const psnode_mlp_f32* m) {
+size_t generic_floats(const psnode_mlp_f32* m) {
     if (!m) return 0;
     size_t tot = 0;
     int k = m->in_dim;
     for (int l = 0; l < m->n_layers; ++l) {
-        tot += round_up((size_t)k * m->out_dim[l], kAlignFloats);
+        tot += round_up(generic_image_floats(k, m->out_dim[l]), kAlignFloats);
         k = m->out_dim[l];
     }
     return tot;
@@ -46,7 +46,7 @@ float* bind_mlp(const psnode_mlp_f32& m, MlpDev& d, float* ws) {
         d.w[l] = m.weight[l];
         d.bias[l] = m.bias[l];
         d.wt[l] = ws;
-        ws += round_up((size_t)k * m.out_dim[l], kAlignFloats);
+        ws += round_up(generic_image_floats(k, m.out_dim[l]), kAlignFloats);
         k = m.out_dim[l];
     }
     return ws;
@@ -102,7 +102,7 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
         e = launch_mfma(d, dae, ws, stream);
     } else {
         if (generic_lds_bytes(d, dae) > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
-        e = launch_pack_transpose(d.de, dae ? &d.ae : nullptr, stream);
+        e = launch_pack_image(d.de, dae ? &d.ae : nullptr, stream);
         if (e == hipSuccess) e = launch_generic(d, dae, stream);
     }
     return e == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
@@ -225,7 +225,7 @@ const char* psnode_status_string(int32_t s) {
 
 size_t psnode_workspace_bytes(const psnode_mlp_f32* de, const psnode_mlp_f32* ae) {
     if (!de) return 0;
-    const size_t f = transposed_floats(de) + transposed_floats(ae) + mfma_pack_floats(de, ae) + kAlignFloats;
+    const size_t f = generic_floats(de) + generic_floats(ae) + mfma_pack_floats(de, ae) + kAlignFloats;
     return f * sizeof(float);
 }
 

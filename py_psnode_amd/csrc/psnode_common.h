@@ -16,7 +16,7 @@ struct MlpDev {
     int in_dim;
     int out_dim[kMaxLayers];
     const float* w[kMaxLayers];      // caller's row-major [out,in]
-    const float* wt[kMaxLayers];     // workspace: transposed [in,out] (generic kernel)
+    const float* wt[kMaxLayers];     // workspace: MFMA image + padded bias (generic forward) / transposed [in,out] (generic backward)
     const float* bias[kMaxLayers];
 };
 
@@ -50,6 +50,7 @@ struct IntegrateDev {
     int maxw;              // widest activation vector incl. the MLP inputs (generic kernel buffer A)
     int maxo;              // widest layer OUTPUT (generic kernel buffer B: it only ever holds layer outputs)
     int kern;              // the caller's psnode_*_args_f32::kernel (PSNODE_KERNEL_MFMA_TILE / _WAVE pick between K1 and K1x)
+    unsigned k0_res;       // generic kernel: which layers' weight images are resident in LDS (bit l: DE layer l, bit 8 + l: AE layer l)
 };
 
 // ELU(alpha=1) with the negative branch at expm1 quality: ATen's CPU kernel (what the reference runs) returns
@@ -226,7 +227,9 @@ __host__ __device__ __forceinline__ constexpr float rk_b(int method, int s) {
 // psnode_generic.hip
 hipError_t launch_generic(const IntegrateDev& a, bool dae, hipStream_t stream);
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae);
-hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream);
+hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream);   // generic backward: transposed weights
+hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, hipStream_t stream);       // generic forward: MFMA images
+size_t generic_image_floats(int K, int N);
 
 // psnode_mfma.hip
 bool mfma_ode_supported(const IntegrateDev& a);
