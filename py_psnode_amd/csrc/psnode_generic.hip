@@ -18,6 +18,10 @@
 //     (lds_barrier waits for LDS traffic only);
 //   * output tile nt of a layer belongs to wave nt % 4; bias (padded, in LDS) added behind the MFMAs; ELU on the
 //     accumulator; one barrier per layer.
+// The two MLP inputs (DE: a0 | s - a0 | s, AE: a0 | x | z | v) have their own buffers and keep their constant columns between evaluations:
+// a0 is written once, the externals once per step, and per stage only the state's columns -- by the same pass that applies the stage's
+// update, so an evaluation costs its layers' barriers plus one.  The next grid point's clocks, event index and z | v rows are loaded a
+// step ahead (registers), the AE head's input of the end-of-step evaluation is written by the last stage's update.
 // Padded columns: the image holds zeros there and the input builders write zeros into the pad columns of the first layer's input; a
 // hidden layer's pad units come out of the MFMA as ELU(0 + 0) = 0.
 #include "psnode_common.h"
@@ -46,12 +50,13 @@ __host__ __device__ inline int generic_bias_floats(const IntegrateDev& a, bool d
 
 // One MLP as the time loop sees it: wave-uniform scalars, built once per launch so that no kernel-argument load (a scalar-cache round trip,
 // and an lgkmcnt wait that also drains the LDS queue) sits between two chunks.  The layer loop of mlp_eval is fully unrolled over
-// kMaxLayers, which makes every index below a constant.
+// ML (4 or kMaxLayers: the kernel is instantiated for both), which makes every index below a constant.
+template <int ML>
 struct Tab {
     int L;
-    unsigned dims[kMaxLayers];     // resident << 31 | quads of the contraction (ceil(K / 16)) << 16 | output tiles (ceil(N / 16))
-    unsigned off[kMaxLayers];      // streamed layer: f4 offset of its image from `base`; resident layer: FLOAT offset of its copy in LDS
-    unsigned boff[kMaxLayers];     // float offset of the padded bias in LDS
+    unsigned dims[ML];     // resident << 31 | quads of the contraction (ceil(K / 16)) << 16 | output tiles (ceil(N / 16))
+    unsigned off[ML];      // streamed layer: f4 offset of its image from `base`; resident layer: FLOAT offset of its copy in LDS
+    unsigned boff[ML];     // float offset of the padded bias in LDS
     const f4* base;                // image of layer 0 (workspace)
     unsigned first_off;            // this wave's first STREAMED chunk of an evaluation: f4 offset ...
     int first_q;                   // ... and the quads of that tile (0: the wave owns no tile in a streamed layer of this MLP)
@@ -61,13 +66,14 @@ __device__ __forceinline__ int tab_quads(unsigned d) { return (int)((d >> 16) & 
 __device__ __forceinline__ bool tab_res(unsigned d) { return (d >> 31) != 0; }
 
 // `res`: bit l = layer l's image is resident in LDS; `bias_at` / `img_at`: running float offsets of the LDS regions (advanced)
-__device__ __forceinline__ Tab make_tab(const MlpDev& m, int w, unsigned res, unsigned& bias_at, unsigned& img_at) {
-    Tab t;
+template <int ML>
+__device__ __forceinline__ Tab<ML> make_tab(const MlpDev& m, int w, unsigned res, unsigned& bias_at, unsigned& img_at) {
+    Tab<ML> t;
     t.L = m.n_layers;
     t.base = reinterpret_cast<const f4*>(m.wt[0]);
     t.first_off = 0; t.first_q = 0;
 #pragma unroll
-    for (int l = 0; l < kMaxLayers; ++l) {
+    for (int l = 0; l < ML; ++l) {
         const int K = l ? m.out_dim[l - 1] : m.in_dim, N = m.out_dim[l];
         const unsigned S4 = (K + 15) >> 4, NTL = (N + 15) >> 4;
         const bool on = l < m.n_layers, r = on && ((res >> l) & 1u);
@@ -78,7 +84,7 @@ __device__ __forceinline__ Tab make_tab(const MlpDev& m, int w, unsigned res, un
         if (r) img_at += 256u * NTL * S4;
     }
 #pragma unroll
-    for (int l = kMaxLayers - 1; l >= 0; --l)
+    for (int l = ML - 1; l >= 0; --l)
         if (l < m.n_layers && !tab_res(t.dims[l]) && tab_tiles(t.dims[l]) > w) {
             t.first_off = t.off[l] + (unsigned)w * tab_quads(t.dims[l]) * 64u;
             t.first_q = tab_quads(t.dims[l]);
@@ -86,10 +92,32 @@ __device__ __forceinline__ Tab make_tab(const MlpDev& m, int w, unsigned res, un
     return t;
 }
 
-// copies the biases (always) and the resident images into LDS; no barrier
-__device__ __forceinline__ void load_resident(const MlpDev& m, const Tab& t, float* lds) {
+// field-by-field select (a ternary on the structs goes through a stack copy: scratch)
+template <int ML>
+__device__ __forceinline__ Tab<ML> pick_tab(bool first, const Tab<ML>& x, const Tab<ML>& y) {
+    // readfirstlane: the results are wave-uniform and have to stay scalar -- kept in VGPRs (the compiler does that under SGPR pressure)
+    // every loop bound of mlp_eval turns into exec-mask control flow
+    auto u = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    Tab<ML> t;
+    t.L = (int)u(first ? x.L : y.L);
+    const unsigned long long pb = reinterpret_cast<unsigned long long>(first ? x.base : y.base);
+    t.base = reinterpret_cast<const f4*>((unsigned long long)u((unsigned)(pb >> 32)) << 32 | u((unsigned)pb));
+    t.first_off = u(first ? x.first_off : y.first_off);
+    t.first_q = (int)u(first ? x.first_q : y.first_q);
 #pragma unroll
-    for (int l = 0; l < kMaxLayers; ++l) {
+    for (int l = 0; l < ML; ++l) {
+        t.dims[l] = u(first ? x.dims[l] : y.dims[l]);
+        t.off[l] = u(first ? x.off[l] : y.off[l]);
+        t.boff[l] = u(first ? x.boff[l] : y.boff[l]);
+    }
+    return t;
+}
+
+// copies the biases (always) and the resident images into LDS; no barrier
+template <int ML>
+__device__ __forceinline__ void load_resident(const MlpDev& m, const Tab<ML>& t, float* lds) {
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
         if (l >= t.L) break;
         const int NTL = tab_tiles(t.dims[l]), S4 = tab_quads(t.dims[l]);
         const float* __restrict__ src = m.wt[l];
@@ -99,57 +127,126 @@ __device__ __forceinline__ void load_resident(const MlpDev& m, const Tab& t, flo
     }
 }
 
-// A-operand prefetch carried from one MLP evaluation into the next: the first chunk (up to four f4 = 16 MFMA steps) of the wave's first tile
-// in a streamed layer of the MLP whose image starts at `tag`.  A wrong guess only costs the latency of one L2 read.
+// A-operand look-ahead carried from one layer / MLP evaluation into the next: one chunk (up to four f4 = 16 MFMA steps).
+//   STREAM kernels: the wave's next chunk among the STREAMED layers, from the workspace image (hides the L2 latency);
+//   all-resident kernels: chunk 0 of the wave's first tile of the next layer, read from LDS in front of the layer barrier, so that only
+//   the activations are read behind it.
+// `tag`: the MLP (its workspace image) whose first chunk `a` holds at the start of an evaluation; a wrong guess costs one more read.
 struct Pref {
     f4 a[4];
     const f4* tag;
 };
 
-// MLP over the TB columns.  `in` / `out`: float offsets of the quad-row buffers in `lds`; returns the offset of the buffer that holds the
-// last layer's output.  Ends with a barrier.  Resident layers read both MFMA operands from LDS.  Streamed layers: the A operands run one
-// chunk ahead of the MFMAs that use them, across tile, layer and -- through `pf` -- evaluation boundaries: with one wave per SIMD nothing
-// else hides the L2 latency.  `nx`: the MLP evaluated after this one.
-__device__ __forceinline__ int mlp_eval(const Tab& T, float* lds, int in, int out, Pref& pf, const Tab& nx) {
+#ifndef PSNODE_K0_ABL      // ablation builds (timing only, wrong results): 1 = a quarter of the MFMAs, 2 = no ELU, 3 = no layer barrier, 4 = no MLP at all, 5 = no operand reads / MFMAs, 6 = no look-ahead read
+#define PSNODE_K0_ABL 0
+#endif
+__device__ __forceinline__ void mfma_quad(const f4 av, const f4 bv, f4& acc) {
+#pragma unroll
+    for (int e = 0; e < (PSNODE_K0_ABL == 1 ? 1 : 4); ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+}
+
+// One output tile with both operands in LDS, Q quads, straight-line: every read in flight before the first MFMA, two accumulator chains.
+// PA: the A operands of quads 0 .. 3 come from `pa` (read in front of the layer barrier).  With one wave per SIMD nothing hides a taken
+// branch (an instruction-cache round trip each): a loop over the quads with its guards and tails cost more than the MFMAs it issued
+// (profiles/r06_k0_generic_mfma.txt), so the contraction lengths up to 128 columns get a body each and the layer picks one with a switch.
+template <int Q, bool PA>
+__device__ __forceinline__ f4 tile_body(const f4* at, const f4* bq, const f4 (&pa)[4]) {
+    f4 av[Q], bv[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        bv[c] = bq[c * 64];
+        if (PA && c < 4) av[c] = pa[c]; else av[c] = at[c * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) mfma_quad(av[c], bv[c], (c & 1) ? acc2 : acc);
+    return Q > 1 ? acc + acc2 : acc;
+}
+template <bool PA>
+__device__ __forceinline__ f4 tile_any(int S4, const f4* at, const f4* bq, const f4 (&pa)[4]) {
+    switch (S4) {
+        case 1: return tile_body<1, PA>(at, bq, pa);
+        case 2: return tile_body<2, PA>(at, bq, pa);
+        case 3: return tile_body<3, PA>(at, bq, pa);
+        case 4: return tile_body<4, PA>(at, bq, pa);
+        case 5: return tile_body<5, PA>(at, bq, pa);
+        case 6: return tile_body<6, PA>(at, bq, pa);
+        case 7: return tile_body<7, PA>(at, bq, pa);
+        case 8: return tile_body<8, PA>(at, bq, pa);
+        default: break;
+    }
+    // longer contractions: eight quads straight, then chunks of four and single quads
+    f4 acc = tile_body<8, PA>(at, bq, pa), acc2 = f4{0.f, 0.f, 0.f, 0.f};
+    int q0 = 8;
+    for (; q0 + 4 <= S4; q0 += 4) {
+        f4 av[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { av[c] = at[(q0 + c) * 64]; bv[c] = bq[(q0 + c) * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mfma_quad(av[c], bv[c], (c & 1) ? acc2 : acc);
+    }
+    for (; q0 < S4; ++q0) mfma_quad(at[q0 * 64], bq[q0 * 64], acc);
+    return acc + acc2;
+}
+
+// MLP over the TB columns: layer 0 reads the quad-row buffer at float offset `in`, the layers write `ping` / `pong` alternately; returns
+// the offset of the last layer's output.  Ends with a barrier.  `nx`: the MLP evaluated after this one.
+template <bool STREAM, int ML>
+__device__ __forceinline__ int mlp_eval(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, Pref& pf, const Tab<ML>& nx) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // chunk = quads q0 .. q0 + 3 of one tile, clamped inside the tile's run of the image (in bounds, unused beyond the tile's quads).  The
-    // address comes out of scalar selects and the four loads are unconditional straight-line code: a load inside a conditional block gets
-    // its result copied (and waited for) at the end of that block, in front of the MFMAs it should overlap.
+    // STREAM: chunk = quads q0 .. q0 + 3 of one tile, clamped inside the tile's run of the image (in bounds, unused beyond the tile's quads).
+    // The address comes out of scalar selects and the four loads are unconditional straight-line code: a load inside a conditional block
+    // gets its result copied (and waited for) at the end of that block, in front of the MFMAs it should overlap.
     auto fetch = [&](const f4* base, unsigned off, int rem, f4 (&a)[4]) {
         const f4* __restrict__ A = base + off + lane;
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c] = A[(c < rem ? c : rem - 1) * 64];
     };
-    auto mfma_quad = [&](const f4 av, const f4 bv, f4& acc) {
+    // all-resident: chunk 0 of tile w of layer l of t, from LDS (nothing if the wave has no tile there)
+    auto peek = [&](const Tab<ML>& t, int l, f4 (&a)[4]) {
+        const int S4 = tab_quads(t.dims[l]);
+        if (w < tab_tiles(t.dims[l])) {
+            const f4* at = reinterpret_cast<const f4*>(lds + t.off[l]) + w * S4 * 64 + lane;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+            for (int c = 0; c < 4; ++c) a[c] = at[(c < S4 ? c : S4 - 1) * 64];
+        }
     };
-    if (pf.tag != T.base && T.first_q > 0) fetch(T.base, T.first_off, T.first_q, pf.a);
+    if constexpr (STREAM) {
+        if (pf.tag != T.base && T.first_q > 0) fetch(T.base, T.first_off, T.first_q, pf.a);
+    } else {
+        if (pf.tag != T.base) peek(T, 0, pf.a);
+    }
+    int out = ping;
+    if (PSNODE_K0_ABL == 4) { lds_barrier(); return out; }
 #pragma unroll
-    for (int l = 0; l < kMaxLayers; ++l) {
+    for (int l = 0; l < ML; ++l) {
         if (l >= T.L) break;
+        out = (l & 1) ? pong : ping;
         const int S4 = tab_quads(T.dims[l]), NTL = tab_tiles(T.dims[l]);
         const bool last = (l + 1 == T.L);
         const f4* bq = reinterpret_cast<const f4*>(lds + in) + lane;
         const f4* b16 = reinterpret_cast<const f4*>(lds + T.boff[l]) + (lane >> 4);
-        if (tab_res(T.dims[l])) {
+        f4* oq = reinterpret_cast<f4*>(lds + out) + lane;
+        auto finish = [&](f4 acc, const f4 bias, int nt) {
+            acc = acc + bias;
+            const f4 e = PSNODE_K0_ABL != 2 ? elu_quad(acc) : acc;
+            oq[nt * 64] = last ? acc : e;         // a select, not a branch
+        };
+        if (!STREAM || tab_res(T.dims[l])) {
             const f4* aq = reinterpret_cast<const f4*>(lds + T.off[l]) + lane;
-            for (int nt = w; nt < NTL; nt += 4) {
-                const f4* at = aq + nt * S4 * 64;
-                f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-                int q0 = 0;
-                for (; q0 + 4 <= S4; q0 += 4) {
-                    f4 av[4], bv[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { av[c] = at[(q0 + c) * 64]; bv[c] = bq[(q0 + c) * 64]; }
-                    __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first MFMA
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) mfma_quad(av[c], bv[c], acc);
+            int nt = w;
+            if constexpr (!STREAM) {
+                if (nt < NTL) {                              // first tile: the A operands of its first four quads were read in front of the barrier
+                    const f4 bias = b16[4 * nt];
+                    finish(PSNODE_K0_ABL == 5 ? bias : tile_any<true>(S4, aq + nt * S4 * 64, bq, pf.a), bias, nt);
+                    nt += 4;
                 }
-                for (; q0 < S4; ++q0) mfma_quad(at[q0 * 64], bq[q0 * 64], acc);
-                acc = acc + b16[4 * nt];
-                if (!last) acc = elu_quad(acc);
-                reinterpret_cast<f4*>(lds + out)[nt * 64 + lane] = acc;
+            }
+            for (; nt < NTL; nt += 4) {
+                const f4 bias = b16[4 * nt];
+                finish(tile_any<false>(S4, aq + nt * S4 * 64, bq, pf.a), bias, nt);
             }
         } else {
             // where this wave's A stream continues behind its last chunk of layer l: its first tile of a later streamed layer, else of the
@@ -158,11 +255,12 @@ __device__ __forceinline__ int mlp_eval(const Tab& T, float* lds, int in, int ou
             unsigned toff = nx.first_off;
             int tq = nx.first_q > 0 ? nx.first_q : 1;
 #pragma unroll
-            for (int nl = kMaxLayers - 1; nl > l; --nl)
+            for (int nl = ML - 1; nl > l; --nl)
                 if (nl < T.L && !tab_res(T.dims[nl]) && tab_tiles(T.dims[nl]) > w) {
                     tbase = T.base; toff = T.off[nl] + (unsigned)w * tab_quads(T.dims[nl]) * 64u; tq = tab_quads(T.dims[nl]);
                 }
             for (int nt = w; nt < NTL; nt += 4) {
+                const f4 bias = b16[4 * nt];
                 f4 acc = f4{0.f, 0.f, 0.f, 0.f};
                 const unsigned coff = T.off[l] + (unsigned)(nt * S4) * 64u;
                 for (int q0 = 0; q0 < S4; q0 += 4) {
@@ -186,20 +284,113 @@ __device__ __forceinline__ int mlp_eval(const Tab& T, float* lds, int in, int ou
                         for (int c = 0; q0 + c < S4; ++c) mfma_quad(c == 0 ? cur[0] : (c == 1 ? cur[1] : cur[2]), bq[(q0 + c) * 64], acc);
                     }
                 }
-                acc = acc + b16[4 * nt];
-                if (!last) acc = elu_quad(acc);
-                reinterpret_cast<f4*>(lds + out)[nt * 64 + lane] = acc;
+                finish(acc, bias, nt);
             }
         }
-        lds_barrier();
-        const int tmp = in; in = out; out = tmp;
+        if constexpr (!STREAM && PSNODE_K0_ABL != 6) {       // the next layer's first A operands, in front of the barrier
+            if (!last) peek(T, l + 1 < ML ? l + 1 : l, pf.a);
+            else peek(nx, 0, pf.a);
+        }
+        if (PSNODE_K0_ABL != 3) lds_barrier();
+        in = out;
     }
-    if (T.first_q > 0) pf.tag = nx.base;        // a wave without a streamed tile in T has fetched nothing
-    return in;
+    if constexpr (STREAM) { if (T.first_q > 0) pf.tag = nx.base; }      // a wave without a streamed tile in T has fetched nothing
+    else pf.tag = nx.base;
+    return out;
 }
 
-template <bool DAE>
+// ---- register mode: every layer has at most four output tiles (one per wave), the first contraction at most 16 QM columns (QM = 4 or 8),
+// the others at most 64.  The wave's A operands of the WHOLE MLP stay in registers for the launch (wr[l][q]: quad q of its tile of layer l, zero where
+// the wave has no tile or the tile is shorter), as in the specialised tile integrators: a layer then reads only the activations from LDS.
+// Why it matters: a ds_read_b128 costs a wave about 64 cycles of LDS-to-register transfer, so reading both operands from LDS (8 reads per
+// 16 MFMAs) takes as long as the MFMAs themselves (ablation builds, profiles/r06_k0_generic_mfma.txt).
+template <int Q, int QM>
+__device__ __forceinline__ f4 tile_reg(const f4* bq, const f4 (&wa)[QM]) {
+    f4 bv[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) bv[c] = bq[c * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) mfma_quad(wa[c], bv[c], (c & 1) ? acc2 : acc);
+    return Q > 1 ? acc + acc2 : acc;
+}
+
+// the wave's operand registers of one MLP: layer 0 (the only one whose contraction can exceed 64 columns: the other layers read a layer
+// output of at most 64 units) holds QM quads, the others four
+template <int ML, int QM>
+struct WReg {
+    f4 first[QM];
+    f4 rest[ML - 1][4];
+};
+
+template <int ML, int QM>
+__device__ __forceinline__ void load_regs(const MlpDev& m, const Tab<ML>& t, WReg<ML, QM>& wr) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
+        const int S4 = l < t.L ? tab_quads(t.dims[l]) : 0, NTL = l < t.L ? tab_tiles(t.dims[l]) : 0;
+        const f4* __restrict__ A = reinterpret_cast<const f4*>(m.wt[l < t.L ? l : 0]) + (size_t)(w < NTL ? w : 0) * S4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < (l ? 4 : QM); ++q) {
+            const f4 v = (w < NTL && q < S4) ? A[q * 64] : f4{0.f, 0.f, 0.f, 0.f};
+            if (l == 0) wr.first[q] = v; else wr.rest[l - 1][q] = v;
+        }
+    }
+}
+
+template <int QM>
+__device__ __forceinline__ f4 tile_reg_any(int S4, const f4* bq, const f4 (&wa)[QM]) {
+    if constexpr (QM > 4) {
+        switch (S4) {
+            case 5: return tile_reg<5, QM>(bq, wa);
+            case 6: return tile_reg<6, QM>(bq, wa);
+            case 7: return tile_reg<7, QM>(bq, wa);
+            case 8: return tile_reg<8, QM>(bq, wa);
+            default: break;
+        }
+    }
+    switch (S4) {
+        case 1: return tile_reg<1, QM>(bq, wa);
+        case 2: return tile_reg<2, QM>(bq, wa);
+        case 3: return tile_reg<3, QM>(bq, wa);
+        default: return tile_reg<4, QM>(bq, wa);
+    }
+}
+
+template <int ML, int QM>
+__device__ __forceinline__ int mlp_reg(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WReg<ML, QM>& wr) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int out = ping;
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
+        if (l >= T.L) break;
+        out = (l & 1) ? pong : ping;
+        const int S4 = tab_quads(T.dims[l]);
+        const bool last = (l + 1 == T.L);
+        if (w < tab_tiles(T.dims[l])) {
+            const f4* bq = reinterpret_cast<const f4*>(lds + in) + lane;
+            const f4 bias = reinterpret_cast<const f4*>(lds + T.boff[l])[4 * w + (lane >> 4)];
+            f4 acc;
+            if (l == 0) acc = tile_reg_any<QM>(S4, bq, wr.first);
+            else acc = tile_reg_any<4>(S4, bq, wr.rest[l ? l - 1 : 0]);
+            acc = acc + bias;
+            const f4 e = elu_quad(acc);
+            reinterpret_cast<f4*>(lds + out)[w * 64 + lane] = last ? acc : e;
+        }
+        lds_barrier();
+        in = out;
+    }
+    return out;
+}
+
+// PF: z | v values a thread keeps in flight for the next grid point (items tid + 256 j); rows beyond 16 PF are loaded where they are used
+constexpr int PF = 4;
+
+// MODE 0: weights in registers (mlp_reg; QM = 4 or 8 quads per tile), 1: every image resident in LDS, 2: some layers streamed
+template <bool DAE, int MODE, int ML, int QM = 4>
 __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
+    constexpr bool STREAM = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * TB;
@@ -207,17 +398,23 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     const int vd = DAE ? a.vd : 0, id = DAE ? a.id : 0;
     const int n = xd + zd + vd + id;   // width of all_initial
     const int ne = n - xd;             // external rows: z | v | i
+    const int nzv = zd + vd;
+    const int kae = n + xd + nzv;      // width of the AE input
 
-    constexpr int actA = 0;                    // quad-row activation buffers (float offsets into lds): the MLP inputs and every second layer
-    const int actB = up16(a.maxw) * TB;        // ping-pong partner: holds layer outputs only -> maxo rows
-    float* a0 = lds + actB + up16(a.maxo) * TB;    // [n][TB]
+    // quad-row buffers (float offsets): the two MLP inputs keep their constant columns (a0; the externals of a step) between evaluations,
+    // only the columns that change are rewritten -- per stage that is the state x alone
+    constexpr int inDE = 0;
+    const int inAE = up16(3 * n) * TB;
+    const int ping = inAE + (DAE ? up16(kae) * TB : 0);
+    const int pong = ping + up16(a.maxo) * TB;
+    float* a0 = lds + pong + up16(a.maxo) * TB;   // [n][TB]
     float* ext = a0 + n * TB;          // [ne][TB] z | v | i fed to the DE stages of this step
     float* xcur = ext + ne * TB;       // [xd][TB] running state
     float* xsrc = xcur + xd * TB;      // [xd][TB] start of this step (xcur, or dataset x under teacher forcing)
-    float* xst = xsrc + xd * TB;       // [xd][TB] stage argument
-    float* kbuf = xst + xd * TB;       // [4][xd][TB]
+    float* kbuf = xsrc + xd * TB;      // [4][xd][TB]
     float* icur = kbuf + 4 * xd * TB;  // [id][TB]
-    float* dts = icur + id * TB;       // [TB]
+    float* zvn = icur + id * TB;       // [nzv][TB] dataset z | v of the NEXT grid point
+    float* dts = zvn + nzv * TB;       // [TB]
 
 #ifdef PSNODE_K0_PROF      // discriminator builds only: cycles per phase of workgroup 0, printed by its first thread
     long long prof[6] = {0, 0, 0, 0, 0, 0};
@@ -230,155 +427,197 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     pf.tag = nullptr;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned bias_at = (unsigned)(dts + TB - lds), img_at = bias_at + (unsigned)generic_bias_floats(a, DAE);
-    const Tab tde = make_tab(a.de, wv, a.k0_res & 0xffu, bias_at, img_at);
-    const Tab tae = DAE ? make_tab(a.ae, wv, (a.k0_res >> 8) & 0xffu, bias_at, img_at) : tde;
+    const Tab<ML> tde = make_tab<ML>(a.de, wv, a.k0_res & 0xffu, bias_at, img_at);
+    const Tab<ML> tae = DAE ? make_tab<ML>(a.ae, wv, (a.k0_res >> 8) & 0xffu, bias_at, img_at) : tde;
     load_resident(a.de, tde, lds);
     if constexpr (DAE) load_resident(a.ae, tae, lds);
+    WReg<MODE == 0 ? ML : 2, MODE == 0 ? QM : 1> wde;
+    WReg<(MODE == 0 && DAE) ? ML : 2, (MODE == 0 && DAE) ? QM : 1> wae;
+    if constexpr (MODE == 0) {
+        load_regs<ML, QM>(a.de, tde, wde);
+        if constexpr (DAE) load_regs<ML, QM>(a.ae, tae, wae);
+    }
+
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
     const bool true_x = (a.flags & PSNODE_FLAG_INPUT_TRUE_X) != 0;
     const bool true_i = DAE && (a.flags & PSNODE_FLAG_INPUT_TRUE_I) != 0;
     const int nx = xd * TB;
+    // dataset z | v row r of trajectory column c at grid point j
+    auto zv_at = [&](long long j, int r, int c) -> float {
+        const long long b = gb(c);
+        return r < zd ? a.z.p[j * a.z.st + b * a.z.sb + r] : a.v.p[j * a.v.st + b * a.v.sb + (r - zd)];
+    };
+    // external row r (z | v | i order) of the DE input: columns n + xd + r (s - a0) and 2 n + xd + r (s)
+    auto put_ext = [&](int r, int c, float v) {
+        ext[r * TB + c] = v;
+        lds[inDE + qi(n + xd + r, c)] = v - a0[(xd + r) * TB + c];
+        lds[inDE + qi(2 * n + xd + r, c)] = v;
+    };
+    auto put_x = [&](int r, int c, float v) {
+        lds[inDE + qi(n + r, c)] = v - a0[r * TB + c];
+        lds[inDE + qi(2 * n + r, c)] = v;
+    };
 
-    // ---- per-trajectory constants and the initial state
+    // ---- per-trajectory constants, the constant and pad columns of both inputs, the initial state, z | v of grid point 0
     for (int idx = tid; idx < n * TB; idx += NT) {
         const int r = idx / TB, c = idx % TB;
-        a0[idx] = a.a0[gb(c) * n + r];
+        const float v = a.a0[gb(c) * n + r];
+        a0[idx] = v;
+        lds[inDE + qi(r, c)] = v;
+        if constexpr (DAE) lds[inAE + qi(r, c)] = v;
     }
+    for (int idx = 3 * n * TB + tid; idx < up16(3 * n) * TB; idx += NT) lds[inDE + qi(idx / TB, idx % TB)] = 0.0f;
+    if constexpr (DAE)
+        for (int idx = kae * TB + tid; idx < up16(kae) * TB; idx += NT) lds[inAE + qi(idx / TB, idx % TB)] = 0.0f;
     for (int idx = tid; idx < nx; idx += NT) {
         const int r = idx / TB, c = idx % TB;
         const long long b = gb(c);
         const float v = DAE ? a.x_init[b * xd + r] : a.x.p[b * a.x.sb + r];
         xcur[idx] = v;
         if (b0 + c < a.B) a.xo[b * xd + r] = v;
+        if constexpr (DAE) lds[inAE + qi(n + r, c)] = true_x ? a.x.p[b * a.x.sb + r] : v;      // my_solvers.py:95
+    }
+    for (int idx = tid; idx < nzv * TB; idx += NT) {
+        const float v = zv_at(0, idx / TB, idx % TB);
+        zvn[idx] = v;
+        if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = v;
     }
     lds_barrier();
 
-    // AE head g(x; z, v) -> icur.  jx >= 0: x from the dataset at grid point jx, else xcur.
-    // jzv >= 0: z, v from the dataset at grid point jzv, else the (possibly jumped) rows of `ext`.
-    auto ae_eval = [&](long long jx, long long jzv) {
-        if constexpr (DAE) {
-            const int m = n + xd + zd + vd;
-            for (int idx = tid; idx < up16(m) * TB; idx += NT) {
-                const int r = idx / TB, c = idx % TB;
-                const long long b = gb(c);
-                float v;
-                if (r >= m) v = 0.0f;            // pad columns of the first layer's K
-                else if (r < n) v = a0[idx];
-                else if (r < n + xd) v = jx >= 0 ? a.x.p[jx * a.x.st + b * a.x.sb + (r - n)] : xcur[(r - n) * TB + c];
-                else if (r < n + xd + zd) v = jzv >= 0 ? a.z.p[jzv * a.z.st + b * a.z.sb + (r - n - xd)] : ext[(r - n - xd) * TB + c];
-                else v = jzv >= 0 ? a.v.p[jzv * a.v.st + b * a.v.sb + (r - n - xd - zd)] : ext[(r - n - xd) * TB + c];
-                lds[actA + qi(r, c)] = v;
-            }
-            lds_barrier();
-            const int out = mlp_eval(tae, lds, actA, actB, pf, tde);
-            for (int idx = tid; idx < id * TB; idx += NT) icur[idx] = lds[out + qi(idx / TB, idx % TB)];
-            lds_barrier();
-        }
-    };
-
-    if constexpr (DAE) {
-        ae_eval(true_x ? 0 : -1, 0);   // my_solvers.py:95
-        for (int idx = tid; idx < id * TB; idx += NT) {
-            const int r = idx / TB, c = idx % TB;
-            if (b0 + c < a.B) a.io[(b0 + c) * id + r] = icur[idx];
-        }
-    }
-
-    // DE right-hand side at xst with this step's frozen externals -> offset of the quad-row buffer holding [xd] columns
-    auto de_eval = [&](bool next_ae) -> int {
-        for (int idx = tid; idx < n * TB; idx += NT) {
-            const int r = idx / TB, c = idx % TB;
-            const float s = r < xd ? xst[idx] : ext[idx - nx];
-            const float i0 = a0[idx];
-            lds[actA + qi(r, c)] = i0;
-            lds[actA + qi(n + r, c)] = s - i0;
-            lds[actA + qi(2 * n + r, c)] = s;
-        }
-        for (int idx = 3 * n * TB + tid; idx < up16(3 * n) * TB; idx += NT) lds[actA + qi(idx / TB, idx % TB)] = 0.0f;   // pad columns
-        lds_barrier();
-        K0_PROF(1)
-        const int r_ = next_ae ? mlp_eval(tde, lds, actA, actB, pf, tae) : mlp_eval(tde, lds, actA, actB, pf, tde);
-        K0_PROF(2)
-        return r_;
-    };
-
     const int nstage = a.method == PSNODE_EULER ? 1 : (a.method == PSNODE_MIDPOINT ? 2 : 4);
+    // look-ahead registers: clocks (threads < TB), the next step's event index, the next grid point's z | v
+    float tc = 0.0f, tn = 0.0f;
+    if (tid < TB) {
+        tc = a.t.p[gb(tid) * a.t.sb];
+        tn = a.T > 1 ? a.t.p[a.t.st + gb(tid) * a.t.sb] : tc;
+    }
+    int evn = (a.ev && a.T > 1) ? a.ev[0] : -1;
+    float pz[PF];
 
-    for (long long k = 0; k + 1 < a.T; ++k) {
+    // One MLP call site for every evaluation (the unrolled layer code exists once: it has to stay inside the instruction cache).  Slots of
+    // step k: 0 = the AE head at an event (my_solvers.py:110), 1 .. S = the DE stages, S + 1 = the AE head at grid point k + 1
+    // (my_solvers.py:95, 121); the pseudo-step k = -1 of the DAE is that last slot alone, for grid point 0.
+    for (long long k = DAE ? -1 : 0; k + 1 < a.T; ++k) {
         K0_PROF(5)
-        const int ev = a.ev ? a.ev[k] : -1;
-        // ---- this step's inputs (zero-order hold: the left grid point feeds every stage)
-        if (tid < TB) {
-            const long long b = gb(tid);
-            dts[tid] = a.t.p[(k + 1) * a.t.st + b * a.t.sb] - a.t.p[k * a.t.st + b * a.t.sb];
-        }
-        for (int idx = tid; idx < (zd + vd) * TB; idx += NT) {
-            const int r = idx / TB, c = idx % TB;
-            const long long b = gb(c);
-            float v;
-            if (r < zd) v = ev >= 0 ? a.zj[b * a.zjb + ev * a.zje + r] : a.z.p[k * a.z.st + b * a.z.sb + r];
-            else v = ev >= 0 ? a.vj[b * a.vjb + ev * a.vje + (r - zd)] : a.v.p[k * a.v.st + b * a.v.sb + (r - zd)];
-            ext[idx] = v;
-        }
-        for (int idx = tid; idx < nx; idx += NT) {
-            const int r = idx / TB, c = idx % TB;
-            const float v = true_x ? a.x.p[k * a.x.st + gb(c) * a.x.sb + r] : xcur[idx];
-            xsrc[idx] = v;
-            xst[idx] = v;
-        }
-        lds_barrier();
-        K0_PROF(0)
-        if constexpr (DAE) {
-            if (ev >= 0) ae_eval(-1, -1);   // my_solvers.py:110: i0 = i_func(x0, z0_jump, v0_jump)
-            for (int idx = tid; idx < id * TB; idx += NT) {
+        const int ev = k >= 0 ? evn : -1;
+        if (k >= 0) {
+            // ---- this step's inputs (zero-order hold: the left grid point feeds every stage)
+            if (tid < TB) dts[tid] = tn - tc;
+            for (int idx = tid; idx < nzv * TB; idx += NT) {
                 const int r = idx / TB, c = idx % TB;
-                ext[(zd + vd) * TB + idx] = true_i ? a.i.p[k * a.i.st + gb(c) * a.i.sb + r] : icur[idx];
+                float v;
+                if (ev >= 0) { const long long b = gb(c); v = r < zd ? a.zj[b * a.zjb + ev * a.zje + r] : a.vj[b * a.vjb + ev * a.vje + (r - zd)]; }
+                else v = zvn[idx];
+                put_ext(r, c, v);
+                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(n + xd + r, c)] = v;      // the event's AE evaluation sees the jumped rows
+            }
+            for (int idx = tid; idx < nx; idx += NT) {
+                const int r = idx / TB, c = idx % TB;
+                const float v = true_x ? a.x.p[k * a.x.st + gb(c) * a.x.sb + r] : xcur[idx];
+                xsrc[idx] = v;
+                put_x(r, c, v);
+                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(n + r, c)] = xcur[idx];   // ... and the computed state
+            }
+            if constexpr (DAE) {
+                if (ev < 0)
+                    for (int idx = tid; idx < id * TB; idx += NT) {
+                        const int r = idx / TB, c = idx % TB;
+                        put_ext(nzv + r, c, true_i ? a.i.p[k * a.i.st + gb(c) * a.i.sb + r] : icur[idx]);
+                    }
+            }
+            // ---- look-ahead for grid point k + 1
+            const long long k1 = k + 1, k2 = k + 2 < a.T ? k + 2 : a.T - 1;
+            if (tid < TB) { tc = tn; tn = a.t.p[k2 * a.t.st + gb(tid) * a.t.sb]; }
+            evn = (a.ev && k1 + 1 < a.T) ? a.ev[k1] : -1;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int idx = tid + NT * j;
+                const int ii = idx < nzv * TB ? idx : 0;
+                pz[j] = nzv > 0 ? zv_at(k1, ii / TB, ii % TB) : 0.0f;
             }
             lds_barrier();
         }
-
-        // ---- stages (my_fixed_grid.py:15-18, 23-32, 38-51)
-        for (int s = 0; s < nstage; ++s) {
-            const int f = de_eval(DAE && s + 1 == nstage);
+        K0_PROF(0)
+        const int e_end = DAE ? nstage + 1 : nstage;
+        for (int e = k < 0 ? nstage + 1 : ((DAE && ev >= 0) ? 0 : 1); e <= e_end; ++e) {
+            const bool is_ae = DAE && (e == 0 || e == nstage + 1);
+            const bool ae_next = DAE && e == nstage;
+            int f;
+            if constexpr (MODE == 0) {      // two call sites: the operands are two different register sets
+                if (is_ae) { if constexpr (DAE) f = mlp_reg<ML, QM>(tae, lds, inAE, ping, pong, wae); else f = ping; }
+                else f = mlp_reg<ML, QM>(tde, lds, inDE, ping, pong, wde);
+            } else {
+                f = DAE ? mlp_eval<STREAM, ML>(pick_tab(is_ae, tae, tde), lds, is_ae ? inAE : inDE, ping, pong, pf, pick_tab(ae_next, tae, tde))
+                        : mlp_eval<STREAM, ML>(tde, lds, inDE, ping, pong, pf, tde);
+            }
+            K0_PROF(2)
+            if (is_ae) {
+                if constexpr (DAE) {
+                    for (int idx = tid; idx < id * TB; idx += NT) {
+                        const int r = idx / TB, c = idx % TB;
+                        const float v = lds[f + qi(r, c)];
+                        icur[idx] = v;       // read back by the same thread (below, or at the top of the next step)
+                        if (e == 0) put_ext(nzv + r, c, true_i ? a.i.p[k * a.i.st + gb(c) * a.i.sb + r] : v);
+                        else if (b0 + c < a.B) a.io[((k + 1) * a.B + b0 + c) * id + r] = v;
+                    }
+                    if (e == 0) lds_barrier();
+                }
+                K0_PROF(4)
+                continue;
+            }
+            // ---- stage s: ONE pass that forms the next stage's argument straight into the DE input (my_fixed_grid.py:15-18, 23-32, 38-51)
+            //      or, behind the last stage, the new state, its output row, the AE input and the look-ahead rows
+            const int s_ = e - 1;
+            const bool final_stage = s_ + 1 == nstage;
             for (int idx = tid; idx < nx; idx += NT) {
-                const float h = dts[idx % TB];
+                const int r = idx / TB, c = idx % TB;
+                const float h = dts[c];
                 const float x0 = xsrc[idx];
-                const float ks = lds[f + qi(idx / TB, idx % TB)];
-                kbuf[s * nx + idx] = ks;
+                const float ks = lds[f + qi(r, c)];
+                float v;
                 if (a.method == PSNODE_EULER) {
-                    xcur[idx] = x0 + h * ks;
+                    v = x0 + h * ks;
                 } else if (a.method == PSNODE_MIDPOINT) {
-                    if (s == 0) xst[idx] = x0 + ks * (0.5f * h);
-                    else xcur[idx] = x0 + h * ks;
+                    v = s_ == 0 ? x0 + ks * (0.5f * h) : x0 + h * ks;
                 } else {
+                    if (s_ < 3) kbuf[s_ * nx + idx] = ks;
                     const float k1 = kbuf[idx];
-                    if (s == 0) xst[idx] = x0 + h * k1 * kOneThird;
-                    else if (s == 1) xst[idx] = x0 + h * (ks - k1 * kOneThird);
-                    else if (s == 2) xst[idx] = x0 + h * (k1 - kbuf[nx + idx] + ks);
-                    else xcur[idx] = x0 + (k1 + 3.0f * (kbuf[nx + idx] + kbuf[2 * nx + idx]) + ks) * h * 0.125f;
+                    if (s_ == 0) v = x0 + h * k1 * kOneThird;
+                    else if (s_ == 1) v = x0 + h * (ks - k1 * kOneThird);
+                    else if (s_ == 2) v = x0 + h * (k1 - kbuf[nx + idx] + ks);
+                    else v = x0 + (k1 + 3.0f * (kbuf[nx + idx] + kbuf[2 * nx + idx]) + ks) * h * 0.125f;
+                }
+                if (!final_stage) {
+                    put_x(r, c, v);
+                } else {
+                    xcur[idx] = v;
+                    if (b0 + c < a.B) a.xo[((k + 1) * a.B + b0 + c) * xd + r] = v;
+                    if constexpr (DAE) lds[inAE + qi(n + r, c)] = true_x ? a.x.p[(k + 1) * a.x.st + gb(c) * a.x.sb + r] : v;   // my_solvers.py:121
+                }
+            }
+            if (final_stage) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    const int idx = tid + NT * j;
+                    if (idx < nzv * TB) {
+                        zvn[idx] = pz[j];
+                        if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = pz[j];
+                    }
+                }
+                for (int idx = tid + NT * PF; idx < nzv * TB; idx += NT) {
+                    const float v = zv_at(k + 1, idx / TB, idx % TB);
+                    zvn[idx] = v;
+                    if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = v;
                 }
             }
             lds_barrier();
             K0_PROF(3)
         }
-
-        for (int idx = tid; idx < nx; idx += NT) {
-            const int r = idx / TB, c = idx % TB;
-            if (b0 + c < a.B) a.xo[((k + 1) * a.B + b0 + c) * xd + r] = xcur[idx];
-        }
-        if constexpr (DAE) {
-            ae_eval(true_x ? k + 1 : -1, k + 1);   // my_solvers.py:121
-            for (int idx = tid; idx < id * TB; idx += NT) {
-                const int r = idx / TB, c = idx % TB;
-                if (b0 + c < a.B) a.io[((k + 1) * a.B + b0 + c) * id + r] = icur[idx];
-            }
-        }
-        K0_PROF(4)
     }
 #ifdef PSNODE_K0_PROF
     if (blockIdx.x == 0 && tid == 0)
-        printf("K0 phases (cycles of clock64, workgroup 0): step inputs %lld | build %lld | mlp %lld | update %lld | output %lld | loop %lld\n", prof[0], prof[1],
-               prof[2], prof[3], prof[4], prof[5]);
+        printf("K0 phases (cycles of clock64, workgroup 0): step inputs %lld | mlp %lld | update %lld | AE head + output %lld | loop %lld\n", prof[0], prof[2],
+               prof[3], prof[4], prof[5]);
 #endif
 #undef K0_PROF
 }
@@ -484,15 +723,36 @@ hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, hipStream_t str
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae) {
     const int vd = dae ? a.vd : 0, id = dae ? a.id : 0;
     const int n = a.xd + a.zd + vd + id;
-    const size_t rows = (size_t)up16(a.maxw) + up16(a.maxo) + n + (n - a.xd) + 3 * (size_t)a.xd + 4 * (size_t)a.xd + id + 1;
+    const int nzv = a.zd + vd;
+    // DE input, AE input, two layer-output buffers, a0, ext, xcur + xsrc, kbuf, icur, zvn, dts
+    const size_t rows = (size_t)up16(3 * n) + (dae ? up16(n + a.xd + nzv) : 0) + 2 * (size_t)up16(a.maxo) + n + (n - a.xd) + 2 * (size_t)a.xd +
+                        4 * (size_t)a.xd + id + nzv + 1;
     return (rows * TB + generic_bias_floats(a, dae)) * sizeof(float);
 }
 
 // Which layers' images become resident: greedy in layer order, DE (evaluated once per stage) before AE (once per step).  Returns the
 // launch's LDS bytes; `mask`: bit l = DE layer l, bit 8 + l = AE layer l.
+// Register mode (mlp_reg): layers of at most four tiles (one per wave), the first layer's contraction within 16 * QM columns; at most four
+// layers per MLP for the DAE (two MLPs: 160 operand registers at QM 8), eight for the ODE (144).  Returns QM (4 or 8), or 0.
+int generic_reg_mode(const IntegrateDev& a, bool dae) {
+    int qmax = 0;
+    for (int m = 0; m < (dae ? 2 : 1); ++m) {
+        const MlpDev& d = m ? a.ae : a.de;
+        if (d.n_layers > (dae ? 4 : kMaxLayers)) return 0;
+        int K = d.in_dim;
+        for (int l = 0; l < d.n_layers; ++l) {
+            if (d.out_dim[l] > 64 || K > 128) return 0;
+            qmax = (K + 15) / 16 > qmax ? (K + 15) / 16 : qmax;
+            K = d.out_dim[l];
+        }
+    }
+    return qmax <= 4 ? 4 : 8;
+}
+
 size_t generic_plan(const IntegrateDev& a, bool dae, unsigned& mask) {
     size_t bytes = generic_lds_bytes(a, dae);
     mask = 0;
+    if (generic_reg_mode(a, dae)) return bytes;
     const size_t limit = 160 * 1024;
     for (int m = 0; m < (dae ? 2 : 1); ++m) {
         const MlpDev& d = m ? a.ae : a.de;
@@ -506,21 +766,35 @@ size_t generic_plan(const IntegrateDev& a, bool dae, unsigned& mask) {
     return bytes;
 }
 
-hipError_t launch_generic(const IntegrateDev& a_in, bool dae, hipStream_t stream) {
+hipError_t launch_generic(const IntegrateDev& a_in, bool dae, hipStream_t stream_) {
     IntegrateDev a = a_in;
     const size_t lds = generic_plan(a, dae, a.k0_res);
     const unsigned grid = (unsigned)((a.B + TB - 1) / TB);
-    hipError_t e;
-    if (dae) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    unsigned all = (1u << a.de.n_layers) - 1u;
+    if (dae) all |= ((1u << a.ae.n_layers) - 1u) << 8;
+    const bool stream = a.k0_res != all;          // some layer's image does not fit LDS
+    // Up to one workgroup per CU in the launch: ask for more than half a CU's LDS, so that the dispatcher cannot put two workgroups on one CU
+    // (two waves per SIMD sharing the MFMA pipe) while other CUs stay empty.
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const size_t lds_launch = (grid <= (unsigned)cus && lds < 81 * 1024) ? 81 * 1024 : lds;
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(generic_kernel<true>, dim3(grid), dim3(NT), lds, stream, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(generic_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_launch, stream_, a);
+        return hipGetLastError();
+    };
+    const int qm = generic_reg_mode(a, dae);
+    const bool deep = a.de.n_layers > 4 || (dae && a.ae.n_layers > 4);      // the layer loop is unrolled 4 or kMaxLayers times
+    if (qm && deep) return qm == 4 ? go(&generic_kernel<false, 0, kMaxLayers, 4>) : go(&generic_kernel<false, 0, kMaxLayers, 8>);
+    if (qm == 4) return dae ? go(&generic_kernel<true, 0, 4, 4>) : go(&generic_kernel<false, 0, 4, 4>);
+    if (qm == 8) return dae ? go(&generic_kernel<true, 0, 4, 8>) : go(&generic_kernel<false, 0, 4, 8>);
+    if (deep) {
+        if (dae) return stream ? go(&generic_kernel<true, 2, kMaxLayers>) : go(&generic_kernel<true, 1, kMaxLayers>);
+        return stream ? go(&generic_kernel<false, 2, kMaxLayers>) : go(&generic_kernel<false, 1, kMaxLayers>);
     }
-    return hipGetLastError();
+    if (dae) return stream ? go(&generic_kernel<true, 2, 4>) : go(&generic_kernel<true, 1, 4>);
+    return stream ? go(&generic_kernel<false, 2, 4>) : go(&generic_kernel<false, 1, 4>);
 }
 
 }  // namespace psnode

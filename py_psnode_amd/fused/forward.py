@@ -22,12 +22,12 @@ def _mfma_miss(rc: int, kernel: str, what: str, de_layers: Layers):
         widths = [int(w.shape[0]) for w, _ in de_layers[:-1]]
         raise _lib.UnsupportedShapeError(
             f"{what}: no MFMA integrator for hidden widths {widths}.  {_MFMA_CLASSES}.  kernel='auto' runs this shape on the generic "
-            "kernel K0 (any width that fits the 160 KB LDS), at roughly 10x the time per state-step (40.5 vs 3.9 ms per 4096 x 1000 "
-            "RK4 batch at hidden 64; DESIGN.md 'Shapes without an MFMA specialisation')")
+            "kernel K0 (any layer count and widths that fit the 160 KB LDS; MFMA layers since round 6), at 2.5-4x the time per "
+            "state-step of a specialised integrator (9.5 vs 3.5 ms per 4096 x 1000 RK4 batch at hidden 64; DESIGN.md 'K0')")
 
 
 def _note_k0(lib, args, dae: bool, de_layers: Layers):
-    """AUTO landing on K0 with a no_encode-style MLP wider than the MFMA classes: never silently ~10x slower."""
+    """AUTO landing on K0 with a no_encode-style MLP wider than the MFMA classes: never silently slower (2.5-4x per flop)."""
     global _k0_warned
     if _k0_warned or len(de_layers) != 4:
         return
@@ -38,8 +38,8 @@ def _note_k0(lib, args, dae: bool, de_layers: Layers):
     if k == _lib.KERNEL_GENERIC:
         _k0_warned = True
         import warnings
-        warnings.warn(f"hidden width {widths[0]} runs on the generic kernel K0, roughly 10x the time per state-step of the MFMA "
-                      f"integrators.  {_MFMA_CLASSES}", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"hidden width {widths[0]} runs on the generic kernel K0 (weights streamed from L2), at 2-3x the time per flop of the "
+                      f"MFMA integrators.  {_MFMA_CLASSES}", RuntimeWarning, stacklevel=3)
 
 
 def ode_integrate(method: str, de_layers: Layers, t, x, z, all_initial, event_t=None, z_jump=None,

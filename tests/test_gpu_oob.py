@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script", ["oob_probe_k3f.py", "oob_probe_round5.py", "oob_probe_models.py", "oob_probe_more.py", "oob_probe_round6.py"])
+@pytest.mark.parametrize("script", ["oob_probe_k3f.py", "oob_probe_round5.py", "oob_probe_models.py", "oob_probe_more.py", "oob_probe_round6.py", "oob_probe_generic.py"])
 def test_no_kernel_touches_memory_beyond_its_inputs(script):
     env = dict(os.environ, HIP_LAUNCH_BLOCKING="1")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", script)], capture_output=True, text=True, timeout=900, env=env,
