@@ -48,6 +48,10 @@ WORKLOADS = {
     # the whole DAE_02 direct_encode forward as the script ships it (hidden 64, neural_01_DAE_02_direct_encode.py:267):
     # Init_Func, four encoders, latent integrate_DAE, both decoders of the solution, both reconstructions -- one launch behind Init_Func (K3g)
     "dae02": dict(kind="dae02_model", B=4096, T=1001, xd=8, zd=2, vd=2, id=2, H=64, nh=1),
+    # round 6: data-defined dims outside the specialised integrators' classes (x_dim > 16; z + v + i > 8) -> the generic integrator K0,
+    # on MFMA since round 6 (neural_00_ODE_01_no_encode.py:293: the dims come from the npz)
+    "ode01_x20": dict(kind="ode", B=4096, T=1001, xd=20, zd=2, H=64, nh=3),
+    "dae01_zvi16": dict(kind="dae", B=4096, T=1001, xd=8, zd=4, vd=6, id=6, H=64, nh=3),
 }
 
 
@@ -227,6 +231,11 @@ def executed_flops_per_state_step(w, p, method, kname):
         else:
             n_mfma = stages * per_stage + 16 + 148               # + the DE's per-step constant + the AE head (740 per RK4 step)
         return n_mfma * 512 / 4
+    if kname == "generic" and w["kind"] in ("ode", "dae"):
+        # K0 issues the dense graph, every layer padded to 16 x 16 tiles of v_mfma_f32_16x16x4_f32
+        up = lambda v: (v + 15) // 16 * 16
+        pad = lambda ls: 2 * sum(up(wt.shape[0]) * up(wt.shape[1]) for wt, _ in ls)
+        return stages * pad(p["de"]) + (pad(p["ae"]) if w["kind"] == "dae" else 0)
     if kname == "mfma" and w["kind"] == "ode" and w["H"] in (32, 64, 128) and w["xd"] <= 8:
         nw = w["H"] // 16                                      # K1: nw waves x 16 trajectories on v_mfma_f32_16x16x4_f32 (2048 flop)
         per_wave_stage = 2 + 2 * 4 * nw + 4
@@ -616,6 +625,8 @@ MODEL_TRAIN_EXTRAS = [("dae02", "rk4"), ("dae02", "euler"), ("ode02", "rk4")]
 # 160-162, neural_01_DAE_02_direct_encode.py:246-248): K3w / K9w with their weight gradients still contracted by library GEMMs -- on the line so
 # that the cost is visible.  Euler = the solver the scripts ship with.
 MODEL_H128_EXTRAS = [("ode02", "euler", 128), ("dae02", "euler", 128)]
+# round 6, last: shapes without a specialisation, on the generic integrator K0 (register form)
+GENERIC_EXTRAS = [("ode01_x20", "rk4", "x_dim 20: generic integrator K0"), ("dae01_zvi16", "rk4", "z + v + i = 16: generic integrator K0")]
 
 
 def safe_line(label, fn):
@@ -1088,6 +1099,8 @@ def main():
                     res["extra"].append(safe_line(f"{wl} {m}: H{h} forward", lambda: extra_line(lib, _lib, fused, wl, m, dev, steps=3, warmup=2, hidden=h,
                                                                                               note="the scripts' argparse default --hidden 128")))
                     res["extra"].append(safe_line(f"{wl} {m} MODEL TRAIN H{h}", lambda: model_train_extra_line(wl, m, dev, steps=3, warmup=2, hidden=h)))
+            for wl, m, n in GENERIC_EXTRAS:
+                res["extra"].append(safe_line(f"{wl} {m}", lambda: extra_line(lib, _lib, fused, wl, m, dev, steps=3, warmup=2, note=n)))
             outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method, gpu_out=None if args.train else outs[0])

@@ -20,7 +20,7 @@ r = lambda *s: (0.1 * torch.randn(*s)).to(dev)
 torch.manual_seed(0)
 # ---- ODE: register form (QM 8, QM 4), LDS form (5 layers), streamed form
 for (B, T, xd, zd, hidden) in [(37, 9, 20, 2, (64, 64, 64)), (5, 1, 20, 2, (64, 64, 64)), (3, 2, 8, 2, (64, 64)), (18, 6, 8, 2, (64, 64, 64, 64)),
-                               (21, 5, 8, 2, (320, 320, 320)), (9, 4, 4, 70, (64, 64))]:
+                               (21, 5, 8, 2, (320, 320, 320)), (9, 4, 4, 70, (64, 64)), (19, 6, 20, 2, (128, 128, 128)), (3, 2, 8, 2, (100,))]:
     ls = lin([3 * (xd + zd)] + list(hidden) + [xd])
     t = (torch.arange(T, dtype=torch.float32) * 0.01).view(T, 1, 1).repeat(1, B, 1).to(dev)
     x, z = r(T, B, xd), r(T, B, zd)

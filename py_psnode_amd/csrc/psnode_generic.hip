@@ -384,10 +384,108 @@ __device__ __forceinline__ int mlp_reg(const Tab<ML>& T, float* lds, int in, con
     return out;
 }
 
+// ---- wide register form: hidden layers of up to 128 units = up to EIGHT tiles, two per wave (nt = w and w + 4), contractions up to 128
+// columns; the last layer at most four tiles.  2 .. 4 layers.  The wave's two tiles share the activation reads: half the LDS traffic per
+// MFMA of the one-tile form.  224 operand registers at four layers (the compiler parks part of them in AGPRs).
+template <int ML>
+struct WRegW {
+    f4 first[2][8];
+    f4 mid[ML - 2][2][8];
+    f4 last[8];
+};
+
+template <int ML>
+__device__ __forceinline__ void load_regs_wide(const MlpDev& m, const Tab<ML>& t, WRegW<ML>& wr) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
+        const bool on = l < t.L, is_last = l + 1 == t.L;
+        const int S4 = on ? tab_quads(t.dims[l]) : 0, NTL = on ? tab_tiles(t.dims[l]) : 0;
+        const f4* __restrict__ A = reinterpret_cast<const f4*>(m.wt[on ? l : 0]) + lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nt = w + 4 * j;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f4 v = (nt < NTL && q < S4) ? A[((size_t)(nt < NTL ? nt : 0) * S4 + (q < S4 ? q : 0)) * 64] : zero;
+                if (is_last) { if (j == 0) wr.last[q] = v; }
+                else if (l == 0) wr.first[j][q] = v;
+                else if (l < ML - 1) wr.mid[l - 1 < ML - 2 ? l - 1 : 0][j][q] = v;
+            }
+        }
+    }
+}
+
+// Q quads, one or two tiles on the same activation reads
+template <int Q, bool TWO>
+__device__ __forceinline__ void tile2_reg(const f4* bq, const f4 (&wa)[8], const f4 (&wb)[8], f4& ra, f4& rb) {
+    f4 bv[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) bv[c] = bq[c * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    f4 a0 = f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        mfma_quad(wa[c], bv[c], (c & 1) ? a1 : a0);
+        if (TWO) mfma_quad(wb[c], bv[c], (c & 1) ? b1 : b0);
+    }
+    ra = Q > 1 ? a0 + a1 : a0;
+    rb = Q > 1 ? b0 + b1 : b0;
+}
+template <bool TWO>
+__device__ __forceinline__ void tile2_any(int S4, const f4* bq, const f4 (&wa)[8], const f4 (&wb)[8], f4& ra, f4& rb) {
+    switch (S4) {
+        case 1: tile2_reg<1, TWO>(bq, wa, wb, ra, rb); break;
+        case 2: tile2_reg<2, TWO>(bq, wa, wb, ra, rb); break;
+        case 3: tile2_reg<3, TWO>(bq, wa, wb, ra, rb); break;
+        case 4: tile2_reg<4, TWO>(bq, wa, wb, ra, rb); break;
+        case 5: tile2_reg<5, TWO>(bq, wa, wb, ra, rb); break;
+        case 6: tile2_reg<6, TWO>(bq, wa, wb, ra, rb); break;
+        case 7: tile2_reg<7, TWO>(bq, wa, wb, ra, rb); break;
+        default: tile2_reg<8, TWO>(bq, wa, wb, ra, rb); break;
+    }
+}
+
+template <int ML>
+__device__ __forceinline__ int mlp_regw(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WRegW<ML>& wr) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int out = ping;
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
+        if (l >= T.L) break;
+        out = (l & 1) ? pong : ping;
+        const int S4 = tab_quads(T.dims[l]), NTL = tab_tiles(T.dims[l]);
+        const bool last = (l + 1 == T.L);
+        if (w < NTL) {
+            const f4* bq = reinterpret_cast<const f4*>(lds + in) + lane;
+            const f4* b16 = reinterpret_cast<const f4*>(lds + T.boff[l]) + (lane >> 4);
+            f4* oq = reinterpret_cast<f4*>(lds + out) + lane;
+            const bool two = !last && w + 4 < NTL;
+            const f4 bias0 = b16[4 * w], bias1 = b16[4 * (two ? w + 4 : w)];
+            f4 ra, rb;
+            if (last) tile2_any<false>(S4, bq, wr.last, wr.last, ra, rb);
+            else if (l == 0) { if (two) tile2_any<true>(S4, bq, wr.first[0], wr.first[1], ra, rb); else tile2_any<false>(S4, bq, wr.first[0], wr.first[0], ra, rb); }
+            else {
+                constexpr int MI = ML - 2;
+                const int mi = l - 1 < MI ? l - 1 : 0;
+                if (two) tile2_any<true>(S4, bq, wr.mid[mi][0], wr.mid[mi][1], ra, rb); else tile2_any<false>(S4, bq, wr.mid[mi][0], wr.mid[mi][0], ra, rb);
+            }
+            ra = ra + bias0;
+            oq[w * 64] = last ? ra : elu_quad(ra);
+            if (two) { rb = rb + bias1; oq[(w + 4) * 64] = elu_quad(rb); }
+        }
+        lds_barrier();
+        in = out;
+    }
+    return out;
+}
+
 // PF: z | v values a thread keeps in flight for the next grid point (items tid + 256 j); rows beyond 16 PF are loaded where they are used
 constexpr int PF = 4;
 
-// MODE 0: weights in registers (mlp_reg; QM = 4 or 8 quads per tile), 1: every image resident in LDS, 2: some layers streamed
+// MODE 0: weights in registers (mlp_reg; QM = 4 or 8 quads per tile), 1: every image resident in LDS, 2: some layers streamed,
+// 3: the DE in the wide register form (mlp_regw)
 template <bool DAE, int MODE, int ML, int QM = 4>
 __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     constexpr bool STREAM = MODE == 2;
@@ -432,6 +530,8 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     load_resident(a.de, tde, lds);
     if constexpr (DAE) load_resident(a.ae, tae, lds);
     WReg<MODE == 0 ? ML : 2, MODE == 0 ? QM : 1> wde;
+    WRegW<MODE == 3 ? ML : 3> wdw;
+    if constexpr (MODE == 3) load_regs_wide<ML>(a.de, tde, wdw);
     WReg<(MODE == 0 && DAE) ? ML : 2, (MODE == 0 && DAE) ? QM : 1> wae;
     if constexpr (MODE == 0) {
         load_regs<ML, QM>(a.de, tde, wde);
@@ -543,7 +643,9 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
             const bool is_ae = DAE && (e == 0 || e == nstage + 1);
             const bool ae_next = DAE && e == nstage;
             int f;
-            if constexpr (MODE == 0) {      // two call sites: the operands are two different register sets
+            if constexpr (MODE == 3) {
+                f = mlp_regw<ML>(tde, lds, inDE, ping, pong, wdw);
+            } else if constexpr (MODE == 0) {      // two call sites: the operands are two different register sets
                 if (is_ae) { if constexpr (DAE) f = mlp_reg<ML, QM>(tae, lds, inAE, ping, pong, wae); else f = ping; }
                 else f = mlp_reg<ML, QM>(tde, lds, inDE, ping, pong, wde);
             } else {
@@ -749,10 +851,18 @@ int generic_reg_mode(const IntegrateDev& a, bool dae) {
     return qmax <= 4 ? 4 : 8;
 }
 
+// Wide register form (mlp_regw; ODE): 2 .. 4 layers, hidden layers within 128 units, every contraction within 128 columns, at most 64 outputs
+bool generic_wide_mode(const IntegrateDev& a, bool dae) {
+    if (dae || a.de.n_layers < 2 || a.de.n_layers > 4 || a.de.in_dim > 128) return false;
+    for (int l = 0; l < a.de.n_layers; ++l)
+        if (a.de.out_dim[l] > (l + 1 == a.de.n_layers ? 64 : 128)) return false;
+    return true;
+}
+
 size_t generic_plan(const IntegrateDev& a, bool dae, unsigned& mask) {
     size_t bytes = generic_lds_bytes(a, dae);
     mask = 0;
-    if (generic_reg_mode(a, dae)) return bytes;
+    if (generic_reg_mode(a, dae) || generic_wide_mode(a, dae)) return bytes;
     const size_t limit = 160 * 1024;
     for (int m = 0; m < (dae ? 2 : 1); ++m) {
         const MlpDev& d = m ? a.ae : a.de;
@@ -789,6 +899,7 @@ hipError_t launch_generic(const IntegrateDev& a_in, bool dae, hipStream_t stream
     if (qm && deep) return qm == 4 ? go(&generic_kernel<false, 0, kMaxLayers, 4>) : go(&generic_kernel<false, 0, kMaxLayers, 8>);
     if (qm == 4) return dae ? go(&generic_kernel<true, 0, 4, 4>) : go(&generic_kernel<false, 0, 4, 4>);
     if (qm == 8) return dae ? go(&generic_kernel<true, 0, 4, 8>) : go(&generic_kernel<false, 0, 4, 8>);
+    if (generic_wide_mode(a, dae)) return go(&generic_kernel<false, 3, 4>);
     if (deep) {
         if (dae) return stream ? go(&generic_kernel<true, 2, kMaxLayers>) : go(&generic_kernel<true, 1, kMaxLayers>);
         return stream ? go(&generic_kernel<false, 2, kMaxLayers>) : go(&generic_kernel<false, 1, kMaxLayers>);

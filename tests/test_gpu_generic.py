@@ -1,7 +1,8 @@
 """The generic integrator K0 (csrc/psnode_generic.hip) in each of its three forms, against the CPU oracle: the shapes outside the
 specialised integrators' classes -- x_dim > 16, z + v + i > 8, depth != 3 hidden layers, mixed and very wide layers; all of them data- or
 user-defined upstream (neural_00_ODE_01_no_encode.py:293).
-  register form : <= 4 layers of <= 64 units, first contraction <= 128 columns (the wave's MFMA A operands stay in VGPRs);
+  register form : layers of <= 64 units, first contraction <= 128 columns (the wave's MFMA A operands stay in VGPRs);
+  wide register form (ODE): 2..4 layers, hidden layers of <= 128 units = two tiles per wave on shared activation reads;
   LDS form      : every layer's weight image fits the LDS left over;
   streamed form : the layers that do not fit are read from the L2-resident workspace image one chunk ahead.
 Events (with the i0 recompute), the four teacher-forcing combinations, per-trajectory clocks, ragged last tiles, T = 1 and 2."""
@@ -107,13 +108,22 @@ def test_register_form_dae_differing_depths():
     check_dae(19, 9, 8, 2, 2, 2, (64, 32), (40, 40, 40), "rk4")
 
 
-# ---- LDS form: more than four layers, or a layer wider than 64 whose images still fit
+# ---- wide register form (ODE): hidden layers of 65 .. 128 units -- the scripts' argparse default --hidden 128 at x_dim > 16
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("xd,zd,hidden", [(20, 2, (128, 128, 128)), (32, 4, (128, 128)), (17, 0, (100, 90, 70)), (8, 2, (128,)),
+                                          (8, 2, (128, 64, 32)), (40, 2, (72, 128, 16))])
+def test_wide_register_form_ode(xd, zd, hidden, method):
+    check_ode(35, 10, xd, zd, hidden, method)
+
+
+# ---- LDS form: a DAE with more than four layers, contractions beyond 128 columns, a last layer beyond 64 outputs
 @pytest.mark.parametrize("method", ("euler", "rk4"))
-@pytest.mark.parametrize("xd,zd,hidden", [(8, 2, (64, 64, 64, 64)),             # depth 4 (five Linear layers: the 8-layer instance)
+@pytest.mark.parametrize("xd,zd,hidden", [(8, 2, (64, 64, 64, 64)),             # depth 4: five Linear layers (register form, 8-layer instance)
                                           (8, 2, (32, 32, 32, 32, 32, 32)),     # seven Linear layers
-                                          (8, 2, (128, 64, 32)),                # mixed widths, 8 tiles in the first layer
+                                          (8, 2, (128, 128, 128, 128)),         # five layers of 128: beyond both register forms
+                                          (70, 10, (64, 64)),                   # 70 outputs: five tiles in the last layer
                                           (40, 10, (96, 96))])                  # 150 columns = 10 quads: beyond the straight-line bodies
-def test_lds_form_ode(xd, zd, hidden, method):
+def test_deep_and_lds_form_ode(xd, zd, hidden, method):
     check_ode(35, 9, xd, zd, hidden, method)
 
 
@@ -124,7 +134,7 @@ def test_lds_form_dae():
 
 # ---- streamed form
 @pytest.mark.parametrize("method", ("euler", "rk4"))
-@pytest.mark.parametrize("xd,zd,hidden", [(20, 2, (128, 128, 128)),     # first layers resident, the last ones streamed
+@pytest.mark.parametrize("xd,zd,hidden", [(20, 2, (160, 160, 160)),     # first layers resident, the last ones streamed
                                           (8, 2, (320, 320, 320)),      # every H -> H layer streamed, 20 tiles = 5 per wave, 20 quads
                                           (8, 2, (200, 72, 200))])      # partial chunks, a wave without a tile in a streamed layer
 def test_streamed_form_ode(xd, zd, hidden, method):
