@@ -102,7 +102,7 @@ int dispatch(IntegrateDev& d, bool dae, int kernel, const psnode_mlp_f32* de, co
         e = launch_mfma(d, dae, ws, stream);
     } else {
         if (generic_lds_bytes(d, dae) > 160 * 1024) return PSNODE_ERR_UNSUPPORTED;
-        e = launch_pack_image(d.de, dae ? &d.ae : nullptr, stream);
+        e = launch_pack_image(d.de, dae ? &d.ae : nullptr, d.xd, d.xd + d.zd + (dae ? d.vd + d.id : 0), d.zd + (dae ? d.vd : 0), stream);
         if (e == hipSuccess) e = launch_generic(d, dae, stream);
     }
     return e == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;

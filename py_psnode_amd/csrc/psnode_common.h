@@ -228,7 +228,7 @@ __host__ __device__ __forceinline__ constexpr float rk_b(int method, int s) {
 hipError_t launch_generic(const IntegrateDev& a, bool dae, hipStream_t stream);
 size_t generic_lds_bytes(const IntegrateDev& a, bool dae);
 hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream);   // generic backward: transposed weights
-hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, hipStream_t stream);       // generic forward: MFMA images
+hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, int xd, int n, int nzv, hipStream_t stream);   // generic forward: MFMA images
 size_t generic_image_floats(int K, int N);
 
 // psnode_mfma.hip

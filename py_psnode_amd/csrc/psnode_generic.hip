@@ -38,8 +38,35 @@ constexpr int NT = 256;   // threads per workgroup (4 waves)
 __host__ __device__ constexpr int up16(int v) { return (v + 15) & ~15; }
 // float offset of (column r, trajectory c) in a quad-row activation buffer
 __device__ __forceinline__ int qi(int r, int c) { return ((((r >> 2) * TB) + c) << 2) | (r & 3); }
+// Column order of the two MLP inputs (the first layers' images use the same one): the columns that change most often come first and end on
+// a quad boundary, so that the register forms can fold everything behind them into a per-step (DE) / per-trajectory (AE) constant.
+//   DE  cat(a0, s - a0, s) (DE_Func.forward):   [ (s - a0)_x | s_x | pad to SX ] [ a0 | (s - a0)_ext | s_ext | pad ]    ext = z | v | i
+//   AE  cat(a0, x, z, v)   (AE_Func.forward):   [ x | z | v | pad to SA ] [ a0 | pad ]
+__host__ __device__ constexpr int de_sx(int xd) { return up16(2 * xd); }
+__host__ __device__ constexpr int de_k16(int xd, int n) { return de_sx(xd) + up16(n + 2 * (n - xd)); }
+__host__ __device__ inline int de_orig_col(int k, int xd, int n) {      // -> column of the nn.Linear weight, -1: pad
+    const int ne = n - xd;
+    if (k < xd) return n + k;
+    if (k < 2 * xd) return 2 * n + (k - xd);
+    if (k < de_sx(xd)) return -1;
+    k -= de_sx(xd);
+    if (k < n) return k;
+    if (k < n + ne) return n + xd + (k - n);
+    if (k < n + 2 * ne) return 2 * n + xd + (k - n - ne);
+    return -1;
+}
+__host__ __device__ constexpr int ae_sa(int xd, int nzv) { return up16(xd + nzv); }
+__host__ __device__ constexpr int ae_k16(int xd, int nzv, int n) { return ae_sa(xd, nzv) + up16(n); }
+__host__ __device__ inline int ae_orig_col(int k, int xd, int nzv, int n) {
+    if (k < xd + nzv) return n + k;
+    if (k < ae_sa(xd, nzv)) return -1;
+    k -= ae_sa(xd, nzv);
+    return k < n ? k : -1;
+}
+
 // floats of one layer's image: N16 x K16 weights + N16 biases
-__host__ __device__ constexpr size_t image_floats(int K, int N) { return (size_t)up16(N) * up16(K) + up16(N); }
+// (+ 16 columns: the two padded blocks of a first layer)
+__host__ __device__ constexpr size_t image_floats(int K, int N) { return (size_t)up16(N) * (up16(K) + 16) + up16(N); }
 // floats of the padded biases of every layer (LDS region behind the kernel's state)
 __host__ __device__ inline int generic_bias_floats(const IntegrateDev& a, bool dae) {
     int tot = 0;
@@ -58,6 +85,7 @@ struct Tab {
     unsigned off[ML];      // streamed layer: f4 offset of its image from `base`; resident layer: FLOAT offset of its copy in LDS
     unsigned boff[ML];     // float offset of the padded bias in LDS
     const f4* base;                // image of layer 0 (workspace)
+    int qx;                        // quads of layer 0's leading block (DE: the state's columns, AE: x | z | v)
     unsigned first_off;            // this wave's first STREAMED chunk of an evaluation: f4 offset ...
     int first_q;                   // ... and the quads of that tile (0: the wave owns no tile in a streamed layer of this MLP)
 };
@@ -66,15 +94,17 @@ __device__ __forceinline__ int tab_quads(unsigned d) { return (int)((d >> 16) & 
 __device__ __forceinline__ bool tab_res(unsigned d) { return (d >> 31) != 0; }
 
 // `res`: bit l = layer l's image is resident in LDS; `bias_at` / `img_at`: running float offsets of the LDS regions (advanced)
+// k0 / qx: layer 0's padded contraction length (de_k16 / ae_k16) and the quads of its leading block
 template <int ML>
-__device__ __forceinline__ Tab<ML> make_tab(const MlpDev& m, int w, unsigned res, unsigned& bias_at, unsigned& img_at) {
+__device__ __forceinline__ Tab<ML> make_tab(const MlpDev& m, int w, unsigned res, unsigned& bias_at, unsigned& img_at, int k0, int qx) {
     Tab<ML> t;
     t.L = m.n_layers;
+    t.qx = qx;
     t.base = reinterpret_cast<const f4*>(m.wt[0]);
     t.first_off = 0; t.first_q = 0;
 #pragma unroll
     for (int l = 0; l < ML; ++l) {
-        const int K = l ? m.out_dim[l - 1] : m.in_dim, N = m.out_dim[l];
+        const int K = l ? m.out_dim[l - 1] : k0, N = m.out_dim[l];
         const unsigned S4 = (K + 15) >> 4, NTL = (N + 15) >> 4;
         const bool on = l < m.n_layers, r = on && ((res >> l) & 1u);
         t.dims[l] = on ? ((r ? 1u << 31 : 0u) | S4 << 16 | NTL) : 0u;
@@ -100,6 +130,7 @@ __device__ __forceinline__ Tab<ML> pick_tab(bool first, const Tab<ML>& x, const 
     auto u = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
     Tab<ML> t;
     t.L = (int)u(first ? x.L : y.L);
+    t.qx = (int)u(first ? x.qx : y.qx);
     const unsigned long long pb = reinterpret_cast<unsigned long long>(first ? x.base : y.base);
     t.base = reinterpret_cast<const f4*>((unsigned long long)u((unsigned)(pb >> 32)) << 32 | u((unsigned)pb));
     t.first_off = u(first ? x.first_off : y.first_off);
@@ -324,6 +355,41 @@ struct WReg {
     f4 rest[ML - 1][4];
 };
 
+// Layer 0 behind its leading block: bias + the products of quads qx .. of tile nt with the input columns that are constant over a step
+// (DE: a0 and the externals) or a trajectory (AE: a0).  Once per step / launch: the A operands come from the workspace image (L2), one
+// chunk ahead.  The register forms start layer 0's accumulator from this value and multiply only the leading block per evaluation.
+template <int ML>
+__device__ __forceinline__ f4 fold0(const Tab<ML>& T, const float* lds, int in, int nt) {
+    const int lane = threadIdx.x & 63;
+    const int S4 = tab_quads(T.dims[0]);
+    const f4* __restrict__ A = T.base + T.off[0] + (unsigned)(nt * S4) * 64u + lane;
+    const f4* bq = reinterpret_cast<const f4*>(lds + in) + lane;
+    f4 acc = reinterpret_cast<const f4*>(lds + T.boff[0])[4 * nt + (lane >> 4)];
+    f4 nxt[4];
+    auto fetch4 = [&](int q0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nxt[c] = A[(q0 + c < S4 ? q0 + c : S4 - 1) * 64];
+    };
+    fetch4(T.qx < S4 ? T.qx : S4 - 1);
+    for (int q0 = T.qx; q0 < S4; q0 += 4) {
+        f4 cur[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+        fetch4(q0 + 4 < S4 ? q0 + 4 : S4 - 1);
+        if (q0 + 4 <= S4) {
+            f4 bv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = bq[(q0 + c) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mfma_quad(cur[c], bv[c], acc);
+        } else {
+            for (int c = 0; q0 + c < S4; ++c) mfma_quad(c == 0 ? cur[0] : (c == 1 ? cur[1] : cur[2]), bq[(q0 + c) * 64], acc);
+        }
+    }
+    return acc;
+}
+
 template <int ML, int QM>
 __device__ __forceinline__ void load_regs(const MlpDev& m, const Tab<ML>& t, WReg<ML, QM>& wr) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -333,7 +399,7 @@ __device__ __forceinline__ void load_regs(const MlpDev& m, const Tab<ML>& t, WRe
         const f4* __restrict__ A = reinterpret_cast<const f4*>(m.wt[l < t.L ? l : 0]) + (size_t)(w < NTL ? w : 0) * S4 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < (l ? 4 : QM); ++q) {
-            const f4 v = (w < NTL && q < S4) ? A[q * 64] : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 v = (w < NTL && q < (l ? S4 : t.qx)) ? A[q * 64] : f4{0.f, 0.f, 0.f, 0.f};      // layer 0: its leading block only
             if (l == 0) wr.first[q] = v; else wr.rest[l - 1][q] = v;
         }
     }
@@ -358,8 +424,9 @@ __device__ __forceinline__ f4 tile_reg_any(int S4, const f4* bq, const f4 (&wa)[
     }
 }
 
+// c0: fold0 of this wave's tile of layer 0 (bias included)
 template <int ML, int QM>
-__device__ __forceinline__ int mlp_reg(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WReg<ML, QM>& wr) {
+__device__ __forceinline__ int mlp_reg(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WReg<ML, QM>& wr, const f4 c0) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int out = ping;
 #pragma unroll
@@ -372,9 +439,8 @@ __device__ __forceinline__ int mlp_reg(const Tab<ML>& T, float* lds, int in, con
             const f4* bq = reinterpret_cast<const f4*>(lds + in) + lane;
             const f4 bias = reinterpret_cast<const f4*>(lds + T.boff[l])[4 * w + (lane >> 4)];
             f4 acc;
-            if (l == 0) acc = tile_reg_any<QM>(S4, bq, wr.first);
-            else acc = tile_reg_any<4>(S4, bq, wr.rest[l ? l - 1 : 0]);
-            acc = acc + bias;
+            if (l == 0) acc = tile_reg_any<QM>(T.qx, bq, wr.first) + c0;
+            else acc = tile_reg_any<4>(S4, bq, wr.rest[l ? l - 1 : 0]) + bias;
             const f4 e = elu_quad(acc);
             reinterpret_cast<f4*>(lds + out)[w * 64 + lane] = last ? acc : e;
         }
@@ -408,7 +474,8 @@ __device__ __forceinline__ void load_regs_wide(const MlpDev& m, const Tab<ML>& t
             const int nt = w + 4 * j;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f4 v = (nt < NTL && q < S4) ? A[((size_t)(nt < NTL ? nt : 0) * S4 + (q < S4 ? q : 0)) * 64] : zero;
+                const int QL = l ? S4 : t.qx;               // layer 0: its leading block only
+                const f4 v = (nt < NTL && q < QL) ? A[((size_t)(nt < NTL ? nt : 0) * S4 + (q < QL ? q : 0)) * 64] : zero;
                 if (is_last) { if (j == 0) wr.last[q] = v; }
                 else if (l == 0) wr.first[j][q] = v;
                 else if (l < ML - 1) wr.mid[l - 1 < ML - 2 ? l - 1 : 0][j][q] = v;
@@ -447,8 +514,10 @@ __device__ __forceinline__ void tile2_any(int S4, const f4* bq, const f4 (&wa)[8
     }
 }
 
+// c0a / c0b: fold0 of the wave's two tiles of layer 0 (bias included)
 template <int ML>
-__device__ __forceinline__ int mlp_regw(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WRegW<ML>& wr) {
+__device__ __forceinline__ int mlp_regw(const Tab<ML>& T, float* lds, int in, const int ping, const int pong, const WRegW<ML>& wr, const f4 c0a,
+                                        const f4 c0b) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int out = ping;
 #pragma unroll
@@ -464,16 +533,17 @@ __device__ __forceinline__ int mlp_regw(const Tab<ML>& T, float* lds, int in, co
             const bool two = !last && w + 4 < NTL;
             const f4 bias0 = b16[4 * w], bias1 = b16[4 * (two ? w + 4 : w)];
             f4 ra, rb;
-            if (last) tile2_any<false>(S4, bq, wr.last, wr.last, ra, rb);
-            else if (l == 0) { if (two) tile2_any<true>(S4, bq, wr.first[0], wr.first[1], ra, rb); else tile2_any<false>(S4, bq, wr.first[0], wr.first[0], ra, rb); }
+            const int QL = l ? S4 : T.qx;
+            if (last && l) tile2_any<false>(QL, bq, wr.last, wr.last, ra, rb);
+            else if (l == 0) { if (two) tile2_any<true>(QL, bq, wr.first[0], wr.first[1], ra, rb); else tile2_any<false>(QL, bq, wr.first[0], wr.first[0], ra, rb); }
             else {
                 constexpr int MI = ML - 2;
                 const int mi = l - 1 < MI ? l - 1 : 0;
                 if (two) tile2_any<true>(S4, bq, wr.mid[mi][0], wr.mid[mi][1], ra, rb); else tile2_any<false>(S4, bq, wr.mid[mi][0], wr.mid[mi][0], ra, rb);
             }
-            ra = ra + bias0;
+            ra = ra + (l ? bias0 : c0a);
             oq[w * 64] = last ? ra : elu_quad(ra);
-            if (two) { rb = rb + bias1; oq[(w + 4) * 64] = elu_quad(rb); }
+            if (two) { rb = rb + (l ? bias1 : c0b); oq[(w + 4) * 64] = elu_quad(rb); }
         }
         lds_barrier();
         in = out;
@@ -497,13 +567,13 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     const int n = xd + zd + vd + id;   // width of all_initial
     const int ne = n - xd;             // external rows: z | v | i
     const int nzv = zd + vd;
-    const int kae = n + xd + nzv;      // width of the AE input
 
     // quad-row buffers (float offsets): the two MLP inputs keep their constant columns (a0; the externals of a step) between evaluations,
     // only the columns that change are rewritten -- per stage that is the state x alone
     constexpr int inDE = 0;
-    const int inAE = up16(3 * n) * TB;
-    const int ping = inAE + (DAE ? up16(kae) * TB : 0);
+    const int SX = de_sx(xd), SA = ae_sa(xd, nzv);      // first column of the second block of the DE / AE input
+    const int inAE = de_k16(xd, n) * TB;
+    const int ping = inAE + (DAE ? ae_k16(xd, nzv, n) * TB : 0);
     const int pong = ping + up16(a.maxo) * TB;
     float* a0 = lds + pong + up16(a.maxo) * TB;   // [n][TB]
     float* ext = a0 + n * TB;          // [ne][TB] z | v | i fed to the DE stages of this step
@@ -525,13 +595,15 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     pf.tag = nullptr;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned bias_at = (unsigned)(dts + TB - lds), img_at = bias_at + (unsigned)generic_bias_floats(a, DAE);
-    const Tab<ML> tde = make_tab<ML>(a.de, wv, a.k0_res & 0xffu, bias_at, img_at);
-    const Tab<ML> tae = DAE ? make_tab<ML>(a.ae, wv, (a.k0_res >> 8) & 0xffu, bias_at, img_at) : tde;
+    const Tab<ML> tde = make_tab<ML>(a.de, wv, a.k0_res & 0xffu, bias_at, img_at, de_k16(xd, n), SX >> 4);
+    const Tab<ML> tae = DAE ? make_tab<ML>(a.ae, wv, (a.k0_res >> 8) & 0xffu, bias_at, img_at, ae_k16(xd, nzv, n), SA >> 4) : tde;
     load_resident(a.de, tde, lds);
     if constexpr (DAE) load_resident(a.ae, tae, lds);
     WReg<MODE == 0 ? ML : 2, MODE == 0 ? QM : 1> wde;
     WRegW<MODE == 3 ? ML : 3> wdw;
     if constexpr (MODE == 3) load_regs_wide<ML>(a.de, tde, wdw);
+    const f4 fzero = f4{0.f, 0.f, 0.f, 0.f};
+    f4 cde = fzero, cde2 = fzero, cae = fzero;       // fold0 of the wave's tile(s) of the DE's / AE's first layer (register forms)
     WReg<(MODE == 0 && DAE) ? ML : 2, (MODE == 0 && DAE) ? QM : 1> wae;
     if constexpr (MODE == 0) {
         load_regs<ML, QM>(a.de, tde, wde);
@@ -550,12 +622,12 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     // external row r (z | v | i order) of the DE input: columns n + xd + r (s - a0) and 2 n + xd + r (s)
     auto put_ext = [&](int r, int c, float v) {
         ext[r * TB + c] = v;
-        lds[inDE + qi(n + xd + r, c)] = v - a0[(xd + r) * TB + c];
-        lds[inDE + qi(2 * n + xd + r, c)] = v;
+        lds[inDE + qi(SX + n + r, c)] = v - a0[(xd + r) * TB + c];
+        lds[inDE + qi(SX + n + ne + r, c)] = v;
     };
     auto put_x = [&](int r, int c, float v) {
-        lds[inDE + qi(n + r, c)] = v - a0[r * TB + c];
-        lds[inDE + qi(2 * n + r, c)] = v;
+        lds[inDE + qi(r, c)] = v - a0[r * TB + c];
+        lds[inDE + qi(xd + r, c)] = v;
     };
 
     // ---- per-trajectory constants, the constant and pad columns of both inputs, the initial state, z | v of grid point 0
@@ -563,27 +635,32 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
         const int r = idx / TB, c = idx % TB;
         const float v = a.a0[gb(c) * n + r];
         a0[idx] = v;
-        lds[inDE + qi(r, c)] = v;
-        if constexpr (DAE) lds[inAE + qi(r, c)] = v;
+        lds[inDE + qi(SX + r, c)] = v;
+        if constexpr (DAE) lds[inAE + qi(SA + r, c)] = v;
     }
-    for (int idx = 3 * n * TB + tid; idx < up16(3 * n) * TB; idx += NT) lds[inDE + qi(idx / TB, idx % TB)] = 0.0f;
+    for (int idx = tid; idx < de_k16(xd, n) * TB; idx += NT)       // pad columns (the others are overwritten below / at the top of every step)
+        if (de_orig_col(idx / TB, xd, n) < 0) lds[inDE + qi(idx / TB, idx % TB)] = 0.0f;
     if constexpr (DAE)
-        for (int idx = kae * TB + tid; idx < up16(kae) * TB; idx += NT) lds[inAE + qi(idx / TB, idx % TB)] = 0.0f;
+        for (int idx = tid; idx < ae_k16(xd, nzv, n) * TB; idx += NT)
+            if (ae_orig_col(idx / TB, xd, nzv, n) < 0) lds[inAE + qi(idx / TB, idx % TB)] = 0.0f;
     for (int idx = tid; idx < nx; idx += NT) {
         const int r = idx / TB, c = idx % TB;
         const long long b = gb(c);
         const float v = DAE ? a.x_init[b * xd + r] : a.x.p[b * a.x.sb + r];
         xcur[idx] = v;
         if (b0 + c < a.B) a.xo[b * xd + r] = v;
-        if constexpr (DAE) lds[inAE + qi(n + r, c)] = true_x ? a.x.p[b * a.x.sb + r] : v;      // my_solvers.py:95
+        if constexpr (DAE) lds[inAE + qi(r, c)] = true_x ? a.x.p[b * a.x.sb + r] : v;      // my_solvers.py:95
     }
     for (int idx = tid; idx < nzv * TB; idx += NT) {
         const float v = zv_at(0, idx / TB, idx % TB);
         zvn[idx] = v;
-        if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = v;
+        if constexpr (DAE) lds[inAE + qi(xd + idx / TB, idx % TB)] = v;
     }
     lds_barrier();
 
+    if constexpr (MODE == 0 && DAE) {       // the AE's a0 block: constant over the trajectory
+        if (wv < tab_tiles(tae.dims[0])) cae = fold0<ML>(tae, lds, inAE, wv);
+    }
     const int nstage = a.method == PSNODE_EULER ? 1 : (a.method == PSNODE_MIDPOINT ? 2 : 4);
     // look-ahead registers: clocks (threads < TB), the next step's event index, the next grid point's z | v
     float tc = 0.0f, tn = 0.0f;
@@ -609,14 +686,14 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
                 if (ev >= 0) { const long long b = gb(c); v = r < zd ? a.zj[b * a.zjb + ev * a.zje + r] : a.vj[b * a.vjb + ev * a.vje + (r - zd)]; }
                 else v = zvn[idx];
                 put_ext(r, c, v);
-                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(n + xd + r, c)] = v;      // the event's AE evaluation sees the jumped rows
+                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(xd + r, c)] = v;      // the event's AE evaluation sees the jumped rows
             }
             for (int idx = tid; idx < nx; idx += NT) {
                 const int r = idx / TB, c = idx % TB;
                 const float v = true_x ? a.x.p[k * a.x.st + gb(c) * a.x.sb + r] : xcur[idx];
                 xsrc[idx] = v;
                 put_x(r, c, v);
-                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(n + r, c)] = xcur[idx];   // ... and the computed state
+                if constexpr (DAE) if (ev >= 0) lds[inAE + qi(r, c)] = xcur[idx];   // ... and the computed state
             }
             if constexpr (DAE) {
                 if (ev < 0)
@@ -643,11 +720,18 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
             const bool is_ae = DAE && (e == 0 || e == nstage + 1);
             const bool ae_next = DAE && e == nstage;
             int f;
+            if constexpr (MODE == 0 || MODE == 3) {
+                if (e == 1) {       // the step's externals are in place (behind an event's AE evaluation too): the DE's per-step constant
+                    const int nt0 = tab_tiles(tde.dims[0]);
+                    if (wv < nt0) cde = fold0<ML>(tde, lds, inDE, wv);
+                    if (MODE == 3 && wv + 4 < nt0) cde2 = fold0<ML>(tde, lds, inDE, wv + 4);
+                }
+            }
             if constexpr (MODE == 3) {
-                f = mlp_regw<ML>(tde, lds, inDE, ping, pong, wdw);
+                f = mlp_regw<ML>(tde, lds, inDE, ping, pong, wdw, cde, cde2);
             } else if constexpr (MODE == 0) {      // two call sites: the operands are two different register sets
-                if (is_ae) { if constexpr (DAE) f = mlp_reg<ML, QM>(tae, lds, inAE, ping, pong, wae); else f = ping; }
-                else f = mlp_reg<ML, QM>(tde, lds, inDE, ping, pong, wde);
+                if (is_ae) { if constexpr (DAE) f = mlp_reg<ML, QM>(tae, lds, inAE, ping, pong, wae, cae); else f = ping; }
+                else f = mlp_reg<ML, QM>(tde, lds, inDE, ping, pong, wde, cde);
             } else {
                 f = DAE ? mlp_eval<STREAM, ML>(pick_tab(is_ae, tae, tde), lds, is_ae ? inAE : inDE, ping, pong, pf, pick_tab(ae_next, tae, tde))
                         : mlp_eval<STREAM, ML>(tde, lds, inDE, ping, pong, pf, tde);
@@ -694,7 +778,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
                 } else {
                     xcur[idx] = v;
                     if (b0 + c < a.B) a.xo[((k + 1) * a.B + b0 + c) * xd + r] = v;
-                    if constexpr (DAE) lds[inAE + qi(n + r, c)] = true_x ? a.x.p[(k + 1) * a.x.st + gb(c) * a.x.sb + r] : v;   // my_solvers.py:121
+                    if constexpr (DAE) lds[inAE + qi(r, c)] = true_x ? a.x.p[(k + 1) * a.x.st + gb(c) * a.x.sb + r] : v;   // my_solvers.py:121
                 }
             }
             if (final_stage) {
@@ -703,13 +787,13 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
                     const int idx = tid + NT * j;
                     if (idx < nzv * TB) {
                         zvn[idx] = pz[j];
-                        if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = pz[j];
+                        if constexpr (DAE) lds[inAE + qi(xd + idx / TB, idx % TB)] = pz[j];
                     }
                 }
                 for (int idx = tid + NT * PF; idx < nzv * TB; idx += NT) {
                     const float v = zv_at(k + 1, idx / TB, idx % TB);
                     zvn[idx] = v;
-                    if constexpr (DAE) lds[inAE + qi(n + xd + idx / TB, idx % TB)] = v;
+                    if constexpr (DAE) lds[inAE + qi(xd + idx / TB, idx % TB)] = v;
                 }
             }
             lds_barrier();
@@ -729,6 +813,8 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
 namespace {
 struct PackArgs {
     int n;                       // layers in total (de then ae)
+    int xd, nall, nzv;           // state dims, width of all_initial, z + v dims: the column orders of the two first layers
+    int perm[2 * kMaxLayers];    // 0: columns as they are, 1: DE first layer (de_orig_col), 2: AE first layer (ae_orig_col)
     int K[2 * kMaxLayers], N[2 * kMaxLayers];
     const float* w[2 * kMaxLayers];
     const float* b[2 * kMaxLayers];
@@ -739,22 +825,25 @@ struct PackArgs {
 // [16 q + 4 (lane / 16) + c] (zero outside the matrix), then the bias padded to 16 * tiles.
 __global__ void pack_image_kernel(const PackArgs p) {
     const int l = blockIdx.y;
-    const int K = p.K[l], N = p.N[l];
-    const int S4 = (K + 15) >> 4, NTL = (N + 15) >> 4;
+    const int K = p.K[l], N = p.N[l], perm = p.perm[l];
+    const int K16 = perm == 1 ? de_k16(p.xd, p.nall) : (perm == 2 ? ae_k16(p.xd, p.nzv, p.nall) : up16(K));
+    const int S4 = K16 >> 4, NTL = (N + 15) >> 4;
     const float* __restrict__ w = p.w[l];
     float* __restrict__ img = p.img[l];
     const int nw = NTL * S4 * 256;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nw + 16 * NTL; idx += gridDim.x * blockDim.x) {
         if (idx >= nw) { const int j = idx - nw; img[idx] = j < N ? p.b[l][j] : 0.0f; continue; }
         const int c = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % S4, nt = (idx >> 8) / S4;
-        const int j = 16 * nt + (lane & 15), k = 16 * q + 4 * (lane >> 4) + c;
-        img[idx] = (j < N && k < K) ? w[(size_t)j * K + k] : 0.0f;
+        const int j = 16 * nt + (lane & 15), kn = 16 * q + 4 * (lane >> 4) + c;
+        const int k = perm == 1 ? de_orig_col(kn, p.xd, p.nall) : (perm == 2 ? ae_orig_col(kn, p.xd, p.nzv, p.nall) : (kn < K ? kn : -1));
+        img[idx] = (j < N && k >= 0) ? w[(size_t)j * K + k] : 0.0f;
     }
 }
 
-void add_pack(PackArgs& p, const MlpDev& d) {
+void add_pack(PackArgs& p, const MlpDev& d, int perm0) {
     int k = d.in_dim;
     for (int l = 0; l < d.n_layers; ++l) {
+        p.perm[p.n] = l ? 0 : perm0;
         p.K[p.n] = k;
         p.N[p.n] = d.out_dim[l];
         p.w[p.n] = d.w[l];
@@ -812,11 +901,12 @@ hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t
 size_t generic_image_floats(int K, int N) { return image_floats(K, N); }
 
 // the MFMA images of one or two MLPs (d.wt[l] = the layer's segment, generic_image_floats each), one launch
-hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, hipStream_t stream) {
+hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, int xd, int n, int nzv, hipStream_t stream) {
     PackArgs p;
     p.n = 0;
-    add_pack(p, de);
-    if (ae) add_pack(p, *ae);
+    p.xd = xd; p.nall = n; p.nzv = nzv;
+    add_pack(p, de, 1);
+    if (ae) add_pack(p, *ae, 2);
     hipLaunchKernelGGL(pack_image_kernel, dim3(16, p.n), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -827,33 +917,32 @@ size_t generic_lds_bytes(const IntegrateDev& a, bool dae) {
     const int n = a.xd + a.zd + vd + id;
     const int nzv = a.zd + vd;
     // DE input, AE input, two layer-output buffers, a0, ext, xcur + xsrc, kbuf, icur, zvn, dts
-    const size_t rows = (size_t)up16(3 * n) + (dae ? up16(n + a.xd + nzv) : 0) + 2 * (size_t)up16(a.maxo) + n + (n - a.xd) + 2 * (size_t)a.xd +
+    const size_t rows = (size_t)de_k16(a.xd, n) + (dae ? ae_k16(a.xd, nzv, n) : 0) + 2 * (size_t)up16(a.maxo) + n + (n - a.xd) + 2 * (size_t)a.xd +
                         4 * (size_t)a.xd + id + nzv + 1;
     return (rows * TB + generic_bias_floats(a, dae)) * sizeof(float);
 }
 
 // Which layers' images become resident: greedy in layer order, DE (evaluated once per stage) before AE (once per step).  Returns the
 // launch's LDS bytes; `mask`: bit l = DE layer l, bit 8 + l = AE layer l.
-// Register mode (mlp_reg): layers of at most four tiles (one per wave), the first layer's contraction within 16 * QM columns; at most four
-// layers per MLP for the DAE (two MLPs: 160 operand registers at QM 8), eight for the ODE (144).  Returns QM (4 or 8), or 0.
+// Register mode (mlp_reg): layers of at most four tiles (one per wave), the first layers' LEADING blocks (DE: 2 x_dim columns, AE: x | z | v)
+// within 16 * QM columns -- the rest of a first layer is folded (fold0), so z / v / i may be as wide as LDS holds; at most four layers per
+// MLP for the DAE (two MLPs: 160 operand registers at QM 8), eight for the ODE (144).  Returns QM (4 or 8), or 0.
 int generic_reg_mode(const IntegrateDev& a, bool dae) {
-    int qmax = 0;
+    // the leading blocks of the two first layers (state columns / x | z | v): what the registers hold of layer 0
+    const int lead_de = de_sx(a.xd), lead_ae = dae ? ae_sa(a.xd, a.zd + a.vd) : 0;
+    if (lead_de > 128 || lead_ae > 128) return 0;
     for (int m = 0; m < (dae ? 2 : 1); ++m) {
         const MlpDev& d = m ? a.ae : a.de;
         if (d.n_layers > (dae ? 4 : kMaxLayers)) return 0;
-        int K = d.in_dim;
-        for (int l = 0; l < d.n_layers; ++l) {
-            if (d.out_dim[l] > 64 || K > 128) return 0;
-            qmax = (K + 15) / 16 > qmax ? (K + 15) / 16 : qmax;
-            K = d.out_dim[l];
-        }
+        for (int l = 0; l < d.n_layers; ++l)
+            if (d.out_dim[l] > 64) return 0;
     }
-    return qmax <= 4 ? 4 : 8;
+    return (lead_de <= 64 && lead_ae <= 64) ? 4 : 8;
 }
 
 // Wide register form (mlp_regw; ODE): 2 .. 4 layers, hidden layers within 128 units, every contraction within 128 columns, at most 64 outputs
 bool generic_wide_mode(const IntegrateDev& a, bool dae) {
-    if (dae || a.de.n_layers < 2 || a.de.n_layers > 4 || a.de.in_dim > 128) return false;
+    if (dae || a.de.n_layers < 2 || a.de.n_layers > 4 || de_sx(a.xd) > 128) return false;
     for (int l = 0; l < a.de.n_layers; ++l)
         if (a.de.out_dim[l] > (l + 1 == a.de.n_layers ? 64 : 128)) return false;
     return true;
@@ -866,7 +955,8 @@ size_t generic_plan(const IntegrateDev& a, bool dae, unsigned& mask) {
     const size_t limit = 160 * 1024;
     for (int m = 0; m < (dae ? 2 : 1); ++m) {
         const MlpDev& d = m ? a.ae : a.de;
-        int K = d.in_dim;
+        const int vd_ = dae ? a.vd : 0, n_ = a.xd + a.zd + vd_ + (dae ? a.id : 0);
+        int K = m ? ae_k16(a.xd, a.zd + vd_, n_) : de_k16(a.xd, n_);
         for (int l = 0; l < d.n_layers; ++l) {
             const size_t img = (size_t)up16(d.out_dim[l]) * up16(K) * sizeof(float);
             if (bytes + img <= limit) { bytes += img; mask |= 1u << (8 * m + l); }
