@@ -180,3 +180,23 @@ def test_full_batch_subset_vs_oracle():
     sel = torch.tensor([0, 1, 15, 16, 17, 2047, 2048, 4079, 4080, 4095])
     ref = O.integrate_ode("rk4", ls, t[:, sel], x[:, sel], z[:, sel], a0[sel], ev[sel], zj[sel])
     assert rel_err(out[:, sel], ref) <= TOL_GPU
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes(seed):
+    """Seeded fuzz over layer counts (1 .. 8 Linear layers), widths, state / external dims, batch and grid sizes, method, events and teacher
+    forcing: whatever form the launch picks, the oracle decides."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    method = METHODS[ri(0, 2)]
+    nh = ri(0, 7)
+    wmax = (24, 64, 64, 130, 200)[ri(0, 4)]
+    hidden = tuple(ri(1, wmax) for _ in range(nh))
+    B, Tn = ri(1, 50), ri(1, 12)
+    if seed % 2 == 0:
+        xd, zd = ri(1, 40), ri(0, 30)
+        check_ode(B, Tn, xd, zd, hidden, method, seed=seed)
+    else:
+        xd, zd, vd, idim = ri(1, 24), ri(0, 20), ri(0, 30), ri(1, 20)
+        hae = tuple(ri(1, wmax) for _ in range(ri(0, 5)))
+        check_dae(B, Tn, xd, zd, vd, idim, hidden[:5], hae, method, seed=seed, combos=((False, False), (True, True), (bool(seed & 2), not (seed & 2))))
