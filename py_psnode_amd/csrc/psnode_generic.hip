@@ -668,7 +668,11 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
         tc = a.t.p[gb(tid) * a.t.sb];
         tn = a.T > 1 ? a.t.p[a.t.st + gb(tid) * a.t.sb] : tc;
     }
-    int evn = (a.ev && a.T > 1) ? a.ev[0] : -1;
+    // the next step's event index travels through a VECTOR load (every lane the same address): a scalar load would be waited for by the
+    // very next LDS wait (SMEM returns out of order, so any lgkmcnt wait is lgkmcnt(0)) -- an L2 round trip at the top of every step
+    const int* evp = a.ev ? a.ev : reinterpret_cast<const int*>(a.t.p);      // (a valid address when there are no events)
+    int evn_v = (a.ev && a.T > 1) ? __builtin_nontemporal_load(evp) : -1;
+
     float pz[PF];
 
     // One MLP call site for every evaluation (the unrolled layer code exists once: it has to stay inside the instruction cache).  Slots of
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
     // (my_solvers.py:95, 121); the pseudo-step k = -1 of the DAE is that last slot alone, for grid point 0.
     for (long long k = DAE ? -1 : 0; k + 1 < a.T; ++k) {
         K0_PROF(5)
-        const int ev = k >= 0 ? evn : -1;
+        const int ev = k >= 0 ? __builtin_amdgcn_readfirstlane(evn_v) : -1;
         if (k >= 0) {
             // ---- this step's inputs (zero-order hold: the left grid point feeds every stage)
             if (tid < TB) dts[tid] = tn - tc;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(NT) void generic_kernel(const IntegrateDev a) {
             // ---- look-ahead for grid point k + 1
             const long long k1 = k + 1, k2 = k + 2 < a.T ? k + 2 : a.T - 1;
             if (tid < TB) { tc = tn; tn = a.t.p[k2 * a.t.st + gb(tid) * a.t.sb]; }
-            evn = (a.ev && k1 + 1 < a.T) ? a.ev[k1] : -1;
+            evn_v = (a.ev && k1 + 1 < a.T) ? evp[k1] : -1;
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 const int idx = tid + NT * j;
