@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from py_psnode_amd import fused  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-B, T = 4096, 1001
+B, T = int(os.environ.get("K0_BATCH", "4096")), int(os.environ.get("K0_GRID", "1001"))
 dev = torch.device("cuda", 0)
 
 
