@@ -62,7 +62,8 @@ __device__ __forceinline__ f4v gm(float a, float b, f4v c) { return __builtin_am
 // forward with stored activations: acts[act[0]] = input rows; writes acts[act[l+1]].
 // out[u][traj] = sum_k W[u][k] in[k][traj]:  A[i][g] = W^T staged in `wbuf` as [k][N] (chunks of input rows, partial sums
 // of multi-chunk layers live in `out`), B[g][j] = in[k = 4q+g][traj j].  Barrier after every chunk.
-__device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
+// (forceinline: as separate functions the buffers arrive as GENERIC pointers and every LDS access becomes a flat_load / flat_store)
+__device__ __forceinline__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     int K = m.in_dim;
     for (int l = 0; l < m.L; ++l) {
@@ -82,13 +83,17 @@ __device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
                 f4v accA, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int uu = 16 * mt + 4 * g + r;
-                    accA[r] = uu < N ? (first ? bias[uu] : out[uu * TP + i]) : 0.0f;
+                    const int uu = 16 * mt + 4 * g + r, uc = uu < N ? uu : N - 1;
+                    const float bv = bias[uc], ov = out[uc * TP + i];      // two address spaces: load both, select the value
+                    accA[r] = uu < N ? (first ? bv : ov) : 0.0f;
                 }
                 for (int kq = 0; kq < kc; kq += 8) {
                     const int ka = kq + g, kb = kq + 4 + g;
-                    const float a0 = (ka < kc && u < N) ? wbuf[ka * N + u] : 0.0f, b0 = ka < kc ? in[(k0 + ka) * TP + i] : 0.0f;
-                    const float a1 = (kb < kc && u < N) ? wbuf[kb * N + u] : 0.0f, b1 = kb < kc ? in[(k0 + kb) * TP + i] : 0.0f;
+                    // clamped addresses, unconditional loads, selects: a predicated LDS load is an exec-masked branch around every operand
+                    const int kac = ka < kc ? ka : kc - 1, kbc = kb < kc ? kb : kc - 1, uc = u < N ? u : N - 1;
+                    const float wa = wbuf[kac * N + uc], ia = in[(k0 + kac) * TP + i], wb = wbuf[kbc * N + uc], ib = in[(k0 + kbc) * TP + i];
+                    const float a0 = (ka < kc && u < N) ? wa : 0.0f, b0 = ka < kc ? ia : 0.0f;
+                    const float a1 = (kb < kc && u < N) ? wb : 0.0f, b1 = kb < kc ? ib : 0.0f;
                     accA = gm(a0, b0, accA);
                     accB = gm(a1, b1, accB);
                 }
@@ -110,14 +115,18 @@ __device__ void g_forward(const GMlp& m, float* acts, float* wbuf) {
 
 // VJP of the MLP: `din` holds delta of the output [N_L][TP]; returns the buffer with the input gradient [in_dim][TP].
 // Accumulates dW, db into gacc.  Ends with a barrier.
-__device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc, float* wbuf) {
+// gacc_l / gacc_g: the parameter-gradient accumulators in LDS or in this workgroup's global slice (gg, a template parameter: a runtime
+// choice between the two pointers makes every access a flat one)
+template <bool gg>
+__device__ __forceinline__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dout, float* gacc_l, float* gacc_g, float* wbuf) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     for (int l = m.L - 1; l >= 0; --l) {
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
         const float* a_in = acts + m.act[l] * TP;
         // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr]: 16x16 tiles, contraction over the 16 trajectories
         //      A[i][g] = delta[16 mt + i][tr = 4q+g], B[g][j] = a_in[16 kt + j][tr]; each tile is owned by one wave
-        float* gw = gacc + m.gw[l];
+        float* gw_l = gacc_l + m.gw[l];
+        float* gw_g = gacc_g + m.gw[l];
         const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
         for (int tile = wave; tile < ntiles; tile += 4) {
             const int mt = tile / ntk, kt = tile % ntk;
@@ -126,12 +135,13 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int tr = 4 * q + g;
-                acc = gm(ju < N ? din[ju * TP + tr] : 0.0f, ku < K ? a_in[ku * TP + tr] : 0.0f, acc);
+                const float dv = din[(ju < N ? ju : N - 1) * TP + tr], av = a_in[(ku < K ? ku : K - 1) * TP + tr];
+                acc = gm(ju < N ? dv : 0.0f, ku < K ? av : 0.0f, acc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jr = 16 * mt + 4 * g + r;
-                if (jr < N && ku < K) gw[jr * K + ku] += acc[r];
+                if (jr < N && ku < K) { if constexpr (gg) gw_g[jr * K + ku] += acc[r]; else gw_l[jr * K + ku] += acc[r]; }
             }
         }
         // ---- db[j] += sum_tr delta[j][tr]
@@ -139,7 +149,7 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < TB; ++c) s += din[j * TP + c];
-            gacc[m.gb[l] + j] += s;
+            if constexpr (gg) gacc_g[m.gb[l] + j] += s; else gacc_l[m.gb[l] + j] += s;
         }
         // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers): A[i][g] = W[j = 4q+g][16 kt + i] from the
         //      row-major weights staged in chunks of output rows, B[g][j] = delta[4q+g][traj]; partial sums in dout
@@ -156,12 +166,15 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kr = 16 * kt + 4 * g + r;
-                    accA[r] = (!first && kr < K) ? dout[kr * TP + i] : 0.0f;
+                    const float dv = dout[(kr < K ? kr : K - 1) * TP + i];
+                    accA[r] = (!first && kr < K) ? dv : 0.0f;
                 }
                 for (int jq = 0; jq < jc; jq += 8) {
                     const int ja = jq + g, jb = jq + 4 + g;
-                    const float a0 = (ja < jc && ku < K) ? wbuf[ja * K + ku] : 0.0f, b0 = ja < jc ? din[(j0 + ja) * TP + i] : 0.0f;
-                    const float a1 = (jb < jc && ku < K) ? wbuf[jb * K + ku] : 0.0f, b1 = jb < jc ? din[(j0 + jb) * TP + i] : 0.0f;
+                    const int jac = ja < jc ? ja : jc - 1, jbc = jb < jc ? jb : jc - 1, kc_ = ku < K ? ku : K - 1;
+                    const float wa = wbuf[jac * K + kc_], da = din[(j0 + jac) * TP + i], wb = wbuf[jbc * K + kc_], db_ = din[(j0 + jbc) * TP + i];
+                    const float a0 = (ja < jc && ku < K) ? wa : 0.0f, b0 = ja < jc ? da : 0.0f;
+                    const float a1 = (jb < jc && ku < K) ? wb : 0.0f, b1 = jb < jc ? db_ : 0.0f;
                     accA = gm(a0, b0, accA);
                     accB = gm(a1, b1, accB);
                 }
@@ -182,6 +195,7 @@ __device__ float* g_vjp(const GMlp& m, const float* acts, float* din, float* dou
     return din;
 }
 
+template <bool gg>
 __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -210,15 +224,15 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     float* wbuf = dts + TP;                       // [kWBuf] staged weights
     // [np_de + np_ae]: in LDS when it fits, else this workgroup's partial slice in global memory (each element is owned by
     // one thread either way, so the read-modify-write needs no atomics)
-    float* gacc = a.gacc_global ? a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0)) : wbuf + kWBuf;
-    float* gacc_ae = gacc + a.de.np;
+    float* gacc_g = a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0));      // (used when gg)
+    float* gacc_l = wbuf + kWBuf;                                                          // (used when !gg)
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
     auto on = [&](int c) -> bool { return b0 + c < a.B; };
     // loops over [rows][TB] tiles: idx -> (r, c)
 #define TILE_LOOP(rows) for (int idx = tid, r = tid / TB, c = tid % TB; idx < (rows) * TB; idx += NT, r = idx / TB, c = idx % TB)
 
-    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) gacc[e] = 0.0f;
+    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) { if constexpr (gg) gacc_g[e] = 0.0f; else gacc_l[e] = 0.0f; }
     TILE_LOOP(n) { a0s[r * TP + c] = a.a0[gb(c) * n + r]; ga0s[r * TP + c] = 0.0f; }
     TILE_LOOP(xd) gxc[r * TP + c] = on(c) ? a.gxs[((a.T - 1) * a.B + gb(c)) * xd + r] : 0.0f;
     TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[((a.T - 1) * a.B + gb(c)) * id + r] : 0.0f;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = g_vjp(a.ae, acts, dA, dB, gacc_ae, wbuf);
+        const float* gu = g_vjp<gg>(a.ae, acts, dA, dB, gacc_l + a.de.np, gacc_g + a.de.np, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
         TILE_LOOP(nzv) {
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
-            const float* gu = g_vjp(a.de, acts, dA, dB, gacc, wbuf);
+            const float* gu = g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf);
             TILE_LOOP(n) {
                 const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
@@ -386,8 +400,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
-    if (!a.gacc_global)
-        for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc[e];
+    if constexpr (!gg)
+        for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc_l[e];
 #undef TILE_LOOP
 }
 
@@ -512,10 +526,11 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     to_dev(a.de, mde);
     if (dae) to_dev(a.ae, mae);
     if (launch_pack_transpose(mde, dae ? &mae : nullptr, stream) != hipSuccess) return PSNODE_ERR_HIP;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    auto kern = a.gacc_global ? &generic_backward_kernel<true> : &generic_backward_kernel<false>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PSNODE_ERR_HIP;
     const unsigned nwg = (unsigned)((B + TB - 1) / TB);
-    hipLaunchKernelGGL(generic_backward_kernel, dim3(nwg), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, stream, a);
     if (hipGetLastError() != hipSuccess) return PSNODE_ERR_HIP;
     return launch_reduce_partials(a.wpart, gparams_de, gparams_ae, a.de.np, dae ? a.ae.np : 0, (int)nwg, stream) == hipSuccess ? PSNODE_OK : PSNODE_ERR_HIP;
 }
