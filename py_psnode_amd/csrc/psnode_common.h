@@ -230,6 +230,7 @@ size_t generic_lds_bytes(const IntegrateDev& a, bool dae);
 hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t stream);   // generic backward: transposed weights
 hipError_t launch_pack_image(const MlpDev& de, const MlpDev* ae, int xd, int n, int nzv, hipStream_t stream);   // generic forward: MFMA images
 size_t generic_image_floats(int K, int N);
+hipError_t launch_pack_plain_images(const MlpDev& m, float* const* img, float* const* imgT, hipStream_t stream);   // generic backward, register path
 
 // psnode_mfma.hip
 bool mfma_ode_supported(const IntegrateDev& a);

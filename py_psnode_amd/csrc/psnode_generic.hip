@@ -818,7 +818,8 @@ namespace {
 struct PackArgs {
     int n;                       // layers in total (de then ae)
     int xd, nall, nzv;           // state dims, width of all_initial, z + v dims: the column orders of the two first layers
-    int perm[2 * kMaxLayers];    // 0: columns as they are, 1: DE first layer (de_orig_col), 2: AE first layer (ae_orig_col)
+    int perm[2 * kMaxLayers];    // 0: columns as they are, 1: DE first layer (de_orig_col), 2: AE first layer (ae_orig_col),
+                                 // 3: the TRANSPOSED matrix (tiles over the layer's inputs, contraction over its outputs; no bias)
     int K[2 * kMaxLayers], N[2 * kMaxLayers];
     const float* w[2 * kMaxLayers];
     const float* b[2 * kMaxLayers];
@@ -830,6 +831,19 @@ struct PackArgs {
 __global__ void pack_image_kernel(const PackArgs p) {
     const int l = blockIdx.y;
     const int K = p.K[l], N = p.N[l], perm = p.perm[l];
+    if (perm == 3) {             // image of W^T: rows j < K, contraction kn < N
+        const int S4 = (N + 15) >> 4, NTL = (K + 15) >> 4;
+        const float* __restrict__ w = p.w[l];
+        float* __restrict__ img = p.img[l];
+        const int nw = NTL * S4 * 256;
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nw + 16 * NTL; idx += gridDim.x * blockDim.x) {
+            if (idx >= nw) { img[idx] = 0.0f; continue; }
+            const int c = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % S4, nt = (idx >> 8) / S4;
+            const int j = 16 * nt + (lane & 15), kn = 16 * q + 4 * (lane >> 4) + c;
+            img[idx] = (j < K && kn < N) ? w[(size_t)kn * K + j] : 0.0f;
+        }
+        return;
+    }
     const int K16 = perm == 1 ? de_k16(p.xd, p.nall) : (perm == 2 ? ae_k16(p.xd, p.nzv, p.nall) : up16(K));
     const int S4 = K16 >> 4, NTL = (N + 15) >> 4;
     const float* __restrict__ w = p.w[l];
@@ -898,6 +912,26 @@ hipError_t launch_pack_transpose(const MlpDev& de, const MlpDev* ae, hipStream_t
     add_pack_t(p, de);
     if (ae) add_pack_t(p, *ae);
     hipLaunchKernelGGL(pack_transpose_kernel, dim3(8, p.n), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// Plain (natural column order, with bias) and transposed images of one MLP's layers for the generic backward's register path: img[l] /
+// imgT[l] must hold generic_image_floats(K_l, N_l) / generic_image_floats(N_l, K_l) floats.
+hipError_t launch_pack_plain_images(const MlpDev& m, float* const* img, float* const* imgT, hipStream_t stream) {
+    PackArgs p;
+    p.n = 0; p.xd = 0; p.nall = 0; p.nzv = 0;
+    int k = m.in_dim;
+    for (int l = 0; l < m.n_layers; ++l) {
+        for (int t = 0; t < 2; ++t) {
+            p.perm[p.n] = t ? 3 : 0;
+            p.K[p.n] = k; p.N[p.n] = m.out_dim[l];
+            p.w[p.n] = m.w[l]; p.b[p.n] = m.bias[l];
+            p.img[p.n] = t ? imgT[l] : img[l];
+            ++p.n;
+        }
+        k = m.out_dim[l];
+    }
+    hipLaunchKernelGGL(pack_image_kernel, dim3(16, p.n), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -49,6 +49,11 @@ struct GBwd {
     float *gx0, *gz, *gv, *gzj, *gvj, *ga0, *wpart;
     int maxw, act_rows;
     int gacc_global;   // parameter-gradient accumulators in this workgroup's slice of wpart (global, L2) instead of LDS
+    // register path of the DE (round 6): <= 4 layers of <= 64 units, 3 n <= 128 input columns.  Plain and transposed MFMA images (workspace;
+    // psnode_generic.hip: launch_pack_plain_images); the wave's A operands of both stay in VGPRs for the launch.
+    int de_reg;
+    const float* fimg[4];
+    const float* timg[4];
 };
 
 __device__ __forceinline__ float delu(float h) { return elu_grad(h); }   // ELU'(pre) from h = ELU(pre)
@@ -195,7 +200,205 @@ __device__ __forceinline__ float* g_vjp(const GMlp& m, const float* acts, float*
     return din;
 }
 
+// ---- register path of the DE (the forward recomputation and the delta propagation of g_vjp): what K0's register form is for the forward
+// pass (psnode_generic.hip).  Activations and deltas additionally live in QUAD-ROW buffers (float index ((col / 4) * 16 + traj) * 4 + col % 4:
+// the B operands of four MFMA steps are one lane-linear ds_read_b128, a D tile one ds_write_b128); the [unit][TP] copies stay, they are what
+// the weight-gradient MFMAs (contraction over the trajectories) and the step's glue read.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int up16(int v) { return (v + 15) & ~15; }
+__device__ __forceinline__ int qi(int r, int c) { return ((((r >> 2) * TB) + c) << 2) | (r & 3); }
+__device__ __forceinline__ void mfma_quad(const f4 av, const f4 bv, f4& acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+}
+template <int Q, int QM>
+__device__ __forceinline__ f4 tile_reg(const f4* bq, const f4 (&wa)[QM]) {
+    f4 bv[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) bv[c] = bq[c * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) mfma_quad(wa[c], bv[c], (c & 1) ? acc2 : acc);
+    return Q > 1 ? acc + acc2 : acc;
+}
+template <int QM>
+__device__ __forceinline__ f4 tile_reg_any(int S4, const f4* bq, const f4 (&wa)[QM]) {
+    if constexpr (QM > 4) {
+        switch (S4) {
+            case 5: return tile_reg<5, QM>(bq, wa);
+            case 6: return tile_reg<6, QM>(bq, wa);
+            case 7: return tile_reg<7, QM>(bq, wa);
+            case 8: return tile_reg<8, QM>(bq, wa);
+            default: break;
+        }
+    }
+    switch (S4) {
+        case 1: return tile_reg<1, QM>(bq, wa);
+        case 2: return tile_reg<2, QM>(bq, wa);
+        case 3: return tile_reg<3, QM>(bq, wa);
+        default: return tile_reg<4, QM>(bq, wa);
+    }
+}
+
+struct RegFwd { f4 first[8]; f4 rest[3][4]; };          // layer 0: <= 128 input columns; layers 1..3: <= 64
+struct RegBwd { f4 first[2][4]; f4 rest[3][4]; };       // transposed: layer 0 has <= 8 tiles over its inputs (two per wave), the others <= 4
+
+__device__ __forceinline__ void load_reg_images(const GBwd& a, RegFwd& fw, RegBwd& bw) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const bool on = l < a.de.L;
+        const int K = on ? (l ? a.de.out_dim[l - 1] : a.de.in_dim) : 0, N = on ? a.de.out_dim[l] : 0;
+        const int SK = (K + 15) >> 4, SN = (N + 15) >> 4;           // quads of the forward contraction / of the transposed one
+        const f4* __restrict__ F = reinterpret_cast<const f4*>(a.fimg[on ? l : 0]) + lane;
+        const f4* __restrict__ Tm = reinterpret_cast<const f4*>(a.timg[on ? l : 0]) + lane;
+#pragma unroll
+        for (int q = 0; q < (l ? 4 : 8); ++q) {
+            const f4 v = (w < SN && q < SK) ? F[((size_t)(w < SN ? w : 0) * SK + (q < SK ? q : 0)) * 64] : zero;
+            if (l == 0) fw.first[q] = v; else fw.rest[l - 1][q] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < (l ? 1 : 2); ++j) {
+            const int kt = w + 4 * j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 v = (kt < SK && q < SN) ? Tm[((size_t)(kt < SK ? kt : 0) * SN + (q < SN ? q : 0)) * 64] : zero;
+                if (l == 0) bw.first[j][q] = v; else bw.rest[l - 1][q] = v;
+            }
+        }
+    }
+}
+
+// quad-row buffers of the register path (float offsets from qb): the DE input, the hidden activations, two delta buffers
+struct QOff { int in, act[3], d0, d1, total; };
+__host__ __device__ inline QOff q_offsets(const GMlp& m) {
+    QOff q;
+    int o = 0;
+    q.in = o; o += up16(m.in_dim) * TB;
+    int mx = 16;
+    for (int l = 0; l < 3; ++l) {
+        q.act[l] = o;
+        if (l + 1 < m.L) o += up16(m.out_dim[l]) * TB;
+    }
+    for (int l = 0; l < m.L; ++l) mx = up16(m.out_dim[l]) > mx ? up16(m.out_dim[l]) : mx;
+    q.d0 = o; o += mx * TB;
+    q.d1 = o; o += mx * TB;
+    q.total = o;
+    return q;
+}
+
+// forward with stored activations, the DE in registers: acts[act[0]] = input rows; writes acts[act[l + 1]] and the quad-row copies
+__device__ __forceinline__ void g_forward_reg(const GBwd& a, float* acts, float* qb, const QOff& qo, const RegFwd& fw) {
+    const GMlp& m = a.de;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, j = lane & 15;
+    {   // the input rows -> quad-row (the pad columns were zeroed at kernel start)
+        const float* u = acts + m.act[0] * TP;
+        for (int idx = tid; idx < m.in_dim * TB; idx += NT) qb[qo.in + qi(idx / TB, idx % TB)] = u[(idx / TB) * TP + idx % TB];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (l >= m.L) break;
+        const int K = l ? m.out_dim[l - 1] : m.in_dim, N = m.out_dim[l];
+        const int S4 = (K + 15) >> 4, NTL = (N + 15) >> 4;
+        const bool last = (l + 1 == m.L);
+        if (w < NTL) {
+            const f4* bq = reinterpret_cast<const f4*>(qb + (l ? qo.act[l - 1 < 3 ? l - 1 : 0] : qo.in)) + lane;
+            const f4 bias = *reinterpret_cast<const f4*>(a.fimg[l] + (size_t)NTL * S4 * 256 + 16 * w + 4 * g);
+            f4 acc;
+            if (l == 0) acc = tile_reg_any<8>(S4, bq, fw.first);
+            else acc = tile_reg_any<4>(S4, bq, fw.rest[l - 1 < 3 ? l - 1 : 0]);
+            acc = acc + bias;
+            const f4 e = last ? acc : elu_quad(acc);
+            float* out = acts + m.act[l + 1] * TP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int uu = 16 * w + 4 * g + r;
+                if (uu < N) out[uu * TP + j] = e[r];
+            }
+            if (!last) reinterpret_cast<f4*>(qb + qo.act[l < 3 ? l : 0])[w * 64 + lane] = e;
+        }
+        __syncthreads();
+    }
+}
+
+// VJP of the DE with the delta propagation in registers (the weight-gradient part is g_vjp's)
 template <bool gg>
+__device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, float* din, float* dout, float* gacc_l, float* gacc_g, float* qb,
+                                            const QOff& qo, const RegBwd& bw) {
+    const GMlp& m = a.de;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    int qd = qo.d0, qn = qo.d1;
+    {   // the output gradient -> quad-row, pad columns zero
+        const int N = m.out_dim[m.L - 1];
+        for (int idx = tid; idx < up16(N) * TB; idx += NT) qb[qd + qi(idx / TB, idx % TB)] = idx / TB < N ? din[(idx / TB) * TP + idx % TB] : 0.0f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int l = 3; l >= 0; --l) {
+        if (l >= m.L) continue;
+        const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
+        const float* a_in = acts + m.act[l] * TP;
+        // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr],  db[j] += sum_tr delta[j][tr]      (as g_vjp)
+        float* gw_l = gacc_l + m.gw[l];
+        float* gw_g = gacc_g + m.gw[l];
+        const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            const int mt = tile / ntk, kt = tile % ntk;
+            const int ju = 16 * mt + i, ku = 16 * kt + i;
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tr = 4 * q + g;
+                const float dv = din[(ju < N ? ju : N - 1) * TP + tr], av = a_in[(ku < K ? ku : K - 1) * TP + tr];
+                acc = gm(ju < N ? dv : 0.0f, ku < K ? av : 0.0f, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = 16 * mt + 4 * g + r;
+                if (jr < N && ku < K) { if constexpr (gg) gw_g[jr * K + ku] += acc[r]; else gw_l[jr * K + ku] += acc[r]; }
+            }
+        }
+        for (int jj = tid; jj < N; jj += NT) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < TB; ++c) s += din[jj * TP + c];
+            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[m.gb[l] + jj] += s;
+        }
+        // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers): tiles over k, A operands (W^T) in registers
+        const int SN = (N + 15) >> 4, NTK = (K + 15) >> 4;
+        const f4* bq = reinterpret_cast<const f4*>(qb + qd) + lane;
+#pragma unroll
+        for (int jt = 0; jt < (l ? 1 : 2); ++jt) {
+            const int kt = w + 4 * jt;
+            if (kt < NTK) {
+                f4 acc = l == 0 ? tile_reg_any<4>(SN, bq, bw.first[jt]) : tile_reg_any<4>(SN, bq, bw.rest[l > 0 ? l - 1 : 0]);
+                // layer 0 stores the accumulator as it is: on the taken edge of the switch's exit branch the compiler's hazard count is one
+                // wait state short of the MFMA's write (ISA lint check B); the tied nop puts the distance on every path
+                asm volatile("s_nop 3" : "+v"(acc));
+                if (l > 0) {
+                    const f4 h = reinterpret_cast<const f4*>(qb + qo.act[l - 1 >= 0 ? l - 1 : 0])[kt * 64 + lane];
+                    acc = acc * elu_grad_quad(h);
+                    reinterpret_cast<f4*>(qb + qn)[kt * 64 + lane] = acc;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = 16 * kt + 4 * g + r;
+                    if (kr < K) dout[kr * TP + i] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        { float* tmp = din; din = dout; dout = tmp; }
+        { const int t_ = qd; qd = qn; qn = t_; }
+    }
+    return din;
+}
+
+template <bool gg, bool REG>
 __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -226,6 +429,16 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // one thread either way, so the read-modify-write needs no atomics)
     float* gacc_g = a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0));      // (used when gg)
     float* gacc_l = wbuf + kWBuf;                                                          // (used when !gg)
+    // register path of the DE: quad-row buffers behind the accumulators, the wave's MFMA operands of both passes in VGPRs
+    const int np_all = a.de.np + (a.dae ? a.ae.np : 0);
+    float* qb = gacc_l + (gg ? 0 : ((np_all + 3) & ~3));
+    const QOff qo = q_offsets(a.de);
+    RegFwd rfw;
+    RegBwd rbw;
+    if constexpr (REG) {
+        load_reg_images(a, rfw, rbw);
+        for (int e = tid; e < qo.total; e += NT) qb[e] = 0.0f;         // (the pad columns stay zero)
+    }
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
     auto on = [&](int c) -> bool { return b0 + c < a.B; };
@@ -333,7 +546,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             }
             __syncthreads();
             de_input(xst + s * nx);
-            g_forward(a.de, acts, wbuf);
+            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw); else g_forward(a.de, acts, wbuf);
             const float* out = acts + a.de.act[a.de.L] * TP;
             TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
             __syncthreads();
@@ -348,10 +561,10 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         __syncthreads();
         for (int s = S - 1; s >= 0; --s) {
             de_input(xst + s * nx);
-            g_forward(a.de, acts, wbuf);
+            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw); else g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
-            const float* gu = g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf);
+            const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, gacc_g, qb, qo, rbw) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf);
             TILE_LOOP(n) {
                 const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
@@ -429,15 +642,40 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
+    const size_t np_all = (size_t)a.de.np + (a.dae ? a.ae.np : 0);
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + kWBuf + (a.gacc_global ? 0 : a.de.np + (a.dae ? a.ae.np : 0));
+           (size_t)id * TP + TP + kWBuf + (a.gacc_global ? 0 : ((np_all + 3) & ~(size_t)3)) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
 }
-// 1: everything in LDS; 2: only with the parameter-gradient accumulators in global memory; 0: does not fit
+// the DE's shape class of the register path
+bool de_reg_class(const psnode_mlp_f32& de) {
+    if (de.n_layers > 4 || de.in_dim > 128) return false;
+    for (int l = 0; l < de.n_layers; ++l)
+        if (de.out_dim[l] > 64) return false;
+    return true;
+}
+size_t reg_image_floats(const psnode_mlp_f32& de) {       // plain + transposed images of every layer
+    size_t tot = 0;
+    int k = de.in_dim;
+    for (int l = 0; l < de.n_layers; ++l) {
+        tot += (generic_image_floats(k, de.out_dim[l]) + 63) / 64 * 64 + (generic_image_floats(de.out_dim[l], k) + 63) / 64 * 64;
+        k = de.out_dim[l];
+    }
+    return tot;
+}
+// 1: everything in LDS; 2: only with the parameter-gradient accumulators in global memory; 0: does not fit.  a.de_reg (the DE's class
+// allows the register path) is kept when its quad-row buffers fit next to the LDS accumulators, else dropped.
 int gbwd_mode(GBwd& a) {
-    a.gacc_global = 0;
-    if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
+    const int want_reg = a.de_reg;
+    for (int reg = want_reg; reg >= 0; --reg) {
+        a.de_reg = reg;
+        a.gacc_global = 0;
+        if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
+    }
     a.gacc_global = 1;
-    if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
+    for (int reg = want_reg; reg >= 0; --reg) {
+        a.de_reg = reg;
+        if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
+    }
     return 0;
 }
 
@@ -469,7 +707,8 @@ bool mlp_ok(const psnode_mlp_f32& m, int in_dim, int out_dim) {
 // shared by the ODE and DAE entry points (psnode_backward.hip calls this for kernel = generic / unsupported MFMA shapes)
 size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B) {
     const size_t nwg = (size_t)((B + TB - 1) / TB);
-    return mlp_wt_floats(*de) + (ae ? mlp_wt_floats(*ae) : 0) + nwg * (size_t)(mlp_np(*de) + (ae ? mlp_np(*ae) : 0)) + 64;
+    return mlp_wt_floats(*de) + (ae ? mlp_wt_floats(*ae) : 0) + nwg * (size_t)(mlp_np(*de) + (ae ? mlp_np(*ae) : 0)) + 64 +
+           (de_reg_class(*de) ? reg_image_floats(*de) + 64 : 0);
 }
 
 int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd, int zd, int vd, int id) {
@@ -485,6 +724,7 @@ int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd,
         a.maxw = mlp_maxw(*ae) > a.maxw ? mlp_maxw(*ae) : a.maxw;
     }
     a.act_rows = rows;
+    a.de_reg = de_reg_class(*de) ? 1 : 0;
     return gbwd_mode(a);
 }
 
@@ -512,7 +752,21 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     a.act_rows = rows;
     a.t = t; a.z = z; a.v = v; a.a0 = a0; a.ev = ev; a.zj = zj; a.zjb = zjb; a.zje = zje; a.vj = vj; a.vjb = vjb; a.vje = vje;
     a.n_events = n_events; a.xs = xs; a.is_ = is_; a.gxs = gxs; a.gis = gis; a.gx0 = gx0; a.gz = gz; a.gv = gv; a.gzj = gzj; a.gvj = gvj;
-    a.ga0 = ga0; a.wpart = ws;
+    a.ga0 = ga0;
+    a.de_reg = de_reg_class(*de) ? 1 : 0;
+    float* img[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* imgT[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (a.de_reg) {             // the plain / transposed images sit in front of the per-workgroup partials
+        ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+        int k = de->in_dim;
+        for (int l = 0; l < de->n_layers; ++l) {
+            img[l] = ws; ws += (generic_image_floats(k, de->out_dim[l]) + 63) / 64 * 64;
+            imgT[l] = ws; ws += (generic_image_floats(de->out_dim[l], k) + 63) / 64 * 64;
+            a.fimg[l] = img[l]; a.timg[l] = imgT[l];
+            k = de->out_dim[l];
+        }
+    }
+    a.wpart = ws;
     if (!gbwd_mode(a)) return PSNODE_ERR_UNSUPPORTED;
     const size_t lds = gbwd_lds_floats(a) * sizeof(float);
     // transposed weights for the forward recomputation
@@ -526,7 +780,9 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     to_dev(a.de, mde);
     if (dae) to_dev(a.ae, mae);
     if (launch_pack_transpose(mde, dae ? &mae : nullptr, stream) != hipSuccess) return PSNODE_ERR_HIP;
-    auto kern = a.gacc_global ? &generic_backward_kernel<true> : &generic_backward_kernel<false>;
+    if (a.de_reg && launch_pack_plain_images(mde, img, imgT, stream) != hipSuccess) return PSNODE_ERR_HIP;
+    auto kern = a.de_reg ? (a.gacc_global ? &generic_backward_kernel<true, true> : &generic_backward_kernel<false, true>)
+                         : (a.gacc_global ? &generic_backward_kernel<true, false> : &generic_backward_kernel<false, false>);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PSNODE_ERR_HIP;
     const unsigned nwg = (unsigned)((B + TB - 1) / TB);
