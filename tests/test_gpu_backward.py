@@ -380,7 +380,11 @@ def test_head_grads_kernel_against_torch(hidden, R, B, nzv, ev_layout):
 
 
 @pytest.mark.parametrize("method", ["euler", "rk4"])
-@pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2), (8, 2, 128, 3), (8, 2, 32, 3)])
+@pytest.mark.parametrize("xd,zd,H,nh", [(8, 2, 64, 3), (16, 16, 16, 1), (5, 3, 24, 2), (8, 2, 128, 3), (8, 2, 32, 3),
+                                        # round 6, the DE's register path (<= 4 layers of <= 64 units, 3 n <= 128 input columns) and its edges:
+                                        (20, 2, 64, 3), (32, 4, 48, 2), (17, 0, 33, 3), (40, 2, 64, 1), (8, 2, (33, 17, 64), 3), (5, 3, (16, 64, 16), 3),
+                                        (44, 0, 40, 2),            # 132 input columns: back on the staged path
+                                        (8, 2, 64, 4)])            # five Linear layers: staged path
 def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
     """K5 (kernel='generic') on the MFMA shape, the direct_encode latent shape, an odd shape, and the --hidden 128 / 32 shapes
     (at 128 the parameter-gradient accumulators no longer fit LDS and live in the workgroup's global partial slice), raw-tensor API."""
@@ -389,7 +393,7 @@ def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
     g = torch.Generator().manual_seed(7)
     torch.manual_seed(7)
     n = xd + zd
-    dims = [3 * n] + [H] * nh + [xd]
+    dims = [3 * n] + (list(H) if isinstance(H, tuple) else [H] * nh) + [xd]
     seq64 = nn.Sequential(*[m for k in range(len(dims) - 1) for m in ([nn.Linear(dims[k], dims[k + 1])] + ([nn.ELU()] if k + 2 < len(dims) else []))]).double()
     t = (torch.arange(Tn, dtype=torch.float32) * 0.01).view(Tn, 1, 1).repeat(1, B, 1)
     x0, z = 0.1 * torch.randn(B, xd, generator=g), 0.1 * torch.randn(Tn, B, zd, generator=g)
@@ -416,9 +420,9 @@ def test_generic_backward_kernel_ode(method, xd, zd, H, nh):
     # x0 and z[0] also enter through all_initial: compare the totals autograd reports
     gx0_tot = gx0 + ga0[:, :xd]
     _close(gx0_tot, x0q.grad, "grad x0")
-    gz_tot = gz.clone()
-    gz_tot[0] += ga0[:, xd:]
     if zd:
+        gz_tot = gz.clone()
+        gz_tot[0] += ga0[:, xd:]
         _close(gz_tot, zq.grad, "grad z")
     for k, (a, m) in enumerate(zip(gp, [q for mm in lin for q in (mm.weight, mm.bias)])):
         _close(a, m.grad, f"grad param {k}")
@@ -485,11 +489,13 @@ def test_backward_edge_sizes(B, Tn, kernel):
         _close(a, b, f"grad param {k}")
 
 
-def test_dae_backward_without_z_and_odd_widths():
-    """DAE generic backward with z_dim = 0 and non-multiple-of-16 widths (raw-tensor API) vs fp64 autograd of the oracle loop."""
+@pytest.mark.parametrize("xd,zd,vd,idim,H", [(5, 0, 3, 2, 24), (8, 4, 6, 6, 64), (12, 3, 4, 9, 40), (20, 10, 20, 10, 64)])
+def test_dae_backward_without_z_and_odd_widths(xd, zd, vd, idim, H):
+    """DAE generic backward with z_dim = 0 and non-multiple-of-16 widths (raw-tensor API) vs fp64 autograd of the oracle loop; round 6: the
+    shapes outside K7f's classes (z + v + i > 8, x_dim > 8) with the DE on K5's register path, and 180 input columns (staged path)."""
     from oracle import psnode_oracle as O
     from py_psnode_amd import fused
-    B, Tn, xd, zd, vd, idim, H = 9, 6, 5, 0, 3, 2, 24
+    B, Tn = 9, 6
     g = torch.Generator().manual_seed(77)
     torch.manual_seed(77)
     n = xd + zd + vd + idim
