@@ -289,6 +289,21 @@ __host__ __device__ inline QOff q_offsets(const GMlp& m) {
     return q;
 }
 
+// Register path with the accumulators in LDS: the DE's weight gradients are kept TILE-MAJOR -- [tile = mt * ntk + kt][lane][4], the MFMA D layout:
+// one ds_read_b128 + one ds_write_b128 per tile instead of four predicated b32 read-modify-writes (13 of 77 ms at x_dim 20, hidden 64) -- and
+// un-permuted into nn.Linear order once, when the workgroup's partial is written out.  Per layer: 16 x 16 tiles padded, then all the biases.
+__host__ __device__ inline int tm_dw_off(const GMlp& m, int l) {
+    int o = 0, k = m.in_dim;
+    for (int q = 0; q < l; ++q) { o += up16(m.out_dim[q]) * up16(k); k = m.out_dim[q]; }
+    return o;
+}
+__host__ __device__ inline int tm_db_off(const GMlp& m, int l) {
+    int o = tm_dw_off(m, m.L);
+    for (int q = 0; q < l; ++q) o += m.out_dim[q];
+    return o;
+}
+__host__ __device__ inline int tm_total(const GMlp& m) { return (tm_db_off(m, m.L) + 3) & ~3; }
+
 // forward with stored activations, the DE in registers: acts[act[0]] = input rows; writes acts[act[l + 1]] and the quad-row copies
 __device__ __forceinline__ void g_forward_reg(const GBwd& a, float* acts, float* qb, const QOff& qo, const RegFwd& fw) {
     const GMlp& m = a.de;
@@ -343,30 +358,39 @@ __device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, fl
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
         const float* a_in = acts + m.act[l] * TP;
         // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr],  db[j] += sum_tr delta[j][tr]      (as g_vjp)
-        float* gw_l = gacc_l + m.gw[l];
         float* gw_g = gacc_g + m.gw[l];
+        float* tw = gacc_l + tm_dw_off(m, l);            // (!gg) tile-major accumulators of this layer
         const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
-        for (int tile = wave; tile < ntiles; tile += 4) {
+#ifndef PSNODE_K5_ABL
+#define PSNODE_K5_ABL 0      // timing-only builds: 1 = no accumulation into gacc, 2 = no weight-gradient tiles at all, 3 = no forward recomputation
+#endif
+        for (int tile = wave; tile < (PSNODE_K5_ABL == 2 ? 0 : ntiles); tile += 4) {
             const int mt = tile / ntk, kt = tile % ntk;
             const int ju = 16 * mt + i, ku = 16 * kt + i;
+            // MFMA step q contracts the trajectories 4 g + q (slot g): a lane's four operands are ONE 16-byte read of its row (TP = 20 floats:
+            // 80-byte rows, 16-byte aligned)
+            const f4 dv = *reinterpret_cast<const f4*>(din + (ju < N ? ju : N - 1) * TP + 4 * g);
+            const f4 av = *reinterpret_cast<const f4*>(a_in + (ku < K ? ku : K - 1) * TP + 4 * g);
             f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tr = 4 * q + g;
-                const float dv = din[(ju < N ? ju : N - 1) * TP + tr], av = a_in[(ku < K ? ku : K - 1) * TP + tr];
-                acc = gm(ju < N ? dv : 0.0f, ku < K ? av : 0.0f, acc);
-            }
+            for (int q = 0; q < 4; ++q) acc = gm(ju < N ? dv[q] : 0.0f, ku < K ? av[q] : 0.0f, acc);
+            if (PSNODE_K5_ABL == 1) { if (acc[0] == 123.456f) tw[0] = acc[0]; continue; }
+            if constexpr (gg) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jr = 16 * mt + 4 * g + r;
-                if (jr < N && ku < K) { if constexpr (gg) gw_g[jr * K + ku] += acc[r]; else gw_l[jr * K + ku] += acc[r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const int jr = 16 * mt + 4 * g + r;
+                    if (jr < N && ku < K) gw_g[jr * K + ku] += acc[r];
+                }
+            } else {
+                f4* t4 = reinterpret_cast<f4*>(tw) + tile * 64 + lane;      // rows / columns beyond the matrix accumulate zeros
+                *t4 = *t4 + acc;
             }
         }
         for (int jj = tid; jj < N; jj += NT) {
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < TB; ++c) s += din[jj * TP + c];
-            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[m.gb[l] + jj] += s;
+            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
         }
         // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers): tiles over k, A operands (W^T) in registers
         const int SN = (N + 15) >> 4, NTK = (K + 15) >> 4;
@@ -428,9 +452,10 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // [np_de + np_ae]: in LDS when it fits, else this workgroup's partial slice in global memory (each element is owned by
     // one thread either way, so the read-modify-write needs no atomics)
     float* gacc_g = a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0));      // (used when gg)
-    float* gacc_l = wbuf + kWBuf;                                                          // (used when !gg)
+    float* gacc_l = wbuf + ((REG && !a.dae) ? 0 : kWBuf);     // (used when !gg; an ODE on the register path stages no weights: no wbuf)
     // register path of the DE: quad-row buffers behind the accumulators, the wave's MFMA operands of both passes in VGPRs
-    const int np_all = a.de.np + (a.dae ? a.ae.np : 0);
+    const int de_acc = (REG && !gg) ? tm_total(a.de) : a.de.np;      // floats of the DE's accumulators in LDS (tile-major on the register path)
+    const int np_all = de_acc + (a.dae ? a.ae.np : 0);
     float* qb = gacc_l + (gg ? 0 : ((np_all + 3) & ~3));
     const QOff qo = q_offsets(a.de);
     RegFwd rfw;
@@ -445,7 +470,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // loops over [rows][TB] tiles: idx -> (r, c)
 #define TILE_LOOP(rows) for (int idx = tid, r = tid / TB, c = tid % TB; idx < (rows) * TB; idx += NT, r = idx / TB, c = idx % TB)
 
-    for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) { if constexpr (gg) gacc_g[e] = 0.0f; else gacc_l[e] = 0.0f; }
+    for (int e = tid; e < (gg ? a.de.np + (dae ? a.ae.np : 0) : np_all); e += NT) { if constexpr (gg) gacc_g[e] = 0.0f; else gacc_l[e] = 0.0f; }
     TILE_LOOP(n) { a0s[r * TP + c] = a.a0[gb(c) * n + r]; ga0s[r * TP + c] = 0.0f; }
     TILE_LOOP(xd) gxc[r * TP + c] = on(c) ? a.gxs[((a.T - 1) * a.B + gb(c)) * xd + r] : 0.0f;
     TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[((a.T - 1) * a.B + gb(c)) * id + r] : 0.0f;
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = g_vjp<gg>(a.ae, acts, dA, dB, gacc_l + a.de.np, gacc_g + a.de.np, wbuf);
+        const float* gu = g_vjp<gg>(a.ae, acts, dA, dB, gacc_l + de_acc, gacc_g + a.de.np, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
         TILE_LOOP(nzv) {
@@ -561,7 +586,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         __syncthreads();
         for (int s = S - 1; s >= 0; --s) {
             de_input(xst + s * nx);
-            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw); else g_forward(a.de, acts, wbuf);
+            if constexpr (REG) { if (PSNODE_K5_ABL != 3) g_forward_reg(a, acts, qb, qo, rfw); } else g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
             const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, gacc_g, qb, qo, rbw) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf);
@@ -613,8 +638,22 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
-    if constexpr (!gg)
-        for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc_l[e];
+    if constexpr (!gg) {
+        if constexpr (REG) {        // the DE's tile-major accumulators -> nn.Linear order
+            for (int l = 0; l < a.de.L; ++l) {
+                const int N = a.de.out_dim[l], K = l ? a.de.out_dim[l - 1] : a.de.in_dim, ntk = (K + 15) / 16;
+                const float* tw = gacc_l + tm_dw_off(a.de, l);
+                for (int e = tid; e < N * K; e += NT) {
+                    const int j = e / K, k = e % K;
+                    wp[a.de.gw[l] + e] = tw[(((j >> 4) * ntk + (k >> 4)) * 64 + ((j & 15) >> 2) * 16 + (k & 15)) * 4 + (j & 3)];
+                }
+                for (int e = tid; e < N; e += NT) wp[a.de.gb[l] + e] = gacc_l[tm_db_off(a.de, l) + e];
+            }
+            for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) wp[a.de.np + e] = gacc_l[de_acc + e];
+        } else {
+            for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc_l[e];
+        }
+    }
 #undef TILE_LOOP
 }
 
@@ -642,9 +681,9 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
-    const size_t np_all = (size_t)a.de.np + (a.dae ? a.ae.np : 0);
+    const size_t np_all = (size_t)((a.de_reg && !a.gacc_global) ? tm_total(a.de) : a.de.np) + (a.dae ? a.ae.np : 0);
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + kWBuf + (a.gacc_global ? 0 : ((np_all + 3) & ~(size_t)3)) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
+           (size_t)id * TP + TP + ((a.de_reg && !a.dae) ? 0 : kWBuf) + (a.gacc_global ? 0 : ((np_all + 3) & ~(size_t)3)) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
 }
 // the DE's shape class of the register path
 bool de_reg_class(const psnode_mlp_f32& de) {
