@@ -705,14 +705,11 @@ size_t reg_image_floats(const psnode_mlp_f32& de) {       // plain + transposed 
 // allows the register path) is kept when its quad-row buffers fit next to the LDS accumulators, else dropped.
 int gbwd_mode(GBwd& a) {
     const int want_reg = a.de_reg;
-    for (int reg = want_reg; reg >= 0; --reg) {
+    for (int reg = want_reg; reg >= 0; --reg) {          // register path first: with LDS accumulators, else with global ones
         a.de_reg = reg;
         a.gacc_global = 0;
         if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
-    }
-    a.gacc_global = 1;
-    for (int reg = want_reg; reg >= 0; --reg) {
-        a.de_reg = reg;
+        a.gacc_global = 1;
         if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
     }
     return 0;
