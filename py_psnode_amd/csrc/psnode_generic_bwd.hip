@@ -48,7 +48,8 @@ struct GBwd {
     const float *xs, *is_, *gxs, *gis;
     float *gx0, *gz, *gv, *gzj, *gvj, *ga0, *wpart;
     int maxw, act_rows;
-    int gacc_global;   // parameter-gradient accumulators in this workgroup's slice of wpart (global, L2) instead of LDS
+    int gacc_global;   // parameter-gradient accumulators in this workgroup's slice of wpart (global, L2) instead of LDS: 0 = none,
+                       // 1 = both MLPs', 2 = the AE's only (register path of a DAE: the DE's tile-major accumulators stay in LDS)
     // register path of the DE (round 6): <= 4 layers of <= 64 units, 3 n <= 128 input columns.  Plain and transposed MFMA images (workspace;
     // psnode_generic.hip: launch_pack_plain_images); the wave's A operands of both stay in VGPRs for the launch.
     int de_reg;
@@ -422,7 +423,8 @@ __device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, fl
     return din;
 }
 
-template <bool gg, bool REG>
+// gg / ggA: the DE's / the AE's accumulators live in the workgroup's global slice
+template <bool gg, bool REG, bool ggA = gg>
 __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -455,8 +457,9 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     float* gacc_l = wbuf + ((REG && !a.dae) ? 0 : kWBuf);     // (used when !gg; an ODE on the register path stages no weights: no wbuf)
     // register path of the DE: quad-row buffers behind the accumulators, the wave's MFMA operands of both passes in VGPRs
     const int de_acc = (REG && !gg) ? tm_total(a.de) : a.de.np;      // floats of the DE's accumulators in LDS (tile-major on the register path)
-    const int np_all = de_acc + (a.dae ? a.ae.np : 0);
-    float* qb = gacc_l + (gg ? 0 : ((np_all + 3) & ~3));
+    const int ae_at = gg ? 0 : de_acc;                                 // the AE's accumulators in LDS (when !ggA) sit behind the DE's
+    const int np_all = ae_at + ((a.dae && !ggA) ? a.ae.np : 0);       // floats of LDS accumulators
+    float* qb = gacc_l + ((np_all + 3) & ~3);
     const QOff qo = q_offsets(a.de);
     RegFwd rfw;
     RegBwd rbw;
@@ -470,7 +473,9 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // loops over [rows][TB] tiles: idx -> (r, c)
 #define TILE_LOOP(rows) for (int idx = tid, r = tid / TB, c = tid % TB; idx < (rows) * TB; idx += NT, r = idx / TB, c = idx % TB)
 
-    for (int e = tid; e < (gg ? a.de.np + (dae ? a.ae.np : 0) : np_all); e += NT) { if constexpr (gg) gacc_g[e] = 0.0f; else gacc_l[e] = 0.0f; }
+    for (int e = tid; e < np_all; e += NT) gacc_l[e] = 0.0f;
+    if constexpr (gg) for (int e = tid; e < a.de.np; e += NT) gacc_g[e] = 0.0f;
+    if constexpr (ggA) for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) gacc_g[a.de.np + e] = 0.0f;
     TILE_LOOP(n) { a0s[r * TP + c] = a.a0[gb(c) * n + r]; ga0s[r * TP + c] = 0.0f; }
     TILE_LOOP(xd) gxc[r * TP + c] = on(c) ? a.gxs[((a.T - 1) * a.B + gb(c)) * xd + r] : 0.0f;
     TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[((a.T - 1) * a.B + gb(c)) * id + r] : 0.0f;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = g_vjp<gg>(a.ae, acts, dA, dB, gacc_l + de_acc, gacc_g + a.de.np, wbuf);
+        const float* gu = g_vjp<ggA>(a.ae, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
         TILE_LOOP(nzv) {
@@ -638,6 +643,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
+    if constexpr (!ggA)
+        for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) wp[a.de.np + e] = gacc_l[ae_at + e];
     if constexpr (!gg) {
         if constexpr (REG) {        // the DE's tile-major accumulators -> nn.Linear order
             for (int l = 0; l < a.de.L; ++l) {
@@ -649,9 +656,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
                 }
                 for (int e = tid; e < N; e += NT) wp[a.de.gb[l] + e] = gacc_l[tm_db_off(a.de, l) + e];
             }
-            for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) wp[a.de.np + e] = gacc_l[de_acc + e];
         } else {
-            for (int e = tid; e < a.de.np + (dae ? a.ae.np : 0); e += NT) wp[e] = gacc_l[e];
+            for (int e = tid; e < a.de.np; e += NT) wp[e] = gacc_l[e];
         }
     }
 #undef TILE_LOOP
@@ -681,9 +687,10 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
-    const size_t np_all = (size_t)((a.de_reg && !a.gacc_global) ? tm_total(a.de) : a.de.np) + (a.dae ? a.ae.np : 0);
+    const size_t de_acc = a.gacc_global == 1 ? 0 : (size_t)(a.de_reg ? tm_total(a.de) : a.de.np);
+    const size_t np_all = de_acc + ((a.dae && a.gacc_global == 0) ? a.ae.np : 0);
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + ((a.de_reg && !a.dae) ? 0 : kWBuf) + (a.gacc_global ? 0 : ((np_all + 3) & ~(size_t)3)) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
+           (size_t)id * TP + TP + ((a.de_reg && !a.dae) ? 0 : kWBuf) + ((np_all + 3) & ~(size_t)3) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
 }
 // the DE's shape class of the register path
 bool de_reg_class(const psnode_mlp_f32& de) {
@@ -705,10 +712,14 @@ size_t reg_image_floats(const psnode_mlp_f32& de) {       // plain + transposed 
 // allows the register path) is kept when its quad-row buffers fit next to the LDS accumulators, else dropped.
 int gbwd_mode(GBwd& a) {
     const int want_reg = a.de_reg;
-    for (int reg = want_reg; reg >= 0; --reg) {          // register path first: with LDS accumulators, else with global ones
+    for (int reg = want_reg; reg >= 0; --reg) {          // register path first: LDS accumulators, the AE's in the global slice, both there
         a.de_reg = reg;
         a.gacc_global = 0;
         if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
+        if (reg && a.dae) {
+            a.gacc_global = 2;
+            if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
+        }
         a.gacc_global = 1;
         if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
     }
@@ -817,7 +828,8 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     if (dae) to_dev(a.ae, mae);
     if (launch_pack_transpose(mde, dae ? &mae : nullptr, stream) != hipSuccess) return PSNODE_ERR_HIP;
     if (a.de_reg && launch_pack_plain_images(mde, img, imgT, stream) != hipSuccess) return PSNODE_ERR_HIP;
-    auto kern = a.de_reg ? (a.gacc_global ? &generic_backward_kernel<true, true> : &generic_backward_kernel<false, true>)
+    auto kern = a.de_reg ? (a.gacc_global == 1 ? &generic_backward_kernel<true, true> : (a.gacc_global == 2 ? &generic_backward_kernel<false, true, true>
+                                                                                                              : &generic_backward_kernel<false, true>))
                          : (a.gacc_global ? &generic_backward_kernel<true, false> : &generic_backward_kernel<false, false>);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PSNODE_ERR_HIP;
