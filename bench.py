@@ -562,6 +562,9 @@ TRAIN_EXTRAS = [("ode01", "rk4", 64), ("dae01", "rk4", 64), ("ode01", "euler", 6
 def backward_kernel_name(fused, w, p, method):
     """Which backward kernel AUTO runs for a saved-activation training step of this workload (round 6: K4x, the one-wave-per-4-trajectories
     backward, takes the ODE at hidden 33..64 up to 4608 trajectories per GPU; K4f / K7f otherwise)."""
+    mfma_class = (w["xd"] <= 16 and w["zd"] <= 8) if w["kind"] == "ode" else (w["xd"] <= 8 and w["zd"] + w["vd"] + w["id"] <= 8)
+    if not mfma_class:
+        return "k5"           # the generic backward (register path of the DE since round 6)
     if w["kind"] == "dae":
         return "k7f+k7h"
     return "k4x" if (w["B"] <= 4608 and fused.ode_backward_supported(method, p["de"], w["xd"], w["zd"], "wave")) else "k4f"
@@ -627,6 +630,8 @@ MODEL_TRAIN_EXTRAS = [("dae02", "rk4"), ("dae02", "euler"), ("ode02", "rk4")]
 MODEL_H128_EXTRAS = [("ode02", "euler", 128), ("dae02", "euler", 128)]
 # round 6, last: shapes without a specialisation, on the generic integrator K0 (register form)
 GENERIC_EXTRAS = [("ode01_x20", "rk4", "x_dim 20: generic integrator K0"), ("dae01_zvi16", "rk4", "z + v + i = 16: generic integrator K0")]
+# ... and a training step on them: K0 forward + K6 loss + the generic backward K5 (Euler: the scripts' solver)
+GENERIC_TRAIN_EXTRAS = [("ode01_x20", "euler", 64)]
 
 
 def safe_line(label, fn):
@@ -1101,6 +1106,9 @@ def main():
                     res["extra"].append(safe_line(f"{wl} {m} MODEL TRAIN H{h}", lambda: model_train_extra_line(wl, m, dev, steps=3, warmup=2, hidden=h)))
             for wl, m, n in GENERIC_EXTRAS:
                 res["extra"].append(safe_line(f"{wl} {m}", lambda: extra_line(lib, _lib, fused, wl, m, dev, steps=3, warmup=2, note=n)))
+            if not args.no_train_extras:
+                for wl, m, h in GENERIC_TRAIN_EXTRAS:
+                    res["extra"].append(safe_line(f"{wl} {m} TRAIN", lambda: train_extra_line(fused, wl, m, h, dev, steps=3, warmup=2)))
             outs = (out0,)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, p_cpu, args.method, gpu_out=None if args.train else outs[0])
