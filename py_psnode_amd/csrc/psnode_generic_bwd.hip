@@ -539,17 +539,50 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         __syncthreads();
     };
 
+    // Look-ahead (round 6): the rows a step reads from HBM -- the clocks, the dataset z | v, xs[k], the incoming gradient of grid point k --
+    // are requested one step early into registers (items tid + 256 j, j < LA: up to 32 rows each; rows beyond that are loaded where they are
+    // used), so that their latency hides behind the previous step instead of standing at the top and the bottom of every step.
+    constexpr int LA = 2;
+    float la_x[LA], la_g[LA], la_zv[LA], la_t = 0.0f, la_tn = 0.0f;
+    auto look_ahead = [&](long long kk) {       // grid point kk >= 0
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int idx = tid + NT * j;
+            const int ix = idx < xd * TB ? idx : 0, rx = ix / TB, cx = ix % TB;
+            la_x[j] = a.xs[(kk * a.B + gb(cx)) * xd + rx];
+            la_g[j] = a.gxs[(kk * a.B + gb(cx)) * xd + rx];
+            const int iz = idx < nzv * TB ? idx : 0, rz = iz / TB;
+            const long long b = gb(iz % TB);
+            la_zv[j] = nzv == 0 ? 0.0f : (rz < zd ? a.z.p[kk * a.z.st + b * a.z.sb + rz] : a.v.p[kk * a.v.st + b * a.v.sb + (rz - zd)]);
+        }
+        if (tid < TB) la_t = a.t.p[kk * a.t.st + gb(tid) * a.t.sb];
+    };
+    if (a.T >= 2) {
+        if (tid < TB) la_tn = a.t.p[(a.T - 1) * a.t.st + gb(tid) * a.t.sb];
+        look_ahead(a.T - 2);
+    }
     for (long long k = a.T - 2; k >= 0; --k) {
         const int ev = a.ev ? a.ev[k] : -1;
-        if (tid < TB) dts[tid] = a.t.p[(k + 1) * a.t.st + gb(tid) * a.t.sb] - a.t.p[k * a.t.st + gb(tid) * a.t.sb];
+        if (tid < TB) dts[tid] = la_tn - la_t;
+        float gx_in[LA];                             // the incoming gradient of grid point k, consumed at the bottom of the step
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int idx = tid + NT * j;
+            gx_in[j] = la_g[j];
+            if (idx < xd * TB) x0[(idx / TB) * TP + idx % TB] = la_x[j];
+            if (idx < nzv * TB && ev < 0) ext[(idx / TB) * TP + idx % TB] = la_zv[j];
+        }
+        for (int idx = tid + NT * LA; idx < xd * TB; idx += NT) x0[(idx / TB) * TP + idx % TB] = a.xs[(k * a.B + gb(idx % TB)) * xd + idx / TB];
         TILE_LOOP(nzv) {
+            if (ev < 0 && idx < NT * LA) continue;                                      // (came through the look-ahead registers)
             const long long b = gb(c);
             float v;
             if (r < zd) v = ev >= 0 ? a.zj[b * a.zjb + ev * a.zje + r] : a.z.p[k * a.z.st + b * a.z.sb + r];
             else v = ev >= 0 ? a.vj[b * a.vjb + ev * a.vje + (r - zd)] : a.v.p[k * a.v.st + b * a.v.sb + (r - zd)];
             ext[r * TP + c] = v;
         }
-        TILE_LOOP(xd) x0[r * TP + c] = a.xs[(k * a.B + gb(c)) * xd + r];
+        if (tid < TB) la_tn = la_t;
+        if (k > 0) look_ahead(k - 1);
         __syncthreads();
         if (dae) {
             // (1) AE head at the end of step k: i_{k+1} = g(x_{k+1}; z[k+1], v[k+1]) carries gic
@@ -632,7 +665,15 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             }
         }
         __syncthreads();
-        TILE_LOOP(xd) gxc[r * TP + c] = gx0[r * TP + c] + (on(c) ? a.gxs[(k * a.B + gb(c)) * xd + r] : 0.0f);
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int idx = tid + NT * j;
+            if (idx < xd * TB) gxc[(idx / TB) * TP + idx % TB] = gx0[(idx / TB) * TP + idx % TB] + (on(idx % TB) ? gx_in[j] : 0.0f);
+        }
+        for (int idx = tid + NT * LA; idx < xd * TB; idx += NT) {
+            const int r = idx / TB, c = idx % TB;
+            gxc[r * TP + c] = gx0[r * TP + c] + (on(c) ? a.gxs[(k * a.B + gb(c)) * xd + r] : 0.0f);
+        }
         __syncthreads();
     }
     if (dae) {   // i_0 = g(x_0; z[0], v[0])   (my_solvers.py:95)
