@@ -53,8 +53,13 @@ struct GBwd {
     // register path of the DE (round 6): <= 4 layers of <= 64 units, 3 n <= 128 input columns.  Plain and transposed MFMA images (workspace;
     // psnode_generic.hip: launch_pack_plain_images); the wave's A operands of both stay in VGPRs for the launch.
     int de_reg;
-    const float* fimg[4];
-    const float* timg[4];
+    const float* fimg[kMaxLayers];
+    const float* timg[kMaxLayers];
+    // streamed path (round 6): the MLPs that are not on the register path -- str 1: the AE head of a DAE whose DE is, 2: both MLPs -- read
+    // their MFMA A operands from the same kind of images (L2-resident), one chunk ahead; no staging through LDS
+    int str;
+    const float* fimgA[kMaxLayers];
+    const float* timgA[kMaxLayers];
 };
 
 __device__ __forceinline__ float delu(float h) { return elu_grad(h); }   // ELU'(pre) from h = ELU(pre)
@@ -273,13 +278,13 @@ __device__ __forceinline__ void load_reg_images(const GBwd& a, RegFwd& fw, RegBw
 }
 
 // quad-row buffers of the register path (float offsets from qb): the DE input, the hidden activations, two delta buffers
-struct QOff { int in, act[3], d0, d1, total; };
+struct QOff { int in, act[kMaxLayers - 1], d0, d1, total; };
 __host__ __device__ inline QOff q_offsets(const GMlp& m) {
     QOff q;
     int o = 0;
     q.in = o; o += up16(m.in_dim) * TB;
     int mx = 16;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < kMaxLayers - 1; ++l) {
         q.act[l] = o;
         if (l + 1 < m.L) o += up16(m.out_dim[l]) * TB;
     }
@@ -309,9 +314,10 @@ __host__ __device__ inline int tm_total(const GMlp& m) { return (tm_db_off(m, m.
 __device__ __forceinline__ void g_forward_reg(const GBwd& a, float* acts, float* qb, const QOff& qo, const RegFwd& fw) {
     const GMlp& m = a.de;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, j = lane & 15;
-    {   // the input rows -> quad-row (the pad columns were zeroed at kernel start)
+    {   // the input rows -> quad-row, pad columns zero
         const float* u = acts + m.act[0] * TP;
-        for (int idx = tid; idx < m.in_dim * TB; idx += NT) qb[qo.in + qi(idx / TB, idx % TB)] = u[(idx / TB) * TP + idx % TB];
+        for (int idx = tid; idx < up16(m.in_dim) * TB; idx += NT)
+            qb[qo.in + qi(idx / TB, idx % TB)] = idx / TB < m.in_dim ? u[(idx / TB) * TP + idx % TB] : 0.0f;
         __syncthreads();
     }
 #pragma unroll
@@ -423,9 +429,138 @@ __device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, fl
     return din;
 }
 
-// gg / ggA: the DE's / the AE's accumulators live in the workgroup's global slice
-template <bool gg, bool REG, bool ggA = gg>
+// ---- streamed path: one output tile with its A operands read from the image (L2), one chunk of four quads ahead of the MFMAs that use
+// them; B operands from the quad-row buffer.  (The loads are unconditional on clamped addresses: see psnode_generic.hip, mlp_eval.)
+__device__ __forceinline__ f4 tile_stream(const f4* __restrict__ A, const int S4, const f4* bq) {
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+    f4 nxt[4];
+    auto fetch4 = [&](int q0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nxt[c] = A[(q0 + c < S4 ? q0 + c : S4 - 1) * 64];
+    };
+    fetch4(0);
+    for (int q0 = 0; q0 < S4; q0 += 4) {
+        f4 cur[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+        fetch4(q0 + 4 < S4 ? q0 + 4 : S4 - 1);
+        if (q0 + 4 <= S4) {
+            f4 bv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = bq[(q0 + c) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mfma_quad(cur[c], bv[c], (c & 1) ? acc2 : acc);
+        } else {
+            for (int c = 0; q0 + c < S4; ++c) mfma_quad(c == 0 ? cur[0] : (c == 1 ? cur[1] : cur[2]), bq[(q0 + c) * 64], acc);
+        }
+    }
+    return acc + acc2;
+}
+
+// forward with stored activations, streamed: acts[act[0]] = input rows; writes acts[act[l + 1]] and the quad-row copies
+__device__ __forceinline__ void g_forward_str(const GMlp& m, const float* const* fimg, float* acts, float* qb, const QOff& qo) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, j = lane & 15;
+    {
+        const float* u = acts + m.act[0] * TP;
+        for (int idx = tid; idx < up16(m.in_dim) * TB; idx += NT)
+            qb[qo.in + qi(idx / TB, idx % TB)] = idx / TB < m.in_dim ? u[(idx / TB) * TP + idx % TB] : 0.0f;
+        __syncthreads();
+    }
+    for (int l = 0; l < m.L; ++l) {
+        const int K = l ? m.out_dim[l - 1] : m.in_dim, N = m.out_dim[l];
+        const int S4 = (K + 15) >> 4, NTL = (N + 15) >> 4;
+        const bool last = (l + 1 == m.L);
+        const f4* bq = reinterpret_cast<const f4*>(qb + (l ? qo.act[l - 1] : qo.in)) + lane;
+        float* out = acts + m.act[l + 1] * TP;
+        for (int nt = w; nt < NTL; nt += 4) {
+            const f4 bias = *reinterpret_cast<const f4*>(fimg[l] + (size_t)NTL * S4 * 256 + 16 * nt + 4 * g);
+            f4 acc = tile_stream(reinterpret_cast<const f4*>(fimg[l]) + (size_t)nt * S4 * 64 + lane, S4, bq) + bias;
+            const f4 e = last ? acc : elu_quad(acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int uu = 16 * nt + 4 * g + r;
+                if (uu < N) out[uu * TP + j] = e[r];
+            }
+            if (!last) reinterpret_cast<f4*>(qb + qo.act[l])[nt * 64 + lane] = e;
+        }
+        __syncthreads();
+    }
+}
+
+// VJP, streamed: weight gradients as on the register path (tile-major LDS accumulators at gacc_l when !gg), delta propagation on the
+// transposed images
+template <bool gg>
+__device__ __forceinline__ float* g_vjp_str(const GMlp& m, const float* const* timg, const float* acts, float* din, float* dout, float* gacc_l,
+                                            float* gacc_g, float* qb, const QOff& qo) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    int qd = qo.d0, qn = qo.d1;
+    {
+        const int N = m.out_dim[m.L - 1];
+        for (int idx = tid; idx < up16(N) * TB; idx += NT) qb[qd + qi(idx / TB, idx % TB)] = idx / TB < N ? din[(idx / TB) * TP + idx % TB] : 0.0f;
+        __syncthreads();
+    }
+    for (int l = m.L - 1; l >= 0; --l) {
+        const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
+        const float* a_in = acts + m.act[l] * TP;
+        float* gw_g = gacc_g + m.gw[l];
+        float* tw = gacc_l + tm_dw_off(m, l);
+        const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            const int mt = tile / ntk, kt = tile % ntk;
+            const int ju = 16 * mt + i, ku = 16 * kt + i;
+            const f4 dv = *reinterpret_cast<const f4*>(din + (ju < N ? ju : N - 1) * TP + 4 * g);
+            const f4 av = *reinterpret_cast<const f4*>(a_in + (ku < K ? ku : K - 1) * TP + 4 * g);
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = gm(ju < N ? dv[q] : 0.0f, ku < K ? av[q] : 0.0f, acc);
+            if constexpr (gg) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jr = 16 * mt + 4 * g + r;
+                    if (jr < N && ku < K) gw_g[jr * K + ku] += acc[r];
+                }
+            } else {
+                f4* t4 = reinterpret_cast<f4*>(tw) + tile * 64 + lane;
+                *t4 = *t4 + acc;
+            }
+        }
+        for (int jj = tid; jj < N; jj += NT) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < TB; ++c) s += din[jj * TP + c];
+            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
+        }
+        const int SN = (N + 15) >> 4, NTK = (K + 15) >> 4;
+        const f4* bq = reinterpret_cast<const f4*>(qb + qd) + lane;
+        for (int kt = w; kt < NTK; kt += 4) {
+            f4 acc = tile_stream(reinterpret_cast<const f4*>(timg[l]) + (size_t)kt * SN * 64 + lane, SN, bq);
+            asm volatile("s_nop 3" : "+v"(acc));       // (as on the register path: the store below may sit on a taken branch edge)
+            if (l > 0) {
+                const f4 h = reinterpret_cast<const f4*>(qb + qo.act[l - 1])[kt * 64 + lane];
+                acc = acc * elu_grad_quad(h);
+                reinterpret_cast<f4*>(qb + qn)[kt * 64 + lane] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kr = 16 * kt + 4 * g + r;
+                if (kr < K) dout[kr * TP + i] = acc[r];
+            }
+        }
+        __syncthreads();
+        { float* tmp = din; din = dout; dout = tmp; }
+        { const int t_ = qd; qd = qn; qn = t_; }
+    }
+    return din;
+}
+
+// gg / ggA: the DE's / the AE's accumulators live in the workgroup's global slice.  REG: the DE on the register path.  STR: 1 = the AE
+// head streamed, 2 = both MLPs streamed (0: whatever is not on the register path stages its weights through LDS).
+template <bool gg, bool REG, bool ggA = gg, int STR = 0>
 __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
+    constexpr bool DE_TM = REG || STR == 2;      // the DE's LDS accumulators are tile-major
+    constexpr bool AE_TM = STR >= 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * TB;
@@ -454,19 +589,18 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // [np_de + np_ae]: in LDS when it fits, else this workgroup's partial slice in global memory (each element is owned by
     // one thread either way, so the read-modify-write needs no atomics)
     float* gacc_g = a.wpart + (size_t)blockIdx.x * (a.de.np + (a.dae ? a.ae.np : 0));      // (used when gg)
-    float* gacc_l = wbuf + ((REG && !a.dae) ? 0 : kWBuf);     // (used when !gg; an ODE on the register path stages no weights: no wbuf)
+    const bool stages = (!REG && STR != 2) || (a.dae && STR == 0);      // some MLP still stages its weights through LDS
+    float* gacc_l = wbuf + (stages ? kWBuf : 0);
     // register path of the DE: quad-row buffers behind the accumulators, the wave's MFMA operands of both passes in VGPRs
-    const int de_acc = (REG && !gg) ? tm_total(a.de) : a.de.np;      // floats of the DE's accumulators in LDS (tile-major on the register path)
+    const int de_acc = (DE_TM && !gg) ? tm_total(a.de) : a.de.np;      // floats of the DE's accumulators in LDS (tile-major off the staged path)
     const int ae_at = gg ? 0 : de_acc;                                 // the AE's accumulators in LDS (when !ggA) sit behind the DE's
-    const int np_all = ae_at + ((a.dae && !ggA) ? a.ae.np : 0);       // floats of LDS accumulators
+    const int ae_acc = (AE_TM && !ggA) ? tm_total(a.ae) : a.ae.np;
+    const int np_all = ae_at + ((a.dae && !ggA) ? ae_acc : 0);        // floats of LDS accumulators
     float* qb = gacc_l + ((np_all + 3) & ~3);
-    const QOff qo = q_offsets(a.de);
+    const QOff qo = q_offsets(a.de), qoA = q_offsets(a.ae);           // (one region: the two MLPs' evaluations never overlap in time)
     RegFwd rfw;
     RegBwd rbw;
-    if constexpr (REG) {
-        load_reg_images(a, rfw, rbw);
-        for (int e = tid; e < qo.total; e += NT) qb[e] = 0.0f;         // (the pad columns stay zero)
-    }
+    if constexpr (REG) load_reg_images(a, rfw, rbw);
 
     auto gb = [&](int c) -> long long { const long long b = b0 + c; return b < a.B ? b : a.B - 1; };
     auto on = [&](int c) -> bool { return b0 + c < a.B; };
@@ -517,10 +651,11 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     // adds to gx_dst, ga0s, and to the z|v gradients (global gz/gv at jzv, or the jump gradients of event ev)
     auto ae_vjp = [&](const float* xrows, long long jzv, int ev, const float* gi, float* gx_dst) {
         ae_input(xrows, jzv);
-        g_forward(a.ae, acts, wbuf);
+        if constexpr (STR >= 1) g_forward_str(a.ae, a.fimgA, acts, qb, qoA); else g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = g_vjp<ggA>(a.ae, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, wbuf);
+        const float* gu = STR >= 1 ? g_vjp_str<ggA>(a.ae, a.timgA, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, qb, qoA)
+                                   : g_vjp<ggA>(a.ae, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
         TILE_LOOP(nzv) {
@@ -592,7 +727,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             // (2) algebraic input of this step's DE
             if (ev >= 0) {
                 ae_input(x0, -1);
-                g_forward(a.ae, acts, wbuf);
+                if constexpr (STR >= 1) g_forward_str(a.ae, a.fimgA, acts, qb, qoA); else g_forward(a.ae, acts, wbuf);
                 const float* out = acts + a.ae.act[a.ae.L] * TP;
                 TILE_LOOP(id) ext[(nzv + r) * TP + c] = out[r * TP + c];
             } else {
@@ -609,7 +744,9 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             }
             __syncthreads();
             de_input(xst + s * nx);
-            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw); else g_forward(a.de, acts, wbuf);
+            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw);
+            else if constexpr (STR == 2) g_forward_str(a.de, a.fimg, acts, qb, qo);
+            else g_forward(a.de, acts, wbuf);
             const float* out = acts + a.de.act[a.de.L] * TP;
             TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
             __syncthreads();
@@ -624,10 +761,13 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         __syncthreads();
         for (int s = S - 1; s >= 0; --s) {
             de_input(xst + s * nx);
-            if constexpr (REG) { if (PSNODE_K5_ABL != 3) g_forward_reg(a, acts, qb, qo, rfw); } else g_forward(a.de, acts, wbuf);
+            if constexpr (REG) { if (PSNODE_K5_ABL != 3) g_forward_reg(a, acts, qb, qo, rfw); }
+            else if constexpr (STR == 2) g_forward_str(a.de, a.fimg, acts, qb, qo);
+            else g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
-            const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, gacc_g, qb, qo, rbw) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf);
+            const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, gacc_g, qb, qo, rbw)
+                                  : (STR == 2 ? g_vjp_str<gg>(a.de, a.timg, acts, dA, dB, gacc_l, gacc_g, qb, qo) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf));
             TILE_LOOP(n) {
                 const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
@@ -684,22 +824,27 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(xd) if (on(c)) a.gx0[(b0 + c) * xd + r] = gxc[r * TP + c];
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
-    if constexpr (!ggA)
-        for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) wp[a.de.np + e] = gacc_l[ae_at + e];
-    if constexpr (!gg) {
-        if constexpr (REG) {        // the DE's tile-major accumulators -> nn.Linear order
-            for (int l = 0; l < a.de.L; ++l) {
-                const int N = a.de.out_dim[l], K = l ? a.de.out_dim[l - 1] : a.de.in_dim, ntk = (K + 15) / 16;
-                const float* tw = gacc_l + tm_dw_off(a.de, l);
-                for (int e = tid; e < N * K; e += NT) {
-                    const int j = e / K, k = e % K;
-                    wp[a.de.gw[l] + e] = tw[(((j >> 4) * ntk + (k >> 4)) * 64 + ((j & 15) >> 2) * 16 + (k & 15)) * 4 + (j & 3)];
-                }
-                for (int e = tid; e < N; e += NT) wp[a.de.gb[l] + e] = gacc_l[tm_db_off(a.de, l) + e];
+    // the LDS accumulators -> this workgroup's partial in nn.Linear order (tile-major ones un-permuted)
+    auto unpermute = [&](const GMlp& m, const float* base, float* dst) {
+        for (int l = 0; l < m.L; ++l) {
+            const int N = m.out_dim[l], K = l ? m.out_dim[l - 1] : m.in_dim, ntk = (K + 15) / 16;
+            const float* tw = base + tm_dw_off(m, l);
+            for (int e = tid; e < N * K; e += NT) {
+                const int j = e / K, k = e % K;
+                dst[m.gw[l] + e] = tw[(((j >> 4) * ntk + (k >> 4)) * 64 + ((j & 15) >> 2) * 16 + (k & 15)) * 4 + (j & 3)];
             }
-        } else {
-            for (int e = tid; e < a.de.np; e += NT) wp[e] = gacc_l[e];
+            for (int e = tid; e < N; e += NT) dst[m.gb[l] + e] = base[tm_db_off(m, l) + e];
         }
+    };
+    if constexpr (!ggA) {
+        if (dae) {
+            if constexpr (AE_TM) unpermute(a.ae, gacc_l + ae_at, wp + a.de.np);
+            else for (int e = tid; e < a.ae.np; e += NT) wp[a.de.np + e] = gacc_l[ae_at + e];
+        }
+    }
+    if constexpr (!gg) {
+        if constexpr (DE_TM) unpermute(a.de, gacc_l, wp);
+        else for (int e = tid; e < a.de.np; e += NT) wp[e] = gacc_l[e];
     }
 #undef TILE_LOOP
 }
@@ -728,10 +873,15 @@ int fill_gmlp(const psnode_mlp_f32& m, GMlp& g, float*& ws) {
 
 size_t gbwd_lds_floats(const GBwd& a) {
     const int vd = a.dae ? a.vd : 0, id = a.dae ? a.id : 0, ne = a.zd + vd + id, n = a.xd + ne;
-    const size_t de_acc = a.gacc_global == 1 ? 0 : (size_t)(a.de_reg ? tm_total(a.de) : a.de.np);
-    const size_t np_all = de_acc + ((a.dae && a.gacc_global == 0) ? a.ae.np : 0);
+    const bool de_tm = a.de_reg || a.str == 2, ae_tm = a.str >= 1;
+    const size_t de_acc = a.gacc_global == 1 ? 0 : (size_t)(de_tm ? tm_total(a.de) : a.de.np);
+    const size_t np_all = de_acc + ((a.dae && a.gacc_global == 0) ? (size_t)(ae_tm ? tm_total(a.ae) : a.ae.np) : 0);
+    const bool stages = (!a.de_reg && a.str != 2) || (a.dae && a.str == 0);
+    size_t q = 0;
+    if (de_tm) q = (size_t)q_offsets(a.de).total;
+    if (a.dae && ae_tm && (size_t)q_offsets(a.ae).total > q) q = (size_t)q_offsets(a.ae).total;
     return (size_t)a.act_rows * TP + 2 * (size_t)a.maxw * TP + 2 * (size_t)n * TP + 2 * (size_t)ne * TP + (size_t)a.xd * TP * (1 + 12 + 2) +
-           (size_t)id * TP + TP + ((a.de_reg && !a.dae) ? 0 : kWBuf) + ((np_all + 3) & ~(size_t)3) + (a.de_reg ? (size_t)q_offsets(a.de).total : 0);
+           (size_t)id * TP + TP + (stages ? kWBuf : 0) + ((np_all + 3) & ~(size_t)3) + q;
 }
 // the DE's shape class of the register path
 bool de_reg_class(const psnode_mlp_f32& de) {
@@ -753,11 +903,16 @@ size_t reg_image_floats(const psnode_mlp_f32& de) {       // plain + transposed 
 // allows the register path) is kept when its quad-row buffers fit next to the LDS accumulators, else dropped.
 int gbwd_mode(GBwd& a) {
     const int want_reg = a.de_reg;
-    for (int reg = want_reg; reg >= 0; --reg) {          // register path first: LDS accumulators, the AE's in the global slice, both there
-        a.de_reg = reg;
+    // paths in order of preference: register DE (+ streamed AE head), everything streamed, then the staged paths; for each, the accumulators
+    // in LDS, the AE's in the global slice, both there
+    const int cand[4][2] = {{want_reg, a.dae ? 1 : 0}, {0, 2}, {want_reg, 0}, {0, 0}};      // {de_reg, str}
+    for (int c = 0; c < 4; ++c) {
+        if (c == 0 && !want_reg) continue;
+        if (c == 2 && (!want_reg || !a.dae)) continue;
+        a.de_reg = cand[c][0]; a.str = cand[c][1];
         a.gacc_global = 0;
         if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 1;
-        if (reg && a.dae) {
+        if (a.dae && (a.de_reg || a.str == 2)) {
             a.gacc_global = 2;
             if (gbwd_lds_floats(a) * sizeof(float) <= 160 * 1024) return 2;
         }
@@ -796,7 +951,7 @@ bool mlp_ok(const psnode_mlp_f32& m, int in_dim, int out_dim) {
 size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B) {
     const size_t nwg = (size_t)((B + TB - 1) / TB);
     return mlp_wt_floats(*de) + (ae ? mlp_wt_floats(*ae) : 0) + nwg * (size_t)(mlp_np(*de) + (ae ? mlp_np(*ae) : 0)) + 64 +
-           (de_reg_class(*de) ? reg_image_floats(*de) + 64 : 0);
+           reg_image_floats(*de) + 64 + (ae ? reg_image_floats(*ae) + 64 : 0);
 }
 
 int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd, int zd, int vd, int id) {
@@ -842,16 +997,19 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     a.n_events = n_events; a.xs = xs; a.is_ = is_; a.gxs = gxs; a.gis = gis; a.gx0 = gx0; a.gz = gz; a.gv = gv; a.gzj = gzj; a.gvj = gvj;
     a.ga0 = ga0;
     a.de_reg = de_reg_class(*de) ? 1 : 0;
-    float* img[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* imgT[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (a.de_reg) {             // the plain / transposed images sit in front of the per-workgroup partials
+    float* img[kMaxLayers] = {}, *imgT[kMaxLayers] = {}, *imgA[kMaxLayers] = {}, *imgTA[kMaxLayers] = {};
+    {                           // the plain / transposed images of both MLPs sit in front of the per-workgroup partials
         ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-        int k = de->in_dim;
-        for (int l = 0; l < de->n_layers; ++l) {
-            img[l] = ws; ws += (generic_image_floats(k, de->out_dim[l]) + 63) / 64 * 64;
-            imgT[l] = ws; ws += (generic_image_floats(de->out_dim[l], k) + 63) / 64 * 64;
-            a.fimg[l] = img[l]; a.timg[l] = imgT[l];
-            k = de->out_dim[l];
+        for (int m = 0; m < (dae ? 2 : 1); ++m) {
+            const psnode_mlp_f32* mm = m ? ae : de;
+            int k = mm->in_dim;
+            for (int l = 0; l < mm->n_layers; ++l) {
+                float* f = ws; ws += (generic_image_floats(k, mm->out_dim[l]) + 63) / 64 * 64;
+                float* t_ = ws; ws += (generic_image_floats(mm->out_dim[l], k) + 63) / 64 * 64;
+                if (m) { imgA[l] = f; imgTA[l] = t_; a.fimgA[l] = f; a.timgA[l] = t_; }
+                else { img[l] = f; imgT[l] = t_; a.fimg[l] = f; a.timg[l] = t_; }
+                k = mm->out_dim[l];
+            }
         }
     }
     a.wpart = ws;
@@ -868,10 +1026,15 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
     to_dev(a.de, mde);
     if (dae) to_dev(a.ae, mae);
     if (launch_pack_transpose(mde, dae ? &mae : nullptr, stream) != hipSuccess) return PSNODE_ERR_HIP;
-    if (a.de_reg && launch_pack_plain_images(mde, img, imgT, stream) != hipSuccess) return PSNODE_ERR_HIP;
-    auto kern = a.de_reg ? (a.gacc_global == 1 ? &generic_backward_kernel<true, true> : (a.gacc_global == 2 ? &generic_backward_kernel<false, true, true>
-                                                                                                              : &generic_backward_kernel<false, true>))
-                         : (a.gacc_global ? &generic_backward_kernel<true, false> : &generic_backward_kernel<false, false>);
+    if ((a.de_reg || a.str == 2) && launch_pack_plain_images(mde, img, imgT, stream) != hipSuccess) return PSNODE_ERR_HIP;
+    if (dae && a.str >= 1 && launch_pack_plain_images(mae, imgA, imgTA, stream) != hipSuccess) return PSNODE_ERR_HIP;
+    // <DE accumulators global, DE on the register path, AE accumulators global, streamed MLPs>
+    void (*kern)(const GBwd) = nullptr;
+    const int g = a.gacc_global;
+    if (a.de_reg && a.str == 1) kern = g == 1 ? &generic_backward_kernel<true, true, true, 1> : (g == 2 ? &generic_backward_kernel<false, true, true, 1> : &generic_backward_kernel<false, true, false, 1>);
+    else if (a.de_reg) kern = g == 1 ? &generic_backward_kernel<true, true, true, 0> : (g == 2 ? &generic_backward_kernel<false, true, true, 0> : &generic_backward_kernel<false, true, false, 0>);
+    else if (a.str == 2) kern = g == 1 ? &generic_backward_kernel<true, false, true, 2> : (g == 2 ? &generic_backward_kernel<false, false, true, 2> : &generic_backward_kernel<false, false, false, 2>);
+    else kern = g ? &generic_backward_kernel<true, false, true, 0> : &generic_backward_kernel<false, false, false, 0>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PSNODE_ERR_HIP;
     const unsigned nwg = (unsigned)((B + TB - 1) / TB);
