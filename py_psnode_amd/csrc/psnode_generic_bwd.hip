@@ -58,6 +58,7 @@ struct GBwd {
     // streamed path (round 6): the MLPs that are not on the register path -- str 1: the AE head of a DAE whose DE is, 2: both MLPs -- read
     // their MFMA A operands from the same kind of images (L2-resident), one chunk ahead; no staging through LDS
     int str;
+    float* tmpart;     // per-workgroup TILE-MAJOR global accumulators of the MLPs off the staged path (gacc_global != 0): tm_total(de) + tm_total(ae)
     const float* fimgA[kMaxLayers];
     const float* timgA[kMaxLayers];
 };
@@ -365,12 +366,16 @@ __device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, fl
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
         const float* a_in = acts + m.act[l] * TP;
         // ---- dW[j][k] += sum_tr delta[j][tr] * a_in[k][tr],  db[j] += sum_tr delta[j][tr]      (as g_vjp)
-        float* gw_g = gacc_g + m.gw[l];
-        float* tw = gacc_l + tm_dw_off(m, l);            // (!gg) tile-major accumulators of this layer
         const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
 #ifndef PSNODE_K5_ABL
 #define PSNODE_K5_ABL 0      // timing-only builds: 1 = no accumulation into gacc, 2 = no weight-gradient tiles at all, 3 = no forward recomputation
 #endif
+        // weight-gradient tiles.  Global accumulators (gg) are tile-major like the LDS ones -- one 16-byte read-modify-write per lane and tile
+        // -- and the NEXT tile's old value is requested before this tile's MFMAs: four predicated b32 read-modify-writes per tile with the
+        // L2 round trip exposed cost 56 of 95 ms at hidden 128.
+        f4* T4 = reinterpret_cast<f4*>(gg ? gacc_g + tm_dw_off(m, l) : gacc_l + tm_dw_off(m, l)) + lane;
+        f4 oldn = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (gg) { if (wave < ntiles) oldn = T4[wave * 64]; }
         for (int tile = wave; tile < (PSNODE_K5_ABL == 2 ? 0 : ntiles); tile += 4) {
             const int mt = tile / ntk, kt = tile % ntk;
             const int ju = 16 * mt + i, ku = 16 * kt + i;
@@ -378,26 +383,20 @@ __device__ __forceinline__ float* g_vjp_reg(const GBwd& a, const float* acts, fl
             // 80-byte rows, 16-byte aligned)
             const f4 dv = *reinterpret_cast<const f4*>(din + (ju < N ? ju : N - 1) * TP + 4 * g);
             const f4 av = *reinterpret_cast<const f4*>(a_in + (ku < K ? ku : K - 1) * TP + 4 * g);
+            f4 old = oldn;
+            if constexpr (gg) oldn = T4[(tile + 4 < ntiles ? tile + 4 : tile) * 64];
+            else old = T4[tile * 64];
             f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = gm(ju < N ? dv[q] : 0.0f, ku < K ? av[q] : 0.0f, acc);
-            if (PSNODE_K5_ABL == 1) { if (acc[0] == 123.456f) tw[0] = acc[0]; continue; }
-            if constexpr (gg) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jr = 16 * mt + 4 * g + r;
-                    if (jr < N && ku < K) gw_g[jr * K + ku] += acc[r];
-                }
-            } else {
-                f4* t4 = reinterpret_cast<f4*>(tw) + tile * 64 + lane;      // rows / columns beyond the matrix accumulate zeros
-                *t4 = *t4 + acc;
-            }
+            if (PSNODE_K5_ABL == 1) { if (acc[0] == 123.456f) T4[0] = acc; continue; }
+            T4[tile * 64] = old + acc;                   // rows / columns beyond the matrix accumulate zeros
         }
         for (int jj = tid; jj < N; jj += NT) {
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < TB; ++c) s += din[jj * TP + c];
-            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
+            if constexpr (gg) gacc_g[tm_db_off(m, l) + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
         }
         // ---- delta_in[k] = sum_j W[j][k] delta[j]  (* ELU'(a_in[k]) for hidden layers): tiles over k, A operands (W^T) in registers
         const int SN = (N + 15) >> 4, NTK = (K + 15) >> 4;
@@ -504,33 +503,34 @@ __device__ __forceinline__ float* g_vjp_str(const GMlp& m, const float* const* t
     for (int l = m.L - 1; l >= 0; --l) {
         const int N = m.out_dim[l], K = l == 0 ? m.in_dim : m.out_dim[l - 1];
         const float* a_in = acts + m.act[l] * TP;
-        float* gw_g = gacc_g + m.gw[l];
-        float* tw = gacc_l + tm_dw_off(m, l);
         const int ntk = (K + 15) / 16, ntiles = ((N + 15) / 16) * ntk;
-        for (int tile = wave; tile < ntiles; tile += 4) {
+        // weight-gradient tiles.  Global accumulators (gg) are tile-major like the LDS ones -- one 16-byte read-modify-write per lane and tile
+        // -- and the NEXT tile's old value is requested before this tile's MFMAs: four predicated b32 read-modify-writes per tile with the
+        // L2 round trip exposed cost 56 of 95 ms at hidden 128.
+        f4* T4 = reinterpret_cast<f4*>(gg ? gacc_g + tm_dw_off(m, l) : gacc_l + tm_dw_off(m, l)) + lane;
+        f4 oldn = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (gg) { if (wave < ntiles) oldn = T4[wave * 64]; }
+        for (int tile = wave; tile < (PSNODE_K5_ABL == 2 ? 0 : ntiles); tile += 4) {
             const int mt = tile / ntk, kt = tile % ntk;
             const int ju = 16 * mt + i, ku = 16 * kt + i;
+            // MFMA step q contracts the trajectories 4 g + q (slot g): a lane's four operands are ONE 16-byte read of its row (TP = 20 floats:
+            // 80-byte rows, 16-byte aligned)
             const f4 dv = *reinterpret_cast<const f4*>(din + (ju < N ? ju : N - 1) * TP + 4 * g);
             const f4 av = *reinterpret_cast<const f4*>(a_in + (ku < K ? ku : K - 1) * TP + 4 * g);
+            f4 old = oldn;
+            if constexpr (gg) oldn = T4[(tile + 4 < ntiles ? tile + 4 : tile) * 64];
+            else old = T4[tile * 64];
             f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = gm(ju < N ? dv[q] : 0.0f, ku < K ? av[q] : 0.0f, acc);
-            if constexpr (gg) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jr = 16 * mt + 4 * g + r;
-                    if (jr < N && ku < K) gw_g[jr * K + ku] += acc[r];
-                }
-            } else {
-                f4* t4 = reinterpret_cast<f4*>(tw) + tile * 64 + lane;
-                *t4 = *t4 + acc;
-            }
+            if (PSNODE_K5_ABL == 1) { if (acc[0] == 123.456f) T4[0] = acc; continue; }
+            T4[tile * 64] = old + acc;                   // rows / columns beyond the matrix accumulate zeros
         }
         for (int jj = tid; jj < N; jj += NT) {
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < TB; ++c) s += din[jj * TP + c];
-            if constexpr (gg) gacc_g[m.gb[l] + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
+            if constexpr (gg) gacc_g[tm_db_off(m, l) + jj] += s; else gacc_l[tm_db_off(m, l) + jj] += s;
         }
         const int SN = (N + 15) >> 4, NTK = (K + 15) >> 4;
         const f4* bq = reinterpret_cast<const f4*>(qb + qd) + lane;
@@ -608,8 +608,19 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
 #define TILE_LOOP(rows) for (int idx = tid, r = tid / TB, c = tid % TB; idx < (rows) * TB; idx += NT, r = idx / TB, c = idx % TB)
 
     for (int e = tid; e < np_all; e += NT) gacc_l[e] = 0.0f;
-    if constexpr (gg) for (int e = tid; e < a.de.np; e += NT) gacc_g[e] = 0.0f;
-    if constexpr (ggA) for (int e = tid; e < (dae ? a.ae.np : 0); e += NT) gacc_g[a.de.np + e] = 0.0f;
+    // global accumulators: tile-major slices (tmpart) for the MLPs off the staged path, the natural partial slice itself for a staged one
+    float* tmg = a.tmpart + (size_t)blockIdx.x * (tm_total(a.de) + (a.dae ? tm_total(a.ae) : 0));
+    float* tmgA = tmg + tm_total(a.de);
+    if constexpr (gg) {
+        if constexpr (DE_TM) { for (int e = tid; e < tm_total(a.de); e += NT) tmg[e] = 0.0f; }
+        else { for (int e = tid; e < a.de.np; e += NT) gacc_g[e] = 0.0f; }
+    }
+    if constexpr (ggA) {
+        if (dae) {
+            if constexpr (AE_TM) { for (int e = tid; e < tm_total(a.ae); e += NT) tmgA[e] = 0.0f; }
+            else { for (int e = tid; e < a.ae.np; e += NT) gacc_g[a.de.np + e] = 0.0f; }
+        }
+    }
     TILE_LOOP(n) { a0s[r * TP + c] = a.a0[gb(c) * n + r]; ga0s[r * TP + c] = 0.0f; }
     TILE_LOOP(xd) gxc[r * TP + c] = on(c) ? a.gxs[((a.T - 1) * a.B + gb(c)) * xd + r] : 0.0f;
     TILE_LOOP(id) gic[r * TP + c] = (on(c) && a.gis) ? a.gis[((a.T - 1) * a.B + gb(c)) * id + r] : 0.0f;
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         if constexpr (STR >= 1) g_forward_str(a.ae, a.fimgA, acts, qb, qoA); else g_forward(a.ae, acts, wbuf);
         TILE_LOOP(id) dA[r * TP + c] = gi[r * TP + c];
         __syncthreads();
-        const float* gu = STR >= 1 ? g_vjp_str<ggA>(a.ae, a.timgA, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, qb, qoA)
+        const float* gu = STR >= 1 ? g_vjp_str<ggA>(a.ae, a.timgA, acts, dA, dB, gacc_l + ae_at, tmgA, qb, qoA)
                                    : g_vjp<ggA>(a.ae, acts, dA, dB, gacc_l + ae_at, gacc_g + a.de.np, wbuf);
         TILE_LOOP(n) ga0s[r * TP + c] += gu[r * TP + c];
         TILE_LOOP(xd) gx_dst[r * TP + c] += gu[(n + r) * TP + c];
@@ -766,8 +777,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
             else g_forward(a.de, acts, wbuf);
             TILE_LOOP(xd) dA[r * TP + c] = gks[s * nx + r * TP + c];
             __syncthreads();
-            const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, gacc_g, qb, qo, rbw)
-                                  : (STR == 2 ? g_vjp_str<gg>(a.de, a.timg, acts, dA, dB, gacc_l, gacc_g, qb, qo) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf));
+            const float* gu = REG ? g_vjp_reg<gg>(a, acts, dA, dB, gacc_l, tmg, qb, qo, rbw)
+                                  : (STR == 2 ? g_vjp_str<gg>(a.de, a.timg, acts, dA, dB, gacc_l, tmg, qb, qo) : g_vjp<gg>(a.de, acts, dA, dB, gacc_l, gacc_g, wbuf));
             TILE_LOOP(n) {
                 const float gs = gu[(n + r) * TP + c] + gu[(2 * n + r) * TP + c];
                 ga0s[r * TP + c] += gu[r * TP + c] - gu[(n + r) * TP + c];
@@ -825,10 +836,11 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
     TILE_LOOP(n) if (on(c)) a.ga0[(b0 + c) * n + r] = ga0s[r * TP + c];
     float* wp = a.wpart + (size_t)blockIdx.x * (a.de.np + (dae ? a.ae.np : 0));
     // the LDS accumulators -> this workgroup's partial in nn.Linear order (tile-major ones un-permuted)
-    auto unpermute = [&](const GMlp& m, const float* base, float* dst) {
+    // (volatile: the global tile-major slices were written by other lanes of this workgroup; read them past the vector L1)
+    auto unpermute = [&](const GMlp& m, const volatile float* base, float* dst) {
         for (int l = 0; l < m.L; ++l) {
             const int N = m.out_dim[l], K = l ? m.out_dim[l - 1] : m.in_dim, ntk = (K + 15) / 16;
-            const float* tw = base + tm_dw_off(m, l);
+            const volatile float* tw = base + tm_dw_off(m, l);
             for (int e = tid; e < N * K; e += NT) {
                 const int j = e / K, k = e % K;
                 dst[m.gw[l] + e] = tw[(((j >> 4) * ntk + (k >> 4)) * 64 + ((j & 15) >> 2) * 16 + (k & 15)) * 4 + (j & 3)];
@@ -846,6 +858,8 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
         if constexpr (DE_TM) unpermute(a.de, gacc_l, wp);
         else for (int e = tid; e < a.de.np; e += NT) wp[e] = gacc_l[e];
     }
+    if constexpr (gg && DE_TM) { __threadfence(); __syncthreads(); unpermute(a.de, tmg, wp); }
+    if constexpr (ggA && AE_TM) { if (dae) { __threadfence(); __syncthreads(); unpermute(a.ae, tmgA, wp + a.de.np); } }
 #undef TILE_LOOP
 }
 
@@ -889,6 +903,17 @@ bool de_reg_class(const psnode_mlp_f32& de) {
     for (int l = 0; l < de.n_layers; ++l)
         if (de.out_dim[l] > 64) return false;
     return true;
+}
+size_t tm_floats(const psnode_mlp_f32& de, const psnode_mlp_f32* ae) {      // one workgroup's tile-major global accumulators (both MLPs)
+    size_t tot = 0;
+    for (int m = 0; m < (ae ? 2 : 1); ++m) {
+        const psnode_mlp_f32& mm = m ? *ae : de;
+        size_t t = 0;
+        int k = mm.in_dim;
+        for (int l = 0; l < mm.n_layers; ++l) { t += (size_t)up16(mm.out_dim[l]) * up16(k) + mm.out_dim[l]; k = mm.out_dim[l]; }
+        tot += (t + 3) & ~(size_t)3;
+    }
+    return tot;
 }
 size_t reg_image_floats(const psnode_mlp_f32& de) {       // plain + transposed images of every layer
     size_t tot = 0;
@@ -951,7 +976,7 @@ bool mlp_ok(const psnode_mlp_f32& m, int in_dim, int out_dim) {
 size_t generic_bwd_workspace_floats(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, long long B) {
     const size_t nwg = (size_t)((B + TB - 1) / TB);
     return mlp_wt_floats(*de) + (ae ? mlp_wt_floats(*ae) : 0) + nwg * (size_t)(mlp_np(*de) + (ae ? mlp_np(*ae) : 0)) + 64 +
-           reg_image_floats(*de) + 64 + (ae ? reg_image_floats(*ae) + 64 : 0);
+           reg_image_floats(*de) + 64 + (ae ? reg_image_floats(*ae) + 64 : 0) + nwg * tm_floats(*de, ae) + 64;
 }
 
 int generic_bwd_fits(const psnode_mlp_f32* de, const psnode_mlp_f32* ae, int xd, int zd, int vd, int id) {
@@ -1013,6 +1038,11 @@ int generic_backward_launch(int method, int xd, int zd, int vd, int id, long lon
         }
     }
     a.wpart = ws;
+    {
+        const size_t nwg_ = (size_t)((B + TB - 1) / TB);
+        float* tm = ws + nwg_ * (size_t)(a.de.np + (dae ? a.ae.np : 0));
+        a.tmpart = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tm) + 255) & ~(uintptr_t)255);
+    }
     if (!gbwd_mode(a)) return PSNODE_ERR_UNSUPPORTED;
     const size_t lds = gbwd_lds_floats(a) * sizeof(float);
     // transposed weights for the forward recomputation
