@@ -631,7 +631,7 @@ MODEL_H128_EXTRAS = [("ode02", "euler", 128), ("dae02", "euler", 128)]
 # round 6, last: shapes without a specialisation, on the generic integrator K0 (register form)
 GENERIC_EXTRAS = [("ode01_x20", "rk4", "x_dim 20: generic integrator K0"), ("dae01_zvi16", "rk4", "z + v + i = 16: generic integrator K0")]
 # ... and a training step on them: K0 forward + K6 loss + the generic backward K5 (Euler: the scripts' solver)
-GENERIC_TRAIN_EXTRAS = [("ode01_x20", "euler", 64)]
+GENERIC_TRAIN_EXTRAS = [("ode01_x20", "euler", 64), ("dae01_zvi16", "euler", 64)]
 
 
 def safe_line(label, fn):
