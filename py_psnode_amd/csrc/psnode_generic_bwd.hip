@@ -754,13 +754,15 @@ __global__ __launch_bounds__(NT) void generic_backward_kernel(const GBwd a) {
                 xst[s * nx + r * TP + c] = s == 0 ? x0[r * TP + c] : x0[r * TP + c] + dts[c] * acc;
             }
             __syncthreads();
-            de_input(xst + s * nx);
-            if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw);
-            else if constexpr (STR == 2) g_forward_str(a.de, a.fimg, acts, qb, qo);
-            else g_forward(a.de, acts, wbuf);
-            const float* out = acts + a.de.act[a.de.L] * TP;
-            TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
-            __syncthreads();
+            if (s + 1 < S) {               // (the last stage's slope feeds no stage input: its evaluation is (3b)'s first, not done here)
+                de_input(xst + s * nx);
+                if constexpr (REG) g_forward_reg(a, acts, qb, qo, rfw);
+                else if constexpr (STR == 2) g_forward_str(a.de, a.fimg, acts, qb, qo);
+                else g_forward(a.de, acts, wbuf);
+                const float* out = acts + a.de.act[a.de.L] * TP;
+                TILE_LOOP(xd) ks[s * nx + r * TP + c] = out[r * TP + c];
+                __syncthreads();
+            }
         }
         // (3b) stages backwards
         TILE_LOOP(xd) {
